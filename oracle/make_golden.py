@@ -1,0 +1,182 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON in the build container.
+
+Run once, here (the reference never travels to the GPU box):
+    python oracle/make_golden.py
+
+Two groups of vectors:
+  * blocks_*.npz  - `/root/reference/source/scripts/blocks.py` imported as is (it needs only torch).
+  * nets_*.npz    - `nets.Urnet` / `nets.Urnetv2` from `/root/reference/source/scripts/nets.py`.
+                    nets.py imports torchvision (absent in this image) for models that are not on
+                    the hot path; the import is satisfied by empty placeholder modules whose only
+                    function is a 6-line `center_crop` (identity for every supported patch size).
+                    No reference source is copied: the classes are the reference's.
+Fixtures hold inputs, parameters' seeds, outputs, losses, gradient summaries and post-step
+weights; `tests/test_oracle_golden.py` replays them against `oracle/unet_oracle.py`.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/source/scripts"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+import unet_oracle as O  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def summarise(t):
+    t = t.detach().double().reshape(-1)
+    return np.array([t.sum().item(), t.norm().item(), t.abs().max().item()]), t[:64].float().numpy()
+
+
+def blocks_golden():
+    import blocks  # the reference module, unmodified
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    x = torch.randint(0, 256, (2, 3, 16, 16), generator=g).float()
+    enc = blocks.UnetEncodeLayer(3, 8, padding=1)
+    dec = blocks.UnetForwardDecodeLayer(8, 4, padding=1)
+    up = blocks.UnetUpscaleLayer(2, 8)
+    for name, m in (("enc", enc), ("dec", dec), ("up", up)):
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                with torch.no_grad():
+                    v.copy_(torch.randn(v.shape, generator=g) * 0.3 + (1.0 if "running_var" in k else 0.0))
+                    if "running_var" in k:
+                        v.abs_()
+                out[f"{name}.{k}"] = v.detach().clone().numpy()
+    out["x"] = x.numpy()
+    x.requires_grad_(True)
+    enc.train(); dec.train(); up.train()
+    h = enc(x)
+    y = dec(h)
+    u = up(h)
+    out["enc.out_train"] = h.detach().numpy()
+    out["dec.out_train"] = y.detach().numpy()
+    out["up.out_train"] = u.detach().numpy()
+    loss = (y * y).mean() + (u * torch.arange(u.numel()).reshape(u.shape).float() / u.numel()).mean()
+    loss.backward()
+    out["loss"] = np.array(loss.item())
+    out["x.grad"] = x.grad.numpy()
+    for name, m in (("enc", enc), ("dec", dec), ("up", up)):
+        for k, v in m.named_parameters():
+            out[f"{name}.{k}.grad"] = v.grad.numpy()
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                out[f"{name}.{k}.after"] = v.detach().clone().numpy()
+    enc.eval(); dec.eval(); up.eval()
+    with torch.no_grad():
+        h = enc(x)
+        out["enc.out_eval"] = h.numpy()
+        out["dec.out_eval"] = dec(h).numpy()
+        out["up.out_eval"] = up(h).numpy()
+    np.savez_compressed(os.path.join(OUT, "blocks_ref.npz"), **out)
+    print("blocks_ref.npz", len(out), "arrays")
+
+
+def import_nets():
+    import transformers  # noqa: F401  (nets.py imports Segformer classes from it)
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+    v2 = types.ModuleType("torchvision.transforms.v2")
+    fn = types.ModuleType("torchvision.transforms.functional")
+    mo = types.ModuleType("torchvision.models")
+    sg = types.ModuleType("torchvision.models.segmentation")
+
+    def center_crop(img, output_size):
+        s = output_size if isinstance(output_size, int) else output_size[0]
+        h, w = img.shape[-2:]
+        top, left = int(round((h - s) / 2.0)), int(round((w - s) / 2.0))
+        return img[..., top:top + s, left:left + s]
+    fn.center_crop = center_crop
+    for n in ("deeplabv3_resnet101", "deeplabv3_mobilenet_v3_large", "deeplabv3_resnet50"):
+        setattr(sg, n, None)
+    tv.transforms, tr.v2, tr.functional, tv.models, mo.segmentation = tr, v2, fn, mo, sg
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.transforms.v2": v2,
+                        "torchvision.transforms.functional": fn, "torchvision.models": mo,
+                        "torchvision.models.segmentation": sg})
+    import nets
+    return nets
+
+
+def nets_golden(nets, variant, cls, NC, B, S, opt_name, ignore_index, weighted, tag):
+    net = cls(NC)
+    sd = net.state_dict()
+    keys = [k for k in sd if not k.endswith("num_batches_tracked")]
+    spec = O.param_spec(variant, NC)
+    assert keys == [n for n, _ in spec], (keys[:5], spec[:5])
+    assert [tuple(sd[k].shape) for k in keys] == [s for _, s in spec]
+    p0 = O.init_params(variant, NC, seed=3)
+    net.load_state_dict(p0, strict=False)
+    img, lab = O.synthetic_tiles(B, S, NC, seed=11)
+    out = {"img": img.numpy(), "lab": lab.numpy(), "NC": np.array(NC), "seed": np.array(3),
+           "keys": np.array(keys), "shapes": np.array([str(tuple(sd[k].shape)) for k in keys])}
+    weight = None
+    if weighted:
+        counts = np.bincount(lab.numpy().reshape(-1), minlength=NC)
+        weight = torch.tensor(O.class_weights(counts, ignore_background=(ignore_index == 0)))
+        out["class_weight"] = weight.numpy()
+    crit = torch.nn.CrossEntropyLoss(weight=weight, ignore_index=ignore_index)
+    if opt_name == "SGD2":
+        opt = torch.optim.SGD(net.parameters(), lr=0.006, momentum=0.9, weight_decay=0.00001)
+        sched = torch.optim.lr_scheduler.PolynomialLR(opt, total_iters=20)
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=0.005)
+        sched = torch.optim.lr_scheduler.PolynomialLR(opt, total_iters=4, power=2.0)
+    net.train()
+    losses = []
+    for step in range(3):  # S/train.py:121-126 order
+        pred = net(img.type(torch.float32), None)
+        loss = crit(pred, lab.type(torch.long))
+        losses.append(loss.item())
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["logits_train0"] = pred.detach().numpy()
+            for k, v in net.named_parameters():
+                s, head = summarise(v.grad)
+                out[f"grad0.sum.{k}"] = s
+                out[f"grad0.head.{k}"] = head
+        opt.step()
+        if step == 1:
+            sched.step()  # one epoch boundary inside the fixture
+    out["losses"] = np.array(losses)
+    for k, v in net.state_dict().items():
+        if v.dtype.is_floating_point:
+            s, head = summarise(v)
+            out[f"after.sum.{k}"] = s
+            out[f"after.head.{k}"] = head
+    net.eval()
+    with torch.no_grad():
+        ev = net(img.type(torch.float32), None)
+    out["logits_eval"] = ev.numpy()
+    out["labels_eval"] = torch.argmax(ev, 1).numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"nets_{tag}.npz"), **out)
+    print(f"nets_{tag}.npz losses", losses)
+
+
+def converter_golden():
+    from converters import GID15Converter
+    c = GID15Converter()
+    cols = np.array(list(c.color_to_label.keys()), dtype=np.uint8)
+    labs = np.array(list(c.color_to_label.values()), dtype=np.int64)
+    m = torch.arange(16).reshape(4, 4)
+    np.savez_compressed(os.path.join(OUT, "converter_ref.npz"), colors=cols, labels=labs,
+                        iconvert_4x4=c.iconvert(m).numpy())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    blocks_golden()
+    converter_golden()
+    nets = import_nets()
+    nets_golden(nets, "Unetv2", nets.Urnetv2, 5, 2, 32, "SGD2", 0, False, "unetv2_sgd2")
+    nets_golden(nets, "Unetv2", nets.Urnetv2, 16, 2, 32, "ADAM1", -100, True, "unetv2_adam1_wcel")
+    nets_golden(nets, "Unet", nets.Urnet, 5, 2, 32, "SGD2", 0, True, "unet_sgd2_wcel")

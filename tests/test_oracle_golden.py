@@ -1,0 +1,151 @@
+"""Pins `oracle/unet_oracle.py` against vectors produced by the reference's own Python
+(`oracle/make_golden.py`, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_blocks_reference_vectors(golden_dir):
+    """S/blocks.py:8-49 imported unmodified: encode (conv-BN-ReLU), decode (conv-ReLU-BN x2),
+    upscale (bilinear + conv); train and eval mode, grads and running stats."""
+    g = _load(golden_dir, "blocks_ref.npz")
+    p = {}
+    for k in g.files:
+        if k.startswith(("enc.layer", "dec.layer", "up.layer")) and not k.endswith((".grad", ".after")):
+            p[k] = torch.tensor(g[k]).requires_grad_(not ("running" in k))
+    x = torch.tensor(g["x"]).requires_grad_(True)
+    h = O.encode_layer(x, {k[4:]: v for k, v in p.items() if k.startswith("enc.")}, "layer", True)
+    dp = {k[4:]: v for k, v in p.items() if k.startswith("dec.")}
+    y = O.decode_layer(h, dp, "layer", True)
+    up = {"upscale1.0." + k[3:]: v for k, v in p.items() if k.startswith("up.")}
+    u = O.upscale(h, up, 1, "Unet")
+    np.testing.assert_allclose(h.detach().numpy(), g["enc.out_train"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.detach().numpy(), g["dec.out_train"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(u.detach().numpy(), g["up.out_train"], rtol=1e-5, atol=1e-4)
+    loss = (y * y).mean() + (u * torch.arange(u.numel()).reshape(u.shape).float() / u.numel()).mean()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["x.grad"], rtol=1e-4, atol=1e-7)
+    for k, v in p.items():
+        if v.requires_grad:
+            np.testing.assert_allclose(v.grad.numpy(), g[k + ".grad"], rtol=2e-4, atol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(v.numpy(), g[k + ".after"], rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        h = O.encode_layer(x, {k[4:]: v for k, v in p.items() if k.startswith("enc.")}, "layer", False)
+        np.testing.assert_allclose(h.numpy(), g["enc.out_eval"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(O.decode_layer(h, dp, "layer", False).numpy(), g["dec.out_eval"],
+                                   rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,variant,opt,ignore,epochs", [
+    ("unetv2_sgd2", "Unetv2", "SGD2", 0, 20),
+    ("unetv2_adam1_wcel", "Unetv2", "ADAM1", -100, 4),
+    ("unet_sgd2_wcel", "Unet", "SGD2", 0, 20),
+])
+def test_nets_reference_vectors(golden_dir, tag, variant, opt, ignore, epochs):
+    """nets.Urnet / nets.Urnetv2 (S/nets.py:34-199), CE loss (S/utils.py:230,238), SGD2 / ADAM1 +
+    PolynomialLR (S/utils.py:213-218), three steps in S/train.py:121-126 order."""
+    g = _load(golden_dir, f"nets_{tag}.npz")
+    NC = int(g["NC"])
+    spec = O.param_spec(variant, NC)
+    assert [n for n, _ in spec] == list(g["keys"])
+    assert [str(s) for _, s in spec] == list(g["shapes"])
+    w = torch.tensor(g["class_weight"]) if "class_weight" in g.files else None
+    tr = O.OracleTrainer(variant, NC, opt=opt, epochs=epochs, ignore_index=ignore, weight=w, seed=int(g["seed"]))
+    img, lab = torch.tensor(g["img"]), torch.tensor(g["lab"])
+    for step in range(3):
+        loss, logits, grads = tr.step(img, lab)
+        assert abs(loss - g["losses"][step]) < 2e-4 * abs(g["losses"][step]), (step, loss, g["losses"][step])
+        if step == 0:
+            ref = g["logits_train0"]
+            assert np.abs(logits.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+            for k, gr in grads.items():
+                s = g[f"grad0.sum.{k}"]
+                assert abs(gr.double().norm().item() - s[1]) <= 2e-3 * s[1] + 1e-9, k
+                np.testing.assert_allclose(gr.reshape(-1)[:64].numpy(), g[f"grad0.head.{k}"],
+                                           rtol=5e-2, atol=2e-3 * s[2] + 1e-9, err_msg=k)
+        if step == 1:
+            tr.end_epoch()
+    for k, v in tr.p.items():
+        s = g[f"after.sum.{k}"]
+        if opt == "ADAM1" and k.startswith("encode") and k.endswith(".layer.0.bias"):
+            # a conv bias in front of a train-mode BN has an exactly-zero true gradient; what is left
+            # is rounding noise, which Adam's m/sqrt(v) turns into +-lr steps: not reproducible
+            # across thread counts / summation orders even inside torch.  Not compared.
+            continue
+        tol = 1e-3 if opt == "ADAM1" else 1e-4
+        assert abs(v.detach().double().norm().item() - s[1]) <= tol * s[1] + 1e-7, k
+    with torch.no_grad():
+        ev = O.unet_forward(tr.p, img.float(), variant, train=False)
+    ref = g["logits_eval"]
+    assert np.abs(ev.numpy() - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    agree = (O.predict_labels(ev).numpy() == g["labels_eval"]).mean()
+    assert agree > 0.999, agree
+
+
+def test_converter_palette(golden_dir):
+    g = _load(golden_dir, "converter_ref.npz")
+    assert g["colors"].shape == (16, 3) and list(g["labels"]) == list(range(16))
+
+
+def test_numpy_twins_agree_with_aten():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 5, 9, 11)).astype(np.float32)
+    w = rng.normal(size=(7, 5, 3, 3)).astype(np.float32)
+    b = rng.normal(size=(7,)).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(b), padding=1).numpy()
+    np.testing.assert_allclose(O.numpy_conv3x3(x, w, b), ref, rtol=1e-4, atol=1e-4)
+    gamma, beta = rng.normal(size=7).astype(np.float32), rng.normal(size=7).astype(np.float32)
+    bn = torch.nn.functional.batch_norm(torch.tensor(ref), None, None, torch.tensor(gamma), torch.tensor(beta),
+                                        training=True).numpy()
+    np.testing.assert_allclose(O.numpy_batch_norm_train(ref, gamma, beta), bn, rtol=1e-4, atol=1e-4)
+    z = rng.normal(size=(3, 6, 4, 5)).astype(np.float32) * 4
+    t = rng.integers(0, 6, size=(3, 4, 5))
+    cw = rng.uniform(0.1, 2, size=6).astype(np.float32)
+    zt = torch.tensor(z, requires_grad=True)
+    loss = O.cross_entropy(zt, torch.tensor(t), torch.tensor(cw), ignore_index=0)
+    loss.backward()
+    l2, d2 = O.numpy_cross_entropy(z, t, cw, ignore_index=0)
+    assert abs(loss.item() - l2) < 1e-5
+    np.testing.assert_allclose(zt.grad.numpy(), d2, rtol=1e-4, atol=1e-7)
+
+
+def test_confusion_and_metrics_hand_case():
+    """S/utils.py:76-78 (rows = target, ignore drops TARGET==0) and S/utils.py:311-364."""
+    t = np.array([0, 1, 1, 2, 2, 2, 3])
+    p = np.array([1, 1, 2, 2, 2, 1, 0])
+    c = O.confusion_matrix(p, t, 4, ignore_index=0)
+    assert c.tolist() == [[0, 0, 0, 0], [0, 1, 1, 0], [0, 1, 2, 0], [1, 0, 0, 0]]
+    m = O.metrics(c)
+    # class0 excluded (no targets); IoU1 = 1/3, IoU2 = 2/4, IoU3 = 0/1
+    assert m["excluded"] == [0]
+    assert abs(m["mIoU"] - (1 / 3 + 0.5 + 0) / 3) < 1e-6
+    assert abs(m["oa_score"] - 3 / 6) < 1e-12
+    from sklearn.metrics import confusion_matrix as skc
+    keep = t != 0
+    assert (skc(t[keep], p[keep], labels=[0, 1, 2, 3]) == c).all()
+
+
+def test_class_weights():
+    w = O.class_weights([10, 20, 0, 70], ignore_background=True)
+    np.testing.assert_allclose(w, [0, 90 / (3 * 20), 0, 90 / (3 * 70)], rtol=1e-6)
+    w = O.class_weights([10, 20, 0, 70], ignore_background=False)
+    np.testing.assert_allclose(w, [100 / 40, 100 / 80, 0, 100 / 280], rtol=1e-6)
+
+
+def test_polynomial_lr_matches_torch():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.006)
+    s = torch.optim.lr_scheduler.PolynomialLR(opt, total_iters=20)
+    for e in range(25):
+        assert abs(opt.param_groups[0]["lr"] - O.polynomial_lr(0.006, e, 20, 1.0)) < 1e-12
+        opt.step(); s.step()
