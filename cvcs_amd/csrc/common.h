@@ -1,0 +1,83 @@
+// Shared helpers for libcvcs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cvcs_hip.h"
+
+namespace cvcs {
+
+void set_error(const char* fmt, ...);
+
+#define CVCS_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::cvcs::set_error(__VA_ARGS__);        \
+      return CVCS_EINVAL;                    \
+    }                                        \
+  } while (0)
+
+#define CVCS_CHECK_LAUNCH(name)                                                  \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      ::cvcs::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+      return CVCS_EHIP;                                                          \
+    }                                                                            \
+  } while (0)
+
+typedef uint16_t bf16_t;  // storage type of a bfloat16
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPer16 = 4;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  // unpack a 16-byte chunk into kPer16 floats / pack back
+  __device__ static __forceinline__ void unpack(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPer16 = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  __device__ static __forceinline__ void unpack(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    uint4 u;
+    u.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    u.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+    u.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    return u;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace cvcs

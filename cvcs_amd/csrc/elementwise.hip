@@ -1,0 +1,612 @@
+// HBM-bound kernels of the per-tile path on gfx950: BatchNorm finalize / apply (+ReLU, +MaxPool 2x2) and its
+// two-pass backward, bilinear x2, and the NCHW<->packed layout changes at the boundary.
+//
+// Every activation access is one 16-byte chunk per lane (8 bf16 / 4 f32 channels of one pixel), lanes of a
+// wave walking consecutive chunks: whole 128-byte lines per pixel row.  Per-channel reductions keep a channel
+// chunk fixed per thread, accumulate in registers over a grid-stride of pixels, combine the workgroup's pixel
+// lanes through LDS and write one partial row per workgroup; a tiny f64 finalize sums the rows in a fixed
+// order (bitwise reproducible, no float atomics).
+//
+// Reference ops replaced: nn.BatchNorm2d (S/blocks.py:14,42,45), nn.ReLU (S/blocks.py:17,41,44), nn.MaxPool2d(2,2)
+// (S/nets.py:130,135,140,145), nn.Upsample(x2, bilinear) (S/blocks.py:29), `.type(torch.float32)` (S/train.py:121)
+// and their autograd backward (S/train.py:125).
+#include "common.h"
+
+namespace cvcs {
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+// Chan et al. combination of per-row-block (count, sum, M2) -> mean / biased var; f64 throughout.
+__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2, int rows, int64_t M,
+                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, int train,
+                                   float* scale, float* shift, float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (!train) {
+    const float is = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+    return;
+  }
+  double tot = 0.0;
+  for (int r = 0; r < rows; ++r) tot += (double)ssum[(int64_t)r * C + c];
+  const double mean = tot / (double)M;
+  double m2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    int64_t n = M - (int64_t)r * 64;
+    n = n > 64 ? 64 : n;
+    if (n <= 0) break;
+    const double mr = (double)ssum[(int64_t)r * C + c] / (double)n;
+    m2 += (double)sm2[(int64_t)r * C + c] + (double)n * (mr - mean) * (mr - mean);
+  }
+  const double var = m2 / (double)M;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+// ------------------------------------------------------------------------------------------------ BN apply fwd
+struct BnActArgs {
+  const char* y; char* out; char* pool;
+  int64_t y_ld, out_ld, pool_ld;
+  const float* scale; const float* shift;
+  int B, H, W, C, relu;
+};
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = p.C / V;
+  const int64_t items = POOL ? (int64_t)p.B * (p.H / 2) * (p.W / 2) : (int64_t)p.B * p.H * p.W;
+  const int64_t total = items * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t it = id / CC;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = p.scale[cc * V + k]; sh[k] = p.shift[cc * V + k]; }
+    if constexpr (!POOL) {
+      float f[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.y + (it * p.y_ld) * ES + cc * 16), f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        f[k] = f[k] * sc[k] + sh[k];
+        if (p.relu) f[k] = fmaxf(f[k], 0.f);
+      }
+      *reinterpret_cast<uint4*>(p.out + (it * p.out_ld) * ES + cc * 16) = Elem<T>::pack(f);
+    } else {
+      const int W2 = p.W / 2, H2 = p.H / 2;
+      const int px = (int)(it % W2);
+      const int64_t t = it / W2;
+      const int py = (int)(t % H2);
+      const int64_t b = t / H2;
+      float mx[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) mx[k] = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int64_t pix = (b * p.H + 2 * py + (w >> 1)) * p.W + 2 * px + (w & 1);
+        float f[V];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.y + (pix * p.y_ld) * ES + cc * 16), f);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          f[k] = f[k] * sc[k] + sh[k];
+          if (p.relu) f[k] = fmaxf(f[k], 0.f);
+          mx[k] = fmaxf(mx[k], f[k]);
+        }
+        *reinterpret_cast<uint4*>(p.out + (pix * p.out_ld) * ES + cc * 16) = Elem<T>::pack(f);
+      }
+      *reinterpret_cast<uint4*>(p.pool + (it * p.pool_ld) * ES + cc * 16) = Elem<T>::pack(mx);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN backward
+struct BnBwdArgs {
+  const char* y; const char* g1; const char* g2; char* dy;
+  int64_t y_ld, g1_ld, g2_ld, dy_ld;
+  const float* scale; const float* shift; const float* mean; const float* invstd;
+  const float* ca; const float* cb;
+  float* part0; float* part1;   // reduce: (dz, dz*xhat); apply: (db, unused)
+  int B, H, W, C, mode;
+};
+
+// One work item = one pixel (POOL=false) or one 2x2 window (POOL=true) x one 16-byte channel chunk.
+// APPLY=false: accumulate sum(dz), sum(dz*xhat).  APPLY=true: write dy, accumulate sum(dy).
+template <typename T, bool POOL, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  constexpr int NPIX = POOL ? 4 : 1;
+  __shared__ float red[2][256 * V];
+  const int CC = p.C / V;
+  const int ccw = CC < 256 ? CC : 256;      // chunk lanes per workgroup
+  const int PL = 256 / ccw;                 // pixel lanes per workgroup
+  const int tid = threadIdx.x;
+  const int cl = tid % ccw, pl = tid / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  const int64_t items = POOL ? (int64_t)p.B * (p.H / 2) * (p.W / 2) : (int64_t)p.B * p.H * p.W;
+  float sc[V], sh[V], mu[V], is[V], ca[V], cb[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int c = cc * V + k;
+    sc[k] = p.scale[c]; sh[k] = p.shift[c]; mu[k] = p.mean[c]; is[k] = p.invstd[c];
+    ca[k] = APPLY ? p.ca[c] : 0.f; cb[k] = APPLY ? p.cb[c] : 0.f;
+  }
+  float s0[V], s1[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
+
+  for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < items; it += (int64_t)gridDim.x * PL) {
+    int64_t pix[NPIX];
+    if constexpr (POOL) {
+      const int W2 = p.W / 2, H2 = p.H / 2;
+      const int px = (int)(it % W2);
+      const int64_t t = it / W2;
+      const int py = (int)(t % H2);
+      const int64_t b = t / H2;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) pix[w] = (b * p.H + 2 * py + (w >> 1)) * p.W + 2 * px + (w & 1);
+    } else {
+      pix[0] = it;
+    }
+    float yv[NPIX][V], gv[NPIX][V];
+#pragma unroll
+    for (int w = 0; w < NPIX; ++w) {
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.y + (pix[w] * p.y_ld) * ES + cc * 16), yv[w]);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.g1 + (pix[w] * p.g1_ld) * ES + cc * 16), gv[w]);
+    }
+    if constexpr (POOL) {
+      // MaxPool2d backward: the pooled gradient goes to the FIRST maximum of the window in scan order
+      float g2[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.g2 + (it * p.g2_ld) * ES + cc * 16), g2);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        float best = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float a = yv[w][k] * sc[k] + sh[k];
+          a = fmaxf(a, 0.f);
+          if (a > best) { best = a; arg = w; }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) gv[w][k] += (w == arg) ? g2[k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < NPIX; ++w) {
+      float out[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = (yv[w][k] - mu[k]) * is[k];
+        float dz = gv[w][k];
+        if (p.mode == 0) dz = (yv[w][k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;  // encoder: ReLU after BN
+        if constexpr (!APPLY) {
+          s0[k] += dz;
+          s1[k] += dz * xh;
+        } else {
+          float d = sc[k] * (dz - ca[k] - xh * cb[k]);
+          if (p.mode == 1) d = (yv[w][k] > 0.f) ? d : 0.f;                  // decoder: ReLU before BN
+          out[k] = d;
+          s0[k] += d;
+        }
+      }
+      if constexpr (APPLY)
+        *reinterpret_cast<uint4*>(p.dy + (pix[w] * p.dy_ld) * ES + cc * 16) = Elem<T>::pack(out);
+    }
+  }
+  // ---- combine the PL pixel lanes
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[0][tid * V + k] = s0[k]; red[1][tid * V + k] = s1[k]; }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float a = 0.f, b2 = 0.f;
+      for (int q = 0; q < PL; ++q) { a += red[0][(q * ccw + cl) * V + k]; b2 += red[1][(q * ccw + cl) * V + k]; }
+      const int64_t o = (int64_t)blockIdx.x * p.C + cc * V + k;
+      p.part0[o] = a;
+      if constexpr (!APPLY) p.part1[o] = b2;
+    }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ pdz, const float* __restrict__ pdzx, int rows, int64_t M,
+                                       int C, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* dgamma, float* dbeta, float* ca, float* cb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int r = 0; r < rows; ++r) { a += (double)pdz[(int64_t)r * C + c]; b += (double)pdzx[(int64_t)r * C + c]; }
+  dbeta[c] = (float)a;
+  dgamma[c] = (float)b;
+  ca[c] = (float)(a / (double)M);
+  cb[c] = (float)(b / (double)M);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int rows, int C, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int r = 0; r < rows; ++r) a += (double)part[(int64_t)r * C + c];
+  out[c] = (float)a;
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear x2
+// align_corners=False, scale 2: out row 2k   = .25*in[k-1] + .75*in[k]   (k=0: in[0])
+//                               out row 2k+1 = .75*in[k]   + .25*in[k+1] (k=H-1: in[H-1]); columns alike.
+__device__ __forceinline__ void up_taps(int o, int n, int& i0, int& i1, float& w0, float& w1) {
+  const int k = o >> 1;
+  if (o & 1) { i0 = k; i1 = k + 1 < n ? k + 1 : k; w0 = 0.75f; w1 = 0.25f; }
+  else       { i0 = k > 0 ? k - 1 : 0; i1 = k; w0 = k > 0 ? 0.25f : 0.f; w1 = k > 0 ? 0.75f : 1.f; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const char* in, int64_t in_ld, int B, int H, int W, int C,
+                                                            char* out, int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int64_t total = (int64_t)B * 2 * H * 2 * W * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    int64_t t = id / CC;
+    const int ox = (int)(t % (2 * W)); t /= 2 * W;
+    const int oy = (int)(t % (2 * H));
+    const int64_t b = t / (2 * H);
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    up_taps(oy, H, y0, y1, wy0, wy1);
+    up_taps(ox, W, x0, x1, wx0, wx1);
+    float a[V], bb[V], c[V], d[V], o[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(in + (((b * H + y0) * W + x0) * in_ld) * ES + cc * 16), a);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(in + (((b * H + y0) * W + x1) * in_ld) * ES + cc * 16), bb);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(in + (((b * H + y1) * W + x0) * in_ld) * ES + cc * 16), c);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(in + (((b * H + y1) * W + x1) * in_ld) * ES + cc * 16), d);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = wy0 * (wx0 * a[k] + wx1 * bb[k]) + wy1 * (wx0 * c[k] + wx1 * d[k]);
+    *reinterpret_cast<uint4*>(out + ((((b * 2 * H) + oy) * (2 * W) + ox) * out_ld) * ES + cc * 16) = Elem<T>::pack(o);
+  }
+}
+
+// gather form of the transpose: input row y collects output rows 2y-1 (.25), 2y (.75 | 1), 2y+1 (.75 | 1), 2y+2 (.25)
+__device__ __forceinline__ void up_taps_t(int i, int n, int o[4], float w[4]) {
+  o[0] = 2 * i - 1; w[0] = i > 0 ? 0.25f : 0.f;
+  o[1] = 2 * i;     w[1] = i > 0 ? 0.75f : 1.f;
+  o[2] = 2 * i + 1; w[2] = i < n - 1 ? 0.75f : 1.f;
+  o[3] = 2 * i + 2; w[3] = i < n - 1 ? 0.25f : 0.f;
+  if (i == 0) o[0] = 0;
+  if (i == n - 1) o[3] = 2 * n - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const char* g, int64_t g_ld, int B, int H, int W, int C,
+                                                            char* gin, int64_t gin_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int64_t total = (int64_t)B * H * W * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    int64_t t = id / CC;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int64_t b = t / H;
+    int oy[4], ox[4]; float wy[4], wx[4];
+    up_taps_t(y, H, oy, wy);
+    up_taps_t(x, W, ox, wx);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float w = wy[i] * wx[j];
+        if (w == 0.f) continue;
+        float f[V];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(g + ((((b * 2 * H) + oy[i]) * (2 * W) + ox[j]) * g_ld) * ES + cc * 16), f);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += w * f[k];
+      }
+    *reinterpret_cast<uint4*>(gin + (((b * H + y) * W + x) * gin_ld) * ES + cc * 16) = Elem<T>::pack(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ boundary packs
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void pack_input_kernel(const S* __restrict__ src, int B, int C, int H, int W, char* dst,
+                                                        int Cpad) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < total; pidx += (int64_t)gridDim.x * 256) {
+    const int64_t b = pidx / HW, hw = pidx - b * HW;
+    for (int c0 = 0; c0 < Cpad; c0 += V) {
+      float f[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) f[k] = (c0 + k < C) ? (float)src[(b * C + c0 + k) * HW + hw] : 0.f;
+      *reinterpret_cast<uint4*>(dst + (pidx * Cpad + c0) * ES) = Elem<T>::pack(f);
+    }
+  }
+}
+
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                                        T* wf, T* wd) {
+  const int taps = KH * KW;
+  const int64_t nf = (int64_t)taps * Cout * Cin_pad;
+  const int64_t nd = wd ? (int64_t)taps * Cin * Cout : 0;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < nf + nd; id += (int64_t)gridDim.x * blockDim.x) {
+    if (id < nf) {
+      const int ci = (int)(id % Cin_pad);
+      const int64_t r = id / Cin_pad;
+      const int co = (int)(r % Cout);
+      const int t = (int)(r / Cout);
+      const float v = ci < Cin ? w[((int64_t)co * Cin + ci) * taps + t] : 0.f;
+      Elem<T>::st(wf + id, v);
+    } else {
+      // data-gradient operand: wd[t'][ci][co] = w[co][ci][KH-1-kh'][KW-1-kw'] (180-degree flip, roles swapped)
+      const int64_t j = id - nf;
+      const int co = (int)(j % Cout);
+      const int64_t r = j / Cout;
+      const int ci = (int)(r % Cin);
+      const int tp = (int)(r / Cin);
+      const int t = taps - 1 - tp;
+      Elem<T>::st(wd + j, w[((int64_t)co * Cin + ci) * taps + t]);
+    }
+  }
+}
+
+// ConvTranspose2d(k2,s2) weight [Cin][Cout][2][2]:
+//   forward  operand wf[n = t*Cout + co][ci] (a 1x1 conv to 4*Cout columns, pixel-shuffled by the epilogue)
+//   backward operand wd[t][ci][co]           (a 2x2 stride-2 conv over the output gradient)
+template <typename T>
+__global__ void pack_convT_weight_kernel(const float* __restrict__ w, int Cin, int Cout, T* wf, float* bias4,
+                                         const float* __restrict__ bias, T* wd) {
+  const int64_t n = (int64_t)4 * Cout * Cin;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < 2 * n + 4 * Cout; id += (int64_t)gridDim.x * blockDim.x) {
+    if (id < n) {
+      const int ci = (int)(id % Cin);
+      const int64_t r = id / Cin;
+      const int co = (int)(r % Cout);
+      const int t = (int)(r / Cout);
+      Elem<T>::st(wf + id, w[((int64_t)ci * Cout + co) * 4 + t]);
+    } else if (id < 2 * n) {
+      const int64_t j = id - n;
+      const int co = (int)(j % Cout);
+      const int64_t r = j / Cout;
+      const int ci = (int)(r % Cin);
+      const int t = (int)(r / Cin);
+      if (wd) Elem<T>::st(wd + j, w[((int64_t)ci * Cout + co) * 4 + t]);
+    } else {
+      const int j = (int)(id - 2 * n);
+      bias4[j] = bias ? bias[j % Cout] : 0.f;
+    }
+  }
+}
+
+static inline int grid_for(int64_t total, int per_block = 256, int cap = 256 * 16) {
+  int64_t g = cdiv(total, per_block);
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace cvcs
+
+using namespace cvcs;
+
+#define DT_OK(dt) ((dt) == CVCS_F32 || (dt) == CVCS_BF16)
+
+extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, int rows, int64_t M, int C, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                int train, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+  CVCS_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "cvcs_bn_finalize: null argument");
+  if (train) {
+    CVCS_CHECK_ARG(stat_sum && stat_m2 && save_mean && save_invstd && M > 0, "cvcs_bn_finalize: train needs statistics");
+    CVCS_CHECK_ARG(rows == cvcs_conv_stat_rows(M), "cvcs_bn_finalize: rows=%d but M=%lld gives %d", rows, (long long)M,
+                   cvcs_conv_stat_rows(M));
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stat_sum, stat_m2,
+                     rows, M, C, gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean,
+                     save_invstd);
+  CVCS_CHECK_LAUNCH("cvcs_bn_finalize");
+  return CVCS_OK;
+}
+
+static int check_view(const char* fn, const void* p, int64_t ld, int C, int es) {
+  CVCS_CHECK_ARG(p != nullptr, "%s: null tensor", fn);
+  CVCS_CHECK_ARG(((uintptr_t)p % 16) == 0 && (ld * es) % 16 == 0 && ld >= C, "%s: view must be 16-byte aligned, ld >= C", fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C, const float* scale, const float* shift,
+                           int relu, void* out, int64_t out_ld, void* pool, int64_t pool_ld, int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_bn_act: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "cvcs_bn_act: bad shape");
+  int rc;
+  if ((rc = check_view("cvcs_bn_act", y, y_ld, C, es))) return rc;
+  if ((rc = check_view("cvcs_bn_act", out, out_ld, C, es))) return rc;
+  if (pool) {
+    if ((rc = check_view("cvcs_bn_act", pool, pool_ld, C, es))) return rc;
+    CVCS_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "cvcs_bn_act: pooling needs even H, W");
+  }
+  CVCS_CHECK_ARG(scale && shift, "cvcs_bn_act: null scale/shift");
+  BnActArgs a{(const char*)y, (char*)out, (char*)pool, y_ld, out_ld, pool_ld, scale, shift, B, H, W, C, relu};
+  const int64_t total = (pool ? (int64_t)B * (H / 2) * (W / 2) : (int64_t)B * H * W) * (C / (16 / es));
+  dim3 grid(grid_for(total, 256, 256 * 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) {
+    if (pool) hipLaunchKernelGGL((bn_act_kernel<float, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_kernel<float, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (pool) hipLaunchKernelGGL((bn_act_kernel<bf16_t, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_kernel<bf16_t, false>), grid, dim3(256), 0, st, a);
+  }
+  CVCS_CHECK_LAUNCH("cvcs_bn_act");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_bwd_rows(int64_t M) {
+  int64_t r = cdiv(M, 256);
+  return (int)(r < 1 ? 1 : (r > 1024 ? 1024 : r));
+}
+
+static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld, const void* g1, int64_t g1_ld,
+                         const void* g2, int64_t g2_ld, int B, int H, int W, int C, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, const float* ca, const float* cb, int mode, void* dy,
+                         int64_t dy_ld, float* part0, float* part1, int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  const int V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0, "%s: bad shape", fn);
+  const int CC = C / V;
+  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % 256 == 0, "%s: C/%d must be a power of two (or a multiple of 256)", fn, V);
+  CVCS_CHECK_ARG(mode == 0 || mode == 1, "%s: bad mode", fn);
+  CVCS_CHECK_ARG(!(g2 && mode == 1), "%s: pooled gradient only in encoder mode", fn);
+  int rc;
+  if ((rc = check_view(fn, y, y_ld, C, es))) return rc;
+  if ((rc = check_view(fn, g1, g1_ld, C, es))) return rc;
+  if (g2) {
+    if ((rc = check_view(fn, g2, g2_ld, C, es))) return rc;
+    CVCS_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "%s: pooling needs even H, W", fn);
+  }
+  if (apply && (rc = check_view(fn, dy, dy_ld, C, es))) return rc;
+  CVCS_CHECK_ARG(scale && shift && mean && invstd && part0 && (apply ? (ca && cb) : part1 != nullptr), "%s: null argument", fn);
+  BnBwdArgs a{(const char*)y, (const char*)g1, (const char*)g2, (char*)dy, y_ld, g1_ld, g2_ld, dy_ld, scale, shift, mean,
+              invstd, ca, cb, part0, part1, B, H, W, C, mode};
+  const int ccw = CC < 256 ? CC : 256;
+  dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)B * H * W), (unsigned)(CC / ccw));
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BNB(TT)                                                                                      \
+  do {                                                                                                      \
+    if (g2) { if (apply) hipLaunchKernelGGL((bn_bwd_kernel<TT, true, true>), grid, dim3(256), 0, st, a);    \
+              else hipLaunchKernelGGL((bn_bwd_kernel<TT, true, false>), grid, dim3(256), 0, st, a); }       \
+    else    { if (apply) hipLaunchKernelGGL((bn_bwd_kernel<TT, false, true>), grid, dim3(256), 0, st, a);   \
+              else hipLaunchKernelGGL((bn_bwd_kernel<TT, false, false>), grid, dim3(256), 0, st, a); }      \
+  } while (0)
+  if (dtype == CVCS_F32) LAUNCH_BNB(float); else LAUNCH_BNB(bf16_t);
+#undef LAUNCH_BNB
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_bwd_reduce(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, const void* g2, int64_t g2_ld,
+                                  int B, int H, int W, int C, const float* scale, const float* shift, const float* save_mean,
+                                  const float* save_invstd, int mode, float* part_dz, float* part_dzx, int dtype, void* stream) {
+  return bn_bwd_common("cvcs_bn_bwd_reduce", false, y, y_ld, g1, g1_ld, g2, g2_ld, B, H, W, C, scale, shift, save_mean,
+                       save_invstd, nullptr, nullptr, mode, nullptr, 0, part_dz, part_dzx, dtype, stream);
+}
+
+extern "C" int cvcs_bn_bwd_finalize(const float* part_dz, const float* part_dzx, int rows, int64_t M, int C, const float* gamma,
+                                    const float* save_invstd, float* dgamma, float* dbeta, float* coef_a, float* coef_b,
+                                    void* stream) {
+  CVCS_CHECK_ARG(part_dz && part_dzx && dgamma && dbeta && coef_a && coef_b && C > 0 && M > 0, "cvcs_bn_bwd_finalize: null argument");
+  CVCS_CHECK_ARG(rows == cvcs_bn_bwd_rows(M), "cvcs_bn_bwd_finalize: rows");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part_dz, part_dzx,
+                     rows, M, C, gamma, save_invstd, dgamma, dbeta, coef_a, coef_b);
+  CVCS_CHECK_LAUNCH("cvcs_bn_bwd_finalize");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, const void* g2, int64_t g2_ld,
+                                 int B, int H, int W, int C, const float* scale, const float* shift, const float* save_mean,
+                                 const float* save_invstd, const float* coef_a, const float* coef_b, int mode, void* dy,
+                                 int64_t dy_ld, float* part_db, int dtype, void* stream) {
+  return bn_bwd_common("cvcs_bn_bwd_apply", true, y, y_ld, g1, g1_ld, g2, g2_ld, B, H, W, C, scale, shift, save_mean,
+                       save_invstd, coef_a, coef_b, mode, dy, dy_ld, part_db, nullptr, dtype, stream);
+}
+
+extern "C" int cvcs_colsum_finalize(const float* part, int rows, int C, float* out, void* stream) {
+  CVCS_CHECK_ARG(part && out && rows > 0 && C > 0, "cvcs_colsum_finalize: bad argument");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, rows, C, out);
+  CVCS_CHECK_LAUNCH("cvcs_colsum_finalize");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_upsample2x_fwd(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
+                                   int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_upsample2x_fwd: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "cvcs_upsample2x_fwd: bad shape");
+  int rc;
+  if ((rc = check_view("cvcs_upsample2x_fwd", in, in_ld, C, es))) return rc;
+  if ((rc = check_view("cvcs_upsample2x_fwd", out, out_ld, C, es))) return rc;
+  const int64_t total = (int64_t)B * 4 * H * W * (C / (16 / es));
+  dim3 grid(grid_for(total, 256, 256 * 32));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((upsample2x_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
+  else
+    hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH("cvcs_upsample2x_fwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_upsample2x_bwd(const void* gout, int64_t gout_ld, int B, int H, int W, int C, void* gin, int64_t gin_ld,
+                                   int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_upsample2x_bwd: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "cvcs_upsample2x_bwd: bad shape");
+  int rc;
+  if ((rc = check_view("cvcs_upsample2x_bwd", gout, gout_ld, C, es))) return rc;
+  if ((rc = check_view("cvcs_upsample2x_bwd", gin, gin_ld, C, es))) return rc;
+  const int64_t total = (int64_t)B * H * W * (C / (16 / es));
+  dim3 grid(grid_for(total, 256, 256 * 32));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gout, gout_ld, B, H, W, C, (char*)gin, gin_ld);
+  else
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gout, gout_ld, B, H, W, C, (char*)gin, gin_ld);
+  CVCS_CHECK_LAUNCH("cvcs_upsample2x_bwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_pack_input(const void* src, int src_is_u8, int B, int C, int H, int W, void* dst, int Cpad, int dtype,
+                               void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_pack_input: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % (16 / es) == 0, "cvcs_pack_input: bad shape");
+  CVCS_CHECK_ARG(((uintptr_t)dst % 16) == 0, "cvcs_pack_input: dst alignment");
+  dim3 grid(grid_for((int64_t)B * H * W, 256, 256 * 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) {
+    if (src_is_u8) hipLaunchKernelGGL((pack_input_kernel<float, uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)src, B, C, H, W, (char*)dst, Cpad);
+    else hipLaunchKernelGGL((pack_input_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, B, C, H, W, (char*)dst, Cpad);
+  } else {
+    if (src_is_u8) hipLaunchKernelGGL((pack_input_kernel<bf16_t, uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)src, B, C, H, W, (char*)dst, Cpad);
+    else hipLaunchKernelGGL((pack_input_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const float*)src, B, C, H, W, (char*)dst, Cpad);
+  }
+  CVCS_CHECK_LAUNCH("cvcs_pack_input");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int Cin_pad, void* w_fwd, void* w_dgrad,
+                                     int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_pack_conv_weight: bad dtype");
+  CVCS_CHECK_ARG(w && w_fwd && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && Cin_pad >= Cin, "cvcs_pack_conv_weight: bad argument");
+  const int64_t total = (int64_t)KH * KW * Cout * (Cin_pad + (w_dgrad ? Cin : 0));
+  dim3 grid(grid_for(total));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((pack_conv_weight_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH, KW, Cin_pad, (float*)w_fwd, (float*)w_dgrad);
+  else
+    hipLaunchKernelGGL((pack_conv_weight_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH, KW, Cin_pad, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  CVCS_CHECK_LAUNCH("cvcs_pack_conv_weight");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_pack_convT_weight(const float* w, int Cin, int Cout, void* w_fwd, float* bias4, const float* bias,
+                                      void* w_dgrad, int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_pack_convT_weight: bad dtype");
+  CVCS_CHECK_ARG(w && w_fwd && bias4 && Cin > 0 && Cout > 0, "cvcs_pack_convT_weight: bad argument");
+  const int64_t total = (int64_t)8 * Cout * Cin + 4 * Cout;
+  dim3 grid(grid_for(total));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((pack_convT_weight_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, (float*)w_fwd, bias4, bias, (float*)w_dgrad);
+  else
+    hipLaunchKernelGGL((pack_convT_weight_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, (bf16_t*)w_fwd, bias4, bias, (bf16_t*)w_dgrad);
+  CVCS_CHECK_LAUNCH("cvcs_pack_convT_weight");
+  return CVCS_OK;
+}

@@ -1,0 +1,340 @@
+// Classifier head (1x1 conv 64 -> NC), per-pixel softmax cross-entropy, argmax + confusion matrix (gfx950).
+//
+// All of these are HBM-bound per-pixel kernels (2*64*NC FLOP against (64+NC) elements per pixel): one lane owns
+// one pixel, reads its 64 channels as whole 16-byte chunks, keeps the NC logits in registers, and the NCHW f32
+// logits are written/read class-plane by class-plane so that a wave touches 256 contiguous bytes per class.
+// Reductions over pixels (loss, sum of weights, dW of the head, confusion counts) are workgroup partials +
+// a fixed-order finalize (loss, dW) or LDS-privatised integer histograms flushed with 64-bit atomics (counts).
+//
+// Reference ops replaced: nn.Conv2d(64, NC, 1) (S/nets.py:172), nn.CrossEntropyLoss(weight, ignore_index)
+// (S/utils.py:230,238; S/train.py:122), torch.max/argmax (S/utils.py:90,158), MulticlassConfusionMatrix.update
+// (S/utils.py:93-94) and the backward of the first two (S/train.py:125).
+#include "common.h"
+
+namespace cvcs {
+
+constexpr int kHeadC = 64;
+constexpr int kMaxNC = 32;
+
+template <typename T>
+__device__ __forceinline__ void load_pixel64(const char* base, float* x) {
+  constexpr int V = 16 / sizeof(T);
+#pragma unroll
+  for (int c = 0; c < kHeadC / V; ++c) Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + c * 16), x + c * V);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const char* x, int64_t x_ld, int64_t P, int64_t HW,
+                                                      const float* __restrict__ w, const float* __restrict__ bias, int NC,
+                                                      float* logits) {
+  __shared__ float sw[kMaxNC * kHeadC + kMaxNC];
+  for (int i = threadIdx.x; i < NC * kHeadC; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < NC; i += 256) sw[kMaxNC * kHeadC + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * 256) {
+    float xv[kHeadC];
+    load_pixel64<T>(x + pidx * x_ld * sizeof(T), xv);
+    const int64_t b = pidx / HW, hw = pidx - b * HW;
+    for (int c = 0; c < NC; ++c) {
+      float s = sw[kMaxNC * kHeadC + c];
+#pragma unroll
+      for (int k = 0; k < kHeadC; ++k) s += xv[k] * sw[c * kHeadC + k];
+      logits[(b * NC + c) * HW + hw] = s;
+    }
+  }
+}
+
+// dx[p][k] = sum_c dl[p][c] * w[c][k]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dl, int64_t P, int64_t HW,
+                                                         const float* __restrict__ w, int NC, char* dx, int64_t dx_ld) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ float sw[kMaxNC * kHeadC];
+  for (int i = threadIdx.x; i < NC * kHeadC; i += 256) sw[i] = w[i];
+  __syncthreads();
+  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * 256) {
+    const int64_t b = pidx / HW, hw = pidx - b * HW;
+    float o[kHeadC];
+#pragma unroll
+    for (int k = 0; k < kHeadC; ++k) o[k] = 0.f;
+    for (int c = 0; c < NC; ++c) {
+      const float d = dl[(b * NC + c) * HW + hw];
+#pragma unroll
+      for (int k = 0; k < kHeadC; ++k) o[k] += d * sw[c * kHeadC + k];
+    }
+    char* dst = dx + pidx * dx_ld * sizeof(T);
+#pragma unroll
+    for (int c = 0; c < kHeadC / V; ++c) *reinterpret_cast<uint4*>(dst + c * 16) = Elem<T>::pack(o + c * V);
+  }
+}
+
+// partial dW[c][k] = sum_p dl[p][c] * x[p][k], db[c] = sum_p dl[p][c]; one partial row per workgroup:
+// part[row][c*64 + k] for c < NC, then part[row][NC*64 + c].
+constexpr int kDwTile = 128;  // pixels staged per iteration
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl,
+                                                         int64_t P, int64_t HW, int NC, float* part) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ float sx[kDwTile][kHeadC + 1];
+  __shared__ float sd[kDwTile][kMaxNC + 1];
+  const int tid = threadIdx.x;
+  const int k = tid & 63, cq = tid >> 6;  // this thread owns (c = cq + 4j, k)
+  float acc[kMaxNC / 4];
+#pragma unroll
+  for (int j = 0; j < kMaxNC / 4; ++j) acc[j] = 0.f;
+  float accb = 0.f;  // threads tid < NC own db[tid]
+  for (int64_t p0 = (int64_t)blockIdx.x * kDwTile; p0 < P; p0 += (int64_t)gridDim.x * kDwTile) {
+    __syncthreads();
+    // stage x: kDwTile pixels x 64 channels (16-byte chunks)
+    for (int id = tid; id < kDwTile * (kHeadC / V); id += 256) {
+      const int r = id / (kHeadC / V), c = id - r * (kHeadC / V);
+      float f[V];
+      if (p0 + r < P) Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (p0 + r) * x_ld * sizeof(T) + c * 16), f);
+      else
+#pragma unroll
+        for (int q = 0; q < V; ++q) f[q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < V; ++q) sx[r][c * V + q] = f[q];
+    }
+    for (int id = tid; id < kDwTile * NC; id += 256) {
+      const int c = id / kDwTile, r = id - c * kDwTile;
+      float v = 0.f;
+      if (p0 + r < P) {
+        const int64_t pidx = p0 + r, b = pidx / HW, hw = pidx - b * HW;
+        v = dl[(b * NC + c) * HW + hw];
+      }
+      sd[r][c] = v;
+    }
+    __syncthreads();
+    for (int r = 0; r < kDwTile; ++r) {
+      const float xv = sx[r][k];
+#pragma unroll
+      for (int j = 0; j < kMaxNC / 4; ++j)
+        if (cq + 4 * j < NC) acc[j] += sd[r][cq + 4 * j] * xv;
+    }
+    if (tid < NC)
+      for (int r = 0; r < kDwTile; ++r) accb += sd[r][tid];
+  }
+  float* row = part + (int64_t)blockIdx.x * (NC * kHeadC + NC);
+#pragma unroll
+  for (int j = 0; j < kMaxNC / 4; ++j)
+    if (cq + 4 * j < NC) row[(cq + 4 * j) * kHeadC + k] = acc[j];
+  if (tid < NC) row[NC * kHeadC + tid] = accb;
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy
+// workspace layout (floats): [0] = sum of target weights, [1] = loss numerator, [2..2+R) partial weights,
+// [2+R..2+2R) partial numerators, R = ce_rows(P).
+__host__ __device__ inline int ce_rows(int64_t P) {
+  int64_t r = (P + 1023) / 1024;
+  return (int)(r < 1 ? 1 : (r > 1024 ? 1024 : r));
+}
+
+__device__ __forceinline__ int load_target(const void* t, int is_u8, int64_t i) {
+  return is_u8 ? (int)reinterpret_cast<const uint8_t*>(t)[i] : (int)reinterpret_cast<const int64_t*>(t)[i];
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sbuf) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sbuf[wave] = v;
+  __syncthreads();
+  return sbuf[0] + sbuf[1] + sbuf[2] + sbuf[3];
+}
+
+__global__ __launch_bounds__(256) void ce_weight_kernel(const void* target, int is_u8, int64_t P, int NC,
+                                                       const float* __restrict__ cw, int ignore, float* ws) {
+  __shared__ float sbuf[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    const int t = load_target(target, is_u8, i);
+    if (t != ignore && (unsigned)t < (unsigned)NC) s += cw ? cw[t] : 1.f;
+  }
+  s = block_sum_256(s, sbuf);
+  if (threadIdx.x == 0) ws[2 + blockIdx.x] = s;
+}
+
+__global__ void ce_reduce_kernel(float* ws, int R, int which, float* loss_out) {
+  // which 0: ws[0] = sum of partial weights.  which 1: ws[1] = numerator; loss_out = ws[1]/ws[0]
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0;
+  const float* part = ws + 2 + (which ? R : 0);
+  for (int r = 0; r < R; ++r) a += (double)part[r];
+  ws[which] = (float)a;
+  if (which) *loss_out = (float)(a / (double)ws[0]);
+}
+
+template <int NCMAX>
+__global__ __launch_bounds__(256) void ce_main_kernel(const float* __restrict__ logits, const void* target, int is_u8,
+                                                     int64_t P, int64_t HW, int NC, const float* __restrict__ cw, int ignore,
+                                                     float grad_scale, float* dlogits, float* ws, int R) {
+  __shared__ float sbuf[4];
+  const float den = ws[0];
+  const float gmul = grad_scale / den;
+  float num = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW, hw = i - b * HW;
+    const float* zp = logits + b * NC * HW + hw;
+    float z[NCMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < NC) { z[c] = zp[c * HW]; m = fmaxf(m, z[c]); }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < NC) se += expf(z[c] - m);
+    const float lse = m + logf(se);
+    const int t = load_target(target, is_u8, i);
+    const bool valid = (t != ignore) && ((unsigned)t < (unsigned)NC);
+    const float wt = valid ? (cw ? cw[t] : 1.f) : 0.f;
+    float zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < NC && c == t) zt = z[c];
+    if (valid) num += wt * (lse - zt);
+    if (dlogits) {
+      float* dp = dlogits + b * NC * HW + hw;
+      const float f = wt * gmul;
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c)
+        if (c < NC) dp[c * HW] = f * (expf(z[c] - lse) - ((c == t) ? 1.f : 0.f));
+    }
+  }
+  num = block_sum_256(num, sbuf);
+  if (threadIdx.x == 0) ws[2 + R + blockIdx.x] = num;
+}
+
+// ------------------------------------------------------------------------------------------------ argmax + confusion
+template <int NCMAX>
+__global__ __launch_bounds__(256) void argmax_conf_kernel(const float* __restrict__ logits, int64_t P, int64_t HW, int NC,
+                                                         uint8_t* labels, const void* target, int is_u8, int ignore, int K,
+                                                         unsigned long long* conf) {
+  __shared__ unsigned int hist[kMaxNC * kMaxNC];
+  const bool do_conf = conf != nullptr;
+  if (do_conf) {
+    for (int i = threadIdx.x; i < K * K; i += 256) hist[i] = 0;
+    __syncthreads();
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW, hw = i - b * HW;
+    const float* zp = logits + b * NC * HW + hw;
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < NC) {
+        const float v = zp[c * HW];
+        if (v > best || (c == 0)) { best = v; arg = c; }   // strict '>' keeps the FIRST maximum
+      }
+    if (labels) labels[i] = (uint8_t)arg;
+    if (do_conf) {
+      const int t = load_target(target, is_u8, i);
+      if (t != ignore && (unsigned)t < (unsigned)K && arg < K) atomicAdd(&hist[t * K + arg], 1u);
+    }
+  }
+  if (do_conf) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += 256)
+      if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+  }
+}
+
+static inline int pix_grid(int64_t P, int cap = 256 * 16) {
+  int64_t g = cdiv(P, 256);
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace cvcs
+
+using namespace cvcs;
+
+extern "C" int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                             float* logits, int dtype, void* stream) {
+  CVCS_CHECK_ARG(dtype == CVCS_F32 || dtype == CVCS_BF16, "cvcs_head_fwd: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(x && w && logits && B > 0 && H > 0 && W > 0, "cvcs_head_fwd: null argument");
+  CVCS_CHECK_ARG(C == kHeadC, "cvcs_head_fwd: head is built for %d input channels (S/nets.py:172), got %d", kHeadC, C);
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_fwd: NC=%d out of [1,%d]", NC, kMaxNC);
+  CVCS_CHECK_ARG(((uintptr_t)x % 16) == 0 && (x_ld * es) % 16 == 0 && x_ld >= C, "cvcs_head_fwd: x view alignment");
+  const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
+  dim3 grid(pix_grid(P));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((head_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, logits);
+  else
+    hipLaunchKernelGGL((head_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, logits);
+  CVCS_CHECK_LAUNCH("cvcs_head_fwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_head_bwd_rows(int64_t P) {
+  int64_t r = cdiv(P, kDwTile);
+  return (int)(r < 1 ? 1 : (r > 512 ? 512 : r));
+}
+
+extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
+                             void* dx, int64_t dx_ld, float* part_dw, int dtype, void* stream) {
+  CVCS_CHECK_ARG(dtype == CVCS_F32 || dtype == CVCS_BF16, "cvcs_head_bwd: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(x && dlogits && w && dx && part_dw && B > 0 && H > 0 && W > 0, "cvcs_head_bwd: null argument");
+  CVCS_CHECK_ARG(C == kHeadC, "cvcs_head_bwd: head is built for %d input channels, got %d", kHeadC, C);
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_bwd: NC=%d out of [1,%d]", NC, kMaxNC);
+  CVCS_CHECK_ARG(((uintptr_t)x % 16) == 0 && (x_ld * es) % 16 == 0 && x_ld >= C && ((uintptr_t)dx % 16) == 0 &&
+                     (dx_ld * es) % 16 == 0 && dx_ld >= C, "cvcs_head_bwd: view alignment");
+  const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g1(pix_grid(P)), g2((unsigned)cvcs_head_bwd_rows(P));
+  if (dtype == CVCS_F32) {
+    hipLaunchKernelGGL((head_bwd_dx_kernel<float>), g1, dim3(256), 0, st, dlogits, P, HW, w, NC, (char*)dx, dx_ld);
+    hipLaunchKernelGGL((head_bwd_dw_kernel<float>), g2, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, NC, part_dw);
+  } else {
+    hipLaunchKernelGGL((head_bwd_dx_kernel<bf16_t>), g1, dim3(256), 0, st, dlogits, P, HW, w, NC, (char*)dx, dx_ld);
+    hipLaunchKernelGGL((head_bwd_dw_kernel<bf16_t>), g2, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, NC, part_dw);
+  }
+  CVCS_CHECK_LAUNCH("cvcs_head_bwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_ce_workspace_floats(int64_t P) { return 2 + 2 * ce_rows(P); }
+
+extern "C" int cvcs_ce_fwd_bwd(const float* logits, const void* target, int target_is_u8, int B, int NC, int64_t HW,
+                               const float* class_weight, int ignore_index, float grad_scale, float* loss_out, float* dlogits,
+                               float* workspace, void* stream) {
+  CVCS_CHECK_ARG(logits && target && loss_out && workspace && B > 0 && HW > 0, "cvcs_ce_fwd_bwd: null argument");
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_ce_fwd_bwd: NC=%d out of [1,%d]", NC, kMaxNC);
+  const int64_t P = (int64_t)B * HW;
+  const int R = ce_rows(P);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_weight_kernel, dim3(R), dim3(256), 0, st, target, target_is_u8, P, NC, class_weight, ignore_index, workspace);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 0, loss_out);
+  if (NC <= 8)
+    hipLaunchKernelGGL((ce_main_kernel<8>), dim3(R), dim3(256), 0, st, logits, target, target_is_u8, P, HW, NC, class_weight, ignore_index, grad_scale, dlogits, workspace, R);
+  else if (NC <= 16)
+    hipLaunchKernelGGL((ce_main_kernel<16>), dim3(R), dim3(256), 0, st, logits, target, target_is_u8, P, HW, NC, class_weight, ignore_index, grad_scale, dlogits, workspace, R);
+  else
+    hipLaunchKernelGGL((ce_main_kernel<32>), dim3(R), dim3(256), 0, st, logits, target, target_is_u8, P, HW, NC, class_weight, ignore_index, grad_scale, dlogits, workspace, R);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 1, loss_out);
+  CVCS_CHECK_LAUNCH("cvcs_ce_fwd_bwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_argmax_confusion(const float* logits, int B, int NC, int64_t HW, uint8_t* labels, const void* target,
+                                     int target_is_u8, int ignore_index, int K, int64_t* conf, void* stream) {
+  CVCS_CHECK_ARG(logits && B > 0 && HW > 0, "cvcs_argmax_confusion: null argument");
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_argmax_confusion: NC=%d out of [1,%d]", NC, kMaxNC);
+  CVCS_CHECK_ARG(labels || conf, "cvcs_argmax_confusion: nothing to produce");
+  if (conf) CVCS_CHECK_ARG(target && K >= 1 && K <= kMaxNC, "cvcs_argmax_confusion: confusion needs targets and K in [1,%d]", kMaxNC);
+  const int64_t P = (int64_t)B * HW;
+  dim3 grid(pix_grid(P, 1024));
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* c = reinterpret_cast<unsigned long long*>(conf);
+  if (NC <= 8)
+    hipLaunchKernelGGL((argmax_conf_kernel<8>), grid, dim3(256), 0, st, logits, P, HW, NC, labels, target, target_is_u8, ignore_index, K, c);
+  else if (NC <= 16)
+    hipLaunchKernelGGL((argmax_conf_kernel<16>), grid, dim3(256), 0, st, logits, P, HW, NC, labels, target, target_is_u8, ignore_index, K, c);
+  else
+    hipLaunchKernelGGL((argmax_conf_kernel<32>), grid, dim3(256), 0, st, logits, P, HW, NC, labels, target, target_is_u8, ignore_index, K, c);
+  CVCS_CHECK_LAUNCH("cvcs_argmax_confusion");
+  return CVCS_OK;
+}

@@ -1,0 +1,291 @@
+// Weight gradient of a convolution on gfx950: dW[tap][co][ci] = sum_p dy[p][co] * x[pix(p,tap)][ci].
+//
+// GEMM view per tap: M = Cout, N = Cin, K = B*Ho*Wo output pixels.  NHWC tensors are channel-contiguous, i.e.
+// K runs along LDS *rows*: the MFMA fragments are therefore read TRANSPOSED from LDS -
+//   bf16: ds_read_b64_tr_b16 (4 pixel rows x 16 channels -> 4 k-values of one channel per lane),
+//   f32 : four ds_read_b32 (one channel of one pixel each) feeding v_mfma_f32_16x16x4_f32.
+// A K-tile is a TH x TW = 32-pixel rectangle of one image; its dy tile [32][64 co] and its x halo tile
+// [((TH-1)s+KH) x ((TW-1)s+KW)][64 ci] are staged once and reused by all KH*KW taps (a tap is a row offset into
+// the halo tile, and every lane supplies its own row address to the transposed read, so shifts are free).
+// k -> pixel permutation: lane group g takes tile pixels {4g..4g+3} and {16+4g..16+4g+3}; with the 32-byte row
+// padding the two 4x16 blocks of a 32-lane half fall on 8 distinct 32-byte bank slots (conflict-free, stride 1).
+//
+// Workgroup: 256 threads = 4 waves 2(co) x 2(ci), tile 64 co x 64 ci x all taps; wave tile 32 x 32 per tap
+// (NT x 4 accumulators).  Split-K over contiguous K-tile ranges; partials [slice][tap][co][ci] f32, reduced in a
+// fixed order (bitwise reproducible) straight into the reference's OIHW parameter layout.
+//
+// Reference op replaced: weight half of convolution_backward for nn.Conv2d / nn.ConvTranspose2d (S/train.py:125).
+#include "common.h"
+
+namespace cvcs {
+
+struct WgradArgs {
+  const char* x;
+  const char* dy;
+  float* ws;
+  int64_t x_ld, dy_ld;
+  int B, H, W, Cin, Ho, Wo, Cout;
+  int KW, stride, pad;
+  int TH, TW, HR, HC;         // K-tile and halo-tile extents
+  int tiles_x, tiles_y;       // K-tiles per image
+  int ktiles, per_slice;      // total K-tiles, K-tiles per slice
+  int ntile_n;                // Cin tiles
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int PITCH = 64 * ES + 32;      // LDS row pitch (bytes) of both tiles
+  constexpr int CPR = 64 * ES / 16;        // 16-byte chunks per row
+  constexpr int DY_BYTES = 32 * PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sdy = smem;
+  char* sx = smem + DY_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
+  const int co0 = tm * 64, ci0 = tn * 64;
+  const int slice = blockIdx.y;
+  const int kt_begin = slice * p.per_slice;
+  int kt_end = kt_begin + p.per_slice;
+  if (kt_end > p.ktiles) kt_end = p.ktiles;
+
+  f32x4 acc[NT][2][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int hrows = p.HR * p.HC;
+  const int cin_rem = p.Cin - ci0;  // channels of this Cin tile that exist (rest zero-filled)
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int b = kt / (p.tiles_x * p.tiles_y);
+    const int tr = kt - b * (p.tiles_x * p.tiles_y);
+    const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+    __syncthreads();  // previous K-tile's fragment reads are done
+    // ---- stage dy tile: 32 pixels x 64 co
+    for (int id = tid; id < 32 * CPR; id += 256) {
+      const int k = id / CPR, c = id - k * CPR;
+      const int oy = ty0 + k / p.TW, ox = tx0 + k % p.TW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (oy < p.Ho && ox < p.Wo) {
+        const char* src = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0) * ES + c * 16;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      *reinterpret_cast<uint4*>(sdy + k * PITCH + c * 16) = v;
+    }
+    // ---- stage x halo tile: HR x HC pixels x 64 ci
+    const int iy_base = ty0 * p.stride - p.pad, ix_base = tx0 * p.stride - p.pad;
+    for (int id = tid; id < hrows * CPR; id += 256) {
+      const int r = id / CPR, c = id - r * CPR;
+      const int iy = iy_base + r / p.HC, ix = ix_base + r % p.HC;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c * (16 / ES) < cin_rem) {
+        const char* src = p.x + ((((int64_t)b * p.H + iy) * p.W + ix) * p.x_ld + ci0) * ES + c * 16;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      *reinterpret_cast<uint4*>(sx + r * PITCH + c * 16) = v;
+    }
+    __syncthreads();
+
+    if constexpr (ES == 2) {
+      // lane l: group g = l>>4, i = l&15 -> supplies row q = i>>2, columns 4*(i&3).. of its group's block
+      const int q = fr >> 2, pp = fr & 3;
+      const int k0 = 4 * fg + q, k1 = 16 + 4 * fg + q;      // tile pixels of the two transposed reads
+      uint4 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = (wm * 32 + i * 16 + 4 * pp) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sdy + k0 * PITCH + col));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sdy + k1 * PITCH + col));
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        af[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+      }
+      const int hb0 = ((k0 / p.TW) * p.stride) * p.HC + (k0 % p.TW) * p.stride;
+      const int hb1 = ((k1 / p.TW) * p.stride) * p.HC + (k1 % p.TW) * p.stride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int kh = t / p.KW, kw = t - kh * p.KW;
+        const int off = kh * p.HC + kw;
+        uint4 bfr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = (wn * 32 + j * 16 + 4 * pp) * 2;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sx + (hb0 + off) * PITCH + col));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(sx + (hb1 + off) * PITCH + col));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          bfr[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                   __builtin_bit_cast(bf16x8, bfr[j]), acc[t][i][j], 0, 0, 0);
+      }
+    } else {
+      // f32: MFMA pass s contracts tile pixels k = 4s + g (g = lane>>4)
+#pragma unroll 1
+      for (int s = 0; s < 8; ++s) {
+        const int k = 4 * s + fg;
+        float af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const float*>(sdy + k * PITCH + (wm * 32 + i * 16 + fr) * 4);
+        const int hb = ((k / p.TW) * p.stride) * p.HC + (k % p.TW) * p.stride;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int kh = t / p.KW, kw = t - kh * p.KW;
+          const int row = hb + kh * p.HC + kw;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float bv = *reinterpret_cast<const float*>(sx + row * PITCH + (wn * 32 + j * 16 + fr) * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bv, acc[t][i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partials: ws[slice][tap][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
+  const int64_t slice_stride = (int64_t)NT * p.Cout * p.Cin;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 32 + j * 16 + fr;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wm * 32 + i * 16 + fg * 4 + r;
+          p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j][r];
+        }
+      }
+}
+
+// dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int taps,
+                                    int Cout, int Cin, int Cin_real) {
+  const int64_t total = (int64_t)Cout * Cin_real * taps;
+  const int64_t slice_stride = (int64_t)taps * Cout * Cin;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    // iterate in the ws-friendly order: ci fastest
+    const int ci = (int)(id % Cin_real);
+    const int64_t r = id / Cin_real;
+    const int co = (int)(r % Cout);
+    const int t = (int)(r / Cout);
+    const float* src = ws + ((int64_t)t * Cout + co) * Cin + ci;
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += src[k * slice_stride];
+    dw[((int64_t)co * Cin_real + ci) * taps + t] = s;
+  }
+}
+
+struct WgradPlan {
+  int TH, TW, HR, HC, tiles_x, tiles_y, ktiles, nslice, per_slice, tiles_mn;
+};
+
+static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
+  WgradPlan pl;
+  int tw = 1;
+  while (tw < Wo && tw < 32) tw <<= 1;
+  pl.TW = tw;
+  pl.TH = 32 / tw;
+  pl.HR = (pl.TH - 1) * stride + KH;
+  pl.HC = (pl.TW - 1) * stride + KW;
+  pl.tiles_x = (int)cdiv(Wo, pl.TW);
+  pl.tiles_y = (int)cdiv(Ho, pl.TH);
+  pl.ktiles = B * pl.tiles_x * pl.tiles_y;
+  pl.tiles_mn = (Cout / 64) * (int)cdiv(Cin, 64);
+  int want = (int)cdiv(1024, pl.tiles_mn);
+  if (want > pl.ktiles) want = pl.ktiles;
+  if (want < 1) want = 1;
+  pl.per_slice = (int)cdiv(pl.ktiles, want);
+  pl.nslice = (int)cdiv(pl.ktiles, pl.per_slice);
+  return pl;
+}
+
+template <typename T, int NT>
+static int launch(const WgradArgs& a, const WgradPlan& pl, hipStream_t st) {
+  constexpr int ES = sizeof(T);
+  size_t lds = (size_t)(32 + pl.HR * pl.HC) * (64 * ES + 32);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)((32 + 160) * (64 * ES + 32)));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)pl.tiles_mn, (unsigned)pl.nslice);
+  hipLaunchKernelGGL((wgrad_kernel<T, NT>), grid, dim3(256), lds, st, a);
+  CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad");
+  return CVCS_OK;
+}
+
+}  // namespace cvcs
+
+using namespace cvcs;
+
+extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 64 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
+  return make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride).nslice;
+}
+
+extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
+  CVCS_CHECK_ARG(d != nullptr, "cvcs_conv2d_wgrad: null descriptor");
+  CVCS_CHECK_ARG(d->dtype == CVCS_F32 || d->dtype == CVCS_BF16, "cvcs_conv2d_wgrad: bad dtype");
+  const int es = d->dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(d->x && d->dy && d->dw && d->workspace, "cvcs_conv2d_wgrad: null tensor");
+  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 64 == 0, "cvcs_conv2d_wgrad: Cout=%d must be a multiple of 64", d->Cout);
+  CVCS_CHECK_ARG(d->Cin > 0 && d->Cin % (16 / es) == 0, "cvcs_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, 16 / es);
+  CVCS_CHECK_ARG(d->Cin_real > 0 && d->Cin_real <= d->Cin, "cvcs_conv2d_wgrad: Cin_real");
+  const int taps = d->KH * d->KW;
+  CVCS_CHECK_ARG((d->KH == 3 && d->KW == 3) || (d->KH == 2 && d->KW == 2) || (d->KH == 1 && d->KW == 1),
+                 "cvcs_conv2d_wgrad: filter %dx%d not built (3x3, 2x2, 1x1)", d->KH, d->KW);
+  CVCS_CHECK_ARG(d->stride >= 1 && d->stride <= 2 && d->pad >= 0, "cvcs_conv2d_wgrad: stride/pad");
+  const int eh = (d->H + 2 * d->pad - (d->KH - 1) - 1) / d->stride + 1;
+  const int ew = (d->W + 2 * d->pad - (d->KW - 1) - 1) / d->stride + 1;
+  CVCS_CHECK_ARG(eh == d->Ho && ew == d->Wo, "cvcs_conv2d_wgrad: Ho,Wo=%d,%d but geometry gives %d,%d", d->Ho, d->Wo, eh, ew);
+  CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0,
+                 "cvcs_conv2d_wgrad: leading dimensions");
+  CVCS_CHECK_ARG(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad: alignment");
+  WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride);
+  CVCS_CHECK_ARG(pl.HR * pl.HC <= 160, "cvcs_conv2d_wgrad: halo tile too large");
+  WgradArgs a;
+  a.x = (const char*)d->x; a.dy = (const char*)d->dy; a.ws = d->workspace;
+  a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.TH = pl.TH; a.TW = pl.TW; a.HR = pl.HR; a.HC = pl.HC;
+  a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ktiles = pl.ktiles; a.per_slice = pl.per_slice;
+  a.ntile_n = (int)cdiv(d->Cin, 64);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (d->dtype == CVCS_F32)
+    rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
+  else
+    rc = taps == 9 ? launch<bf16_t, 9>(a, pl, st) : taps == 4 ? launch<bf16_t, 4>(a, pl, st) : launch<bf16_t, 1>(a, pl, st);
+  if (rc != CVCS_OK) return rc;
+  const int64_t total = (int64_t)d->Cout * d->Cin_real * taps;
+  int blocks = (int)cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, d->workspace, d->dw, pl.nslice, taps, d->Cout,
+                     d->Cin, d->Cin_real);
+  CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(reduce)");
+  return CVCS_OK;
+}

@@ -1,0 +1,258 @@
+"""Python-side call wrappers over the C-ABI: torch only supplies device memory and the current HIP stream.
+
+An activation is a `View`: a channel range [off, off+C) of an NHWC torch tensor [B, H, W, ld].  Nothing here
+computes on the host; every function is one (or a few) asynchronous launches on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvDesc, WgradDesc, check
+
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+KGROUP = {F32: 16, BF16: 32}  # channels per 64-byte K-step of the conv kernel
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {t}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+@dataclass
+class View:
+    t: torch.Tensor  # [B, H, W, ld], contiguous
+    off: int
+    C: int
+
+    @property
+    def B(self): return self.t.shape[0]
+    @property
+    def H(self): return self.t.shape[1]
+    @property
+    def W(self): return self.t.shape[2]
+    @property
+    def ld(self): return self.t.shape[3]
+    @property
+    def ptr(self): return self.t.data_ptr() + self.off * self.t.element_size()
+    @property
+    def code(self): return dtype_code(self.t.dtype)
+
+    def torch(self):
+        return self.t[..., self.off:self.off + self.C]
+
+
+def view(t: torch.Tensor, off: int = 0, C_: int | None = None) -> View:
+    assert t.dim() == 4 and t.is_contiguous()
+    return View(t, off, t.shape[3] - off if C_ is None else C_)
+
+
+def new_act(B, H, W, C_, dtype, device):
+    return torch.empty((B, H, W, C_), dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+def conv_out_hw(H, W, KH, KW, stride, pad, dil=1):
+    return ((H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1)
+
+
+def conv_stat_rows(M: int) -> int:
+    return _lib.lib().cvcs_conv_stat_rows(M)
+
+
+def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
+           pixel_shuffle=False, stat_sum=None, stat_m2=None):
+    """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle)."""
+    Cout = wt.shape[1]
+    Ho, Wo = conv_out_hw(x.H, x.W, KH, KW, stride, pad, dil)
+    d = ConvDesc()
+    d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    d.wt, d.bias = wt.data_ptr(), _ptr(bias)
+    d.out, d.out_ld, d.Ho, d.Wo, d.Cout = out.ptr, out.ld, Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad, d.dil = KH, KW, stride, pad, dil
+    d.relu, d.pixel_shuffle = int(relu), int(pixel_shuffle)
+    d.stat_sum, d.stat_m2 = _ptr(stat_sum), _ptr(stat_m2)
+    d.dtype = x.code
+    assert wt.shape[0] == KH * KW and wt.shape[2] == x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
+    if pixel_shuffle:
+        assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"
+    else:
+        assert (out.H, out.W, out.C) == (Ho, Wo, Cout), f"output view mismatch {(out.H, out.W, out.C)} vs {(Ho, Wo, Cout)}"
+    assert out.B == x.B
+    check(_lib.lib().cvcs_conv2d(C.byref(d), _stream()), "cvcs_conv2d")
+
+
+def wgrad_workspace_floats(B, Ho, Wo, Cout, Cin, KH, KW, stride) -> int:
+    n = _lib.lib().cvcs_wgrad_slices(B, Ho, Wo, Cout, Cin, KH, KW, stride)
+    if n < 0:
+        raise _lib.CvcsError("cvcs_wgrad_slices: bad shape")
+    return n * KH * KW * Cout * Cin
+
+
+def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, workspace: torch.Tensor, cin_real=None):
+    """dw[Cout][Cin_real][KH][KW] (f32, contiguous) = sum_p dy[p] (x) x[pix(p, tap)]."""
+    d = WgradDesc()
+    d.x, d.x_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    d.dy, d.dy_ld, d.Ho, d.Wo, d.Cout = dy.ptr, dy.ld, dy.H, dy.W, dy.C
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    cin_real = x.C if cin_real is None else cin_real
+    d.dw, d.Cin_real = dw.data_ptr(), cin_real
+    d.workspace = workspace.data_ptr()
+    d.dtype = x.code
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.C * cin_real * KH * KW
+    assert workspace.dtype == torch.float32 and \
+        workspace.numel() >= wgrad_workspace_floats(x.B, dy.H, dy.W, dy.C, x.C, KH, KW, stride), "wgrad workspace too small"
+    check(_lib.lib().cvcs_conv2d_wgrad(C.byref(d), _stream()), "cvcs_conv2d_wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+def bn_finalize(stat_sum, stat_m2, rows, M, C_, gamma, beta, rmean, rvar, train, scale, shift, save_mean, save_invstd,
+                momentum=0.1, eps=1e-5):
+    check(_lib.lib().cvcs_bn_finalize(_ptr(stat_sum), _ptr(stat_m2), rows, M, C_, gamma.data_ptr(), beta.data_ptr(),
+                                      rmean.data_ptr(), rvar.data_ptr(), momentum, eps, int(train), scale.data_ptr(),
+                                      shift.data_ptr(), _ptr(save_mean), _ptr(save_invstd), _stream()), "cvcs_bn_finalize")
+
+
+def bn_act(y: View, scale, shift, relu: bool, out: View, pool: View | None = None):
+    check(_lib.lib().cvcs_bn_act(y.ptr, y.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(relu), out.ptr,
+                                 out.ld, 0 if pool is None else pool.ptr, 0 if pool is None else pool.ld, y.code,
+                                 _stream()), "cvcs_bn_act")
+
+
+def bn_bwd_rows(M: int) -> int:
+    return _lib.lib().cvcs_bn_bwd_rows(M)
+
+
+def bn_bwd_reduce(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, mode, part_dz, part_dzx):
+    check(_lib.lib().cvcs_bn_bwd_reduce(y.ptr, y.ld, g1.ptr, g1.ld, 0 if g2 is None else g2.ptr, 0 if g2 is None else g2.ld,
+                                        y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                        invstd.data_ptr(), mode, part_dz.data_ptr(), part_dzx.data_ptr(), y.code, _stream()),
+          "cvcs_bn_bwd_reduce")
+
+
+def bn_bwd_finalize(part_dz, part_dzx, rows, M, C_, gamma, invstd, dgamma, dbeta, ca, cb):
+    check(_lib.lib().cvcs_bn_bwd_finalize(part_dz.data_ptr(), part_dzx.data_ptr(), rows, M, C_, gamma.data_ptr(),
+                                          invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ca.data_ptr(),
+                                          cb.data_ptr(), _stream()), "cvcs_bn_bwd_finalize")
+
+
+def bn_bwd_apply(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, ca, cb, mode, dy: View, part_db):
+    check(_lib.lib().cvcs_bn_bwd_apply(y.ptr, y.ld, g1.ptr, g1.ld, 0 if g2 is None else g2.ptr, 0 if g2 is None else g2.ld,
+                                       y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                       invstd.data_ptr(), ca.data_ptr(), cb.data_ptr(), mode, dy.ptr, dy.ld,
+                                       part_db.data_ptr(), y.code, _stream()), "cvcs_bn_bwd_apply")
+
+
+def colsum_finalize(part, rows, C_, out):
+    check(_lib.lib().cvcs_colsum_finalize(part.data_ptr(), rows, C_, out.data_ptr(), _stream()), "cvcs_colsum_finalize")
+
+
+# ------------------------------------------------------------------------------------------------ bilinear
+def upsample2x_fwd(x: View, out: View):
+    check(_lib.lib().cvcs_upsample2x_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, x.code, _stream()),
+          "cvcs_upsample2x_fwd")
+
+
+def upsample2x_bwd(gout: View, gin: View):
+    check(_lib.lib().cvcs_upsample2x_bwd(gout.ptr, gout.ld, gin.B, gin.H, gin.W, gin.C, gin.ptr, gin.ld, gin.code, _stream()),
+          "cvcs_upsample2x_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ boundary
+def pack_input(src: torch.Tensor, dst: torch.Tensor):
+    """src NCHW u8|f32 [B,C,H,W] -> dst NHWC [B,H,W,Cpad] (zero padded channels)."""
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype in (torch.uint8, torch.float32)
+    B, C_, H, W = src.shape
+    assert dst.shape[:3] == (B, H, W)
+    check(_lib.lib().cvcs_pack_input(src.data_ptr(), int(src.dtype == torch.uint8), B, C_, H, W, dst.data_ptr(),
+                                     dst.shape[3], dtype_code(dst.dtype), _stream()), "cvcs_pack_input")
+
+
+def pack_conv_weight(w: torch.Tensor, cin_pad: int, dtype, want_dgrad=True):
+    Cout, Cin, KH, KW = w.shape
+    wf = torch.empty((KH * KW, Cout, cin_pad), dtype=dtype, device=w.device)
+    wd = torch.empty((KH * KW, Cin, Cout), dtype=dtype, device=w.device) if want_dgrad else None
+    pack_conv_weight_into(w, wf, wd)
+    return wf, wd
+
+
+def pack_conv_weight_into(w, wf, wd):
+    Cout, Cin, KH, KW = w.shape
+    assert w.is_contiguous() and w.dtype == torch.float32
+    check(_lib.lib().cvcs_pack_conv_weight(w.data_ptr(), Cout, Cin, KH, KW, wf.shape[2], wf.data_ptr(), _ptr(wd),
+                                           dtype_code(wf.dtype), _stream()), "cvcs_pack_conv_weight")
+
+
+def pack_convT_weight_into(w, bias, wf, bias4, wd):
+    """w [Cin][Cout][2][2] -> wf [1][4*Cout][Cin], bias4 [4*Cout], wd [4][Cin][Cout]."""
+    Cin, Cout = w.shape[:2]
+    assert w.is_contiguous() and w.dtype == torch.float32 and tuple(w.shape[2:]) == (2, 2)
+    check(_lib.lib().cvcs_pack_convT_weight(w.data_ptr(), Cin, Cout, wf.data_ptr(), bias4.data_ptr(), _ptr(bias), _ptr(wd),
+                                            dtype_code(wf.dtype), _stream()), "cvcs_pack_convT_weight")
+
+
+# ------------------------------------------------------------------------------------------------ head / loss
+def head_fwd(x: View, w, bias, logits):
+    NC = w.shape[0]
+    check(_lib.lib().cvcs_head_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), _ptr(bias), NC, logits.data_ptr(), x.code,
+                                   _stream()), "cvcs_head_fwd")
+
+
+def head_bwd_rows(P: int) -> int:
+    return _lib.lib().cvcs_head_bwd_rows(P)
+
+
+def head_bwd(x: View, dlogits, w, dx: View, part_dw):
+    NC = w.shape[0]
+    check(_lib.lib().cvcs_head_bwd(x.ptr, x.ld, dlogits.data_ptr(), x.B, x.H, x.W, x.C, w.data_ptr(), NC, dx.ptr, dx.ld,
+                                   part_dw.data_ptr(), x.code, _stream()), "cvcs_head_bwd")
+
+
+def ce_workspace_floats(P: int) -> int:
+    return _lib.lib().cvcs_ce_workspace_floats(P)
+
+
+def ce_fwd_bwd(logits, target, class_weight, ignore_index, grad_scale, loss_out, dlogits, workspace):
+    B, NC = logits.shape[:2]
+    HW = logits.numel() // (B * NC)
+    assert logits.is_contiguous() and logits.dtype == torch.float32 and target.is_contiguous()
+    assert target.dtype in (torch.uint8, torch.int64) and target.numel() == B * HW
+    check(_lib.lib().cvcs_ce_fwd_bwd(logits.data_ptr(), target.data_ptr(), int(target.dtype == torch.uint8), B, NC, HW,
+                                     _ptr(class_weight), ignore_index, grad_scale, loss_out.data_ptr(), _ptr(dlogits),
+                                     workspace.data_ptr(), _stream()), "cvcs_ce_fwd_bwd")
+
+
+def argmax_confusion(logits, labels=None, target=None, ignore_index=-1, K=16, conf=None):
+    B, NC = logits.shape[:2]
+    HW = logits.numel() // (B * NC)
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    if target is not None:
+        assert target.is_contiguous() and target.dtype in (torch.uint8, torch.int64) and target.numel() == B * HW
+    check(_lib.lib().cvcs_argmax_confusion(logits.data_ptr(), B, NC, HW, _ptr(labels), _ptr(target),
+                                           int(target is not None and target.dtype == torch.uint8), ignore_index, K,
+                                           _ptr(conf), _stream()), "cvcs_argmax_confusion")
+
+
+# ------------------------------------------------------------------------------------------------ optimisers
+def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale, first_step):
+    check(_lib.lib().cvcs_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, weight_decay,
+                                   grad_scale, int(first_step), _stream()), "cvcs_sgd_step")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    check(_lib.lib().cvcs_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                                    weight_decay, grad_scale, step, _stream()), "cvcs_adam_step")

@@ -1,0 +1,168 @@
+/* cvcs_hip.h - C-ABI of libcvcs_hip.so: the MI355X (gfx950) replacement for the torch/ATen ops on the
+ * per-tile segmentation hot path of theElandor/CVCS.
+ *
+ * The reference has no FFI of its own: its seam is the Python factories `load_network`, `load_loss`,
+ * `load_optimizer` (source/scripts/utils.py:174-242) and the nn.Module contract (source/scripts/nets.py:12-33).
+ * Each entry point below replaces the ATen op(s) one of those call sites issues; the citation after "replaces:"
+ * is the reference line that issues it (S/ = source/scripts/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CVCS_E* code otherwise; cvcs_last_error() gives the
+ *     message of the calling thread's last failure.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; buffers are caller-owned.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and allocates nothing.
+ *   - activations inside the library are NHWC ("pixel-major") so that the contraction axis of every MFMA
+ *     operand is contiguous; the NCHW u8/f32 tensors of the reference appear only at the boundary calls
+ *     (cvcs_pack_input, cvcs_head_fwd, cvcs_ce_*, cvcs_argmax_*).
+ *   - an activation "view" is (pointer, ld): element (pixel p, channel c) lives at ptr[p*ld + c]; this is how
+ *     torch.concat (S/nets.py:185,189,193,197) disappears: producers write into channel ranges of one buffer.
+ *   - dtype: CVCS_F32 (parity path, exact-f32 MFMA) or CVCS_BF16 (throughput path, bf16 MFMA, f32 accumulate).
+ */
+#ifndef CVCS_HIP_H
+#define CVCS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVCS_ABI_VERSION 1
+
+enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
+enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
+
+const char* cvcs_last_error(void);
+int cvcs_abi_version(void);
+/* number of float partial rows a conv with M output pixels writes per statistic (see cvcs_conv2d) */
+int cvcs_conv_stat_rows(int64_t M);
+/* number of split-K slices cvcs_conv2d_wgrad will use; workspace = slices*KH*KW*Cout*Cin floats */
+int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride);
+
+/* ---- implicit-GEMM convolution (forward, and data-gradient with pre-flipped weights) ------------------
+ * replaces: nn.Conv2d k3 p1 (S/blocks.py:3-4 via :13,:40,:43), nn.ConvTranspose2d k2 s2 (S/nets.py:150,156,162,168;
+ * pixel_shuffle=1), and the input-gradient half of convolution_backward for both (S/train.py:125).
+ *   out[p, n] = act( bias[n] + sum_{kh,kw,c} in[pix(p,kh,kw), c] * wt[kh*KW+kw][n][c] )
+ * M = B*Ho*Wo output pixels; wt is [KH*KW][Cout][Cin] in `dtype`; Cin % (64/sizeof(dtype)) == 0, Cout % 64 == 0.
+ * stat_sum/stat_m2 (optional, f32 [cvcs_conv_stat_rows(M)][Cout]): per 64-pixel row block, per channel, the sum
+ * and the centred second moment of the values written - the BatchNorm batch statistics, fused.           */
+typedef struct {
+  const void* in;   int64_t in_ld;  int32_t B, H, W, Cin;
+  const void* wt;   const float* bias;
+  void* out;        int64_t out_ld; int32_t Ho, Wo, Cout;
+  int32_t KH, KW, stride, pad, dil;
+  int32_t relu;           /* 1: ReLU in the epilogue (decoder order conv->ReLU->BN, S/blocks.py:40-45) */
+  int32_t pixel_shuffle;  /* 1: Cout = 4*Cr, column (dy*2+dx)*Cr+co goes to pixel (2y+dy, 2x+dx), channel co */
+  float* stat_sum;  float* stat_m2;
+  int32_t dtype;
+} cvcs_conv_desc;
+int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
+
+/* ---- weight gradient ---------------------------------------------------------------------------------
+ * replaces: the weight half of convolution_backward (S/train.py:125).
+ *   dW[n][c][kh][kw] = sum_p dy[p, n] * x[pix(p,kh,kw), c]     (p over B*Ho*Wo; pix = p*stride - pad + (kh,kw))
+ * `dw` is f32 in the reference's parameter layout OIHW [Cout][Cin_real][KH][KW]; Cin_real <= Cin lets the
+ * zero-padded first layer drop its padding.  A ConvTranspose2d(k2,s2) weight [Cin_T][Cout_T][2][2] is the same
+ * call with dy := the layer's input, x := the gradient of its output, KH=KW=2, stride=2, pad=0.
+ * Filters built: 3x3, 2x2, 1x1.  workspace: cvcs_wgrad_slices(...) * KH*KW*Cout*Cin floats.               */
+typedef struct {
+  const void* x;    int64_t x_ld;   int32_t B, H, W, Cin;
+  const void* dy;   int64_t dy_ld;  int32_t Ho, Wo, Cout;
+  int32_t KH, KW, stride, pad;
+  float* dw;        int32_t Cin_real;
+  float* workspace;
+  int32_t dtype;
+} cvcs_wgrad_desc;
+int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
+
+/* ---- BatchNorm2d ---------------------------------------------------------------------------------------
+ * replaces: nn.BatchNorm2d (S/blocks.py:14,42,45) forward in train / eval mode and its backward.
+ * cvcs_bn_finalize: combine the conv's partial statistics (rows x C) into scale/shift (f32 [C] each), save
+ * mean/invstd for backward and update running stats (momentum 0.1, unbiased var).  train=0: scale/shift from the
+ * running stats, partials ignored.                                                                        */
+int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, int rows, int64_t M, int C,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, int train,
+                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+
+/* y -> out = relu?(scale*y + shift), optionally also pool[p/2] = max 2x2 (nn.MaxPool2d(2,2), S/nets.py:130,135,140,145).
+ * replaces: BN apply + nn.ReLU (S/blocks.py:17) (+ MaxPool2d).  relu=1: encoder order; relu=0: decoder BN apply. */
+int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C,
+                const float* scale, const float* shift, int relu,
+                void* out, int64_t out_ld, void* pool, int64_t pool_ld, int dtype, void* stream);
+
+/* BatchNorm(+ReLU)(+MaxPool) backward, two passes over (y, g):
+ *   mode 0 (encoder, a = relu(bn(y))): dz = (g1 + unpool(g2)) * (a > 0);  mode 1 (decoder, z = bn(r), r = relu(conv)):
+ *   dz = g1, and the ReLU mask (r > 0) is applied to the result.
+ * pass 1 -> partial sums of dz and dz*xhat ([rows][C] each, rows = cvcs_bn_bwd_rows(B*H*W));
+ * cvcs_bn_bwd_finalize -> dgamma, dbeta and the two per-channel coefficients;
+ * pass 2 -> dy (gradient w.r.t. the conv output) and partial column sums of dy (conv bias gradient).        */
+int cvcs_bn_bwd_rows(int64_t M);
+int cvcs_bn_bwd_reduce(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, const void* g2, int64_t g2_ld,
+                       int B, int H, int W, int C, const float* scale, const float* shift,
+                       const float* save_mean, const float* save_invstd, int mode,
+                       float* part_dz, float* part_dzx, int dtype, void* stream);
+int cvcs_bn_bwd_finalize(const float* part_dz, const float* part_dzx, int rows, int64_t M, int C,
+                         const float* gamma, const float* save_invstd,
+                         float* dgamma, float* dbeta, float* coef_a, float* coef_b, void* stream);
+int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, const void* g2, int64_t g2_ld,
+                      int B, int H, int W, int C, const float* scale, const float* shift,
+                      const float* save_mean, const float* save_invstd, const float* coef_a, const float* coef_b,
+                      int mode, void* dy, int64_t dy_ld, float* part_db, int dtype, void* stream);
+/* column-sum of `rows` partial rows: out[c] = sum_r part[r][c] (f64 accumulate) - conv bias gradients */
+int cvcs_colsum_finalize(const float* part, int rows, int C, float* out, void* stream);
+
+/* ---- bilinear x2 upsampling (Urnet only) -----------------------------------------------------------------
+ * replaces: nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False) (S/blocks.py:29) fwd / bwd. */
+int cvcs_upsample2x_fwd(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
+                        int dtype, void* stream);
+int cvcs_upsample2x_bwd(const void* gout, int64_t gout_ld, int B, int H, int W, int C, void* gin, int64_t gin_ld,
+                        int dtype, void* stream);
+
+/* ---- boundary: NCHW <-> internal ----------------------------------------------------------------------------
+ * cvcs_pack_input replaces `image.type(torch.float32)` (S/train.py:121): u8 (src_is_u8=1) or f32 NCHW [B,3,H,W]
+ * -> NHWC [B,H,W,Cpad] in `dtype`, channels >= 3 zero.                                                    */
+int cvcs_pack_input(const void* src, int src_is_u8, int B, int C, int H, int W, void* dst, int Cpad, int dtype,
+                    void* stream);
+/* parameter layout changes: OIHW f32 -> [KH*KW][Cout][Cin_pad] (fwd) and -> flipped/transposed [KH*KW][Cin][Cout]
+ * (data-gradient operand); ConvTranspose2d IOHW -> [1][(dy*2+dx)*Cout+co][Cin] (fwd) and [4 taps][Cin][Cout] (bwd) */
+int cvcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                          void* w_fwd, void* w_dgrad, int dtype, void* stream);
+int cvcs_pack_convT_weight(const float* w_iohw, int Cin, int Cout, void* w_fwd, float* bias4, const float* bias,
+                           void* w_dgrad, int dtype, void* stream);
+
+/* ---- 1x1 classifier head + loss --------------------------------------------------------------------------
+ * cvcs_head_fwd replaces nn.Conv2d(64, NC, 1) (S/nets.py:172): NHWC `dtype` [P, C] -> NCHW f32 logits [B, NC, H, W]. */
+int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                  float* logits, int dtype, void* stream);
+/* backward of the head: dx (NHWC dtype), partial dW/db rows -> finalize with cvcs_colsum_finalize            */
+int cvcs_head_bwd_rows(int64_t P);
+int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
+                  void* dx, int64_t dx_ld, float* part_dw /* [rows][NC*C + NC] */, int dtype, void* stream);
+
+/* nn.CrossEntropyLoss(weight, ignore_index) (S/utils.py:230,238; called S/train.py:122, S/utils.py:120):
+ *   loss = sum_{t!=ignore} -w[t] log_softmax(z)[t] / sum_{t!=ignore} w[t];   dlogits likewise (may be NULL).
+ * logits f32 NCHW [B,NC,H,W]; target u8 (target_is_u8=1) or int64 [B,H,W]; class_weight f32 [NC] or NULL.
+ * workspace: cvcs_ce_workspace_floats(P) floats; loss_out: 1 float (device).                               */
+int cvcs_ce_workspace_floats(int64_t P);
+int cvcs_ce_fwd_bwd(const float* logits, const void* target, int target_is_u8, int B, int NC, int64_t HW,
+                    const float* class_weight, int ignore_index, float grad_scale,
+                    float* loss_out, float* dlogits, float* workspace, void* stream);
+
+/* argmax over classes (ties -> lowest index; torch.max/argmax S/utils.py:90,158) -> u8 labels [B,H,W], and
+ * confusion-matrix accumulation conf[t*K + p] += 1 for target != ignore (torchmetrics MulticlassConfusionMatrix,
+ * S/utils.py:76-78,93-94; ignore_index < 0: none).  conf: int64 [K*K], accumulated.                          */
+int cvcs_argmax_confusion(const float* logits, int B, int NC, int64_t HW, uint8_t* labels,
+                          const void* target, int target_is_u8, int ignore_index, int K, int64_t* conf, void* stream);
+
+/* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
+ * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).
+ * grad_scale multiplies the gradient first (1/world_size after the sum all-reduce).                           */
+int cvcs_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                  float weight_decay, float grad_scale, int first_step, void* stream);
+int cvcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float grad_scale, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
