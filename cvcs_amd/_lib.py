@@ -59,6 +59,7 @@ SIGNATURES = {
     "cvcs_bn_bwd_apply": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64,
                                _vp, _i, _vp]),
     "cvcs_colsum_finalize": (_i, [_vp, _i, _i, _vp, _vp]),
+    "cvcs_colsum_partial": (_i, [_vp, _i64, _i64, _i, _vp, _i, _vp]),
     "cvcs_upsample2x_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_upsample2x_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_pack_input": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),

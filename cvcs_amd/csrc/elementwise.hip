@@ -218,6 +218,39 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   }
 }
 
+// partial per-channel sums of a view: part[blockIdx.x][c] = sum over this workgroup's pixels (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const char* x, int64_t ld, int64_t M, int C, float* part) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  __shared__ float red[256 * V];
+  const int CC = C / V;
+  const int ccw = CC < 256 ? CC : 256;
+  const int PL = 256 / ccw;
+  const int tid = threadIdx.x;
+  const int cl = tid % ccw, pl = tid / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  float s[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) s[k] = 0.f;
+  for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < M; it += (int64_t)gridDim.x * PL) {
+    float f[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (it * ld) * ES + cc * 16), f);
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] += f[k];
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[tid * V + k] = s[k];
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float a = 0.f;
+      for (int q = 0; q < PL; ++q) a += red[(q * ccw + cl) * V + k];
+      part[(int64_t)blockIdx.x * C + cc * V + k] = a;
+    }
+  }
+}
+
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ pdz, const float* __restrict__ pdzx, int rows, int64_t M,
                                        int C, const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* dgamma, float* dbeta, float* ca, float* cb) {
@@ -525,6 +558,25 @@ extern "C" int cvcs_colsum_finalize(const float* part, int rows, int C, float* o
   CVCS_CHECK_ARG(part && out && rows > 0 && C > 0, "cvcs_colsum_finalize: bad argument");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, rows, C, out);
   CVCS_CHECK_LAUNCH("cvcs_colsum_finalize");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_colsum_partial(const void* x, int64_t x_ld, int64_t M, int C, float* part, int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_colsum_partial: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  const int V = 16 / es;
+  CVCS_CHECK_ARG(M > 0 && C > 0 && C % V == 0 && part, "cvcs_colsum_partial: bad shape");
+  const int CC = C / V;
+  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % 256 == 0, "cvcs_colsum_partial: C/%d must be a power of two", V);
+  int rc;
+  if ((rc = check_view("cvcs_colsum_partial", x, x_ld, C, es))) return rc;
+  const int ccw = CC < 256 ? CC : 256;
+  dim3 grid((unsigned)cvcs_bn_bwd_rows(M), (unsigned)(CC / ccw));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, part);
+  else
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, part);
+  CVCS_CHECK_LAUNCH("cvcs_colsum_partial");
   return CVCS_OK;
 }
 

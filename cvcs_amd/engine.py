@@ -1,0 +1,296 @@
+"""Execution plan of the reference's two U-Nets on the HIP kernels.
+
+`UNetEngine` owns every device buffer of one (batch, tile-size) shape - NHWC activations, their gradients,
+BatchNorm statistics, packed weights - and issues the forward / backward launch sequence through the C-ABI.
+The network wiring follows nets.Urnet.forward (source/scripts/nets.py:93-115) and nets.Urnetv2.forward
+(:176-199); the block order follows blocks.UnetEncodeLayer (conv -> BN -> ReLU, blocks.py:8-23) and
+blocks.UnetForwardDecodeLayer (conv -> ReLU -> BN twice, blocks.py:36-49).
+
+MI355X-first choices (none of them a translation of the reference's op sequence):
+  * torch.concat never runs: the skip tensor and the up-sampled tensor are written by their producers into the two
+    channel halves of one NHWC buffer, and the decoder conv reads it as a single 2C-channel input;
+  * MaxPool is written by the same pass that applies BN+ReLU; its backward is folded into the BN backward passes
+    (the arg-max is recomputed from the saved pre-BN tensor, no index tensor is stored);
+  * BatchNorm batch statistics come out of the conv epilogue; BN backward is two streaming passes;
+  * ConvTranspose2d(k2,s2) is a 1x1 implicit GEMM with a pixel-shuffling epilogue straight into the concat buffer.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import View
+
+WIDTHS = (64, 128, 256, 512, 1024)
+# concat order per decoder stage d=1..4: True -> (skip, up) ; False -> (up, skip)   (nets.py:185,189,193,197)
+SKIP_FIRST = {1: True, 2: True, 3: False, 4: True}
+
+
+class _BN:
+    """per-BatchNorm device state: parameters (views of the flat buffers) + per-step vectors."""
+
+    def __init__(self, C, dev):
+        f = lambda: torch.empty(C, dtype=torch.float32, device=dev)  # noqa: E731
+        self.scale, self.shift, self.mean, self.invstd, self.ca, self.cb = f(), f(), f(), f(), f(), f()
+
+
+class UNetEngine:
+    def __init__(self, variant: str, num_classes: int, dtype: torch.dtype, device):
+        assert variant in ("Unet", "Unetv2")
+        self.variant, self.NC, self.dtype, self.dev = variant, num_classes, dtype, torch.device(device)
+        self.code = ops.dtype_code(dtype)
+        self.KG = ops.KGROUP[self.code]
+        self.shape = None
+        self.P = None   # name -> f32 parameter tensor (views of the module's flat buffer)
+        self.G = None   # name -> f32 gradient tensor (views of the flat gradient buffer)
+        self.Bf = None  # name -> f32 buffer (running stats)
+        self.packed = {}
+        self._saved_train = False
+
+    # ------------------------------------------------------------------------------------------------ binding
+    def bind(self, params, grads, buffers):
+        self.P, self.G, self.Bf = params, grads, buffers
+        dev, dt = self.dev, self.dtype
+        self.packed = {}
+        for name, w in params.items():
+            if w.dim() != 4 or name == "decode_forward4.1.weight":
+                continue
+            key = name[:-len(".weight")]
+            if name.startswith("upscale") and self.variant == "Unetv2":
+                cin, cout = w.shape[:2]
+                self.packed[key] = dict(kind="convT", wf=torch.empty(1, 4 * cout, cin, dtype=dt, device=dev),
+                                        b4=torch.empty(4 * cout, dtype=torch.float32, device=dev),
+                                        wd=torch.empty(4, cin, cout, dtype=dt, device=dev))
+            else:
+                cout, cin, kh, kw = w.shape
+                cpad = max(cin, self.KG) if cin % self.KG else cin
+                first = cin == 3
+                self.packed[key] = dict(kind="conv", wf=torch.empty(kh * kw, cout, cpad, dtype=dt, device=dev),
+                                        wd=None if first else torch.empty(kh * kw, cin, cout, dtype=dt, device=dev))
+
+    def refresh_weights(self):
+        """re-pack the f32 master weights into the MFMA operand layouts (after every optimiser step)."""
+        for key, pk in self.packed.items():
+            w = self.P[key + ".weight"]
+            if pk["kind"] == "convT":
+                ops.pack_convT_weight_into(w, self.P[key + ".bias"], pk["wf"], pk["b4"], pk["wd"])
+            else:
+                ops.pack_conv_weight_into(w, pk["wf"], pk["wd"])
+
+    # ------------------------------------------------------------------------------------------------ planning
+    def plan(self, B, S):
+        if self.shape == (B, S):
+            return
+        assert S % 16 == 0, "tile side must be a multiple of 16 (four 2x2 poolings)"
+        dev, dt = self.dev, self.dtype
+        A = lambda s, c: torch.empty((B, s, s, c), dtype=dt, device=dev)  # noqa: E731
+        self.shape = (B, S)
+        self.sizes = [S >> l for l in range(5)]
+        s_ = self.sizes
+        self.in0 = A(S, self.KG)
+        self.ya, self.aa, self.yb, self.pool, self.cat, self.x5 = {}, {}, {}, {}, {}, None
+        self.g_aa, self.dy_a, self.dy_b, self.g_pool, self.g_cat = {}, {}, {}, {}, {}
+        for L in range(1, 6):
+            w, s = WIDTHS[L - 1], s_[L - 1]
+            self.ya[L], self.aa[L], self.yb[L] = A(s, w), A(s, w), A(s, w)
+            self.g_aa[L], self.dy_a[L], self.dy_b[L] = A(s, w), A(s, w), A(s, w)
+            if L < 5:
+                self.cat[L] = A(s, 2 * w)
+                self.g_cat[L] = A(s, 2 * w)
+                self.pool[L] = A(s // 2, w)
+                self.g_pool[L] = A(s // 2, w)
+        self.x5 = A(s_[4], WIDTHS[4])
+        self.g_x5 = A(s_[4], WIDTHS[4])
+        # decoder stage d works at level L = 5-d
+        self.ra, self.za, self.rb, self.zb = {}, {}, {}, {}
+        self.g_za, self.g_zb, self.ddy_a, self.ddy_b, self.up_in, self.g_up_in = {}, {}, {}, {}, {}, {}
+        for d in range(1, 5):
+            L = 5 - d
+            w, s = WIDTHS[L - 1], s_[L - 1]
+            self.ra[d], self.za[d], self.rb[d], self.zb[d] = A(s, w), A(s, w), A(s, w), A(s, w)
+            self.g_za[d], self.g_zb[d], self.ddy_a[d], self.ddy_b[d] = A(s, w), A(s, w), A(s, w), A(s, w)
+            if self.variant == "Unet":
+                self.up_in[d] = A(s, 2 * w)      # bilinear-upsampled input of the upscale conv
+                self.g_up_in[d] = A(s, 2 * w)
+        self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=dev)
+        # statistics / partial-sum scratch, sized for the largest layer (level 1)
+        M1 = B * S * S
+        self.stat_sum = torch.empty(ops.conv_stat_rows(M1) * 64, dtype=torch.float32, device=dev)
+        self.stat_m2 = torch.empty_like(self.stat_sum)
+        rows1 = ops.bn_bwd_rows(M1)
+        self.part = [torch.empty(rows1 * 1024, dtype=torch.float32, device=dev) for _ in range(3)]
+        self.head_part = torch.empty(ops.head_bwd_rows(M1) * (self.NC * 64 + self.NC), dtype=torch.float32, device=dev)
+        # wgrad split-K workspace: the maximum over all layers
+        need = 0
+        for (Bc, Ho, Cout, Cin, K, st) in self._wgrad_shapes(B):
+            need = max(need, ops.wgrad_workspace_floats(Bc, Ho, Ho, Cout, Cin, K, K, st))
+        self.wg_ws = torch.empty(need, dtype=torch.float32, device=dev)
+        self.bn = {}
+        for name in self.P:
+            if name.endswith(".weight") and self.P[name].dim() == 1:
+                self.bn[name[:-len(".weight")]] = _BN(self.P[name].numel(), dev)
+        # conv statistics need rows*C floats with C up to 1024 at small M: size for the worst layer
+        worst = max(ops.conv_stat_rows(B * s * s) * w for s, w in zip(s_, WIDTHS))
+        if worst > self.stat_sum.numel():
+            self.stat_sum = torch.empty(worst, dtype=torch.float32, device=dev)
+            self.stat_m2 = torch.empty_like(self.stat_sum)
+
+    def _wgrad_shapes(self, B):
+        s_ = self.sizes
+        out = []
+        for L in range(1, 6):
+            w, s = WIDTHS[L - 1], s_[L - 1]
+            cin = self.KG if L == 1 else WIDTHS[L - 2]
+            out += [(B, s, w, cin, 3, 1), (B, s, w, w, 3, 1)]
+        for d in range(1, 5):
+            L = 5 - d
+            w, s = WIDTHS[L - 1], s_[L - 1]
+            out += [(B, s, w, 2 * w, 3, 1), (B, s, w, w, 3, 1)]
+            if self.variant == "Unetv2":
+                out.append((B, s // 2, 2 * w, w, 2, 2))   # ConvTranspose form: "Cout" = 2w (its Cin), "Cin" = w
+            else:
+                out.append((B, s, w, 2 * w, 3, 1))
+        return out
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _skip_up(self, d):
+        """views of the (skip, up) channel halves of the concat buffer of decoder stage d."""
+        L = 5 - d
+        w = WIDTHS[L - 1]
+        so, uo = (0, w) if SKIP_FIRST[d] else (w, 0)
+        return View(self.cat[L], so, w), View(self.cat[L], uo, w), View(self.g_cat[L], so, w), View(self.g_cat[L], uo, w)
+
+    def _conv_bn(self, x: View, conv, bnname, y, out: View, relu_after_bn: bool, train: bool, pool: View | None = None):
+        """conv3x3(+bias) [-> ReLU] with fused statistics, BN finalize, BN apply [-> ReLU] [-> pool]."""
+        pk = self.packed[conv]
+        M = x.B * y.shape[1] * y.shape[2]
+        C_ = y.shape[3]
+        rows = ops.conv_stat_rows(M)
+        ssum = self.stat_sum[:rows * C_] if train else None
+        sm2 = self.stat_m2[:rows * C_] if train else None
+        ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn,
+                   stat_sum=ssum, stat_m2=sm2)
+        st = self.bn[bnname]
+        ops.bn_finalize(ssum, sm2, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
+                        self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], train, st.scale, st.shift,
+                        st.mean if train else None, st.invstd if train else None)
+        ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
+        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)."""
+        B, C_, S, S2 = x.shape
+        assert C_ == 3 and S == S2
+        self.plan(B, S)
+        self.refresh_weights()
+        ops.pack_input(x.contiguous(), self.in0)
+        cur = ops.view(self.in0)
+        for L in range(1, 6):
+            base = 0 if L == 1 else 1
+            ca, cb = f"encode{L}.{base}.layer.0", f"encode{L}.{base + 1}.layer.0"
+            self._conv_bn(cur, ca, f"encode{L}.{base}.layer.1", self.ya[L], ops.view(self.aa[L]), True, train)
+            if L < 5:
+                d = 5 - L
+                skip_v = self._skip_up(d)[0]
+                self._conv_bn(ops.view(self.aa[L]), cb, f"encode{L}.{base + 1}.layer.1", self.yb[L], skip_v, True, train,
+                              pool=ops.view(self.pool[L]))
+                cur = ops.view(self.pool[L])
+            else:
+                self._conv_bn(ops.view(self.aa[L]), cb, f"encode{L}.{base + 1}.layer.1", self.yb[L], ops.view(self.x5), True, train)
+        prev = ops.view(self.x5)
+        for d in range(1, 5):
+            L = 5 - d
+            _, up_v, _, _ = self._skip_up(d)
+            if self.variant == "Unetv2":
+                pk = self.packed[f"upscale{d}.0"]
+                ops.conv2d(prev, pk["wf"], pk["b4"], up_v, 1, 1, pixel_shuffle=True)
+            else:
+                ops.upsample2x_fwd(prev, ops.view(self.up_in[d]))
+                key = f"upscale{d}.0.layer.1"
+                ops.conv2d(ops.view(self.up_in[d]), self.packed[key]["wf"], self.P[key + ".bias"], up_v, 3, 3, 1, 1)
+            pre = f"decode_forward{d}.0.layer"
+            self._conv_bn(ops.view(self.cat[L]), pre + ".0", pre + ".2", self.ra[d], ops.view(self.za[d]), False, train)
+            self._conv_bn(ops.view(self.za[d]), pre + ".3", pre + ".5", self.rb[d], ops.view(self.zb[d]), False, train)
+            prev = ops.view(self.zb[d])
+        hw = self.P["decode_forward4.1.weight"]
+        ops.head_fwd(prev, hw.view(self.NC, 64), self.P["decode_forward4.1.bias"], self.logits)
+        self._saved_train = train
+        return self.logits
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def _bn_backward(self, bnname, conv, y, g1: View, g2, mode, dy):
+        """two-pass BN(+ReLU)(+pool) backward; fills dgamma, dbeta, conv-bias gradient; writes dy."""
+        st = self.bn[bnname]
+        yv = ops.view(y)
+        M = yv.B * yv.H * yv.W
+        C_ = yv.C
+        rows = ops.bn_bwd_rows(M)
+        p0, p1, p2 = (p[:rows * C_] for p in self.part)
+        ops.bn_bwd_reduce(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
+        ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[bnname + ".weight"], st.invstd, self.G[bnname + ".weight"],
+                            self.G[bnname + ".bias"], st.ca, st.cb)
+        ops.bn_bwd_apply(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, ops.view(dy), p2)
+        ops.colsum_finalize(p2, rows, C_, self.G[conv + ".bias"])
+
+    def _conv_backward(self, conv, x: View, dy, gin: View | None, cin_real=None):
+        dyv = ops.view(dy)
+        ops.conv2d_wgrad(x, dyv, self.G[conv + ".weight"], 3, 3, 1, 1, self.wg_ws, cin_real=cin_real)
+        if gin is not None:
+            ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1)
+
+    def backward(self, dlogits: torch.Tensor):
+        """dlogits: NCHW f32 [B,NC,S,S]; fills every gradient view in self.G (overwrites)."""
+        assert self._saved_train, "backward needs a preceding forward in train mode"
+        B, S = self.shape
+        NC = self.NC
+        hw = self.P["decode_forward4.1.weight"]
+        rows = ops.head_bwd_rows(B * S * S)
+        ops.head_bwd(ops.view(self.zb[4]), dlogits.contiguous(), hw.view(NC, 64), ops.view(self.g_zb[4]), self.head_part)
+        # head weight [NC,64,1,1] and bias [NC] are adjacent in the flat gradient buffer (registration order)
+        gw, gb = self.G["decode_forward4.1.weight"], self.G["decode_forward4.1.bias"]
+        assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4
+        ops.colsum_finalize(self.head_part, rows, NC * 64 + NC, gw)
+        g = ops.view(self.g_zb[4])
+        for d in range(4, 0, -1):
+            L = 5 - d
+            w = WIDTHS[L - 1]
+            pre = f"decode_forward{d}.0.layer"
+            _, up_v, gskip_v, gup_v = self._skip_up(d)
+            self._bn_backward(pre + ".5", pre + ".3", self.rb[d], g, None, 1, self.ddy_b[d])
+            self._conv_backward(pre + ".3", ops.view(self.za[d]), self.ddy_b[d], ops.view(self.g_za[d]))
+            self._bn_backward(pre + ".2", pre + ".0", self.ra[d], ops.view(self.g_za[d]), None, 1, self.ddy_a[d])
+            self._conv_backward(pre + ".0", ops.view(self.cat[L]), self.ddy_a[d], ops.view(self.g_cat[L]))
+            prev = ops.view(self.x5) if d == 1 else ops.view(self.zb[d - 1])
+            gprev = ops.view(self.g_x5) if d == 1 else ops.view(self.g_zb[d - 1])
+            M = B * gup_v.H * gup_v.W
+            prow = ops.bn_bwd_rows(M)
+            if self.variant == "Unetv2":
+                key = f"upscale{d}.0"
+                ops.colsum_partial(gup_v, self.part[0][:prow * w])
+                ops.colsum_finalize(self.part[0][:prow * w], prow, w, self.G[key + ".bias"])
+                # dW[ci][co][2][2] = sum_p in[p][ci] * gup[2p+tap][co]: the "output gradient" role is played by the input
+                ops.conv2d_wgrad(gup_v, prev, self.G[key + ".weight"], 2, 2, 2, 0, self.wg_ws)
+                ops.conv2d(gup_v, self.packed[key]["wd"], None, gprev, 2, 2, stride=2, pad=0)
+            else:
+                key = f"upscale{d}.0.layer.1"
+                ops.colsum_partial(gup_v, self.part[0][:prow * w])
+                ops.colsum_finalize(self.part[0][:prow * w], prow, w, self.G[key + ".bias"])
+                ops.conv2d_wgrad(ops.view(self.up_in[d]), gup_v, self.G[key + ".weight"], 3, 3, 1, 1, self.wg_ws)
+                ops.conv2d(gup_v, self.packed[key]["wd"], None, ops.view(self.g_up_in[d]), 3, 3, 1, 1)
+                ops.upsample2x_bwd(ops.view(self.g_up_in[d]), gprev)
+            g = gprev
+        # encoder, deepest level first; g = d(x5)
+        for L in range(5, 0, -1):
+            base = 0 if L == 1 else 1
+            ca, cb = f"encode{L}.{base}.layer.0", f"encode{L}.{base + 1}.layer.0"
+            if L == 5:
+                g1, g2 = g, None
+            else:
+                g1, g2 = self._skip_up(5 - L)[2], ops.view(self.g_pool[L])
+            self._bn_backward(f"encode{L}.{base + 1}.layer.1", cb, self.yb[L], g1, g2, 0, self.dy_b[L])
+            self._conv_backward(cb, ops.view(self.aa[L]), self.dy_b[L], ops.view(self.g_aa[L]))
+            self._bn_backward(f"encode{L}.{base}.layer.1", ca, self.ya[L], ops.view(self.g_aa[L]), None, 0, self.dy_a[L])
+            if L == 1:
+                self._conv_backward(ca, ops.view(self.in0), self.dy_a[L], None, cin_real=3)
+            else:
+                self._conv_backward(ca, ops.view(self.pool[L - 1]), self.dy_a[L], ops.view(self.g_pool[L - 1]))

@@ -1,0 +1,216 @@
+"""Model factory side of the drop-in: `Urnet` / `Urnetv2` with the reference's nn.Module contract
+(source/scripts/nets.py:12-33: `requires_context`, `wrapper`, `returns_logits`, `forward(x, context=None)`),
+the reference's `state_dict()` keys and shapes (nets.py:34-199, blocks.py:8-49), and a forward/backward that runs
+entirely in the HIP library through `UNetEngine`.
+
+The modules hold no torch compute: sub-modules exist only so that parameter names are the reference's
+(`encode1.0.layer.0.weight`, `upscale1.0.weight`, `decode_forward4.1.bias`, ...) and reference checkpoints load.
+All parameters are views of ONE flat f32 buffer (and all gradients of one flat gradient buffer): the fused
+optimiser updates them in a single launch and data-parallel training all-reduces the same buffer in buckets.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .engine import WIDTHS, UNetEngine
+
+PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def unet_param_spec(variant: str, num_classes: int):
+    """(name, shape, kind) in the reference's registration order; kind in {conv_w, conv_b, bn_w, bn_b, rm, rv}."""
+    spec = []
+
+    def conv(p, cin, cout, k=3):
+        spec.append((p + ".weight", (cout, cin, k, k), "conv_w"))
+        spec.append((p + ".bias", (cout,), "conv_b"))
+
+    def bn(p, c):
+        spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b"),
+                     (p + ".running_mean", (c,), "rm"), (p + ".running_var", (c,), "rv"),
+                     (p + ".num_batches_tracked", (), "nbt")])
+
+    cin = 3
+    for lvl, w in enumerate(WIDTHS, start=1):
+        base = 0 if lvl == 1 else 1  # encode2..5 keep the reference's MaxPool2d at index 0 (nets.py:129-147)
+        for j in range(2):
+            p = f"encode{lvl}.{base + j}.layer"
+            conv(p + ".0", cin if j == 0 else w, w)
+            bn(p + ".1", w)
+        cin = w
+    for d in range(1, 5):
+        cin = WIDTHS[5 - d]
+        cout = cin // 2
+        if variant == "Unetv2":
+            spec.append((f"upscale{d}.0.weight", (cin, cout, 2, 2), "conv_w"))  # ConvTranspose2d: [Cin, Cout, 2, 2]
+            spec.append((f"upscale{d}.0.bias", (cout,), "conv_b"))
+        else:
+            conv(f"upscale{d}.0.layer.1", cin, cout)
+        p = f"decode_forward{d}.0.layer"
+        conv(p + ".0", cin, cout)
+        bn(p + ".2", cout)
+        conv(p + ".3", cout, cout)
+        bn(p + ".5", cout)
+    conv("decode_forward4.1", 64, num_classes, k=1)
+    return spec
+
+
+class _Node(nn.Module):
+    """bare container used to reproduce the reference's dotted parameter names."""
+
+
+def _descend(root: nn.Module, dotted: str):
+    parts = dotted.split(".")
+    m = root
+    for part in parts[:-1]:
+        if part not in m._modules:
+            m.add_module(part, _Node())
+        m = m._modules[part]
+    return m, parts[-1]
+
+
+class _UNetFunction(torch.autograd.Function):
+    """glue so that the reference's `loss.backward()` (S/train.py:125) reaches the HIP backward pass."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, net):
+        ctx.net = net
+        # the returned tensor aliases an engine-owned buffer: valid until the next forward of this network
+        return net._engine.forward(x, train=True).view(-1).view(x.shape[0], net.num_classes, x.shape[2], x.shape[3])
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net = ctx.net
+        net._engine.backward(dlogits)
+        net._publish_grads()
+        return None, None, None
+
+
+class _HipUNet(nn.Module):
+    variant = "Unetv2"
+
+    def __init__(self, num_classes: int, precision: str = "bf16"):
+        super().__init__()
+        assert precision in PRECISIONS, f"precision must be one of {list(PRECISIONS)}"
+        self.requires_context = False   # S/nets.py:37,120
+        self.wrapper = False
+        self.returns_logits = True
+        self.num_classes = num_classes
+        self.precision = precision
+        self._spec = unet_param_spec(self.variant, num_classes)
+        self._engine = None
+        self._flat = None
+        self._flat_grad = None
+        self._nbt_pending = 0
+        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        for name, shape, kind in self._spec:
+            holder, leaf = _descend(self, name)
+            if kind == "conv_w":
+                fan_in = shape[1] * shape[2] * shape[3]
+                bound = 1.0 / math.sqrt(fan_in)          # torch's default kaiming_uniform(a=sqrt(5)) bound
+                holder.register_parameter(leaf, nn.Parameter((torch.rand(shape, generator=g) * 2 - 1) * bound))
+            elif kind == "conv_b":
+                w = holder._parameters["weight"]
+                bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
+                holder.register_parameter(leaf, nn.Parameter((torch.rand(shape, generator=g) * 2 - 1) * bound))
+            elif kind == "bn_w":
+                holder.register_parameter(leaf, nn.Parameter(torch.ones(shape)))
+            elif kind == "bn_b":
+                holder.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
+            elif kind == "rm":
+                holder.register_buffer(leaf, torch.zeros(shape))
+            elif kind == "rv":
+                holder.register_buffer(leaf, torch.ones(shape))
+            else:
+                holder.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+
+    # ------------------------------------------------------------------------------------------------ flat storage
+    def _ensure_flat(self):
+        """(re)build the flat f32 parameter / gradient buffers on the parameters' current device and re-point every
+        nn.Parameter at its slice (needed after `.to(device)` / `load_state_dict`, both of which keep the objects)."""
+        params = OrderedDict(self.named_parameters())
+        first = next(iter(params.values()))
+        dev = first.device
+        if dev.type != "cuda":
+            raise RuntimeError("cvcs_amd networks run on the GPU only (config device: gpu); there is no CPU path. "
+                               "Move the network with .to('cuda:0') as the reference's load_network does.")
+        total = sum(_align4(p.numel()) for p in params.values())
+        ok = self._flat is not None and self._flat.device == dev and self._flat.numel() == total
+        if ok:
+            off = 0
+            for p in params.values():
+                if p.data_ptr() != self._flat.data_ptr() + off * 4:
+                    ok = False
+                    break
+                off += _align4(p.numel())
+        if not ok:
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params.values():
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[off:off + n].view(p.shape)
+                off += _align4(n)
+            self._flat = flat
+            self._flat_grad = torch.zeros_like(flat)
+            self._engine = None
+        if self._engine is None:
+            eng = UNetEngine(self.variant, self.num_classes, PRECISIONS[self.precision], dev)
+            P, G, off = OrderedDict(), OrderedDict(), 0
+            for name, p in params.items():
+                n = p.numel()
+                P[name] = p.data
+                G[name] = self._flat_grad[off:off + n].view(p.shape)
+                off += _align4(n)
+            bufs = {k: v for k, v in self.named_buffers() if v.dtype == torch.float32}
+            eng.bind(P, G, bufs)
+            self._engine = eng
+            self._grad_views = G
+
+    def _publish_grads(self):
+        for name, p in self.named_parameters():
+            p.grad = self._grad_views[name]
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        return self._flat, self._flat_grad
+
+    # ------------------------------------------------------------------------------------------------ nn.Module API
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None):
+        """x: [B,3,S,S] u8 or f32 (raw 0..255, S/train.py:121) on the GPU -> f32 logits [B,NC,S,S]."""
+        self._ensure_flat()
+        if x.dtype not in (torch.uint8, torch.float32):
+            x = x.float()
+        if self.training:
+            self._nbt_pending += 1   # BatchNorm2d.num_batches_tracked, materialised lazily in state_dict()
+            if torch.is_grad_enabled():
+                anchor = next(self.parameters())
+                return _UNetFunction.apply(anchor, x, self)
+            return self._engine.forward(x, train=True).clone()
+        return self._engine.forward(x, train=False).clone()
+
+    def state_dict(self, *args, **kwargs):
+        if self._nbt_pending:
+            for name, b in self.named_buffers():
+                if name.endswith("num_batches_tracked"):
+                    b += self._nbt_pending
+            self._nbt_pending = 0
+        return super().state_dict(*args, **kwargs)
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class Urnet(_HipUNet):
+    """U-Net with bilinear x2 + conv3x3 up-sampling (S/nets.py:34-115)."""
+    variant = "Unet"
+
+
+class Urnetv2(_HipUNet):
+    """U-Net with ConvTranspose2d(k2,s2) up-sampling (S/nets.py:117-199)."""
+    variant = "Unetv2"

@@ -161,6 +161,11 @@ def colsum_finalize(part, rows, C_, out):
     check(_lib.lib().cvcs_colsum_finalize(part.data_ptr(), rows, C_, out.data_ptr(), _stream()), "cvcs_colsum_finalize")
 
 
+def colsum_partial(x: View, part):
+    check(_lib.lib().cvcs_colsum_partial(x.ptr, x.ld, x.B * x.H * x.W, x.C, part.data_ptr(), x.code, _stream()),
+          "cvcs_colsum_partial")
+
+
 # ------------------------------------------------------------------------------------------------ bilinear
 def upsample2x_fwd(x: View, out: View):
     check(_lib.lib().cvcs_upsample2x_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, x.code, _stream()),

@@ -1,0 +1,285 @@
+"""The reference's factory / evaluation surface (source/scripts/utils.py), re-implemented over the HIP path.
+
+Same names, argument meaning and error behaviour as the reference for the functions on the hot path:
+`load_device`, `load_network`, `load_loss`, `load_optimizer`, `count_params`, `mask_reshape`,
+`validation_loss`, `eval_model`, the metric helpers and `print_metrics`.  Quirks 1-2 of SURVEY section 5
+(`load_device` crashing on cpu, `SGD1` always raising) are fixed; the config keys are unchanged and three optional
+keys are added: `precision` ('bf16' default | 'fp32'), `eval_batch_size`, `world_size` (informational).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import nets, ops
+from .optim import FusedAdam, FusedSGD, PolynomialLR
+
+labels = {
+    0: "unlabeled", 1: "industrial land", 2: "urban residential", 3: "rural residential", 4: "traffic land",
+    5: "paddy field", 6: "irrigated cropland", 7: "dry cropland", 8: "garden plot", 9: "arbor forest",
+    10: "shrub land", 11: "natural grassland", 12: "artificial grassland", 13: "river", 14: "lake", 15: "pond",
+}
+
+
+# ---------------------------------------------------------------------------------------------------- factories
+def load_device(config):
+    """S/utils.py:273-280 ('gpu' -> 'cuda:0'); the cpu branch no longer calls torch.cuda.get_device_name."""
+    if config["device"] == "gpu":
+        assert torch.cuda.is_available(), "Notebook is not configured properly!"
+        device = "cuda:0" if "LOCAL_RANK" not in __import__("os").environ else f"cuda:{__import__('os').environ['LOCAL_RANK']}"
+        print("Training network on {}".format(torch.cuda.get_device_name(device=device)))
+    else:
+        device = torch.device("cpu")
+        print("Training network on cpu")
+    return device
+
+
+def load_network(config, device):
+    """S/utils.py:174-195.  `Unet` / `Unetv2` are the HIP models; the torchvision / HuggingFace wrappers of the
+    reference (`Resnet101`, `MobileNet`, `SegformerMod`, `Ensemble`) are not on the hot path and not built."""
+    netname = config["net"]
+    classes = config["num_classes"] + 1
+    precision = config.get("precision", "bf16")
+    if netname == "Unet":
+        return nets.Urnet(classes, precision).to(device)
+    elif netname == "Unetv2":
+        return nets.Urnetv2(classes, precision).to(device)
+    elif netname in ("Resnet101", "MobileNet", "Ensemble", "SegformerMod"):
+        raise NotImplementedError(f"network '{netname}' wraps third-party pretrained models in the reference "
+                                  "(S/nets.py:234-356) and is outside the MI355X hot path of this build")
+    else:
+        print("Invalid network name.")
+        raise Exception
+
+
+def count_params(net):
+    return sum(p.numel() for p in net.parameters() if p.requires_grad)
+
+
+class _CEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, crit):
+        B, NC = logits.shape[:2]
+        P = logits.numel() // NC
+        dev = logits.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        if crit._ws is None or crit._ws.numel() < ops.ce_workspace_floats(P) or crit._ws.device != dev:
+            crit._ws = torch.empty(ops.ce_workspace_floats(P), dtype=torch.float32, device=dev)
+        need_grad = logits.requires_grad
+        if need_grad and (crit._dl is None or crit._dl.shape != logits.shape or crit._dl.device != dev):
+            crit._dl = torch.empty_like(logits)
+        w = crit.weight
+        if w is not None and w.device != dev:
+            w = crit.weight = w.to(dev)
+        ops.ce_fwd_bwd(logits.contiguous(), target.contiguous(), w, crit.ignore_index, 1.0, loss,
+                       crit._dl if need_grad else None, crit._ws)
+        ctx.crit = crit
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        dl = ctx.crit._dl
+        dl.mul_(gout)      # d(loss)/d(logits) was produced by the forward launch; scale by the incoming gradient
+        return dl, None, None
+
+
+class CrossEntropyLoss:
+    """nn.CrossEntropyLoss(weight, ignore_index) (S/utils.py:230,238): one fused HIP launch produces the loss and
+    d(loss)/d(logits).  target: uint8 or int64 [B,H,W]."""
+
+    def __init__(self, weight=None, ignore_index=-100):
+        self.weight = None if weight is None else weight.float()
+        self.ignore_index = ignore_index
+        self._ws = None
+        self._dl = None
+
+    def __call__(self, logits, target):
+        if target.dtype not in (torch.uint8, torch.int64):
+            target = target.long()
+        return _CEFunction.apply(logits, target, self)
+
+
+def load_loss(config, device, dataset=None):
+    """S/utils.py:223-242: 'CEL' | 'wCEL' (class-balanced weights from the Loader) ; ignore_index 0 or -100."""
+    classes = config["num_classes"] + 1
+    name = config["loss"]
+    ignore_background = config.get("ignore_background", False)
+    ignore_index = 0 if ignore_background else -100
+    if name == "CEL":
+        return CrossEntropyLoss(ignore_index=ignore_index)
+    elif name == "wCEL":
+        print("Computing class weights, it might take several minutes...", flush=True)
+        weights = dataset.get_class_weights(classes, ignore_background).to(device)
+        for i, score in enumerate(weights):
+            print(f"{labels.get(i, i):>22s} {score.item():.6f}")
+        return CrossEntropyLoss(weight=weights, ignore_index=ignore_index)
+    elif name == "MSE":
+        raise NotImplementedError("MSE loss is not on the HIP path (the reference never trains with it)")
+    else:
+        raise Exception
+
+
+def load_optimizer(config, net):
+    """S/utils.py:208-221 (SGD1 reachable again: the reference's if/if/elif chain always raised for it)."""
+    optimizer = config["opt"]
+    if optimizer == "SGD1":
+        opt = FusedSGD(net, lr=0.001, momentum=0.9, weight_decay=0.00001)
+        sched = PolynomialLR(opt)
+    elif optimizer == "SGD2":
+        opt = FusedSGD(net, lr=0.006, momentum=0.9, weight_decay=0.00001)
+        sched = PolynomialLR(opt, total_iters=20)
+    elif optimizer == "ADAM1":
+        opt = FusedAdam(net, lr=0.005)
+        sched = PolynomialLR(opt, total_iters=config["epochs"], power=2.0)
+    else:
+        raise ValueError("Optimizer name not valid.")
+    return opt, sched
+
+
+def mask_reshape(mask: torch.Tensor):
+    """S/utils.py:557-567: a 4-D mask carries replicated channels; keep channel 0."""
+    if len(mask.shape) == 4:
+        return mask[:, 0, :, :]
+    return mask
+
+
+# ---------------------------------------------------------------------------------------------------- evaluation
+class ConfusionMatrix:
+    """device-side stand-in for torchmetrics' MulticlassConfusionMatrix (S/utils.py:76-78): rows = target,
+    cols = prediction, pixels whose target == ignore_index dropped; `compute()` -> int64 [K,K] on the host."""
+
+    def __init__(self, num_classes=16, ignore_index=None, device="cuda:0"):
+        self.K = num_classes
+        self.ignore_index = -1 if ignore_index is None else ignore_index
+        self.conf = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=device)
+        self._labels = None
+
+    def update_from_logits(self, logits, target):
+        B, NC = logits.shape[:2]
+        if self._labels is None or self._labels.numel() != logits.numel() // NC:
+            self._labels = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device)
+        t = target if target.dtype in (torch.uint8, torch.int64) else target.long()
+        ops.argmax_confusion(logits.contiguous(), self._labels, t.contiguous(), self.ignore_index, self.K, self.conf)
+        return self._labels
+
+    def compute(self):
+        return self.conf.cpu()
+
+
+def eval_model(net, Loader_validation, device, batch_size=1, show_progress=False, ignore_background=False,
+               num_classes=16):
+    """S/utils.py:59-103 with the per-tile logits D2H + CPU argmax replaced by one fused argmax+histogram launch
+    (any batch size).  Returns (flat, normalized): `flat.compute()` is the int64 confusion matrix."""
+    net.eval()
+    ignored_index = 0 if ignore_background else None
+    flat = ConfusionMatrix(num_classes=num_classes, ignore_index=ignored_index, device=device)
+    with torch.no_grad():
+        for c in range(len(Loader_validation)):
+            dataset = Loader_validation.get_iterable_chunk(c)
+            dl = torch.utils.data.DataLoader(dataset, batch_size=batch_size)
+            for x, y, _, context in dl:
+                x, y = x.to(device), mask_reshape(y.to(device))
+                y_pred = net(x, None)
+                flat.update_from_logits(y_pred, y.squeeze(1) if y.dim() == 4 else y)
+    return flat, NormalizedConfusion(flat)
+
+
+class NormalizedConfusion:
+    """row-normalised view (torchmetrics normalize='true') of a ConfusionMatrix."""
+
+    def __init__(self, flat):
+        self.flat = flat
+
+    def compute(self):
+        c = self.flat.compute().double()
+        return c / c.sum(dim=1, keepdim=True).clamp_min(1)
+
+
+def validation_loss(net, Loader_validation, crit, device, bs, show_progress=False):
+    """S/utils.py:106-126."""
+    loss_values = []
+    net.eval()
+    with torch.no_grad():
+        for c in range(len(Loader_validation)):
+            dataset = Loader_validation.get_iterable_chunk(c)
+            dl = torch.utils.data.DataLoader(dataset, batch_size=bs)
+            for image, index_mask, _, context in dl:
+                image, mask = image.to(device), mask_reshape(index_mask.to(device))
+                mask_pred = net(image, None)
+                loss = crit(mask_pred, mask)
+                loss_values.append(loss.item())
+    return loss_values
+
+
+# ---------------------------------------------------------------------------------------------------- metrics
+def _get_class_scores(confusion, formula, ignore_condition):
+    """S/utils.py:319-341."""
+    scores, excluded = [], []
+    _, classes = list(confusion.shape)
+    for i in range(classes):
+        tp = confusion[i, i].item()
+        fp = (torch.sum(confusion[:, i]) - tp).item()
+        fn = (torch.sum(confusion[i, :]) - tp).item()
+        if ignore_condition(tp, fp, fn):
+            scores.append(0)
+            excluded.append(i)
+        else:
+            scores.append(formula(tp, fp, fn))
+    return torch.tensor(scores), excluded
+
+
+def _mean_excluding(scores, excluded):
+    """S/utils.py:343-346."""
+    inc = torch.tensor([x for i, x in enumerate(scores) if i not in excluded])
+    return torch.mean(inc).item()
+
+
+def _score(confusion, formula, ignore_condition, mean, return_excluded):
+    scores, excluded = _get_class_scores(confusion, formula, ignore_condition)
+    m = _mean_excluding(scores, excluded)
+    if mean:
+        return (m, excluded) if return_excluded else m
+    return (scores, excluded) if return_excluded else m
+
+
+def precision(confusion, macro=False, return_excluded=False):
+    return _score(confusion, lambda tp, fp, fn: tp / (tp + fp), lambda tp, fp, fn: tp + fp == 0, macro, return_excluded)
+
+
+def recall(confusion, macro=False, return_excluded=False):
+    return _score(confusion, lambda tp, fp, fn: tp / (tp + fn), lambda tp, fp, fn: tp + fn == 0, macro, return_excluded)
+
+
+def IoU(confusion, mean=False, return_excluded=False):
+    return _score(confusion, lambda tp, fp, fn: tp / (tp + fn + fp), lambda tp, fp, fn: tp + fn == 0, mean, return_excluded)
+
+
+def F1(confusion, mean=False, return_excluded=False):
+    return _score(confusion, lambda tp, fp, fn: (2 * tp) / (2 * tp + fn + fp), lambda tp, fp, fn: tp + fn == 0, mean,
+                  return_excluded)
+
+
+def accuracy(confusion):
+    _, classes = list(confusion.shape)
+    return sum(confusion[i, i].item() for i in range(classes)) / torch.sum(confusion).item()
+
+
+def print_metrics(confusion, silent=False):
+    """S/utils.py:375-403 (plain-text tables: prettytable is not a dependency here)."""
+    out = {"mIoU": IoU(confusion, mean=True), "precision_score": precision(confusion, macro=True),
+           "recall_score": recall(confusion, macro=True), "dice_score": F1(confusion, mean=True),
+           "oa_score": accuracy(confusion)}
+    values, excluded = IoU(confusion, mean=False, return_excluded=True)
+    out["perclass_IoU"] = values.tolist()
+    if not silent:
+        for k, name in (("mIoU", "mIoU"), ("precision_score", "mPrec"), ("recall_score", "mRec"),
+                        ("dice_score", "Dice"), ("oa_score", "OA")):
+            print(f"{name:>6s} {out[k]:.6f}")
+        print(f"Excluded classes (not in target): {list(excluded)}")
+        for i, s in enumerate(out["perclass_IoU"]):
+            print(f"{labels.get(i, str(i)):>22s} {s:.6f}", flush=True)
+    return out
+
+
+def display_configs(configs):
+    for key, value in configs.items():
+        print(f"{key:>28s} : {value}", flush=True)

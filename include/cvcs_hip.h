@@ -110,6 +110,10 @@ int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld
                       int mode, void* dy, int64_t dy_ld, float* part_db, int dtype, void* stream);
 /* column-sum of `rows` partial rows: out[c] = sum_r part[r][c] (f64 accumulate) - conv bias gradients */
 int cvcs_colsum_finalize(const float* part, int rows, int C, float* out, void* stream);
+/* partial per-channel sums of an activation view over its M pixels: part[cvcs_bn_bwd_rows(M)][C]; with
+ * cvcs_colsum_finalize this is the bias gradient of a conv that has no BatchNorm behind it
+ * (nn.ConvTranspose2d S/nets.py:150, UnetUpscaleLayer's conv S/blocks.py:30).                               */
+int cvcs_colsum_partial(const void* x, int64_t x_ld, int64_t M, int C, float* part, int dtype, void* stream);
 
 /* ---- bilinear x2 upsampling (Urnet only) -----------------------------------------------------------------
  * replaces: nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False) (S/blocks.py:29) fwd / bwd. */
