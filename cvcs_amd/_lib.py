@@ -51,7 +51,8 @@ SIGNATURES = {
     "cvcs_wgrad_slices": (_i, [_i] * 8),
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "cvcs_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
-    "cvcs_bn_finalize": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_finalize_workspace_floats": (_i, [_i, _i]),
+    "cvcs_bn_finalize": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_act": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "cvcs_bn_bwd_rows": (_i, [_i64]),
     "cvcs_bn_bwd_reduce": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),

@@ -15,31 +15,83 @@
 namespace cvcs {
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-// Chan et al. combination of per-row-block (count, sum, M2) -> mean / biased var; f64 throughout.
-__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2, int rows, int64_t M,
-                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, float momentum, float eps, int train,
-                                   float* scale, float* shift, float* save_mean, float* save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Chan et al. combination of per-block (count, sum, centred M2) -> mean / biased var; f64 throughout.
+// Workgroup = 16 row-lanes x 16 channels: each thread merges a strided subset of the partial rows, the 16 lanes of a
+// channel are merged through LDS.  With more than kDirectRows partial rows a first stage (one workgroup per
+// (row block, 16 channels)) shrinks them to <= kDirectRows rows of larger pixel count.
+struct Moments { double n, mean, m2; };
+__device__ __forceinline__ void merge(Moments& a, double nb, double mean_b, double m2_b) {
+  if (nb <= 0.0) return;
+  const double n = a.n + nb;
+  const double d = mean_b - a.mean;
+  a.mean += d * (nb / n);
+  a.m2 += m2_b + d * d * (a.n * nb / n);
+  a.n = n;
+}
+
+constexpr int kDirectRows = 2048;
+
+// merge rows [r0, r1) (each covering `ppr` pixels, the last one of the tensor possibly fewer) for channel c
+__device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, const float* __restrict__ sm2, int r0, int r1,
+                                              int rstep, int64_t ppr, int64_t M, int C, int c) {
+  Moments a{0.0, 0.0, 0.0};
+  for (int r = r0; r < r1; r += rstep) {
+    int64_t n = M - (int64_t)r * ppr;
+    n = n > ppr ? ppr : n;
+    if (n <= 0) break;
+    merge(a, (double)n, (double)ssum[(int64_t)r * C + c] / (double)n, (double)sm2[(int64_t)r * C + c]);
+  }
+  return a;
+}
+
+__device__ __forceinline__ Moments merge_lanes(Moments a, int rl, int cl) {
+  __shared__ double sh[3][16][17];
+  sh[0][rl][cl] = a.n; sh[1][rl][cl] = a.mean; sh[2][rl][cl] = a.m2;
+  __syncthreads();
+  Moments t{0.0, 0.0, 0.0};
+  if (rl == 0)
+    for (int q = 0; q < 16; ++q) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+  return t;
+}
+
+// stage 1: grid (nblk, C/16); block b merges rows [b*R, (b+1)*R) -> out_sum/out_m2 [nblk][C] (sum = mean*n)
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
+                                                             int rows, int R, int64_t ppr, int64_t M, int C,
+                                                             float* out_sum, float* out_m2) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 16 + cl;
+  const int r0 = blockIdx.x * R;
+  int r1 = r0 + R;
+  if (r1 > rows) r1 = rows;
+  Moments a = merge_rows(ssum, sm2, r0 + rl, r1, 16, ppr, M, C, c);
+  a = merge_lanes(a, rl, cl);
+  if (rl == 0) {
+    out_sum[(int64_t)blockIdx.x * C + c] = (float)(a.mean * a.n);
+    out_m2[(int64_t)blockIdx.x * C + c] = (float)a.m2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
+                                                         int rows, int64_t ppr, int64_t M, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* running_mean, float* running_var, float momentum, float eps,
+                                                         int train, float* scale, float* shift, float* save_mean,
+                                                         float* save_invstd) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   if (!train) {
-    const float is = 1.0f / sqrtf(running_var[c] + eps);
-    const float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - running_mean[c] * sc;
+    if (rl == 0) {
+      const float is = 1.0f / sqrtf(running_var[c] + eps);
+      const float sc = gamma[c] * is;
+      scale[c] = sc;
+      shift[c] = beta[c] - running_mean[c] * sc;
+    }
     return;
   }
-  double tot = 0.0;
-  for (int r = 0; r < rows; ++r) tot += (double)ssum[(int64_t)r * C + c];
-  const double mean = tot / (double)M;
-  double m2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    int64_t n = M - (int64_t)r * 64;
-    n = n > 64 ? 64 : n;
-    if (n <= 0) break;
-    const double mr = (double)ssum[(int64_t)r * C + c] / (double)n;
-    m2 += (double)sm2[(int64_t)r * C + c] + (double)n * (mr - mean) * (mr - mean);
-  }
+  Moments a = merge_rows(ssum, sm2, rl, rows, 16, ppr, M, C, c);
+  a = merge_lanes(a, rl, cl);
+  if (rl != 0) return;
+  const double mean = a.mean, m2 = a.m2;
   const double var = m2 / (double)M;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -251,25 +303,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* x, int64_t ld, 
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ pdz, const float* __restrict__ pdzx, int rows, int64_t M,
-                                       int C, const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* dgamma, float* dbeta, float* ca, float* cb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int r = 0; r < rows; ++r) { a += (double)pdz[(int64_t)r * C + c]; b += (double)pdzx[(int64_t)r * C + c]; }
+// column sums of up to 1024 partial rows: workgroup = 16 row-lanes x 16 channels, f64 accumulate, fixed order
+__device__ __forceinline__ double colsum16(const float* __restrict__ part, int rows, int C, int c, int rl, int cl, int slot) {
+  __shared__ double sh[2][16][17];
+  double a = 0.0;
+  for (int r = rl; r < rows; r += 16) a += (double)part[(int64_t)r * C + c];
+  sh[slot][rl][cl] = a;
+  __syncthreads();
+  double t = 0.0;
+  if (rl == 0)
+    for (int q = 0; q < 16; ++q) t += sh[slot][q][cl];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ pdz, const float* __restrict__ pdzx,
+                                                             int rows, int64_t M, int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                                             float* ca, float* cb) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const double a = colsum16(pdz, rows, C, c, rl, cl, 0);
+  const double b = colsum16(pdzx, rows, C, c, rl, cl, 1);
+  if (rl != 0) return;
   dbeta[c] = (float)a;
   dgamma[c] = (float)b;
   ca[c] = (float)(a / (double)M);
   cb[c] = (float)(b / (double)M);
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int rows, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0;
-  for (int r = 0; r < rows; ++r) a += (double)part[(int64_t)r * C + c];
-  out[c] = (float)a;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int rows, int C, float* out) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool ok = c < C;
+  const double a = colsum16(part, ok ? rows : 0, C, ok ? c : 0, rl, cl, 0);
+  if (rl == 0 && ok) out[c] = (float)a;
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear x2
@@ -434,18 +501,37 @@ using namespace cvcs;
 
 #define DT_OK(dt) ((dt) == CVCS_F32 || (dt) == CVCS_BF16)
 
+extern "C" int cvcs_bn_finalize_workspace_floats(int rows, int C) {
+  if (rows <= kDirectRows) return 0;
+  const int R = (int)cdiv(rows, 1024);
+  return 2 * (int)cdiv(rows, R) * C;
+}
+
 extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, int rows, int64_t M, int C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                int train, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
-  CVCS_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "cvcs_bn_finalize: null argument");
+                                int train, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                float* workspace, void* stream) {
+  CVCS_CHECK_ARG(C > 0 && C % 16 == 0 && gamma && beta && running_mean && running_var && scale && shift,
+                 "cvcs_bn_finalize: null argument or C %% 16 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t ppr = 64;
   if (train) {
     CVCS_CHECK_ARG(stat_sum && stat_m2 && save_mean && save_invstd && M > 0, "cvcs_bn_finalize: train needs statistics");
     CVCS_CHECK_ARG(rows == cvcs_conv_stat_rows(M), "cvcs_bn_finalize: rows=%d but M=%lld gives %d", rows, (long long)M,
                    cvcs_conv_stat_rows(M));
+    if (rows > kDirectRows) {
+      CVCS_CHECK_ARG(workspace != nullptr, "cvcs_bn_finalize: %d partial rows need the workspace", rows);
+      const int R = (int)cdiv(rows, 1024);
+      const int nblk = (int)cdiv(rows, R);
+      float* o_sum = workspace;
+      float* o_m2 = workspace + (int64_t)nblk * C;
+      hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2,
+                         rows, R, (int64_t)64, M, C, o_sum, o_m2);
+      stat_sum = o_sum; stat_m2 = o_m2; rows = nblk; ppr = (int64_t)64 * R;
+    }
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stat_sum, stat_m2,
-                     rows, M, C, gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean,
-                     save_invstd);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2, rows, ppr, M, C, gamma,
+                     beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean, save_invstd);
   CVCS_CHECK_LAUNCH("cvcs_bn_finalize");
   return CVCS_OK;
 }
@@ -540,7 +626,8 @@ extern "C" int cvcs_bn_bwd_finalize(const float* part_dz, const float* part_dzx,
                                     void* stream) {
   CVCS_CHECK_ARG(part_dz && part_dzx && dgamma && dbeta && coef_a && coef_b && C > 0 && M > 0, "cvcs_bn_bwd_finalize: null argument");
   CVCS_CHECK_ARG(rows == cvcs_bn_bwd_rows(M), "cvcs_bn_bwd_finalize: rows");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part_dz, part_dzx,
+  CVCS_CHECK_ARG(C % 16 == 0, "cvcs_bn_bwd_finalize: C %% 16 != 0");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, (hipStream_t)stream, part_dz, part_dzx,
                      rows, M, C, gamma, save_invstd, dgamma, dbeta, coef_a, coef_b);
   CVCS_CHECK_LAUNCH("cvcs_bn_bwd_finalize");
   return CVCS_OK;
@@ -556,7 +643,7 @@ extern "C" int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, in
 
 extern "C" int cvcs_colsum_finalize(const float* part, int rows, int C, float* out, void* stream) {
   CVCS_CHECK_ARG(part && out && rows > 0 && C > 0, "cvcs_colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, rows, C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, rows, C, out);
   CVCS_CHECK_LAUNCH("cvcs_colsum_finalize");
   return CVCS_OK;
 }

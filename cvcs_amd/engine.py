@@ -46,10 +46,14 @@ class UNetEngine:
         self.Bf = None  # name -> f32 buffer (running stats)
         self.packed = {}
         self._saved_train = False
+        self.on_backward_begin = None   # data-parallel hooks (cvcs_amd.parallel): called at the start of backward,
+        self.on_grad_ready = None       # and with the lowest flat-gradient offset that is complete so far
 
     # ------------------------------------------------------------------------------------------------ binding
     def bind(self, params, grads, buffers):
         self.P, self.G, self.Bf = params, grads, buffers
+        base = min(g.data_ptr() for g in grads.values())
+        self._goff = {k: (g.data_ptr() - base) // 4 for k, g in grads.items()}
         dev, dt = self.dev, self.dtype
         self.packed = {}
         for name, w in params.items():
@@ -125,6 +129,8 @@ class UNetEngine:
         for (Bc, Ho, Cout, Cin, K, st) in self._wgrad_shapes(B):
             need = max(need, ops.wgrad_workspace_floats(Bc, Ho, Ho, Cout, Cin, K, K, st))
         self.wg_ws = torch.empty(need, dtype=torch.float32, device=dev)
+        bn_need = max(ops.bn_finalize_workspace_floats(ops.conv_stat_rows(B * s * s), w) for s, w in zip(s_, WIDTHS))
+        self.bn_ws = torch.empty(max(bn_need, 4), dtype=torch.float32, device=dev)
         self.bn = {}
         for name in self.P:
             if name.endswith(".weight") and self.P[name].dim() == 1:
@@ -173,7 +179,7 @@ class UNetEngine:
         st = self.bn[bnname]
         ops.bn_finalize(ssum, sm2, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
                         self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], train, st.scale, st.shift,
-                        st.mean if train else None, st.invstd if train else None)
+                        st.mean if train else None, st.invstd if train else None, workspace=self.bn_ws)
         ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -241,6 +247,9 @@ class UNetEngine:
     def backward(self, dlogits: torch.Tensor):
         """dlogits: NCHW f32 [B,NC,S,S]; fills every gradient view in self.G (overwrites)."""
         assert self._saved_train, "backward needs a preceding forward in train mode"
+        if self.on_backward_begin is not None:
+            self.on_backward_begin()
+        ready = (lambda name: self.on_grad_ready(self._goff[name])) if self.on_grad_ready is not None else (lambda name: None)
         B, S = self.shape
         NC = self.NC
         hw = self.P["decode_forward4.1.weight"]
@@ -250,6 +259,7 @@ class UNetEngine:
         gw, gb = self.G["decode_forward4.1.weight"], self.G["decode_forward4.1.bias"]
         assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4
         ops.colsum_finalize(self.head_part, rows, NC * 64 + NC, gw)
+        ready("decode_forward4.1.weight")
         g = ops.view(self.g_zb[4])
         for d in range(4, 0, -1):
             L = 5 - d
@@ -260,6 +270,7 @@ class UNetEngine:
             self._conv_backward(pre + ".3", ops.view(self.za[d]), self.ddy_b[d], ops.view(self.g_za[d]))
             self._bn_backward(pre + ".2", pre + ".0", self.ra[d], ops.view(self.g_za[d]), None, 1, self.ddy_a[d])
             self._conv_backward(pre + ".0", ops.view(self.cat[L]), self.ddy_a[d], ops.view(self.g_cat[L]))
+            ready(pre + ".0.weight")
             prev = ops.view(self.x5) if d == 1 else ops.view(self.zb[d - 1])
             gprev = ops.view(self.g_x5) if d == 1 else ops.view(self.g_zb[d - 1])
             M = B * gup_v.H * gup_v.W
@@ -278,6 +289,7 @@ class UNetEngine:
                 ops.conv2d_wgrad(ops.view(self.up_in[d]), gup_v, self.G[key + ".weight"], 3, 3, 1, 1, self.wg_ws)
                 ops.conv2d(gup_v, self.packed[key]["wd"], None, ops.view(self.g_up_in[d]), 3, 3, 1, 1)
                 ops.upsample2x_bwd(ops.view(self.g_up_in[d]), gprev)
+            ready(key + ".weight")
             g = gprev
         # encoder, deepest level first; g = d(x5)
         for L in range(5, 0, -1):
@@ -289,8 +301,10 @@ class UNetEngine:
                 g1, g2 = self._skip_up(5 - L)[2], ops.view(self.g_pool[L])
             self._bn_backward(f"encode{L}.{base + 1}.layer.1", cb, self.yb[L], g1, g2, 0, self.dy_b[L])
             self._conv_backward(cb, ops.view(self.aa[L]), self.dy_b[L], ops.view(self.g_aa[L]))
+            ready(cb + ".weight")
             self._bn_backward(f"encode{L}.{base}.layer.1", ca, self.ya[L], ops.view(self.g_aa[L]), None, 0, self.dy_a[L])
             if L == 1:
                 self._conv_backward(ca, ops.view(self.in0), self.dy_a[L], None, cin_real=3)
             else:
                 self._conv_backward(ca, ops.view(self.pool[L - 1]), self.dy_a[L], ops.view(self.g_pool[L - 1]))
+            ready(ca + ".weight")

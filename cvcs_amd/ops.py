@@ -29,6 +29,33 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimers:
+    """HIP-event brackets around individual launches ON THE STREAM THEY ARE LAUNCHED ON (torch's current stream is the
+    stream handed to the C-ABI).  bench.py switches this on for the timed region to measure the dominant kernels'
+    average launch duration; off (None) by default, so the product path records nothing."""
+
+    def __init__(self):
+        self.records = {}   # kind -> list of (start_event, end_event, algorithmic_flops)
+
+    def bracket(self, kind, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(kind, []).append((s, e, flops))
+        return s, e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[kind] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), flops=fl,
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
+TIMERS: KernelTimers | None = None
+
+
 def _ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
@@ -93,7 +120,12 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     else:
         assert (out.H, out.W, out.C) == (Ho, Wo, Cout), f"output view mismatch {(out.H, out.W, out.C)} vs {(Ho, Wo, Cout)}"
     assert out.B == x.B
+    if TIMERS is not None:
+        ev = TIMERS.bracket("conv_igemm", 2.0 * x.B * Ho * Wo * Cout * x.C * KH * KW)
+        ev[0].record()
     check(_lib.lib().cvcs_conv2d(C.byref(d), _stream()), "cvcs_conv2d")
+    if TIMERS is not None:
+        ev[1].record()
 
 
 def wgrad_workspace_floats(B, Ho, Wo, Cout, Cin, KH, KW, stride) -> int:
@@ -116,15 +148,27 @@ def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, works
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.C * cin_real * KH * KW
     assert workspace.dtype == torch.float32 and \
         workspace.numel() >= wgrad_workspace_floats(x.B, dy.H, dy.W, dy.C, x.C, KH, KW, stride), "wgrad workspace too small"
+    if TIMERS is not None:
+        ev = TIMERS.bracket("wgrad", 2.0 * x.B * dy.H * dy.W * dy.C * x.C * KH * KW)
+        ev[0].record()
     check(_lib.lib().cvcs_conv2d_wgrad(C.byref(d), _stream()), "cvcs_conv2d_wgrad")
+    if TIMERS is not None:
+        ev[1].record()
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
+def bn_finalize_workspace_floats(rows: int, C_: int) -> int:
+    return _lib.lib().cvcs_bn_finalize_workspace_floats(rows, C_)
+
+
 def bn_finalize(stat_sum, stat_m2, rows, M, C_, gamma, beta, rmean, rvar, train, scale, shift, save_mean, save_invstd,
-                momentum=0.1, eps=1e-5):
+                momentum=0.1, eps=1e-5, workspace=None):
+    if train and workspace is None and bn_finalize_workspace_floats(rows, C_) > 0:
+        workspace = torch.empty(bn_finalize_workspace_floats(rows, C_), dtype=torch.float32, device=scale.device)
     check(_lib.lib().cvcs_bn_finalize(_ptr(stat_sum), _ptr(stat_m2), rows, M, C_, gamma.data_ptr(), beta.data_ptr(),
                                       rmean.data_ptr(), rvar.data_ptr(), momentum, eps, int(train), scale.data_ptr(),
-                                      shift.data_ptr(), _ptr(save_mean), _ptr(save_invstd), _stream()), "cvcs_bn_finalize")
+                                      shift.data_ptr(), _ptr(save_mean), _ptr(save_invstd), _ptr(workspace), _stream()),
+          "cvcs_bn_finalize")
 
 
 def bn_act(y: View, scale, shift, relu: bool, out: View, pool: View | None = None):

@@ -79,10 +79,11 @@ int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
  * cvcs_bn_finalize: combine the conv's partial statistics (rows x C) into scale/shift (f32 [C] each), save
  * mean/invstd for backward and update running stats (momentum 0.1, unbiased var).  train=0: scale/shift from the
  * running stats, partials ignored.                                                                        */
+int cvcs_bn_finalize_workspace_floats(int rows, int C);   /* 0 when the partial rows are merged directly */
 int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, int rows, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, int train,
-                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+                     float* scale, float* shift, float* save_mean, float* save_invstd, float* workspace, void* stream);
 
 /* y -> out = relu?(scale*y + shift), optionally also pool[p/2] = max 2x2 (nn.MaxPool2d(2,2), S/nets.py:130,135,140,145).
  * replaces: BN apply + nn.ReLU (S/blocks.py:17) (+ MaxPool2d).  relu=1: encoder order; relu=0: decoder BN apply. */

@@ -96,10 +96,11 @@ def test_conv2d_matches_aten(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv2d_f32_large_mean_statistics(dtype):
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (4, 192, 192)])  # the second has 2304 partial rows: two-stage merge
+def test_conv2d_f32_large_mean_statistics(dtype, B, H, W):
     """raw 0..255 inputs (S/train.py:121, no normalisation): mean >> std must not cancel in the variance."""
     g = torch.Generator().manual_seed(5)
-    B, H, W, Cin, Cout = 2, 16, 16, ops.KGROUP[ops.dtype_code(dtype)], 64
+    Cin, Cout = ops.KGROUP[ops.dtype_code(dtype)], 64
     x = torch.zeros(B, Cin, H, W)
     x[:, :3] = torch.randint(0, 256, (B, 3, H, W), generator=g).float()
     w = rq(torch.rand(Cout, Cin, 3, 3, generator=g) * 0.1, dtype)  # all-positive weights: large positive mean
@@ -117,6 +118,7 @@ def test_conv2d_f32_large_mean_statistics(dtype):
     torch.cuda.synchronize()
     rvar = ref.var(dim=(0, 2, 3), unbiased=False)
     close(invstd.cpu().double(), 1.0 / torch.sqrt(rvar + 1e-5), 1e-2 if dtype == torch.bfloat16 else 1e-4, "invstd")
+    close(mean.cpu().double(), ref.mean(dim=(0, 2, 3)), 1e-2 if dtype == torch.bfloat16 else 1e-5, "mean")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
