@@ -1,0 +1,167 @@
+"""Tile producers with the reference's `Loader` API (source/scripts/dataset.py:228-387): `len(loader)` chunks,
+`get_iterable_chunk(c, random_tps=None)`, `shuffle()`, `specify(idxs)`, `patch_size`, `tpi`, `idxs`,
+`get_class_weights(classes, ignore_background)`.
+
+`Loader` reads GID-15 directories (Image__8bit_NirRGB / Annotation__index / Annotation__color) with PIL + numpy
+(torchvision is not a dependency here); `SyntheticLoader` produces the structured synthetic tiles of SURVEY
+section 8(d) (Voronoi label maps, per-class colour + noise) for parity / mIoU runs without imagery.
+The per-tile hot path consumes uint8 tensors: [3,p,p] image and [p,p] index mask.
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import torch
+
+
+class _Chunk(torch.utils.data.IterableDataset):
+    def __init__(self, patches):
+        super().__init__()
+        self.patches = patches
+        self.chunk_crops = patches
+
+    def __iter__(self):
+        return iter(self.patches)
+
+    def __len__(self):
+        return len(self.patches)
+
+
+def class_weights_from_counts(counts: torch.Tensor, ignore_background: bool):
+    """S/dataset.py:360-384: w_j = N_tot / (bins * N_j); 0 for empty classes; background excluded on request."""
+    c = counts[1:] if ignore_background else counts
+    tot, bins = torch.sum(c), len(c)
+    w = torch.tensor([0.0 if n.item() == 0 else (tot / (bins * n.item())).item() for n in c], dtype=torch.float32)
+    return torch.concat((torch.tensor([0.0]), w)) if ignore_background else w
+
+
+class SyntheticLoader:
+    """`n_images` pseudo-images of `tiles_per_image` tiles each; deterministic in (seed, image index)."""
+
+    def __init__(self, n_images, chunk_size, patch_size=256, num_classes=16, tiles_per_image=16, seed=0):
+        self.patch_size, self.NC, self.tpi = patch_size, num_classes, tiles_per_image
+        self.chunk_size, self.seed = chunk_size, seed
+        self.idxs = list(range(n_images))
+        self._gen_chunks()
+        g = torch.Generator().manual_seed(99)
+        self.base = torch.randint(30, 226, (num_classes, 3), generator=g).float()
+        self.count = None
+
+    def _gen_chunks(self):
+        self.chunks = [self.idxs[i:i + self.chunk_size] for i in range(0, len(self.idxs), self.chunk_size)]
+
+    def __len__(self):
+        return len(self.chunks)
+
+    def shuffle(self):
+        random.shuffle(self.idxs)
+        self._gen_chunks()
+
+    def specify(self, targets):
+        self.idxs = [self.idxs[i] for i in targets]
+        self._gen_chunks()
+
+    def _tile(self, g):
+        S, NC = self.patch_size, self.NC
+        yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+        n = int(torch.randint(8, 33, (1,), generator=g))
+        sy, sx = torch.randint(0, S, (n,), generator=g), torch.randint(0, S, (n,), generator=g)
+        cls = torch.randint(1, NC, (n,), generator=g)
+        cls = torch.where(torch.rand(n, generator=g) < 0.05, torch.zeros_like(cls), cls)
+        d = (yy[None] - sy[:, None, None]) ** 2 + (xx[None] - sx[:, None, None]) ** 2
+        lab = cls[d.argmin(0)]
+        img = self.base[lab].permute(2, 0, 1) + 20.0 * torch.randn(3, S, S, generator=g)
+        return img.clamp(0, 255).to(torch.uint8), lab.to(torch.uint8)
+
+    def get_iterable_chunk(self, idx, random_tps=None):
+        patches = []
+        for image in self.chunks[idx]:
+            g = torch.Generator().manual_seed(self.seed * 100003 + image)
+            for _ in range(self.tpi):
+                img, lab = self._tile(g)
+                patches.append((img, lab, torch.zeros(1), torch.zeros(1)))
+        return _Chunk(patches)
+
+    def get_class_weights(self, classes, ignore_background=False):
+        if self.count is None:
+            self.count = torch.zeros(classes)
+            for c in range(len(self)):
+                for _, lab, _, _ in self.get_iterable_chunk(c):
+                    self.count += torch.bincount(lab.reshape(-1).long(), minlength=classes)[:classes].float()
+        return class_weights_from_counts(self.count, ignore_background)
+
+
+class Loader:
+    """GID-15 chunk loader (S/dataset.py:228-387) without torchvision: full images decoded with PIL, every
+    non-overlapping `patch_size` tile of a chunk's images cropped eagerly (optionally shifted by +-20 px)."""
+
+    def __init__(self, root, chunk_size, random_shift=False, patch_size=224, image_transforms=None, mask_transforms=None,
+                 load_context=False, load_color_mask=False):
+        from PIL import Image  # noqa: F401
+        assert patch_size in (224, 256, 512), "patch_size must be 224, 256 or 512"   # S/dataset.py:268
+        self.root, self.chunk_size, self.random_shift, self.patch_size = root, chunk_size, random_shift, patch_size
+        idir, mdir = os.path.join(root, "Image__8bit_NirRGB"), os.path.join(root, "Annotation__index")
+        self.images = sorted(os.path.join(idir, f) for f in os.listdir(idir))
+        self.index_masks = sorted(os.path.join(mdir, f) for f in os.listdir(mdir))
+        assert len(self.images) == len(self.index_masks)
+        from PIL import Image as I
+        with I.open(self.images[0]) as im:
+            W, H = im.size
+        self.tpi = (H // patch_size) * (W // patch_size)
+        self.H, self.W = H, W
+        self.idxs = list(range(len(self.images)))
+        self._gen_chunks()
+        self.count = None
+
+    def _gen_chunks(self):
+        self.chunks = [self.idxs[i:i + self.chunk_size] for i in range(0, len(self.idxs), self.chunk_size)]
+
+    def __len__(self):
+        return len(self.chunks)
+
+    def shuffle(self):
+        random.shuffle(self.idxs)
+        self._gen_chunks()
+
+    def specify(self, targets):
+        self.idxs = [self.idxs[i] for i in targets]
+        self._gen_chunks()
+
+    def get_iterable_chunk(self, idx, random_tps=None):
+        from PIL import Image
+        p, patches = self.patch_size, []
+        for i in self.chunks[idx]:
+            img = torch.from_numpy(np.array(Image.open(self.images[i]).convert("RGB"))).permute(2, 0, 1).contiguous()
+            mask = torch.from_numpy(np.array(Image.open(self.index_masks[i])))
+            if mask.dim() == 3:
+                mask = mask[..., 0]
+            for ty in range(self.H // p):
+                for tx in range(self.W // p):
+                    y, x = ty * p, tx * p
+                    if self.random_shift:
+                        y = min(max(y + random.randint(-20, 20), 0), self.H - p)
+                        x = min(max(x + random.randint(-20, 20), 0), self.W - p)
+                    patches.append((img[:, y:y + p, x:x + p].contiguous(), mask[y:y + p, x:x + p].contiguous().to(torch.uint8),
+                                    torch.zeros(1), torch.zeros(1)))
+        random.shuffle(patches)
+        return _Chunk(patches)
+
+    def get_class_weights(self, classes, ignore_background=False):
+        from PIL import Image
+        if self.count is None:
+            self.count = torch.zeros(classes, dtype=torch.float32)
+            for f in self.index_masks:
+                m = torch.from_numpy(np.array(Image.open(f))).reshape(-1).long()
+                self.count += torch.bincount(m, minlength=classes)[:classes].float()
+        return class_weights_from_counts(self.count, ignore_background)
+
+
+def make_loader(spec, chunk_size, patch_size, num_classes, random_shift=False, seed=0):
+    """`spec` is a dataset directory, or 'synthetic:<n_images>[:<tiles_per_image>]'."""
+    if isinstance(spec, str) and spec.startswith("synthetic:"):
+        parts = spec.split(":")
+        return SyntheticLoader(int(parts[1]), chunk_size, patch_size, num_classes,
+                               tiles_per_image=int(parts[2]) if len(parts) > 2 else 16, seed=seed)
+    return Loader(spec, chunk_size, random_shift=random_shift, patch_size=patch_size)
