@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
         ("relu", C.c_int32), ("pixel_shuffle", C.c_int32),
-        ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p),
+        ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p), ("stat_cnt", C.c_void_p),
         ("dtype", C.c_int32),
     ]
 
@@ -47,12 +47,12 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "cvcs_last_error": (C.c_char_p, []),
     "cvcs_abi_version": (_i, []),
-    "cvcs_conv_stat_rows": (_i, [_i64]),
+    "cvcs_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "cvcs_wgrad_slices": (_i, [_i] * 8),
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "cvcs_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "cvcs_bn_finalize_workspace_floats": (_i, [_i, _i]),
-    "cvcs_bn_finalize": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_finalize": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_act": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "cvcs_bn_bwd_rows": (_i, [_i64]),
     "cvcs_bn_bwd_reduce": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),

@@ -28,11 +28,13 @@ struct ConvArgs {
   char* out;
   float* stat_sum;
   float* stat_m2;
+  float* stat_cnt;
   int64_t in_ld, out_ld;  // in elements
   int B, H, W, Cin, Ho, Wo, Cout;
   int KH, KW, stride, pad, dil;
   int relu, pixel_shuffle;
   int M;
+  int tiles_x, tiles_y;   // halo kernel: 16x16 output tiles per image
 };
 
 template <typename T> struct Mma;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         p.stat_m2[row * p.Cout + n] = q;
       }
     }
+    if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[(int64_t)blockIdx.x * 2 + wm] = (float)nvalid;
   }
   // ---- transpose through LDS, store whole pixel rows.  (The trailing barrier of the main loop already
   //      separates the last fragment reads from these writes.)
@@ -267,6 +270,284 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 }
 
+
+// ===================================================================================================================
+// 3x3 / stride 1 / pad 1 specialisation ("halo kernel"): the workgroup owns a 16x16 output tile of ONE image, stages
+// the 18x18-pixel input halo of a 64-byte channel slice ONCE and reuses it for all nine taps (a tap is a row offset
+// into the halo tile), so the A operand crosses L2->LDS once per slice instead of nine times; only the weight tile
+// (BN x 64 B per tap, identical for every workgroup -> L2 hits) is streamed per tap.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): a wave-instruction fills 16 LDS rows
+// (1 KiB, lane-linear), the XOR swizzle is applied on the per-lane SOURCE address, padding pixels read a 16-byte zero
+// word.  Weight tiles run two steps ahead in a 3-deep ring, the next slice's halo arrives in 21 pieces spread over
+// the first six tap steps; each step ends with a COUNTED `s_waitcnt vmcnt(k)` (k = DMA instructions this wave issued
+// in this step, so everything older has landed) and a raw s_barrier - the pipeline is never drained in the loop.
+// Fragment reads are inline-asm ds_read_b128 blocks (with their own lgkmcnt wait): hipcc would otherwise put a
+// vmcnt(0) in front of every LDS read while a DMA is in flight.  The swizzle keeps those reads conflict-free for ANY
+// starting halo row (rows r / r+12 and r+4 / r+8 of a ds_read_b128 lane group always differ in bit 2).
+// Waves: WM x WN = 4; wave tile = (16/WM) image rows x 16 pixels x (BN/WN) channels.
+__device__ uint4 g_zero16;  // zero-initialised device word: the DMA source of padding pixels
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_read4(u32x4& a, u32x4& b, u32x4& c, u32x4& d, unsigned pa, unsigned pb, unsigned pc,
+                                          unsigned pd) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+               : "v"(pa), "v"(pb), "v"(pc), "v"(pd)
+               : "memory");
+}
+__device__ __forceinline__ void lds_read2(u32x4& a, u32x4& b, unsigned pa, unsigned pb) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(pa), "v"(pb)
+               : "memory");
+}
+// wait until at most k of this wave's vector-memory operations are outstanding, then the workgroup barrier
+__device__ __forceinline__ void wait_vm_barrier(int k) {
+  if (k <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T> __device__ __forceinline__ f32x4 mma_u(const u32x4& a, const u32x4& b, f32x4 c) {
+  return Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c);
+}
+
+template <typename T, int BN, int WM>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int KG = 64 / ES;
+  constexpr int WN = 4 / WM;
+  constexpr int MREP = 16 / WM;        // image rows per wave
+  constexpr int WNC = BN / WN;         // channels per wave
+  constexpr int NREP = WNC / 16;
+  static_assert(NREP == 4 && (MREP == 4 || MREP == 8), "fragment blocks are written for NREP = 4, MREP = 4 | 8");
+  constexpr int HS = 18, HROWS = HS * HS;
+  constexpr int HGROUPS = (HROWS + 15) / 16;       // 21 DMA pieces of 16 rows
+  constexpr int A_BYTES = HGROUPS * 1024;          // 21504
+  constexpr int B_BYTES = BN * 64;
+  constexpr int BGROUPS = BN / 16;                 // 4 | 8 DMA pieces per weight tile
+  constexpr int BPW = BGROUPS / 4;                 // pieces per wave
+  constexpr int OROW = BN * ES + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                     // [2][A_BYTES]
+  char* sB = smem + 2 * A_BYTES;       // [3][B_BYTES]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int b = blockIdx.x / tiles_per_img;
+  const int trem = blockIdx.x - b * tiles_per_img;
+  const int ty0 = (trem / p.tiles_x) * 16, tx0 = (trem % p.tiles_x) * 16;
+  const int n0 = blockIdx.y * BN;
+  const int nslice = p.Cin / KG;
+  const int total = nslice * 9;
+  const int64_t wt_tap_stride = (int64_t)p.Cout * p.Cin;
+  const int64_t img_base = (int64_t)b * p.H * p.W;
+  const int rr = lane >> 2, pc = lane & 3;   // this lane's row / physical chunk inside a 16-row DMA piece
+
+  // DMA piece g of the halo of slice cs -> buffer buf
+  auto dma_halo = [&](int g, int cs, int buf) {
+    const int row = g * 16 + rr;
+    const int c = swz(row, pc);  // logical chunk stored at physical chunk pc
+    const int hy = row / HS, hx = row - hy * HS;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const char* src = reinterpret_cast<const char*>(&g_zero16);
+    if (row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      src = p.in + ((img_base + (int64_t)iy * p.W + ix) * p.in_ld + (int64_t)cs * KG) * ES + c * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
+  };
+  // this wave's pieces of the weight tile (cs, tap) -> ring slot
+  auto dma_b = [&](int cs, int tap, int slot) {
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const int g = wave + 4 * j;
+      const int row = g * 16 + rr;
+      const int c = swz(row, pc);
+      const char* src = p.wt + ((int64_t)tap * wt_tap_stride + (int64_t)(n0 + row) * p.Cin + (int64_t)cs * KG) * ES + c * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + g * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int i = 0; i < MREP; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: whole halo of slice 0, weight tiles of steps 0 and 1
+  for (int g = wave; g < HGROUPS; g += 4) dma_halo(g, 0, 0);
+  dma_b(0, 0, 0);
+  if (total > 1) dma_b(0, 1, 1);   // total = 9 * nslice >= 9
+  wait_vm_barrier(0);
+
+  // per-lane constant parts of the fragment addresses
+  unsigned baddr[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int r = wn * WNC + j * 16 + fr;
+    baddr[j] = lds0 + 2 * A_BYTES + r * 64 + swz(r, fg) * 16;
+  }
+
+  int cs = 0, tap = 0, slot = 0;   // slot = s % 3
+  for (int s = 0; s < total; ++s) {
+    int k = 0;
+    if (s + 2 < total) {
+      int t2 = tap + 2, c2 = cs;
+      if (t2 >= 9) { t2 -= 9; c2 += 1; }
+      int slot2 = slot + 2; if (slot2 >= 3) slot2 -= 3;
+      dma_b(c2, t2, slot2);
+      k += BPW;
+    }
+    if (cs + 1 < nslice && 4 * tap + wave < HGROUPS) {
+      dma_halo(4 * tap + wave, cs + 1, (cs + 1) & 1);
+      k += 1;
+    }
+    {
+      const unsigned abase = lds0 + (cs & 1) * A_BYTES;
+      const unsigned boff = slot * B_BYTES;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      unsigned aaddr[MREP];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i) {
+        const int row = (wm * MREP + i + kh) * HS + fr + kw;
+        aaddr[i] = abase + row * 64 + swz(row, fg) * 16;
+      }
+      u32x4 bf0, bf1, bf2, bf3, a0, a1, a2, a3;
+      lds_read4(bf0, bf1, bf2, bf3, baddr[0] + boff, baddr[1] + boff, baddr[2] + boff, baddr[3] + boff);
+      if constexpr (MREP == 8) {
+        lds_read4(a0, a1, a2, a3, aaddr[0], aaddr[1], aaddr[2], aaddr[3]);
+      } else {
+        lds_read2(a0, a1, aaddr[0], aaddr[1]);
+      }
+      auto row_mma = [&](int i, const u32x4& af) {
+        acc[i][0] = mma_u<T>(af, bf0, acc[i][0]);
+        acc[i][1] = mma_u<T>(af, bf1, acc[i][1]);
+        acc[i][2] = mma_u<T>(af, bf2, acc[i][2]);
+        acc[i][3] = mma_u<T>(af, bf3, acc[i][3]);
+      };
+      if constexpr (MREP == 8) {
+        u32x4 a4, a5, a6, a7;
+        row_mma(0, a0); row_mma(1, a1);
+        lds_read4(a4, a5, a6, a7, aaddr[4], aaddr[5], aaddr[6], aaddr[7]);
+        row_mma(2, a2); row_mma(3, a3);
+        row_mma(4, a4); row_mma(5, a5); row_mma(6, a6); row_mma(7, a7);
+      } else {
+        row_mma(0, a0);
+        lds_read2(a2, a3, aaddr[2], aaddr[3]);
+        row_mma(1, a1);
+        row_mma(2, a2); row_mma(3, a3);
+      }
+    }
+    wait_vm_barrier(k);
+    if (++tap == 9) { tap = 0; ++cs; }
+    if (++slot == 3) slot = 0;
+  }
+
+  // ---- epilogue: bias / ReLU.  acc[i][j][r]: image row y = wm*MREP + i, pixel x = fg*4 + r, channel = .. + fr
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const float bv = p.bias ? p.bias[n0 + wn * WNC + j * 16 + fr] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        acc[i][j][r] = v;
+      }
+  }
+  int ny = p.H - ty0 - wm * MREP; ny = ny < 0 ? 0 : (ny > MREP ? MREP : ny);
+  int nx = p.W - tx0;             nx = nx > 16 ? 16 : nx;
+  if (p.stat_sum) {
+    const int nvalid = ny * nx;
+    const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
+    const int64_t row = (int64_t)blockIdx.x * WM + wm;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i < ny && fg * 4 + r < nx) s += acc[i][j][r];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * inv;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i < ny && fg * 4 + r < nx) {
+            const float d = acc[i][j][r] - mean;
+            q += d * d;
+          }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (fg == 0) {
+        const int n = n0 + wn * WNC + j * 16 + fr;
+        p.stat_sum[row * p.Cout + n] = s;
+        p.stat_m2[row * p.Cout + n] = q;
+      }
+    }
+    if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[row] = (float)nvalid;
+  }
+  // ---- store: two halves of 8 image rows, transposed through LDS into whole pixel rows
+  constexpr int CPR = BN * ES / 16;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if ((wm * MREP) / 8 == h) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lrow = (wm * MREP + i - h * 8) * 16 + fg * 4 + r;
+            const int col = wn * WNC + j * 16 + fr;
+            Elem<T>::st(reinterpret_cast<T*>(smem + lrow * OROW) + col, acc[i][j][r]);
+          }
+    }
+    __syncthreads();
+    for (int id = tid; id < 128 * CPR; id += 256) {
+      const int lrow = id / CPR, c = id - lrow * CPR;
+      const int y = ty0 + h * 8 + (lrow >> 4), x = tx0 + (lrow & 15);
+      if (y >= p.H || x >= p.W) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + lrow * OROW + c * 16);
+      char* dst = p.out + ((img_base + (int64_t)y * p.W + x) * p.out_ld + n0) * ES + c * 16;
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int BN, int WM>
+static int launch_halo(const ConvArgs& a, hipStream_t st) {
+  constexpr int ES = sizeof(T);
+  size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(BN * 64);
+  size_t epi = (size_t)128 * (BN * ES + 16);
+  size_t lds = stage > epi ? stage : epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)(a.Cout / BN));
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM>), grid, dim3(256), lds, st, a);
+  CVCS_CHECK_LAUNCH("cvcs_conv2d(halo)");
+  return CVCS_OK;
+}
+
 template <typename T, int BN>
 static int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
@@ -289,7 +570,18 @@ static int launch(const ConvArgs& a, hipStream_t st) {
 
 using namespace cvcs;
 
-extern "C" int cvcs_conv_stat_rows(int64_t M) { return (int)(cdiv(M, kBM) * 2); }
+// 3x3 / stride 1 / pad 1 / dil 1 convolutions whose image is at least half a tile wide take the halo kernel
+static bool use_halo(const cvcs_conv_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
+         d->W >= 8;
+}
+static int halo_wm(const cvcs_conv_desc* d) { return d->Cout % 128 == 0 ? 2 : 4; }
+
+extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
+  if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
+  if (use_halo(d)) return d->B * (int)cdiv(d->H, 16) * (int)cdiv(d->W, 16) * halo_wm(d);
+  return (int)(cdiv((int64_t)d->B * d->Ho * d->Wo, kBM) * 2);
+}
 
 extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   CVCS_CHECK_ARG(d != nullptr, "cvcs_conv2d: null descriptor");
@@ -313,7 +605,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
                  "cvcs_conv2d: tensors must be 16-byte aligned");
   const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
   CVCS_CHECK_ARG(M < (1ll << 31) - kBM, "cvcs_conv2d: too many output pixels");
-  CVCS_CHECK_ARG((d->stat_sum == nullptr) == (d->stat_m2 == nullptr), "cvcs_conv2d: stat_sum/stat_m2 go together");
+  CVCS_CHECK_ARG((d->stat_sum == nullptr) == (d->stat_m2 == nullptr) && (d->stat_sum == nullptr) == (d->stat_cnt == nullptr),
+                 "cvcs_conv2d: stat_sum/stat_m2/stat_cnt go together");
   int bn = (d->Cout % 128 == 0) ? 128 : 64;
   if (d->pixel_shuffle) {
     CVCS_CHECK_ARG(d->Cout % 4 == 0 && (d->Cout / 4) % 64 == 0, "cvcs_conv2d: pixel_shuffle needs Cout/4 %% 64 == 0");
@@ -321,12 +614,17 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   }
   ConvArgs a;
   a.in = (const char*)d->in; a.wt = (const char*)d->wt; a.bias = d->bias; a.out = (char*)d->out;
-  a.stat_sum = d->stat_sum; a.stat_m2 = d->stat_m2;
+  a.stat_sum = d->stat_sum; a.stat_m2 = d->stat_m2; a.stat_cnt = d->stat_cnt;
+  a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
+  if (use_halo(d)) {
+    if (d->dtype == CVCS_F32) return halo_wm(d) == 2 ? launch_halo<float, 128, 2>(a, st) : launch_halo<float, 64, 4>(a, st);
+    return halo_wm(d) == 2 ? launch_halo<bf16_t, 128, 2>(a, st) : launch_halo<bf16_t, 64, 4>(a, st);
+  }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

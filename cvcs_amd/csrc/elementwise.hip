@@ -31,15 +31,14 @@ __device__ __forceinline__ void merge(Moments& a, double nb, double mean_b, doub
 
 constexpr int kDirectRows = 2048;
 
-// merge rows [r0, r1) (each covering `ppr` pixels, the last one of the tensor possibly fewer) for channel c
-__device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, const float* __restrict__ sm2, int r0, int r1,
-                                              int rstep, int64_t ppr, int64_t M, int C, int c) {
+// merge partial rows r0, r0+rstep, .. < r1 (row r covers scnt[r] pixels) for channel c
+__device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, const float* __restrict__ sm2,
+                                              const float* __restrict__ scnt, int r0, int r1, int rstep, int C, int c) {
   Moments a{0.0, 0.0, 0.0};
   for (int r = r0; r < r1; r += rstep) {
-    int64_t n = M - (int64_t)r * ppr;
-    n = n > ppr ? ppr : n;
-    if (n <= 0) break;
-    merge(a, (double)n, (double)ssum[(int64_t)r * C + c] / (double)n, (double)sm2[(int64_t)r * C + c]);
+    const double n = (double)scnt[r];
+    if (n <= 0.0) continue;
+    merge(a, n, (double)ssum[(int64_t)r * C + c] / n, (double)sm2[(int64_t)r * C + c]);
   }
   return a;
 }
@@ -56,23 +55,24 @@ __device__ __forceinline__ Moments merge_lanes(Moments a, int rl, int cl) {
 
 // stage 1: grid (nblk, C/16); block b merges rows [b*R, (b+1)*R) -> out_sum/out_m2 [nblk][C] (sum = mean*n)
 __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
-                                                             int rows, int R, int64_t ppr, int64_t M, int C,
-                                                             float* out_sum, float* out_m2) {
+                                                             const float* __restrict__ scnt, int rows, int R, int C,
+                                                             float* out_sum, float* out_m2, float* out_cnt) {
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.y * 16 + cl;
   const int r0 = blockIdx.x * R;
   int r1 = r0 + R;
   if (r1 > rows) r1 = rows;
-  Moments a = merge_rows(ssum, sm2, r0 + rl, r1, 16, ppr, M, C, c);
+  Moments a = merge_rows(ssum, sm2, scnt, r0 + rl, r1, 16, C, c);
   a = merge_lanes(a, rl, cl);
   if (rl == 0) {
     out_sum[(int64_t)blockIdx.x * C + c] = (float)(a.mean * a.n);
     out_m2[(int64_t)blockIdx.x * C + c] = (float)a.m2;
+    if (blockIdx.y == 0 && cl == 0) out_cnt[blockIdx.x] = (float)a.n;   // exact: pixel counts < 2^24
   }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
-                                                         int rows, int64_t ppr, int64_t M, int C,
+                                                         const float* __restrict__ scnt, int rows, int64_t M, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum, float eps,
                                                          int train, float* scale, float* shift, float* save_mean,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     return;
   }
-  Moments a = merge_rows(ssum, sm2, rl, rows, 16, ppr, M, C, c);
+  Moments a = merge_rows(ssum, sm2, scnt, rl, rows, 16, C, c);
   a = merge_lanes(a, rl, cl);
   if (rl != 0) return;
   const double mean = a.mean, m2 = a.m2;
@@ -504,34 +504,33 @@ using namespace cvcs;
 extern "C" int cvcs_bn_finalize_workspace_floats(int rows, int C) {
   if (rows <= kDirectRows) return 0;
   const int R = (int)cdiv(rows, 1024);
-  return 2 * (int)cdiv(rows, R) * C;
+  return (int)cdiv(rows, R) * (2 * C + 1);
 }
 
-extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, int rows, int64_t M, int C, const float* gamma,
-                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                int train, float* scale, float* shift, float* save_mean, float* save_invstd,
-                                float* workspace, void* stream) {
+extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, const float* stat_cnt, int rows, int64_t M, int C,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, int train, float* scale, float* shift, float* save_mean,
+                                float* save_invstd, float* workspace, void* stream) {
   CVCS_CHECK_ARG(C > 0 && C % 16 == 0 && gamma && beta && running_mean && running_var && scale && shift,
                  "cvcs_bn_finalize: null argument or C %% 16 != 0");
   hipStream_t st = (hipStream_t)stream;
-  int64_t ppr = 64;
   if (train) {
-    CVCS_CHECK_ARG(stat_sum && stat_m2 && save_mean && save_invstd && M > 0, "cvcs_bn_finalize: train needs statistics");
-    CVCS_CHECK_ARG(rows == cvcs_conv_stat_rows(M), "cvcs_bn_finalize: rows=%d but M=%lld gives %d", rows, (long long)M,
-                   cvcs_conv_stat_rows(M));
+    CVCS_CHECK_ARG(stat_sum && stat_m2 && stat_cnt && save_mean && save_invstd && M > 0 && rows > 0,
+                   "cvcs_bn_finalize: train needs statistics");
     if (rows > kDirectRows) {
       CVCS_CHECK_ARG(workspace != nullptr, "cvcs_bn_finalize: %d partial rows need the workspace", rows);
       const int R = (int)cdiv(rows, 1024);
       const int nblk = (int)cdiv(rows, R);
       float* o_sum = workspace;
       float* o_m2 = workspace + (int64_t)nblk * C;
+      float* o_cnt = workspace + (int64_t)2 * nblk * C;
       hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2,
-                         rows, R, (int64_t)64, M, C, o_sum, o_m2);
-      stat_sum = o_sum; stat_m2 = o_m2; rows = nblk; ppr = (int64_t)64 * R;
+                         stat_cnt, rows, R, C, o_sum, o_m2, o_cnt);
+      stat_sum = o_sum; stat_m2 = o_m2; stat_cnt = o_cnt; rows = nblk;
     }
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2, rows, ppr, M, C, gamma,
-                     beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean, save_invstd);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2, stat_cnt, rows, M, C,
+                     gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean, save_invstd);
   CVCS_CHECK_LAUNCH("cvcs_bn_finalize");
   return CVCS_OK;
 }

@@ -117,10 +117,13 @@ class UNetEngine:
                 self.up_in[d] = A(s, 2 * w)      # bilinear-upsampled input of the upscale conv
                 self.g_up_in[d] = A(s, 2 * w)
         self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=dev)
-        # statistics / partial-sum scratch, sized for the largest layer (level 1)
+        # conv-epilogue statistics scratch, sized for the worst layer
         M1 = B * S * S
-        self.stat_sum = torch.empty(ops.conv_stat_rows(M1) * 64, dtype=torch.float32, device=dev)
+        rows_c = [(ops.conv_stat_rows(View(self.ya[L], 0, WIDTHS[L - 1]), WIDTHS[L - 1], 3, 3, 1, 1), WIDTHS[L - 1])
+                  for L in range(1, 6)]
+        self.stat_sum = torch.empty(max(r * c for r, c in rows_c), dtype=torch.float32, device=dev)
         self.stat_m2 = torch.empty_like(self.stat_sum)
+        self.stat_cnt = torch.empty(max(r for r, _ in rows_c), dtype=torch.float32, device=dev)
         rows1 = ops.bn_bwd_rows(M1)
         self.part = [torch.empty(rows1 * 1024, dtype=torch.float32, device=dev) for _ in range(3)]
         self.head_part = torch.empty(ops.head_bwd_rows(M1) * (self.NC * 64 + self.NC), dtype=torch.float32, device=dev)
@@ -129,17 +132,12 @@ class UNetEngine:
         for (Bc, Ho, Cout, Cin, K, st) in self._wgrad_shapes(B):
             need = max(need, ops.wgrad_workspace_floats(Bc, Ho, Ho, Cout, Cin, K, K, st))
         self.wg_ws = torch.empty(need, dtype=torch.float32, device=dev)
-        bn_need = max(ops.bn_finalize_workspace_floats(ops.conv_stat_rows(B * s * s), w) for s, w in zip(s_, WIDTHS))
+        bn_need = max(ops.bn_finalize_workspace_floats(r, c) for r, c in rows_c)
         self.bn_ws = torch.empty(max(bn_need, 4), dtype=torch.float32, device=dev)
         self.bn = {}
         for name in self.P:
             if name.endswith(".weight") and self.P[name].dim() == 1:
                 self.bn[name[:-len(".weight")]] = _BN(self.P[name].numel(), dev)
-        # conv statistics need rows*C floats with C up to 1024 at small M: size for the worst layer
-        worst = max(ops.conv_stat_rows(B * s * s) * w for s, w in zip(s_, WIDTHS))
-        if worst > self.stat_sum.numel():
-            self.stat_sum = torch.empty(worst, dtype=torch.float32, device=dev)
-            self.stat_m2 = torch.empty_like(self.stat_sum)
 
     def _wgrad_shapes(self, B):
         s_ = self.sizes
@@ -171,13 +169,11 @@ class UNetEngine:
         pk = self.packed[conv]
         M = x.B * y.shape[1] * y.shape[2]
         C_ = y.shape[3]
-        rows = ops.conv_stat_rows(M)
-        ssum = self.stat_sum[:rows * C_] if train else None
-        sm2 = self.stat_m2[:rows * C_] if train else None
-        ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn,
-                   stat_sum=ssum, stat_m2=sm2)
+        rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1) if train else 0
+        stats = (self.stat_sum, self.stat_m2, self.stat_cnt) if train else None
+        ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats)
         st = self.bn[bnname]
-        ops.bn_finalize(ssum, sm2, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
+        ops.bn_finalize(stats, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
                         self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], train, st.scale, st.shift,
                         st.mean if train else None, st.invstd if train else None, workspace=self.bn_ws)
         ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)

@@ -97,23 +97,44 @@ def conv_out_hw(H, W, KH, KW, stride, pad, dil=1):
     return ((H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1)
 
 
-def conv_stat_rows(M: int) -> int:
-    return _lib.lib().cvcs_conv_stat_rows(M)
-
-
-def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
-           pixel_shuffle=False, stat_sum=None, stat_m2=None):
-    """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle)."""
+def _conv_desc(x: View, wt, bias, out: View, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats):
     Cout = wt.shape[1]
     Ho, Wo = conv_out_hw(x.H, x.W, KH, KW, stride, pad, dil)
     d = ConvDesc()
     d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
-    d.wt, d.bias = wt.data_ptr(), _ptr(bias)
-    d.out, d.out_ld, d.Ho, d.Wo, d.Cout = out.ptr, out.ld, Ho, Wo, Cout
+    d.wt, d.bias = _ptr(wt), _ptr(bias)
+    d.out, d.out_ld, d.Ho, d.Wo, d.Cout = 0 if out is None else out.ptr, 0 if out is None else out.ld, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad, d.dil = KH, KW, stride, pad, dil
     d.relu, d.pixel_shuffle = int(relu), int(pixel_shuffle)
-    d.stat_sum, d.stat_m2 = _ptr(stat_sum), _ptr(stat_m2)
+    if stats is not None:
+        d.stat_sum, d.stat_m2, d.stat_cnt = (_ptr(t) for t in stats)
     d.dtype = x.code
+    return d, Ho, Wo, Cout
+
+
+class _Shape:
+    """shape-only stand-in for a weight tensor ([taps][Cout][Cin]) when only the statistics row count is wanted"""
+    def __init__(self, taps, cout, cin):
+        self.shape = (taps, cout, cin)
+
+    def data_ptr(self):
+        return 0
+
+
+def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
+    """number of partial-statistics rows cvcs_conv2d writes for this geometry"""
+    d, _, _, _ = _conv_desc(x, _Shape(KH * KW, Cout, x.C), None, None, KH, KW, stride, pad, dil, False, False, None)
+    n = _lib.lib().cvcs_conv_stat_rows(C.byref(d))
+    if n < 0:
+        raise _lib.CvcsError("cvcs_conv_stat_rows: bad shape")
+    return n
+
+
+def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
+           pixel_shuffle=False, stats=None):
+    """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
+    stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...)."""
+    d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats)
     assert wt.shape[0] == KH * KW and wt.shape[2] == x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
     if pixel_shuffle:
         assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"
@@ -161,11 +182,13 @@ def bn_finalize_workspace_floats(rows: int, C_: int) -> int:
     return _lib.lib().cvcs_bn_finalize_workspace_floats(rows, C_)
 
 
-def bn_finalize(stat_sum, stat_m2, rows, M, C_, gamma, beta, rmean, rvar, train, scale, shift, save_mean, save_invstd,
+def bn_finalize(stats, rows, M, C_, gamma, beta, rmean, rvar, train, scale, shift, save_mean, save_invstd,
                 momentum=0.1, eps=1e-5, workspace=None):
+    """stats = (sum, m2, cnt) as written by conv2d (ignored when train is False)"""
+    ssum, sm2, scnt = stats if stats is not None else (None, None, None)
     if train and workspace is None and bn_finalize_workspace_floats(rows, C_) > 0:
         workspace = torch.empty(bn_finalize_workspace_floats(rows, C_), dtype=torch.float32, device=scale.device)
-    check(_lib.lib().cvcs_bn_finalize(_ptr(stat_sum), _ptr(stat_m2), rows, M, C_, gamma.data_ptr(), beta.data_ptr(),
+    check(_lib.lib().cvcs_bn_finalize(_ptr(ssum), _ptr(sm2), _ptr(scnt), rows, M, C_, gamma.data_ptr(), beta.data_ptr(),
                                       rmean.data_ptr(), rvar.data_ptr(), momentum, eps, int(train), scale.data_ptr(),
                                       shift.data_ptr(), _ptr(save_mean), _ptr(save_invstd), _ptr(workspace), _stream()),
           "cvcs_bn_finalize")

@@ -33,8 +33,6 @@ enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
 
 const char* cvcs_last_error(void);
 int cvcs_abi_version(void);
-/* number of float partial rows a conv with M output pixels writes per statistic (see cvcs_conv2d) */
-int cvcs_conv_stat_rows(int64_t M);
 /* number of split-K slices cvcs_conv2d_wgrad will use; workspace = slices*KH*KW*Cout*Cin floats */
 int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride);
 
@@ -43,8 +41,11 @@ int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, 
  * pixel_shuffle=1), and the input-gradient half of convolution_backward for both (S/train.py:125).
  *   out[p, n] = act( bias[n] + sum_{kh,kw,c} in[pix(p,kh,kw), c] * wt[kh*KW+kw][n][c] )
  * M = B*Ho*Wo output pixels; wt is [KH*KW][Cout][Cin] in `dtype`; Cin % (64/sizeof(dtype)) == 0, Cout % 64 == 0.
- * stat_sum/stat_m2 (optional, f32 [cvcs_conv_stat_rows(M)][Cout]): per 64-pixel row block, per channel, the sum
- * and the centred second moment of the values written - the BatchNorm batch statistics, fused.           */
+ * stat_sum/stat_m2 (optional, f32 [rows][Cout]) and stat_cnt (f32 [rows]), rows = cvcs_conv_stat_rows(desc): per
+ * wave-sized block of output pixels and channel, the pixel count, the sum and the second moment centred on the
+ * block's own mean of the values written - the BatchNorm batch statistics, fused into the epilogue.
+ * 3x3 / stride 1 / pad 1 convolutions run a specialised kernel that stages each 18x18 input halo once for all
+ * nine taps; every other geometry runs the generic gather kernel.                                          */
 typedef struct {
   const void* in;   int64_t in_ld;  int32_t B, H, W, Cin;
   const void* wt;   const float* bias;
@@ -52,10 +53,12 @@ typedef struct {
   int32_t KH, KW, stride, pad, dil;
   int32_t relu;           /* 1: ReLU in the epilogue (decoder order conv->ReLU->BN, S/blocks.py:40-45) */
   int32_t pixel_shuffle;  /* 1: Cout = 4*Cr, column (dy*2+dx)*Cr+co goes to pixel (2y+dy, 2x+dx), channel co */
-  float* stat_sum;  float* stat_m2;
+  float* stat_sum;  float* stat_m2;  float* stat_cnt;
   int32_t dtype;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
+/* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
+int cvcs_conv_stat_rows(const cvcs_conv_desc* d);
 
 /* ---- weight gradient ---------------------------------------------------------------------------------
  * replaces: the weight half of convolution_backward (S/train.py:125).
@@ -80,7 +83,7 @@ int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
  * mean/invstd for backward and update running stats (momentum 0.1, unbiased var).  train=0: scale/shift from the
  * running stats, partials ignored.                                                                        */
 int cvcs_bn_finalize_workspace_floats(int rows, int C);   /* 0 when the partial rows are merged directly */
-int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, int rows, int64_t M, int C,
+int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, const float* stat_cnt, int rows, int64_t M, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, int train,
                      float* scale, float* shift, float* save_mean, float* save_invstd, float* workspace, void* stream);

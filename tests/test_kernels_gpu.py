@@ -51,6 +51,10 @@ CONV_CASES = [
     (1, 20, 20, 32, 64, 3, 1, 2, 2, False),    # dilation 2 (ASPP-style)
     (1, 17, 13, 32, 64, 3, 2, 1, 1, True),     # stride 2, odd extent
     (2, 2, 2, 128, 256, 3, 1, 1, 1, False),    # deepest level of a 32x32 tile: 2x2 maps
+    (2, 32, 48, 64, 128, 3, 1, 1, 1, True),    # halo kernel, whole 16x16 tiles, BN=128
+    (1, 28, 20, 128, 64, 3, 1, 1, 1, False),   # halo kernel, ragged tiles (28x20), BN=64, 4 channel slices
+    (3, 14, 14, 96, 192, 3, 1, 1, 1, True),    # halo kernel, 14x14 maps (224-tile level 5), Cout % 128 != 0
+    (1, 40, 24, 64, 256, 3, 1, 1, 1, False),   # halo kernel, two column tiles of weights
 ]
 
 
@@ -72,11 +76,9 @@ def test_conv2d_matches_aten(case, dtype):
     Ho, Wo = ops.conv_out_hw(H, W, K, K, stride, pad, dil)
     out = torch.full((B, Ho, Wo, Cout + 64), 7.0, dtype=dtype, device=DEV)  # wider buffer: checks ld / channel offset
     M = B * Ho * Wo
-    rows = ops.conv_stat_rows(M)
-    ssum = torch.zeros(rows, Cout, device=DEV)
-    sm2 = torch.zeros(rows, Cout, device=DEV)
-    ops.conv2d(ops.view(xd), wf, b.to(DEV), ops.View(out, 64, Cout), K, K, stride, pad, dil, relu=relu,
-               stat_sum=ssum, stat_m2=sm2)
+    rows = ops.conv_stat_rows(ops.view(xd), Cout, K, K, stride, pad, dil)
+    stats = (torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, device=DEV))
+    ops.conv2d(ops.view(xd), wf, b.to(DEV), ops.View(out, 64, Cout), K, K, stride, pad, dil, relu=relu, stats=stats)
     torch.cuda.synchronize()
     got = from_nhwc(out[..., 64:])
     close(got, ref, tol(dtype), "conv out")
@@ -85,8 +87,9 @@ def test_conv2d_matches_aten(case, dtype):
     gamma, beta = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
     rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     scale, shift, mean, invstd = (torch.empty(Cout, device=DEV) for _ in range(4))
-    ops.bn_finalize(ssum, sm2, rows, M, Cout, gamma, beta, rm, rv, True, scale, shift, mean, invstd)
+    ops.bn_finalize(stats, rows, M, Cout, gamma, beta, rm, rv, True, scale, shift, mean, invstd)
     torch.cuda.synchronize()
+    assert stats[2].sum().item() == M
     rmean = ref.double().mean(dim=(0, 2, 3))
     rvar = ref.double().var(dim=(0, 2, 3), unbiased=False)
     close(mean.cpu().double(), rmean, 5e-3 if dtype == torch.bfloat16 else 1e-4, "batch mean")
@@ -108,13 +111,14 @@ def test_conv2d_f32_large_mean_statistics(dtype, B, H, W):
     wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype, want_dgrad=False)
     out = torch.empty(B, H, W, Cout, dtype=dtype, device=DEV)
     M = B * H * W
-    rows = ops.conv_stat_rows(M)
-    ssum, sm2 = torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, Cout, device=DEV)
-    ops.conv2d(ops.view(to_nhwc(x, dtype)), wf, None, ops.view(out), 3, 3, 1, 1, stat_sum=ssum, stat_m2=sm2)
+    xv = ops.view(to_nhwc(x, dtype))
+    rows = ops.conv_stat_rows(xv, Cout, 3, 3, 1, 1)
+    stats = (torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, device=DEV))
+    ops.conv2d(xv, wf, None, ops.view(out), 3, 3, 1, 1, stats=stats)
     gamma, beta = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
     rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     scale, shift, mean, invstd = (torch.empty(Cout, device=DEV) for _ in range(4))
-    ops.bn_finalize(ssum, sm2, rows, M, Cout, gamma, beta, rm, rv, True, scale, shift, mean, invstd)
+    ops.bn_finalize(stats, rows, M, Cout, gamma, beta, rm, rv, True, scale, shift, mean, invstd)
     torch.cuda.synchronize()
     rvar = ref.var(dim=(0, 2, 3), unbiased=False)
     close(invstd.cpu().double(), 1.0 / torch.sqrt(rvar + 1e-5), 1e-2 if dtype == torch.bfloat16 else 1e-4, "invstd")

@@ -130,7 +130,7 @@ def test_fp32_gradients_vs_f64_oracle(variant):
         # boundary flips one pixel's mask; with only 2048 pixels in this fixture one flip moves a weight gradient by
         # ~1/sqrt(2048) = 2e-2 and every layer upstream of it by ~7e-3 (torch-CPU fp32 shows the same events).  The
         # last layers cannot be downstream of a flip and are held to the tight bound.
-        tight = k.startswith(("decode_forward4.1", "decode_forward4.0.layer.5", "decode_forward4.0.layer.3"))
+        tight = k.startswith(("decode_forward4.1", "decode_forward4.0.layer.5"))
         assert err < (5e-4 if tight else 5e-2), f"{k}: rel err {err:.2e}"
 
 
