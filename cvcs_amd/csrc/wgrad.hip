@@ -32,19 +32,56 @@ struct WgradArgs {
   int ntile_n;                // Cin tiles
 };
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ uint4 g_wzero16;  // zero word: LDS-DMA source of padding pixels / absent channels
 
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// four transposed LDS reads (4 pixel rows x 16 channels each -> 4 k-values of one channel per lane) + their wait
+__device__ __forceinline__ void tr_read4(u32x2& o0, u32x2& o1, u32x2& o2, u32x2& o3, unsigned a0, unsigned a1, unsigned a2,
+                                         unsigned a3) {
+  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\t"
+               "ds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+               : "memory");
+}
+
+__device__ __forceinline__ void wait_vm_barrier_n(int k) {
+  switch (k) {
+    case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+}
+
+// Staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB lane-linear pieces) into a ring of NS stages, NS-1 K-tiles ahead;
+// each iteration ends with a counted vmcnt (the pieces this wave issued in this iteration may stay in flight) and a
+// raw barrier.  bf16 LDS rows are 128 B, 32-byte chunk cc of row r is stored at chunk cc ^ ((r>>1)&3) (swizzle applied
+// on the DMA source address): the two 4x16 blocks a 32-lane half of ds_read_b64_tr_b16 reads - eight consecutive
+// tile rows - then fall on eight distinct 32-byte bank slots for any starting row.
+template <typename T, int NT, int NS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   constexpr int ES = sizeof(T);
-  constexpr int PITCH = 64 * ES + 32;      // LDS row pitch (bytes) of both tiles
-  constexpr int CPR = 64 * ES / 16;        // 16-byte chunks per row
-  constexpr int DY_BYTES = 32 * PITCH;
+  constexpr int ROWB = 64 * ES;            // LDS row: 64 channels of one pixel
+  constexpr int RPP = 1024 / ROWB;         // rows per DMA piece (8 | 4)
+  constexpr int CPR = ROWB / 16;           // 16-byte chunks per row (8 | 16)
+  constexpr int DY_BYTES = 32 * ROWB;
+  constexpr int X_BYTES = 128 * ROWB;
+  constexpr int STAGE = DY_BYTES + X_BYTES;
+  constexpr int DYP = 32 / RPP;            // dy pieces per K-tile (4 | 8)
+  constexpr int D = NS - 1;                // prefetch distance in K-tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sdy = smem;
-  char* sx = smem + DY_BYTES;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x;
   const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
@@ -64,86 +101,97 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
   const int fr = lane & 15, fg = lane >> 4;
   const int hrows = p.HR * p.HC;
-  const int cin_rem = p.Cin - ci0;  // channels of this Cin tile that exist (rest zero-filled)
+  const int xpieces = (hrows + RPP - 1) / RPP;
+  const int cin_rem = p.Cin - ci0;
+  const int rr = lane / CPR, pc = lane % CPR;   // row / physical 16-byte chunk of this lane inside a DMA piece
+  const int my_pieces = DYP / 4 + (xpieces - wave + 3) / 4;   // DMA instructions this wave issues per K-tile
 
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  auto swz_chunk = [&](int row, int chunk) -> int {   // logical <-> physical 16-byte chunk (involution)
+    if constexpr (ES == 2) return chunk ^ (((row >> 1) & 3) << 1);
+    else return chunk;
+  };
+  auto issue_tile = [&](int kt, int st) {
     const int b = kt / (p.tiles_x * p.tiles_y);
     const int tr = kt - b * (p.tiles_x * p.tiles_y);
     const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
-    __syncthreads();  // previous K-tile's fragment reads are done
-    // ---- stage dy tile: 32 pixels x 64 co
-    for (int id = tid; id < 32 * CPR; id += 256) {
-      const int k = id / CPR, c = id - k * CPR;
+    char* sdy = smem + st * STAGE;
+    char* sx = sdy + DY_BYTES;
+    for (int pi = wave; pi < DYP; pi += 4) {
+      const int k = pi * RPP + rr;
+      const int c = swz_chunk(k, pc);
       const int oy = ty0 + k / p.TW, ox = tx0 + k % p.TW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (oy < p.Ho && ox < p.Wo) {
-        const char* src = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0) * ES + c * 16;
-        v = *reinterpret_cast<const uint4*>(src);
-      }
-      *reinterpret_cast<uint4*>(sdy + k * PITCH + c * 16) = v;
+      const char* src = reinterpret_cast<const char*>(&g_wzero16);
+      if (oy < p.Ho && ox < p.Wo) src = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0) * ES + c * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sdy + pi * 1024), 16, 0, 0);
     }
-    // ---- stage x halo tile: HR x HC pixels x 64 ci
     const int iy_base = ty0 * p.stride - p.pad, ix_base = tx0 * p.stride - p.pad;
-    for (int id = tid; id < hrows * CPR; id += 256) {
-      const int r = id / CPR, c = id - r * CPR;
+    for (int pi = wave; pi < xpieces; pi += 4) {
+      const int r = pi * RPP + rr;
+      const int c = swz_chunk(r, pc);
       const int iy = iy_base + r / p.HC, ix = ix_base + r % p.HC;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c * (16 / ES) < cin_rem) {
-        const char* src = p.x + ((((int64_t)b * p.H + iy) * p.W + ix) * p.x_ld + ci0) * ES + c * 16;
-        v = *reinterpret_cast<const uint4*>(src);
-      }
-      *reinterpret_cast<uint4*>(sx + r * PITCH + c * 16) = v;
+      const char* src = reinterpret_cast<const char*>(&g_wzero16);
+      if (r < hrows && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c * (16 / ES) < cin_rem)
+        src = p.x + ((((int64_t)b * p.H + iy) * p.W + ix) * p.x_ld + ci0) * ES + c * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sx + pi * 1024), 16, 0, 0);
     }
-    __syncthreads();
+  };
 
+  // ---- prologue: the first D K-tiles
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (kt_begin + d < kt_end) issue_tile(kt_begin + d, d);
+  wait_vm_barrier_n(0);
+
+  int st = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    int issued = 0;
+    if (kt + D < kt_end) {
+      int st2 = st + D; if (st2 >= NS) st2 -= NS;
+      issue_tile(kt + D, st2);
+      issued = my_pieces;
+    }
     if constexpr (ES == 2) {
-      // lane l: group g = l>>4, i = l&15 -> supplies row q = i>>2, columns 4*(i&3).. of its group's block
+      const unsigned dyb = lds0 + st * STAGE, xb = dyb + DY_BYTES;
+      // lane l: group g = l>>4, i = l&15 -> supplies row q = i>>2 and 8 bytes at column 4*(i&3) of its group's block
       const int q = fr >> 2, pp = fr & 3;
       const int k0 = 4 * fg + q, k1 = 16 + 4 * fg + q;      // tile pixels of the two transposed reads
-      uint4 af[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int col = (wm * 32 + i * 16 + 4 * pp) * 2;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(sdy + k0 * PITCH + col));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(sdy + k1 * PITCH + col));
-        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        af[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-      }
+      auto addr = [&](unsigned base, int row, int cc) -> unsigned {
+        return base + row * ROWB + ((cc ^ ((row >> 1) & 3)) << 5) + pp * 8;
+      };
+      u32x2 a0l, a0h, a1l, a1h;
+      tr_read4(a0l, a0h, a1l, a1h, addr(dyb, k0, wm * 2), addr(dyb, k1, wm * 2), addr(dyb, k0, wm * 2 + 1),
+               addr(dyb, k1, wm * 2 + 1));
+      const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(a0l.x, a0l.y, a0h.x, a0h.y));
+      const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a1l.x, a1l.y, a1h.x, a1h.y));
       const int hb0 = ((k0 / p.TW) * p.stride) * p.HC + (k0 % p.TW) * p.stride;
       const int hb1 = ((k1 / p.TW) * p.stride) * p.HC + (k1 % p.TW) * p.stride;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int kh = t / p.KW, kw = t - kh * p.KW;
         const int off = kh * p.HC + kw;
-        uint4 bfr[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = (wn * 32 + j * 16 + 4 * pp) * 2;
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(sx + (hb0 + off) * PITCH + col));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(sx + (hb1 + off) * PITCH + col));
-          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-          bfr[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                   __builtin_bit_cast(bf16x8, bfr[j]), acc[t][i][j], 0, 0, 0);
+        u32x2 b0l, b0h, b1l, b1h;
+        tr_read4(b0l, b0h, b1l, b1h, addr(xb, hb0 + off, wn * 2), addr(xb, hb1 + off, wn * 2), addr(xb, hb0 + off, wn * 2 + 1),
+                 addr(xb, hb1 + off, wn * 2 + 1));
+        const bf16x8 bf0 = __builtin_bit_cast(bf16x8, make_uint4(b0l.x, b0l.y, b0h.x, b0h.y));
+        const bf16x8 bf1 = __builtin_bit_cast(bf16x8, make_uint4(b1l.x, b1l.y, b1h.x, b1h.y));
+        acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
+        acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
+        acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
+        acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
       }
     } else {
-      // f32: MFMA pass s contracts tile pixels k = 4s + g (g = lane>>4)
+      // f32 (parity path): plain LDS reads; MFMA pass s contracts tile pixels k = 4s + g (g = lane>>4)
+      const char* sdy = smem + st * STAGE;
+      const char* sx = sdy + DY_BYTES;
 #pragma unroll 1
       for (int s = 0; s < 8; ++s) {
         const int k = 4 * s + fg;
         float af[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          af[i] = *reinterpret_cast<const float*>(sdy + k * PITCH + (wm * 32 + i * 16 + fr) * 4);
+          af[i] = *reinterpret_cast<const float*>(sdy + k * ROWB + (wm * 32 + i * 16 + fr) * 4);
         const int hb = ((k / p.TW) * p.stride) * p.HC + (k % p.TW) * p.stride;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -151,7 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
           const int row = hb + kh * p.HC + kw;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const float bv = *reinterpret_cast<const float*>(sx + row * PITCH + (wn * 32 + j * 16 + fr) * 4);
+            const float bv = *reinterpret_cast<const float*>(sx + row * ROWB + (wn * 32 + j * 16 + fr) * 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
               acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bv, acc[t][i][j], 0, 0, 0);
@@ -159,6 +207,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         }
       }
     }
+    wait_vm_barrier_n(D >= 2 ? issued : 0);
+    if (++st == NS) st = 0;
   }
 
   // ---- partials: ws[slice][tap][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
@@ -224,15 +274,16 @@ static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int
 template <typename T, int NT>
 static int launch(const WgradArgs& a, const WgradPlan& pl, hipStream_t st) {
   constexpr int ES = sizeof(T);
-  size_t lds = (size_t)(32 + pl.HR * pl.HC) * (64 * ES + 32);
+  constexpr int NS = ES == 2 ? 3 : 2;   // bf16: two K-tiles in flight; f32 (parity path): one
+  const size_t lds = (size_t)NS * (32 + 128) * 64 * ES;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)((32 + 160) * (64 * ES + 32)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, NT, NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((unsigned)pl.tiles_mn, (unsigned)pl.nslice);
-  hipLaunchKernelGGL((wgrad_kernel<T, NT>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_kernel<T, NT, NS>), grid, dim3(256), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad");
   return CVCS_OK;
 }
@@ -265,7 +316,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
                  "cvcs_conv2d_wgrad: leading dimensions");
   CVCS_CHECK_ARG(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad: alignment");
   WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride);
-  CVCS_CHECK_ARG(pl.HR * pl.HC <= 160, "cvcs_conv2d_wgrad: halo tile too large");
+  CVCS_CHECK_ARG(pl.HR * pl.HC <= 128, "cvcs_conv2d_wgrad: halo tile too large");
   WgradArgs a;
   a.x = (const char*)d->x; a.dy = (const char*)d->dy; a.ws = d->workspace;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
