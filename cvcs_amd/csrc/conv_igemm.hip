@@ -309,14 +309,16 @@ __device__ __forceinline__ void wait_vm_barrier(int k) {
   if (k <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else if (k == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else if (k == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <typename T> __device__ __forceinline__ f32x4 mma_u(const u32x4& a, const u32x4& b, f32x4 c) {
   return Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c);
 }
 
-template <typename T, int BN, int WM>
+template <typename T, int BN, int WM, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int KG = 64 / ES;
@@ -328,9 +330,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int HS = 18, HROWS = HS * HS;
   constexpr int HGROUPS = (HROWS + 15) / 16;       // 21 DMA pieces of 16 rows
   constexpr int A_BYTES = HGROUPS * 1024;          // 21504
-  constexpr int B_BYTES = BN * 64;
-  constexpr int BGROUPS = BN / 16;                 // 4 | 8 DMA pieces per weight tile
+  // a STEP covers TPS consecutive taps (one filter row when TPS = 3): fewer barriers per MFMA for narrow BN
+  static_assert(TPS == 1 || TPS == 3, "taps per step");
+  constexpr int SPS = 9 / TPS;                     // steps per channel slice
+  constexpr int TAP_BYTES = BN * 64;
+  constexpr int B_BYTES = TPS * TAP_BYTES;         // one ring slot
+  constexpr int BGROUPS = TPS * BN / 16;           // DMA pieces per step
   constexpr int BPW = BGROUPS / 4;                 // pieces per wave
+  constexpr int APW = TPS == 1 ? 1 : 2;            // halo pieces per wave per step (first 6 | 3 steps of a slice)
   constexpr int OROW = BN * ES + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                     // [2][A_BYTES]
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   const int ty0 = (trem / p.tiles_x) * 16, tx0 = (trem % p.tiles_x) * 16;
   const int n0 = blockIdx.y * BN;
   const int nslice = p.Cin / KG;
-  const int total = nslice * 9;
+  const int total = nslice * SPS;
   const int64_t wt_tap_stride = (int64_t)p.Cout * p.Cin;
   const int64_t img_base = (int64_t)b * p.H * p.W;
   const int rr = lane >> 2, pc = lane & 3;   // this lane's row / physical chunk inside a 16-row DMA piece
@@ -364,14 +371,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
   };
-  // this wave's pieces of the weight tile (cs, tap) -> ring slot
-  auto dma_b = [&](int cs, int tap, int slot) {
+  // this wave's pieces of the weight tiles of step (cs, st) [taps st*TPS .. st*TPS+TPS-1] -> ring slot
+  auto dma_b = [&](int cs, int st, int slot) {
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
-      const int g = wave + 4 * j;
-      const int row = g * 16 + rr;
+      const int g = wave + 4 * j;                 // piece index inside the slot
+      const int tt = g / (BN / 16);               // tap inside the step
+      const int row = (g - tt * (BN / 16)) * 16 + rr;
       const int c = swz(row, pc);
-      const char* src = p.wt + ((int64_t)tap * wt_tap_stride + (int64_t)(n0 + row) * p.Cin + (int64_t)cs * KG) * ES + c * 16;
+      const char* src = p.wt + ((int64_t)(st * TPS + tt) * wt_tap_stride + (int64_t)(n0 + row) * p.Cin + (int64_t)cs * KG) * ES + c * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + g * 1024), 16, 0, 0);
     }
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   // ---- prologue: whole halo of slice 0, weight tiles of steps 0 and 1
   for (int g = wave; g < HGROUPS; g += 4) dma_halo(g, 0, 0);
   dma_b(0, 0, 0);
-  if (total > 1) dma_b(0, 1, 1);   // total = 9 * nslice >= 9
+  dma_b(0, 1, 1);                  // every slice has SPS >= 3 steps
   wait_vm_barrier(0);
 
   // per-lane constant parts of the fragment addresses
@@ -397,23 +405,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
     baddr[j] = lds0 + 2 * A_BYTES + r * 64 + swz(r, fg) * 16;
   }
 
-  int cs = 0, tap = 0, slot = 0;   // slot = s % 3
+  int cs = 0, st = 0, slot = 0;   // st = step inside the slice, slot = s % 3
   for (int s = 0; s < total; ++s) {
     int k = 0;
     if (s + 2 < total) {
-      int t2 = tap + 2, c2 = cs;
-      if (t2 >= 9) { t2 -= 9; c2 += 1; }
+      int t2 = st + 2, c2 = cs;
+      if (t2 >= SPS) { t2 -= SPS; c2 += 1; }
       int slot2 = slot + 2; if (slot2 >= 3) slot2 -= 3;
       dma_b(c2, t2, slot2);
       k += BPW;
     }
-    if (cs + 1 < nslice && 4 * tap + wave < HGROUPS) {
-      dma_halo(4 * tap + wave, cs + 1, (cs + 1) & 1);
-      k += 1;
+    if (cs + 1 < nslice) {
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const int g = (st * APW + j) * 4 + wave;
+        if (g < HGROUPS) { dma_halo(g, cs + 1, (cs + 1) & 1); k += 1; }
+      }
     }
-    {
-      const unsigned abase = lds0 + (cs & 1) * A_BYTES;
-      const unsigned boff = slot * B_BYTES;
+    const unsigned abase = lds0 + (cs & 1) * A_BYTES;
+#pragma unroll
+    for (int tt = 0; tt < TPS; ++tt) {
+      const int tap = st * TPS + tt;
+      const unsigned boff = slot * B_BYTES + tt * TAP_BYTES;
       const int kh = tap / 3, kw = tap - kh * 3;
       unsigned aaddr[MREP];
 #pragma unroll
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
       }
     }
     wait_vm_barrier(k);
-    if (++tap == 9) { tap = 0; ++cs; }
+    if (++st == SPS) { st = 0; ++cs; }
     if (++slot == 3) slot = 0;
   }
 
@@ -530,20 +543,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   }
 }
 
-template <typename T, int BN, int WM>
+template <typename T, int BN, int WM, int TPS>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
-  size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(BN * 64);
+  size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(TPS * BN * 64);
   size_t epi = (size_t)128 * (BN * ES + 16);
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM, TPS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)(a.Cout / BN));
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, TPS>), grid, dim3(256), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d(halo)");
   return CVCS_OK;
 }
@@ -622,8 +635,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   if (use_halo(d)) {
-    if (d->dtype == CVCS_F32) return halo_wm(d) == 2 ? launch_halo<float, 128, 2>(a, st) : launch_halo<float, 64, 4>(a, st);
-    return halo_wm(d) == 2 ? launch_halo<bf16_t, 128, 2>(a, st) : launch_halo<bf16_t, 64, 4>(a, st);
+    if (d->dtype == CVCS_F32) return halo_wm(d) == 2 ? launch_halo<float, 128, 2, 1>(a, st) : launch_halo<float, 64, 4, 3>(a, st);
+    return halo_wm(d) == 2 ? launch_halo<bf16_t, 128, 2, 1>(a, st) : launch_halo<bf16_t, 64, 4, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);

@@ -70,22 +70,27 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
 
 // partial dW[c][k] = sum_p dl[p][c] * x[p][k], db[c] = sum_p dl[p][c]; one partial row per workgroup:
 // part[row][c*64 + k] for c < NC, then part[row][NC*64 + c].
-constexpr int kDwTile = 128;  // pixels staged per iteration
+// A [NC x P] x [P x 64] contraction over pixels: staged 64 pixels at a time in LDS (dl as [class][pixel], x as
+// f32 [pixel][channel]) and contracted with the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, A = dl^T, B = x), wave w
+// owning channels 16w..16w+15.  LDS pitches (130 / 80 floats) make both ds_read_b32 fragment reads conflict-free.
+constexpr int kDwTile = 64;   // pixels staged per iteration
+constexpr int kSdPitch = 130, kSxPitch = 80;
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl,
                                                          int64_t P, int64_t HW, int NC, float* part) {
   constexpr int V = 16 / sizeof(T);
-  __shared__ float sx[kDwTile][kHeadC + 1];
-  __shared__ float sd[kDwTile][kMaxNC + 1];
-  const int tid = threadIdx.x;
-  const int k = tid & 63, cq = tid >> 6;  // this thread owns (c = cq + 4j, k)
-  float acc[kMaxNC / 4];
+  __shared__ float sx[kDwTile * kSxPitch];
+  __shared__ float sd[kMaxNC * kSdPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ncb = (NC + 15) / 16;
+  for (int i = tid; i < kMaxNC * kSdPitch; i += 256) sd[i] = 0.f;   // class rows >= NC stay zero
+  f32x4 acc[kMaxNC / 16];
 #pragma unroll
-  for (int j = 0; j < kMaxNC / 4; ++j) acc[j] = 0.f;
+  for (int cb = 0; cb < kMaxNC / 16; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float accb = 0.f;  // threads tid < NC own db[tid]
   for (int64_t p0 = (int64_t)blockIdx.x * kDwTile; p0 < P; p0 += (int64_t)gridDim.x * kDwTile) {
     __syncthreads();
-    // stage x: kDwTile pixels x 64 channels (16-byte chunks)
     for (int id = tid; id < kDwTile * (kHeadC / V); id += 256) {
       const int r = id / (kHeadC / V), c = id - r * (kHeadC / V);
       float f[V];
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t
 #pragma unroll
         for (int q = 0; q < V; ++q) f[q] = 0.f;
 #pragma unroll
-      for (int q = 0; q < V; ++q) sx[r][c * V + q] = f[q];
+      for (int q = 0; q < V; ++q) sx[r * kSxPitch + c * V + q] = f[q];
     }
     for (int id = tid; id < kDwTile * NC; id += 256) {
       const int c = id / kDwTile, r = id - c * kDwTile;
@@ -103,22 +108,27 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t
         const int64_t pidx = p0 + r, b = pidx / HW, hw = pidx - b * HW;
         v = dl[(b * NC + c) * HW + hw];
       }
-      sd[r][c] = v;
+      sd[c * kSdPitch + r] = v;
     }
     __syncthreads();
-    for (int r = 0; r < kDwTile; ++r) {
-      const float xv = sx[r][k];
+#pragma unroll 4
+    for (int s = 0; s < kDwTile / 4; ++s) {
+      const float bv = sx[(4 * s + fg) * kSxPitch + wave * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < kMaxNC / 4; ++j)
-        if (cq + 4 * j < NC) acc[j] += sd[r][cq + 4 * j] * xv;
+      for (int cb = 0; cb < kMaxNC / 16; ++cb)
+        if (cb < ncb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sd[(cb * 16 + fr) * kSdPitch + 4 * s + fg], bv, acc[cb], 0, 0, 0);
     }
     if (tid < NC)
-      for (int r = 0; r < kDwTile; ++r) accb += sd[r][tid];
+      for (int r = 0; r < kDwTile; ++r) accb += sd[tid * kSdPitch + r];
   }
   float* row = part + (int64_t)blockIdx.x * (NC * kHeadC + NC);
 #pragma unroll
-  for (int j = 0; j < kMaxNC / 4; ++j)
-    if (cq + 4 * j < NC) row[(cq + 4 * j) * kHeadC + k] = acc[j];
+  for (int cb = 0; cb < kMaxNC / 16; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cb * 16 + fg * 4 + r;   // D layout: row (class) = fg*4 + r, col (channel) = fr
+      if (cb < ncb && c < NC) row[c * kHeadC + wave * 16 + fr] = acc[cb][r];
+    }
   if (tid < NC) row[NC * kHeadC + tid] = accb;
 }
 
@@ -270,7 +280,7 @@ extern "C" int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, i
 
 extern "C" int cvcs_head_bwd_rows(int64_t P) {
   int64_t r = cdiv(P, kDwTile);
-  return (int)(r < 1 ? 1 : (r > 512 ? 512 : r));
+  return (int)(r < 1 ? 1 : (r > 1024 ? 1024 : r));
 }
 
 extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
