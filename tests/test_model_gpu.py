@@ -200,3 +200,52 @@ def test_cpu_network_fails_loudly():
     net = nets.Urnetv2(5)
     with pytest.raises(RuntimeError, match="GPU only"):
         net(torch.zeros(1, 3, 32, 32))
+
+
+def test_data_parallel_single_rank_matches_plain_training():
+    """cvcs_amd.parallel.DataParallel with RCCL (backend nccl) at world_size 1: the bucketed, side-stream all-reduce
+    and the folded 1/world scaling must leave a training run bit-identical to the unwrapped one."""
+    import torch.distributed as dist
+    from cvcs_amd.parallel import DataParallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    NC, B, S = 5, 2, 64
+    img, lab = O.synthetic_tiles(B, S, NC, seed=4, structured=True)
+
+    def run(wrap):
+        net = _build("Unetv2", NC, "bf16")
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
+        net.train()
+        if wrap:
+            net(img.to(DEV), None)      # materialise flat buffers / engine
+            DataParallel(net, optim, bucket_mb=8.0)
+        losses = []
+        for _ in range(3):
+            loss = crit(net(img.to(DEV), None), lab.to(DEV))
+            optim.zero_grad(); loss.backward(); optim.step()
+            losses.append(loss.item())
+        return losses, net.flat_parameters()[0].clone()
+
+    l0, p0 = run(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        l1, p1 = run(True)
+    finally:
+        dist.destroy_process_group()
+    # the wrapped run had one extra (discarded) forward before step 0: running stats differ, training maths do not
+    assert l0 == l1
+    assert torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_heldout_miou_after_training_matches_cpu_reference(precision):
+    """north star: mIoU on a held-out synthetic set vs the CPU reference (S/utils.py:311-364 definition) after the
+    same 40-step SGD2 schedule on structured tiles.  Measured differences: 0.06 points (bf16), see README."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("miou_parity", os.path.join(os.path.dirname(__file__), "..", "scripts", "miou_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m_o, m_h = mod.run(precision, steps=40, S=64, verbose=False)
+    assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
+    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.5, (m_o["mIoU"], m_h["mIoU"])
