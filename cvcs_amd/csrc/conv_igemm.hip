@@ -17,6 +17,10 @@
 //
 // Reference ops replaced: S/blocks.py:3-4 (conv3x3 via :13,:40,:43), S/nets.py:150,156,162,168 (ConvTranspose2d)
 // and the data-gradient of both (convolution_backward, S/train.py:125) through pre-flipped weights.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace cvcs {
@@ -304,6 +308,68 @@ __device__ __forceinline__ void lds_read2(u32x4& a, u32x4& b, unsigned pa, unsig
                : "v"(pa), "v"(pb)
                : "memory");
 }
+// the same with a compile-time byte offset folded into the instructions (ring slot / halo buffer): no address VALU
+template <int OFF>
+__device__ __forceinline__ void lds_read4o(u32x4& a, u32x4& b, u32x4& c, u32x4& d, unsigned pa, unsigned pb, unsigned pc,
+                                           unsigned pd) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit immediate");
+  asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\t"
+               "ds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+               : "v"(pa), "v"(pb), "v"(pc), "v"(pd), "i"(OFF)
+               : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read2o(u32x4& a, u32x4& b, unsigned pa, unsigned pb) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit immediate");
+  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(pa), "v"(pb), "i"(OFF)
+               : "memory");
+}
+// one base address register, per-read immediates
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_read4q(u32x4& a, u32x4& b, u32x4& c, u32x4& d, unsigned base) {
+  static_assert(O0 >= 0 && O3 < 65536 && O1 < 65536 && O2 < 65536, "ds_read offset is a 16-bit immediate");
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
+               "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+               : "v"(base), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+               : "memory");
+}
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2q(u32x4& a, u32x4& b, unsigned base) {
+  static_assert(O0 >= 0 && O0 < 65536 && O1 < 65536, "ds_read offset is a 16-bit immediate");
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(base), "i"(O0), "i"(O1)
+               : "memory");
+}
+// split form: ISSUE four reads now, WAIT for them later (the wait statement names every destination as "+v", so no
+// consumer can be scheduled above it and the registers stay allocated across the MFMAs issued in between)
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_issue4q(u32x4& a, u32x4& b, u32x4& c, u32x4& d, unsigned base) {
+  static_assert(O0 >= 0 && O3 < 65536 && O1 < 65536 && O2 < 65536, "ds_read offset is a 16-bit immediate");
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
+               "ds_read_b128 %3, %4 offset:%8"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+               : "v"(base), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+               : "memory");
+}
+struct FragSet { u32x4 b0, b1, b2, b3, a0, a1, a2, a3; };
+__device__ __forceinline__ void lds_wait(FragSet& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.b0), "+v"(f.b1), "+v"(f.b2), "+v"(f.b3), "+v"(f.a0), "+v"(f.a1), "+v"(f.a2), "+v"(f.a3)
+               :
+               : "memory");
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 // wait until at most k of this wave's vector-memory operations are outstanding, then the workgroup barrier
 __device__ __forceinline__ void wait_vm_barrier(int k) {
   if (k <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -318,11 +384,12 @@ template <typename T> __device__ __forceinline__ f32x4 mma_u(const u32x4& a, con
   return Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c);
 }
 
-template <typename T, int BN, int WM, int TPS>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
+template <typename T, int BN, int WM, int WN, int TPS>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int KG = 64 / ES;
-  constexpr int WN = 4 / WM;
+  constexpr int NW = WM * WN;          // waves per workgroup (4 | 8)
+  constexpr int NT = NW * 64;
   constexpr int MREP = 16 / WM;        // image rows per wave
   constexpr int WNC = BN / WN;         // channels per wave
   constexpr int NREP = WNC / 16;
@@ -331,13 +398,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int HGROUPS = (HROWS + 15) / 16;       // 21 DMA pieces of 16 rows
   constexpr int A_BYTES = HGROUPS * 1024;          // 21504
   // a STEP covers TPS consecutive taps (one filter row when TPS = 3): fewer barriers per MFMA for narrow BN
-  static_assert(TPS == 1 || TPS == 3, "taps per step");
+  static_assert(TPS == 1 || TPS == 3, "taps per step (ring slot = step % 3 needs 9/TPS % 3 == 0)");
   constexpr int SPS = 9 / TPS;                     // steps per channel slice
   constexpr int TAP_BYTES = BN * 64;
   constexpr int B_BYTES = TPS * TAP_BYTES;         // one ring slot
   constexpr int BGROUPS = TPS * BN / 16;           // DMA pieces per step
-  constexpr int BPW = BGROUPS / 4;                 // pieces per wave
-  constexpr int APW = TPS == 1 ? 1 : 2;            // halo pieces per wave per step (first 6 | 3 steps of a slice)
+  static_assert(BGROUPS % NW == 0, "weight-tile pieces must divide over the waves");
+  constexpr int BPW = BGROUPS / NW;                // pieces per wave
+  constexpr int APW = (21 + NW * SPS - 1) / (NW * SPS) > 1 ? 2 : 1;   // halo pieces per wave per step
   constexpr int OROW = BN * ES + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                     // [2][A_BYTES]
@@ -359,30 +427,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   const int64_t img_base = (int64_t)b * p.H * p.W;
   const int rr = lane >> 2, pc = lane & 3;   // this lane's row / physical chunk inside a 16-row DMA piece
 
-  // DMA piece g of the halo of slice cs -> buffer buf
-  auto dma_halo = [&](int g, int cs, int buf) {
+  // ---- per-lane invariants of the DMA sources and of the fragment addresses (nothing below divides in the loop)
+  // halo pieces of this wave: q-th piece = DMA piece g = q*NW + wave of every slice
+  constexpr int NPA = (HGROUPS + NW - 1) / NW;
+  int aoff[NPA];                 // byte offset inside the image of this lane's 16 bytes, -1: padding -> zero word
+#pragma unroll
+  for (int q = 0; q < NPA; ++q) {
+    const int g = q * NW + wave;
     const int row = g * 16 + rr;
-    const int c = swz(row, pc);  // logical chunk stored at physical chunk pc
     const int hy = row / HS, hx = row - hy * HS;
+    const int c = swz(hx, pc);   // logical chunk stored at physical chunk pc: the halo swizzle is keyed on the COLUMN hx
     const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const char* src = reinterpret_cast<const char*>(&g_zero16);
-    if (row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-      src = p.in + ((img_base + (int64_t)iy * p.W + ix) * p.in_ld + (int64_t)cs * KG) * ES + c * 16;
+    const bool ok = g < HGROUPS && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    aoff[q] = ok ? (int)((((int64_t)iy * p.W + ix) * p.in_ld) * ES + c * 16) : -1;
+  }
+  const char* img_ptr = p.in + img_base * p.in_ld * ES;
+  auto dma_halo = [&](int q, int cs, int buf) {   // q compile-time after unrolling
+    const int g = q * NW + wave;
+    const char* src = aoff[q] >= 0 ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES) : reinterpret_cast<const char*>(&g_zero16);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
   };
-  // this wave's pieces of the weight tiles of step (cs, st) [taps st*TPS .. st*TPS+TPS-1] -> ring slot
-  auto dma_b = [&](int cs, int st, int slot) {
+  // weight pieces of this wave: piece g = wave + NW*j of a step = tap tt = g / (BN/16), rows (g % (BN/16))*16 ..
+  const char* bsrc[BPW];
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-      const int g = wave + 4 * j;                 // piece index inside the slot
-      const int tt = g / (BN / 16);               // tap inside the step
-      const int row = (g - tt * (BN / 16)) * 16 + rr;
-      const int c = swz(row, pc);
-      const char* src = p.wt + ((int64_t)(st * TPS + tt) * wt_tap_stride + (int64_t)(n0 + row) * p.Cin + (int64_t)cs * KG) * ES + c * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + g * 1024), 16, 0, 0);
-    }
+  for (int j = 0; j < BPW; ++j) {
+    const int g = wave + NW * j;
+    const int tt = g / (BN / 16);
+    const int row = (g - tt * (BN / 16)) * 16 + rr;
+    bsrc[j] = p.wt + ((int64_t)tt * wt_tap_stride + (int64_t)(n0 + row) * p.Cin) * ES + swz(row, pc) * 16;
+  }
+  auto dma_b = [&](int cs, int st, int slot) {
+    const int64_t soff = ((int64_t)(st * TPS) * wt_tap_stride + (int64_t)cs * KG) * ES;   // wave-uniform
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + soff),
+                                       (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + (wave + NW * j) * 1024),
+                                       16, 0, 0);
   };
 
   f32x4 acc[MREP][NREP];
@@ -392,77 +473,123 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
     for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: whole halo of slice 0, weight tiles of steps 0 and 1
-  for (int g = wave; g < HGROUPS; g += 4) dma_halo(g, 0, 0);
+#pragma unroll
+  for (int q = 0; q < NPA; ++q)
+    if (q * NW + wave < HGROUPS) dma_halo(q, 0, 0);
   dma_b(0, 0, 0);
   dma_b(0, 1, 1);                  // every slice has SPS >= 3 steps
   wait_vm_barrier(0);
 
-  // per-lane constant parts of the fragment addresses
-  unsigned baddr[NREP];
+  // fragment base addresses.  Weights: rows r0 + 16j share the swizzle bit of r0 -> one register + immediates 1024*j.
+  // Halo: row (y, x) sits at linear row y*18 + x with its chunks swizzled by x -> one register per kw, image rows by
+  // immediates of 18*64 bytes.  (Conflict-freedom of ds_read_b128 only needs rows x and x+12 / x+4 and x+8 of a lane
+  // group to differ in bit 2 of the key, and consecutive linear rows to rotate through the four 64-byte bank quarters.)
+  const int r0 = wn * WNC + fr;
+  const unsigned bbase = lds0 + 2 * A_BYTES + r0 * 64 + swz(r0, fg) * 16;
+  const unsigned bbase_hi = bbase + 32768;   // ring offsets beyond the 16-bit immediate
+  unsigned abase[3];
 #pragma unroll
-  for (int j = 0; j < NREP; ++j) {
-    const int r = wn * WNC + j * 16 + fr;
-    baddr[j] = lds0 + 2 * A_BYTES + r * 64 + swz(r, fg) * 16;
-  }
+  for (int kw = 0; kw < 3; ++kw)
+    abase[kw] = lds0 + ((wm * MREP) * HS + fr + kw) * 64 + swz(fr + kw, fg) * 16;
+  constexpr int RB = HS * 64;   // bytes between image rows of the halo tile
 
-  int cs = 0, st = 0, slot = 0;   // st = step inside the slice, slot = s % 3
-  for (int s = 0; s < total; ++s) {
-    int k = 0;
-    if (s + 2 < total) {
-      int t2 = st + 2, c2 = cs;
-      if (t2 >= SPS) { t2 -= SPS; c2 += 1; }
-      int slot2 = slot + 2; if (slot2 >= 3) slot2 -= 3;
-      dma_b(c2, t2, slot2);
-      k += BPW;
-    }
-    if (cs + 1 < nslice) {
-#pragma unroll
-      for (int j = 0; j < APW; ++j) {
-        const int g = (st * APW + j) * 4 + wave;
-        if (g < HGROUPS) { dma_halo(g, cs + 1, (cs + 1) & 1); k += 1; }
+  // one channel slice = SPS steps, everything indexed by compile-time constants (ring slot = step % 3, halo buffer
+  // = slice parity PAR): the LDS offsets are instruction immediates, the loop body carries no address arithmetic
+  auto slice_body = [&](auto par_, int cs) {
+    constexpr int PAR = decltype(par_)::value;
+    static_for<0, SPS>([&](auto st_) {
+      constexpr int st = decltype(st_)::value;
+      int k = 0;
+      {
+        constexpr int t2 = (st + 2) % SPS;
+        const int c2 = cs + (st + 2) / SPS;
+        if (c2 < nslice) { dma_b(c2, t2, (st + 2) % 3); k += BPW; }   // SPS % 3 == 0: ring slot = st % 3
       }
-    }
-    const unsigned abase = lds0 + (cs & 1) * A_BYTES;
-#pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) {
-      const int tap = st * TPS + tt;
-      const unsigned boff = slot * B_BYTES + tt * TAP_BYTES;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      unsigned aaddr[MREP];
-#pragma unroll
-      for (int i = 0; i < MREP; ++i) {
-        const int row = (wm * MREP + i + kh) * HS + fr + kw;
-        aaddr[i] = abase + row * 64 + swz(row, fg) * 16;
+      if (cs + 1 < nslice) {
+        static_for<0, APW>([&](auto j_) {
+          constexpr int q = st * APW + decltype(j_)::value;
+          if constexpr (q < NPA) {
+            if (q * NW + wave < HGROUPS) { dma_halo(q, cs + 1, PAR ^ 1); k += 1; }
+          }
+        });
       }
-      u32x4 bf0, bf1, bf2, bf3, a0, a1, a2, a3;
-      lds_read4(bf0, bf1, bf2, bf3, baddr[0] + boff, baddr[1] + boff, baddr[2] + boff, baddr[3] + boff);
-      if constexpr (MREP == 8) {
-        lds_read4(a0, a1, a2, a3, aaddr[0], aaddr[1], aaddr[2], aaddr[3]);
+      if constexpr (TPS == 3 && MREP == 4) {
+        // software-pipelined taps: the fragment reads of tap t+1 are in flight while the 16 MFMAs of tap t issue;
+        // three register sets, so no set is rewritten inside a step
+        constexpr int AOFF = PAR * A_BYTES;
+        auto issue = [&](auto tt_, FragSet& f) {
+          constexpr int tt = decltype(tt_)::value;
+          constexpr int tap = st * TPS + tt;
+          constexpr int kh = tap / 3, kw = tap - kh * 3;
+          constexpr int BOFF = (st % 3) * B_BYTES + tt * TAP_BYTES;
+          if constexpr (BOFF + 3072 < 65536) lds_issue4q<BOFF, BOFF + 1024, BOFF + 2048, BOFF + 3072>(f.b0, f.b1, f.b2, f.b3, bbase);
+          else lds_issue4q<BOFF - 32768, BOFF - 32768 + 1024, BOFF - 32768 + 2048, BOFF - 32768 + 3072>(f.b0, f.b1, f.b2, f.b3, bbase_hi);
+          lds_issue4q<AOFF + kh * RB, AOFF + (kh + 1) * RB, AOFF + (kh + 2) * RB, AOFF + (kh + 3) * RB>(f.a0, f.a1, f.a2, f.a3, abase[kw]);
+        };
+        auto mma_set = [&](const FragSet& f) {
+          auto row_mma = [&](int i, const u32x4& af) {
+            acc[i][0] = mma_u<T>(af, f.b0, acc[i][0]);
+            acc[i][1] = mma_u<T>(af, f.b1, acc[i][1]);
+            acc[i][2] = mma_u<T>(af, f.b2, acc[i][2]);
+            acc[i][3] = mma_u<T>(af, f.b3, acc[i][3]);
+          };
+          row_mma(0, f.a0); row_mma(1, f.a1); row_mma(2, f.a2); row_mma(3, f.a3);
+        };
+        FragSet X, Y, Z;
+        issue(std::integral_constant<int, 0>{}, X);
+        lds_wait(X);
+        issue(std::integral_constant<int, 1>{}, Y);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of tap t+1 AHEAD of the MFMAs of tap t
+        mma_set(X);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(Y);
+        issue(std::integral_constant<int, 2>{}, Z);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(Y);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(Z);
+        mma_set(Z);
       } else {
-        lds_read2(a0, a1, aaddr[0], aaddr[1]);
+      static_for<0, TPS>([&](auto tt_) {
+          constexpr int tt = decltype(tt_)::value;
+          constexpr int tap = st * TPS + tt;
+          constexpr int kh = tap / 3, kw = tap - kh * 3;
+          constexpr int BOFF = (st % 3) * B_BYTES + tt * TAP_BYTES;
+          constexpr int AOFF = PAR * A_BYTES;
+          u32x4 bf0, bf1, bf2, bf3, a0, a1, a2, a3;
+          if constexpr (BOFF + 3072 < 65536) lds_read4q<BOFF, BOFF + 1024, BOFF + 2048, BOFF + 3072>(bf0, bf1, bf2, bf3, bbase);
+          else lds_read4q<BOFF - 32768, BOFF - 32768 + 1024, BOFF - 32768 + 2048, BOFF - 32768 + 3072>(bf0, bf1, bf2, bf3, bbase_hi);
+          if constexpr (MREP == 8) {
+            lds_read4q<AOFF + kh * RB, AOFF + (kh + 1) * RB, AOFF + (kh + 2) * RB, AOFF + (kh + 3) * RB>(a0, a1, a2, a3, abase[kw]);
+          } else {
+            lds_read2q<AOFF + kh * RB, AOFF + (kh + 1) * RB>(a0, a1, abase[kw]);
+          }
+          auto row_mma = [&](int i, const u32x4& af) {
+            acc[i][0] = mma_u<T>(af, bf0, acc[i][0]);
+            acc[i][1] = mma_u<T>(af, bf1, acc[i][1]);
+            acc[i][2] = mma_u<T>(af, bf2, acc[i][2]);
+            acc[i][3] = mma_u<T>(af, bf3, acc[i][3]);
+          };
+          if constexpr (MREP == 8) {
+            u32x4 a4, a5, a6, a7;
+            row_mma(0, a0); row_mma(1, a1);
+            lds_read4q<AOFF + (kh + 4) * RB, AOFF + (kh + 5) * RB, AOFF + (kh + 6) * RB, AOFF + (kh + 7) * RB>(a4, a5, a6, a7, abase[kw]);
+            row_mma(2, a2); row_mma(3, a3);
+            row_mma(4, a4); row_mma(5, a5); row_mma(6, a6); row_mma(7, a7);
+          } else {
+            row_mma(0, a0);
+            lds_read2q<AOFF + (kh + 2) * RB, AOFF + (kh + 3) * RB>(a2, a3, abase[kw]);
+            row_mma(1, a1);
+            row_mma(2, a2); row_mma(3, a3);
+          }
+        });
       }
-      auto row_mma = [&](int i, const u32x4& af) {
-        acc[i][0] = mma_u<T>(af, bf0, acc[i][0]);
-        acc[i][1] = mma_u<T>(af, bf1, acc[i][1]);
-        acc[i][2] = mma_u<T>(af, bf2, acc[i][2]);
-        acc[i][3] = mma_u<T>(af, bf3, acc[i][3]);
-      };
-      if constexpr (MREP == 8) {
-        u32x4 a4, a5, a6, a7;
-        row_mma(0, a0); row_mma(1, a1);
-        lds_read4(a4, a5, a6, a7, aaddr[4], aaddr[5], aaddr[6], aaddr[7]);
-        row_mma(2, a2); row_mma(3, a3);
-        row_mma(4, a4); row_mma(5, a5); row_mma(6, a6); row_mma(7, a7);
-      } else {
-        row_mma(0, a0);
-        lds_read2(a2, a3, aaddr[2], aaddr[3]);
-        row_mma(1, a1);
-        row_mma(2, a2); row_mma(3, a3);
-      }
-    }
-    wait_vm_barrier(k);
-    if (++st == SPS) { st = 0; ++cs; }
-    if (++slot == 3) slot = 0;
+      wait_vm_barrier(k);
+    });
+  };
+  for (int cs = 0; cs < nslice; cs += 2) {
+    slice_body(std::integral_constant<int, 0>{}, cs);
+    if (cs + 1 < nslice) slice_body(std::integral_constant<int, 1>{}, cs + 1);
   }
 
   // ---- epilogue: bias / ReLU.  acc[i][j][r]: image row y = wm*MREP + i, pixel x = fg*4 + r, channel = .. + fr
@@ -531,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
           }
     }
     __syncthreads();
-    for (int id = tid; id < 128 * CPR; id += 256) {
+    for (int id = tid; id < 128 * CPR; id += NT) {
       const int lrow = id / CPR, c = id - lrow * CPR;
       const int y = ty0 + h * 8 + (lrow >> 4), x = tx0 + (lrow & 15);
       if (y >= p.H || x >= p.W) continue;
@@ -543,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   }
 }
 
-template <typename T, int BN, int WM, int TPS>
+template <typename T, int BN, int WM, int WN, int TPS>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
   size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(TPS * BN * 64);
@@ -551,12 +678,12 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM, TPS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM, WN, TPS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)(a.Cout / BN));
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, TPS>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, WN, TPS>), grid, dim3(WM * WN * 64), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d(halo)");
   return CVCS_OK;
 }
@@ -588,7 +715,7 @@ static bool use_halo(const cvcs_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
          d->W >= 8;
 }
-static int halo_wm(const cvcs_conv_desc* d) { return d->Cout % 128 == 0 ? 2 : 4; }
+static int halo_wm(const cvcs_conv_desc* d) { (void)d; return 4; }   // every variant splits the 16 tile rows over 4 waves
 
 extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
@@ -635,8 +762,11 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   if (use_halo(d)) {
-    if (d->dtype == CVCS_F32) return halo_wm(d) == 2 ? launch_halo<float, 128, 2, 1>(a, st) : launch_halo<float, 64, 4, 3>(a, st);
-    return halo_wm(d) == 2 ? launch_halo<bf16_t, 128, 2, 1>(a, st) : launch_halo<bf16_t, 64, 4, 3>(a, st);
+    const bool wide = d->Cout % 128 == 0;
+    static const int waves = getenv("CVCS_HALO_WAVES") ? atoi(getenv("CVCS_HALO_WAVES")) : 8;   // tuning knob (4 | 8)
+    if (d->dtype == CVCS_F32) return wide ? launch_halo<float, 128, 4, 2, 1>(a, st) : launch_halo<float, 64, 4, 1, 3>(a, st);
+    if (wide) return waves == 4 ? launch_halo<bf16_t, 128, 4, 2, 1>(a, st) : launch_halo<bf16_t, 128, 4, 2, 3>(a, st);
+    return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
