@@ -499,19 +499,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     constexpr int PAR = decltype(par_)::value;
     static_for<0, SPS>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
+      // DMA issue order matters for the counted wait: halo pieces FIRST, weight pieces after them.  vmcnt(k) lets the k
+      // youngest operations stay in flight; the halo pieces issued in the LAST step of a slice are read by the very
+      // next step, so there they are not counted (k = weight pieces only, which are younger) and have landed.
       int k = 0;
-      {
-        constexpr int t2 = (st + 2) % SPS;
-        const int c2 = cs + (st + 2) / SPS;
-        if (c2 < nslice) { dma_b(c2, t2, (st + 2) % 3); k += BPW; }   // SPS % 3 == 0: ring slot = st % 3
-      }
       if (cs + 1 < nslice) {
         static_for<0, APW>([&](auto j_) {
           constexpr int q = st * APW + decltype(j_)::value;
           if constexpr (q < NPA) {
-            if (q * NW + wave < HGROUPS) { dma_halo(q, cs + 1, PAR ^ 1); k += 1; }
+            if (q * NW + wave < HGROUPS) { dma_halo(q, cs + 1, PAR ^ 1); if constexpr (st < SPS - 1) k += 1; }
           }
         });
+      }
+      {
+        constexpr int t2 = (st + 2) % SPS;
+        const int c2 = cs + (st + 2) / SPS;
+        if (c2 < nslice) { dma_b(c2, t2, (st + 2) % 3); k += BPW; }   // SPS % 3 == 0: ring slot = st % 3
       }
       if constexpr (TPS == 3 && MREP == 4) {
         // software-pipelined taps: the fragment reads of tap t+1 are in flight while the 16 MFMAs of tap t issue;

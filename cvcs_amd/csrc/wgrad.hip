@@ -15,6 +15,8 @@
 // fixed order (bitwise reproducible) straight into the reference's OIHW parameter layout.
 //
 // Reference op replaced: weight half of convolution_backward for nn.Conv2d / nn.ConvTranspose2d (S/train.py:125).
+#include <type_traits>
+
 #include "common.h"
 
 namespace cvcs {
@@ -229,6 +231,201 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       }
 }
 
+// ===================================================================================================================
+// Fast path: bf16, 3x3 / stride 1 / pad 1, K-tiles of 1 x 32 pixels (Wo > 16).  Same algorithm and LDS-DMA ring as the
+// generic kernel, with everything the inner loop needs made loop-invariant:
+//   * the halo tile is stored with a row pitch of 40 pixels (34 used): a filter row is then 40*128 bytes = a multiple
+//     of the swizzle period, so the swizzled address of a transposed read depends on (k + kw) only -> 12 per-lane
+//     registers cover all nine taps, the tap row and the ring stage are instruction immediates;
+//   * per-lane DMA source offsets are computed once (no divisions per K-tile), the K-tile origin is scalar;
+//   * the transposed reads of tap t+1 are issued before the four MFMAs of tap t (three rotating register sets).
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void tr_issue4(u32x2& o0, u32x2& o1, u32x2& o2, u32x2& o3, unsigned a0, unsigned a1, unsigned a2,
+                                          unsigned a3) {
+  static_assert(O0 >= 0 && O0 < 65536 && O1 < 65536 && O2 < 65536 && O3 < 65536, "ds_read offset is a 16-bit immediate");
+  asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%8\n\tds_read_b64_tr_b16 %1, %5 offset:%9\n\t"
+               "ds_read_b64_tr_b16 %2, %6 offset:%10\n\tds_read_b64_tr_b16 %3, %7 offset:%11"
+               : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
+               : "memory");
+}
+struct TrSet { u32x2 r0, r1, r2, r3; };
+__device__ __forceinline__ void tr_wait(TrSet& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r0), "+v"(f.r1), "+v"(f.r2), "+v"(f.r3) : : "memory");
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wg_static_for<I + 1, N>(f);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
+  constexpr int ROWB = 128, HP = 40;               // LDS row bytes (64 bf16), padded halo pitch in pixels
+  constexpr int DY_BYTES = 32 * ROWB, X_ROWS = 3 * HP, X_BYTES = X_ROWS * ROWB;
+  constexpr int STAGE = DY_BYTES + X_BYTES;        // 19456
+  constexpr int XP = X_ROWS / 8;                   // 15 halo DMA pieces
+  constexpr int NS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
+  const int co0 = tm * 64, ci0 = tn * 64;
+  const int slice = blockIdx.y;
+  const int kt_begin = slice * p.per_slice;
+  int kt_end = kt_begin + p.per_slice;
+  if (kt_end > p.ktiles) kt_end = p.ktiles;
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int cin_rem = p.Cin - ci0;
+  const int rr = lane >> 3, pc = lane & 7;   // row / physical 16-byte chunk of this lane inside a DMA piece
+  auto swzc = [](int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); };
+
+  // ---- per-lane DMA sources.  dy: piece `wave`, tile pixel k = wave*8 + rr.  halo: pieces wave + 4j (j < 4).
+  const int kdy = wave * 8 + rr;
+  const int off_dy = (kdy * (int)p.dy_ld + co0) * 2 + swzc(kdy, pc) * 16;
+  int off_x[4], hyx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave + 4 * j) * 8 + rr;
+    const int hy = r / HP, hx = r - hy * HP;
+    const int c = swzc(r, pc);
+    const bool ok = (wave + 4 * j) < XP && hx < 34 && c * 8 < cin_rem;
+    off_x[j] = ((hy * p.W + hx) * (int)p.x_ld + ci0) * 2 + c * 16;
+    hyx[j] = ok ? ((hy << 8) | hx) : -1;
+  }
+  const int my_pieces = 1 + (XP - wave + 3) / 4;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+  auto issue_tile = [&](int kt, int st) {
+    const int b = kt / tiles_per_img;                 // wave-uniform scalars
+    const int tr = kt - b * tiles_per_img;
+    const int oy = tr / p.tiles_x, tx0 = (tr - oy * p.tiles_x) * 32;
+    char* sdy = smem + st * STAGE;
+    char* sx = sdy + DY_BYTES;
+    const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
+    const char* src = (tx0 + kdy < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sdy + wave * 1024), 16, 0, 0);
+    const int iy0 = oy - 1, ix0 = tx0 - 1;
+    const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;   // may lie before the tensor: only
+#pragma unroll                                                                        // dereferenced for valid pixels
+    for (int j = 0; j < 4; ++j) {
+      if (wave + 4 * j < XP) {
+        const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
+        const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
+        const char* s2 = ok ? xorg + off_x[j] : reinterpret_cast<const char*>(&g_wzero16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2,
+                                         (__attribute__((address_space(3))) void*)(sx + (wave + 4 * j) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane transposed-read addresses (relative to the stage base)
+  const int q = fr >> 2, pp = fr & 3;
+  const int k0 = 4 * fg + q, k1 = 16 + 4 * fg + q;
+  auto taddr = [&](int row, int cc) -> unsigned { return lds0 + row * ROWB + ((cc ^ ((row >> 1) & 3)) << 5) + pp * 8; };
+  const unsigned ad0 = taddr(k0, wm * 2), ad1 = taddr(k1, wm * 2), ad2 = taddr(k0, wm * 2 + 1), ad3 = taddr(k1, wm * 2 + 1);
+  unsigned ax[3][4];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    ax[kw][0] = taddr(k0 + kw, wn * 2);
+    ax[kw][1] = taddr(k1 + kw, wn * 2);
+    ax[kw][2] = taddr(k0 + kw, wn * 2 + 1);
+    ax[kw][3] = taddr(k1 + kw, wn * 2 + 1);
+  }
+
+  // ---- prologue
+  if (kt_begin < kt_end) issue_tile(kt_begin, 0);
+  if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
+  wait_vm_barrier_n(0);
+
+  auto tile_body = [&](auto st_, int kt) {
+    constexpr int ST = decltype(st_)::value;
+    int issued = 0;
+    if (kt + 2 < kt_end) { issue_tile(kt + 2, (ST + 2) % NS); issued = my_pieces; }
+    constexpr int SB = ST * STAGE;
+    TrSet A;
+    tr_issue4<SB, SB, SB, SB>(A.r0, A.r1, A.r2, A.r3, ad0, ad1, ad2, ad3);
+    TrSet X, Y, Z;
+    auto issue_tap = [&](auto t_, TrSet& f) {
+      constexpr int t = decltype(t_)::value;
+      constexpr int kh = t / 3, kw = t - kh * 3;
+      constexpr int O = SB + DY_BYTES + kh * HP * ROWB;
+      tr_issue4<O, O, O, O>(f.r0, f.r1, f.r2, f.r3, ax[kw][0], ax[kw][1], ax[kw][2], ax[kw][3]);
+    };
+    issue_tap(std::integral_constant<int, 0>{}, X);
+    tr_wait(A);
+    tr_wait(X);
+    const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(A.r0.x, A.r0.y, A.r1.x, A.r1.y));
+    const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(A.r2.x, A.r2.y, A.r3.x, A.r3.y));
+    auto mma_tap = [&](auto t_, const TrSet& f) {
+      constexpr int t = decltype(t_)::value;
+      const bf16x8 bf0 = __builtin_bit_cast(bf16x8, make_uint4(f.r0.x, f.r0.y, f.r1.x, f.r1.y));
+      const bf16x8 bf1 = __builtin_bit_cast(bf16x8, make_uint4(f.r2.x, f.r2.y, f.r3.x, f.r3.y));
+      acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
+      acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
+      acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
+      acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
+    };
+    // taps 0..8 over three rotating register sets: reads of tap t+1 in flight during the MFMAs of tap t
+    wg_static_for<0, 3>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;   // taps 3g, 3g+1, 3g+2 use X, Y, Z
+      issue_tap(std::integral_constant<int, 3 * g + 1>{}, Y);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tap(std::integral_constant<int, 3 * g>{}, X);
+      __builtin_amdgcn_sched_barrier(0);
+      tr_wait(Y);
+      issue_tap(std::integral_constant<int, 3 * g + 2>{}, Z);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tap(std::integral_constant<int, 3 * g + 1>{}, Y);
+      __builtin_amdgcn_sched_barrier(0);
+      tr_wait(Z);
+      if constexpr (g < 2) issue_tap(std::integral_constant<int, 3 * g + 3>{}, X);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tap(std::integral_constant<int, 3 * g + 2>{}, Z);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g < 2) tr_wait(X);
+    });
+    wait_vm_barrier_n(issued);
+  };
+  for (int kt = kt_begin; kt < kt_end; kt += 3) {
+    tile_body(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < kt_end) tile_body(std::integral_constant<int, 1>{}, kt + 1);
+    if (kt + 2 < kt_end) tile_body(std::integral_constant<int, 2>{}, kt + 2);
+  }
+
+  const int64_t slice_stride = (int64_t)9 * p.Cout * p.Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 32 + j * 16 + fr;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wm * 32 + i * 16 + fg * 4 + r;
+          p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j][r];
+        }
+      }
+}
+
+
 // dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int taps,
                                     int Cout, int Cin, int Cin_real) {
@@ -329,7 +526,18 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   int rc;
   if (d->dtype == CVCS_F32)
     rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
-  else
+  else if (taps == 9 && d->stride == 1 && d->pad == 1 && pl.TW == 32 && pl.TH == 1 &&
+           (int64_t)d->H * d->W * d->x_ld * 2 < (1ll << 31) && (int64_t)32 * d->dy_ld * 2 < (1ll << 31)) {
+    static bool attr_done = false;
+    const int lds = 3 * (32 + 120) * 128;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_fast_kernel, dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(256), lds, st, a);
+    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(fast)");
+    rc = CVCS_OK;
+  } else
     rc = taps == 9 ? launch<bf16_t, 9>(a, pl, st) : taps == 4 ? launch<bf16_t, 4>(a, pl, st) : launch<bf16_t, 1>(a, pl, st);
   if (rc != CVCS_OK) return rc;
   const int64_t total = (int64_t)d->Cout * d->Cin_real * taps;

@@ -180,6 +180,9 @@ WGRAD_CASES = [
     (2, 8, 8, 64, 64, 128, 2, 2, 0),     # ConvTranspose weight gradient form (2x2, stride 2)
     (1, 14, 14, 64, 64, 64, 3, 1, 1),    # 14x14 (level 5 of a 224 tile)
     (2, 5, 9, 64, 64, 64, 1, 1, 0),      # 1x1
+    (2, 7, 64, 128, 128, 64, 3, 1, 1),   # fast path: 1x32 K-tiles, two Cin tiles, whole rows
+    (3, 5, 50, 64, 64, 128, 3, 1, 1),    # fast path: ragged row tiles (50 = 32 + 18)
+    (1, 33, 96, 192, 192, 64, 3, 1, 1),  # fast path: 3 Cin tiles, many K-tiles per slice
 ]
 
 

@@ -249,3 +249,29 @@ def test_heldout_miou_after_training_matches_cpu_reference(precision):
     m_o, m_h = mod.run(precision, steps=40, S=64, verbose=False)
     assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
     assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.5, (m_o["mIoU"], m_h["mIoU"])
+
+
+@pytest.mark.parametrize("variant,B,S", [("Unetv2", 4, 128), ("Unet", 2, 128), ("Unetv2", 2, 256)])
+def test_training_is_bitwise_reproducible(variant, B, S):
+    """No float atomics, fixed-order reductions, and - the point of this test - no read-before-landed race in the
+    LDS-DMA pipelines of the conv / wgrad kernels: two runs of the same schedule must agree bit for bit."""
+    NC = 16
+    img, lab = O.synthetic_tiles(B, S, NC, seed=21, structured=True)
+
+    def run():
+        net = _build(variant, NC, "bf16")
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
+        net.train()
+        losses = []
+        for _ in range(3):
+            loss = crit(net(img.to(DEV), None), lab.to(DEV))
+            optim.zero_grad(); loss.backward(); optim.step()
+            losses.append(loss.item())
+        return losses, net.flat_parameters()[0].clone()
+
+    l0, p0 = run()
+    for _ in range(2):
+        l1, p1 = run()
+        assert l0 == l1
+        assert torch.equal(p0, p1)
