@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b32_s512_bf16.json")  # scripts/pmc_traffic.py output
 
 
 def cpu_baseline(nc, tile, tiles, steps):
@@ -138,7 +139,7 @@ def main():
             c = timers["conv_igemm"]
             out["roofline"] = {"bound": "mfma", "achieved": round(c["tflops"], 2), "peak": PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3,
                                "unit": "TFLOP/s", "frac": round(c["tflops"] / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
-                               "traffic": None, "kernel": "conv_igemm_kernel (forward + data-gradient + ConvTranspose launches)",
+                               "traffic": None, "kernel": "conv3x3_halo_kernel + conv_igemm_kernel (forward, data-gradient and ConvTranspose launches)",
                                "launches_per_step": c["launches"] // a.steps, "avg_launch_us": round(c["avg_us"], 2),
                                "algorithmic_gflop_per_step": round(c["flops"] / a.steps / 1e9, 1)}
             if "wgrad" in timers:
@@ -147,6 +148,13 @@ def main():
                                          "frac": round(w["tflops"] / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
                                          "launches_per_step": w["launches"] // a.steps, "avg_launch_us": round(w["avg_us"], 2),
                                          "algorithmic_gflop_per_step": round(w["flops"] / a.steps / 1e9, 1)}
+            # HBM traffic of the same kernel family from the rocprofv3 PMC passes of this exact workload (FETCH_SIZE
+            # doubled per the gfx950 correction, WRITE_SIZE exact), collected with scripts/pmc_traffic.py
+            if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and a.net == "Unetv2" and os.path.exists(PMC_FILE):
+                pm = json.load(open(PMC_FILE)).get("conv_igemm")
+                if pm:
+                    out["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
+                    out["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/r01_pmc_traffic_b32_s512_bf16.json)"
             tot = sum(t["total_ms"] for t in timers.values())
             out["mfma_kernels_share_of_step"] = round(tot / (1e3 * dt), 3)
         if world == 1 and not a.no_cpu_baseline:
