@@ -39,6 +39,7 @@ struct ConvArgs {
   int relu, pixel_shuffle;
   int M;
   int tiles_x, tiles_y;   // halo kernel: 16x16 output tiles per image
+  int dbg_skip;           // timing experiments only (CVCS_DBG_SKIP): 1 = skip the output store, 2 = skip statistics too
 };
 
 template <typename T> struct Mma;
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   }
   int ny = p.H - ty0 - wm * MREP; ny = ny < 0 ? 0 : (ny > MREP ? MREP : ny);
   int nx = p.W - tx0;             nx = nx > 16 ? 16 : nx;
-  if (p.stat_sum) {
+  if (p.stat_sum && p.dbg_skip < 2) {
     const int nvalid = ny * nx;
     const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
     const int64_t row = (int64_t)blockIdx.x * WM + wm;
@@ -646,6 +647,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   }
   // ---- store: two halves of 8 image rows, transposed through LDS into whole pixel rows
   constexpr int CPR = BN * ES / 16;
+  if (p.dbg_skip) {   // keep the accumulators alive without the staging / store
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 1.2345e-30f) p.out[0] = 1;
+    return;
+  }
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if ((wm * MREP) / 8 == h) {
@@ -759,6 +769,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.in = (const char*)d->in; a.wt = (const char*)d->wt; a.bias = d->bias; a.out = (char*)d->out;
   a.stat_sum = d->stat_sum; a.stat_m2 = d->stat_m2; a.stat_cnt = d->stat_cnt;
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
+  static const int dbg_skip = getenv("CVCS_DBG_SKIP") ? atoi(getenv("CVCS_DBG_SKIP")) : 0;
+  a.dbg_skip = dbg_skip;
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;

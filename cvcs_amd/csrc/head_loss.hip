@@ -251,6 +251,56 @@ __global__ __launch_bounds__(256) void argmax_conf_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------ inference boundary
+// crop n tiles (S x S, origin = tile origin - (S-p)/2, zero outside the image) out of one u8 CHW image
+__global__ __launch_bounds__(256) void crop_tiles_kernel(const uint8_t* __restrict__ src, int C, int H, int W, uint8_t* dst,
+                                                        int n, int first_tile, int tiles_per_row, int p, int S) {
+  const int off = -(S - p) / 2;
+  const int64_t total = (int64_t)n * C * S * S;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int x = (int)(id % S);
+    int64_t t = id / S;
+    const int y = (int)(t % S); t /= S;
+    const int c = (int)(t % C);
+    const int tile = first_tile + (int)(t / C);
+    const int ty = tile / tiles_per_row, tx = tile - ty * tiles_per_row;
+    const int sy = ty * p + off + y, sx = tx * p + off + x;
+    dst[id] = ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) ? src[((int64_t)c * H + sy) * W + sx] : (uint8_t)0;
+  }
+}
+
+// argmax over classes of the centre p x p window of every tile, palette lookup, write into the stitched maps
+template <int NCMAX>
+__global__ __launch_bounds__(256) void argmax_stitch_kernel(const float* __restrict__ logits, int n, int NC, int S, int p,
+                                                           int first_tile, int tiles_per_row, const uint8_t* __restrict__ palette,
+                                                           uint8_t* rgb, uint8_t* labels, int Hout, int Wout) {
+  const int m = (S - p) / 2;
+  const int64_t total = (int64_t)n * p * p;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int x = (int)(id % p);
+    int64_t t = id / p;
+    const int y = (int)(t % p);
+    const int ti = (int)(t / p);
+    const float* zp = logits + (((int64_t)ti * NC) * S + (y + m)) * S + (x + m);
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < NC) {
+        const float v = zp[(int64_t)c * S * S];
+        if (v > best || c == 0) { best = v; arg = c; }
+      }
+    const int tile = first_tile + ti;
+    const int ty = tile / tiles_per_row, tx = tile - ty * tiles_per_row;
+    const int oy = ty * p + y, ox = tx * p + x;
+    if (oy < Hout && ox < Wout) {
+      const int64_t o = (int64_t)oy * Wout + ox;
+      if (labels) labels[o] = (uint8_t)arg;
+      if (rgb) { rgb[o * 3] = palette[arg * 3]; rgb[o * 3 + 1] = palette[arg * 3 + 1]; rgb[o * 3 + 2] = palette[arg * 3 + 2]; }
+    }
+  }
+}
+
 static inline int pix_grid(int64_t P, int cap = 256 * 16) {
   int64_t g = cdiv(P, 256);
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -346,5 +396,33 @@ extern "C" int cvcs_argmax_confusion(const float* logits, int B, int NC, int64_t
   else
     hipLaunchKernelGGL((argmax_conf_kernel<32>), grid, dim3(256), 0, st, logits, P, HW, NC, labels, target, target_is_u8, ignore_index, K, c);
   CVCS_CHECK_LAUNCH("cvcs_argmax_confusion");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_crop_tiles(const uint8_t* src, int C, int H, int W, uint8_t* dst, int n, int first_tile, int tiles_per_row,
+                               int p, int S, void* stream) {
+  CVCS_CHECK_ARG(src && dst && C > 0 && H > 0 && W > 0 && n > 0 && tiles_per_row > 0 && p > 0 && S >= p && (S - p) % 2 == 0 &&
+                     first_tile >= 0, "cvcs_crop_tiles: bad argument");
+  hipLaunchKernelGGL(crop_tiles_kernel, dim3(pix_grid((int64_t)n * C * S * S, 4096)), dim3(256), 0, (hipStream_t)stream, src, C, H,
+                     W, dst, n, first_tile, tiles_per_row, p, S);
+  CVCS_CHECK_LAUNCH("cvcs_crop_tiles");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_argmax_stitch(const float* logits, int n, int NC, int S, int p, int first_tile, int tiles_per_row,
+                                  const uint8_t* palette, uint8_t* rgb, uint8_t* labels, int Hout, int Wout, void* stream) {
+  CVCS_CHECK_ARG(logits && n > 0 && S >= p && p > 0 && (S - p) % 2 == 0 && tiles_per_row > 0 && first_tile >= 0 && Hout > 0 &&
+                     Wout > 0, "cvcs_argmax_stitch: bad argument");
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_argmax_stitch: NC=%d out of [1,%d]", NC, kMaxNC);
+  CVCS_CHECK_ARG((rgb == nullptr || palette != nullptr) && (rgb || labels), "cvcs_argmax_stitch: rgb needs a palette; nothing to write");
+  dim3 grid(pix_grid((int64_t)n * p * p, 4096));
+  hipStream_t st = (hipStream_t)stream;
+  if (NC <= 8)
+    hipLaunchKernelGGL((argmax_stitch_kernel<8>), grid, dim3(256), 0, st, logits, n, NC, S, p, first_tile, tiles_per_row, palette, rgb, labels, Hout, Wout);
+  else if (NC <= 16)
+    hipLaunchKernelGGL((argmax_stitch_kernel<16>), grid, dim3(256), 0, st, logits, n, NC, S, p, first_tile, tiles_per_row, palette, rgb, labels, Hout, Wout);
+  else
+    hipLaunchKernelGGL((argmax_stitch_kernel<32>), grid, dim3(256), 0, st, logits, n, NC, S, p, first_tile, tiles_per_row, palette, rgb, labels, Hout, Wout);
+  CVCS_CHECK_LAUNCH("cvcs_argmax_stitch");
   return CVCS_OK;
 }

@@ -319,6 +319,23 @@ def argmax_confusion(logits, labels=None, target=None, ignore_index=-1, K=16, co
                                            _ptr(conf), _stream()), "cvcs_argmax_confusion")
 
 
+def crop_tiles(image_chw, dst, first_tile, tiles_per_row, p):
+    """image u8 [C,H,W] -> dst u8 [n,C,S,S]: S-windows centred on tiles first_tile.. of side p"""
+    assert image_chw.dtype == torch.uint8 and dst.dtype == torch.uint8 and image_chw.is_contiguous() and dst.is_contiguous()
+    C_, H, W = image_chw.shape
+    n, _, S, _ = dst.shape
+    check(_lib.lib().cvcs_crop_tiles(image_chw.data_ptr(), C_, H, W, dst.data_ptr(), n, first_tile, tiles_per_row, p, S,
+                                     _stream()), "cvcs_crop_tiles")
+
+
+def argmax_stitch(logits, p, first_tile, tiles_per_row, palette, rgb, labels):
+    n, NC, S, _ = logits.shape
+    Hout, Wout = (rgb.shape[0], rgb.shape[1]) if rgb is not None else labels.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    check(_lib.lib().cvcs_argmax_stitch(logits.data_ptr(), n, NC, S, p, first_tile, tiles_per_row, _ptr(palette), _ptr(rgb),
+                                        _ptr(labels), Hout, Wout, _stream()), "cvcs_argmax_stitch")
+
+
 # ------------------------------------------------------------------------------------------------ optimisers
 def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale, first_step):
     check(_lib.lib().cvcs_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, weight_decay,

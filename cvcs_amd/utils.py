@@ -135,6 +135,35 @@ def load_optimizer(config, net):
     return opt, sched
 
 
+def save_model(epoch, net, opt, scheduler, train_loss, val_loss, macro_precision, weighted_precision, conf_flat,
+               conf_normalized, batch_size, checkpoint_dir, optimizer):
+    """S/utils.py:128-142: same dictionary keys and file name (`checkpoint<epoch+1>`); `model_state_dict` has the
+    reference's parameter names / shapes, so either side loads the other's weights."""
+    import os
+    torch.save({
+        "epoch": epoch, "model_state_dict": net.state_dict(), "optimizer_state_dict": opt.state_dict(),
+        "scheduler_state_dict": scheduler.state_dict(), "training_loss_values": train_loss,
+        "validation_loss_values": val_loss, "batch_size": batch_size, "macro_precision": macro_precision,
+        "weighted_precision": weighted_precision, "conf_flat": conf_flat, "conf_normalized": conf_normalized,
+        "optimizer": optimizer,
+    }, os.path.join(checkpoint_dir, "checkpoint{}".format(epoch + 1)))
+
+
+def load_checkpoint(config, net, load_confusion=False):
+    """S/utils.py:282-299.  Accepts checkpoints written by the reference (torch modules, possibly under a
+    DataParallel `module.` prefix, S/nets.py:252-257) or by save_model above."""
+    if "load_checkpoint" in config.keys():
+        checkpoint = torch.load(config["load_checkpoint"], map_location="cpu", weights_only=False)
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint["model_state_dict"].items()}
+        net.load_state_dict(sd)
+        TL, VL = checkpoint.get("training_loss_values", []), checkpoint.get("validation_loss_values", [])
+        mIoU, wIoU = checkpoint.get("macro_precision", []), checkpoint.get("weighted_precision", [])
+        print("Loaded checkpoint {}".format(config["load_checkpoint"]), flush=True)
+        if load_confusion:
+            return TL, VL, mIoU, wIoU, checkpoint.get("conf_flat"), checkpoint.get("conf_normalized")
+        return TL, VL, mIoU, wIoU
+
+
 def mask_reshape(mask: torch.Tensor):
     """S/utils.py:557-567: a 4-D mask carries replicated channels; keep channel 0."""
     if len(mask.shape) == 4:

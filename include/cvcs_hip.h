@@ -162,6 +162,19 @@ int cvcs_ce_fwd_bwd(const float* logits, const void* target, int target_is_u8, i
 int cvcs_argmax_confusion(const float* logits, int B, int NC, int64_t HW, uint8_t* labels,
                           const void* target, int target_is_u8, int ignore_index, int K, int64_t* conf, void* stream);
 
+/* ---- whole-image inference boundary -----------------------------------------------------------------------------
+ * replaces: GID15.__getitem__ crop / _get_padded_patch (S/dataset.py:18-23,70-96), CenterCrop + argmax + iconvert +
+ * per-tile PNG + stitching (S/utils.py:145-171, S/inference.py:40-57, S/converters.py:23-36).
+ * cvcs_crop_tiles: tiles first_tile .. first_tile+n-1 (row-major, tiles_per_row per image row, stride p) of one u8
+ * CHW image -> u8 [n,C,S,S]; S >= p is the border-corrected size, the S-window is CENTRED on the p-tile (the
+ * reference crops it at offset S-p, S/dataset.py:19-22, and re-centres by (S-p)/2: its quirk 6), zero outside.
+ * cvcs_argmax_stitch: f32 logits [n,NC,S,S] -> argmax of the centre p x p window -> palette colour (u8 [K][3]) and/or
+ * label written at the tile's place in the stitched maps (u8 [Hout][Wout][3] / [Hout][Wout]).                    */
+int cvcs_crop_tiles(const uint8_t* src, int C, int H, int W, uint8_t* dst, int n, int first_tile, int tiles_per_row,
+                    int p, int S, void* stream);
+int cvcs_argmax_stitch(const float* logits, int n, int NC, int S, int p, int first_tile, int tiles_per_row,
+                       const uint8_t* palette, uint8_t* rgb, uint8_t* labels, int Hout, int Wout, void* stream);
+
 /* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
  * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).
  * grad_scale multiplies the gradient first (1/world_size after the sum all-reduce).                           */

@@ -1,0 +1,100 @@
+"""Whole-image inference (border correction + stitching) and checkpoint compatibility on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cvcs_amd import nets, ops, utils  # noqa: E402
+from cvcs_amd.converters import GID15Converter  # noqa: E402
+from cvcs_amd.inference import segment_image  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def test_crop_tiles_matches_slicing():
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (3, 70, 100), dtype=torch.uint8, generator=g)
+    p, S = 32, 48
+    Wn = 100 // p
+    m = (S - p) // 2
+    dst = torch.empty(4, 3, S, S, dtype=torch.uint8, device=DEV)
+    ops.crop_tiles(img.to(DEV), dst, 1, Wn, p)          # tiles 1..4 of a 2 x 3 grid
+    torch.cuda.synchronize()
+    padded = F.pad(img, (m, S, m, S))                    # zero ring
+    for t in range(4):
+        ty, tx = divmod(1 + t, Wn)
+        ref = padded[:, ty * p:ty * p + S, tx * p:tx * p + S]
+        assert torch.equal(dst[t].cpu(), ref), t
+
+
+@pytest.mark.parametrize("bc", [None, 48])
+def test_segment_image_matches_oracle(bc):
+    """utils.inference + stitching (S/utils.py:145-171, S/inference.py:40-57) with centred border correction."""
+    NC, p = 5, 32
+    S = bc or p
+    m = (S - p) // 2
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (3, 64 + 7, 96 + 5), dtype=torch.uint8, generator=g)   # 2 x 3 tiles + ragged edge
+    net = nets.Urnetv2(NC, "fp32")
+    net.load_state_dict(O.init_params("Unetv2", NC, seed=3), strict=False)
+    net = net.to(DEV)
+    rgb, labels = segment_image(net, img.to(DEV), p, bc, batch=4)
+    torch.cuda.synchronize()
+    assert labels.shape == (64, 96) and rgb.shape == (64, 96, 3)
+    params = O.init_params("Unetv2", NC, seed=3)
+    padded = F.pad(img, (m, S, m, S)).float()
+    pal = GID15Converter().palette_u8()
+    agree, total = 0, 0
+    for ty in range(2):
+        for tx in range(3):
+            win = padded[None, :, ty * p:ty * p + S, tx * p:tx * p + S]
+            with torch.no_grad():
+                ref = O.unet_forward(params, win, "Unetv2", train=False)[0, :, m:m + p, m:m + p]
+            top2 = torch.topk(ref, 2, dim=0).values
+            decided = (top2[0] - top2[1]) > 1e-3 * ref.abs().max()
+            got = labels[ty * p:(ty + 1) * p, tx * p:(tx + 1) * p].cpu().long()
+            assert torch.equal(got[decided], ref.argmax(0)[decided])
+            agree += (got == ref.argmax(0)).sum().item(); total += p * p
+            assert torch.equal(rgb[ty * p:(ty + 1) * p, tx * p:(tx + 1) * p].cpu(), pal[got])
+    assert agree / total > 0.999
+
+
+def test_checkpoint_round_trip_and_reference_layout(tmp_path):
+    """save_model / load_checkpoint (S/utils.py:128-142, 282-299): reference keys; a checkpoint holding a reference-style
+    state dict under a DataParallel `module.` prefix loads; weights survive the round trip bit for bit."""
+    NC = 5
+    net = nets.Urnetv2(NC, "fp32").to(DEV)
+    opt, sched = utils.load_optimizer({"opt": "SGD2", "epochs": 2}, net)
+    img, lab = O.synthetic_tiles(2, 32, NC, seed=1)
+    crit = utils.CrossEntropyLoss(ignore_index=0)
+    net.train()
+    loss = crit(net(img.to(DEV), None), lab.to(DEV))
+    opt.zero_grad(); loss.backward(); opt.step()
+    utils.save_model(0, net, opt, sched, [loss.item()], [], [], [], [], [], 2, str(tmp_path), "SGD2")
+    ck = torch.load(os.path.join(tmp_path, "checkpoint1"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "training_loss_values",
+                       "validation_loss_values", "batch_size", "macro_precision", "weighted_precision", "conf_flat",
+                       "conf_normalized", "optimizer"}
+    assert int(ck["model_state_dict"]["encode1.0.layer.1.num_batches_tracked"]) == 1
+    net2 = nets.Urnetv2(NC, "fp32").to(DEV)
+    utils.load_checkpoint({"load_checkpoint": os.path.join(tmp_path, "checkpoint1")}, net2)
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # reference-style checkpoint: torch-CPU tensors with a `module.` prefix
+    ref_sd = {"module." + k: v for k, v in O.init_params("Unetv2", NC, seed=9).items()}
+    torch.save({"model_state_dict": ref_sd}, os.path.join(tmp_path, "ref_ckpt"))
+    net3 = nets.Urnetv2(NC, "fp32")
+    missing = utils.load_checkpoint  # noqa: F841
+    sd = {k[len("module."):]: v for k, v in ref_sd.items()}
+    net3.load_state_dict(sd, strict=False)
+    net3 = net3.to(DEV)
+    net3.eval()
+    with torch.no_grad():
+        out = net3(img.to(DEV), None).cpu()
+        ref = O.unet_forward(O.init_params("Unetv2", NC, seed=9), img.float(), "Unetv2", train=False)
+    assert (out - ref).abs().max() < 1e-3 * ref.abs().max()
