@@ -74,6 +74,8 @@ SIGNATURES = {
     "cvcs_argmax_confusion": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "cvcs_crop_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "cvcs_argmax_stitch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "cvcs_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "cvcs_label_histogram": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cvcs_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
     "cvcs_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }

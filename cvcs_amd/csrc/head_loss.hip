@@ -269,6 +269,33 @@ __global__ __launch_bounds__(256) void crop_tiles_kernel(const uint8_t* __restri
   }
 }
 
+// tile producer: gather n tiles (S x S) at arbitrary origins (int32 [n][2] = (top, left), e.g. randomly shifted grid
+// positions) out of one resident u8 CHW image / HW index mask; zero outside the image
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const uint8_t* __restrict__ src, int C, int H, int W,
+                                                          const int* __restrict__ origins, int n, int S, uint8_t* dst) {
+  const int64_t total = (int64_t)n * C * S * S;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int x = (int)(id % S);
+    int64_t t = id / S;
+    const int y = (int)(t % S); t /= S;
+    const int c = (int)(t % C);
+    const int ti = (int)(t / C);
+    const int sy = origins[2 * ti] + y, sx = origins[2 * ti + 1] + x;
+    dst[id] = ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) ? src[((int64_t)c * H + sy) * W + sx] : (uint8_t)0;
+  }
+}
+
+// per-class pixel counts of a u8 label image (Loader._get_class_count, S/dataset.py:346-358): LDS-privatised histogram
+__global__ __launch_bounds__(256) void label_histogram_kernel(const uint8_t* __restrict__ lab, int64_t n, int K,
+                                                             unsigned long long* counts) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) atomicAdd(&h[lab[i]], 1u);
+  __syncthreads();
+  if ((int)threadIdx.x < K && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 // argmax over classes of the centre p x p window of every tile, palette lookup, write into the stitched maps
 template <int NCMAX>
 __global__ __launch_bounds__(256) void argmax_stitch_kernel(const float* __restrict__ logits, int n, int NC, int S, int p,
@@ -424,5 +451,22 @@ extern "C" int cvcs_argmax_stitch(const float* logits, int n, int NC, int S, int
   else
     hipLaunchKernelGGL((argmax_stitch_kernel<32>), grid, dim3(256), 0, st, logits, n, NC, S, p, first_tile, tiles_per_row, palette, rgb, labels, Hout, Wout);
   CVCS_CHECK_LAUNCH("cvcs_argmax_stitch");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_gather_tiles(const uint8_t* src, int C, int H, int W, const int32_t* origins, int n, int S, uint8_t* dst,
+                                 void* stream) {
+  CVCS_CHECK_ARG(src && dst && origins && C > 0 && H > 0 && W > 0 && n > 0 && S > 0, "cvcs_gather_tiles: bad argument");
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3(pix_grid((int64_t)n * C * S * S, 4096)), dim3(256), 0, (hipStream_t)stream, src, C,
+                     H, W, origins, n, S, dst);
+  CVCS_CHECK_LAUNCH("cvcs_gather_tiles");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_label_histogram(const uint8_t* labels, int64_t n, int K, int64_t* counts, void* stream) {
+  CVCS_CHECK_ARG(labels && counts && n > 0 && K >= 1 && K <= 256, "cvcs_label_histogram: bad argument");
+  hipLaunchKernelGGL(label_histogram_kernel, dim3(pix_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, labels, n, K,
+                     reinterpret_cast<unsigned long long*>(counts));
+  CVCS_CHECK_LAUNCH("cvcs_label_histogram");
   return CVCS_OK;
 }

@@ -158,6 +158,70 @@ class Loader:
         return class_weights_from_counts(self.count, ignore_background)
 
 
+class DeviceChunk:
+    """A chunk whose full images (u8 CHW) and index masks (u8 HW) are RESIDENT on the device; batches are produced by one
+    gather launch each (cvcs_gather_tiles) instead of the reference's eager per-patch Python crop (S/dataset.py:136-172).
+    Iterating yields (image u8 [B,3,p,p], index_mask u8 [B,p,p], color_mask, context) already on the device, i.e. what
+    the reference's DataLoader + `.to(device)` hand to the batch loop (S/train.py:114-115)."""
+
+    def __init__(self, images, masks, patch_size, batch_size, random_shift=False, shuffle=True, seed=0):
+        from . import ops
+        self.ops = ops
+        self.images, self.masks = images, masks
+        self.p, self.bs = patch_size, batch_size
+        g = torch.Generator().manual_seed(seed)
+        items = []
+        for i, im in enumerate(images):
+            H, W = im.shape[-2:]
+            for ty in range(H // patch_size):
+                for tx in range(W // patch_size):
+                    y, x = ty * patch_size, tx * patch_size
+                    if random_shift:   # S/dataset.py:25-26,143: +-20 px; pixels past the border read 0
+                        y += int(torch.randint(-20, 21, (1,), generator=g))
+                        x += int(torch.randint(-20, 21, (1,), generator=g))
+                    items.append((i, y, x))
+        if shuffle:
+            perm = torch.randperm(len(items), generator=g).tolist()
+            items = [items[j] for j in perm]
+        self.items = items
+        self.chunk_crops = items
+
+    def __len__(self):
+        return (len(self.items) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        dev = self.images[0].device
+        p = self.p
+        for b0 in range(0, len(self.items), self.bs):
+            batch = self.items[b0:b0 + self.bs]
+            img = torch.empty((len(batch), 3, p, p), dtype=torch.uint8, device=dev)
+            msk = torch.empty((len(batch), p, p), dtype=torch.uint8, device=dev)
+            by_image = {}
+            for j, (i, y, x) in enumerate(batch):     # one gather launch per source image present in the batch
+                by_image.setdefault(i, []).append((j, y, x))
+            for i, lst in by_image.items():
+                idx = torch.tensor([j for j, _, _ in lst], device=dev)
+                org = torch.tensor([[y, x] for _, y, x in lst], dtype=torch.int32, device=dev)
+                ti = torch.empty((len(lst), 3, p, p), dtype=torch.uint8, device=dev)
+                tm = torch.empty((len(lst), p, p), dtype=torch.uint8, device=dev)
+                self.ops.gather_tiles(self.images[i], org, ti)
+                self.ops.gather_tiles(self.masks[i], org, tm)
+                if len(by_image) == 1:
+                    img, msk = ti, tm
+                else:
+                    img[idx], msk[idx] = ti, tm
+            yield img, msk, torch.zeros(1), torch.zeros(1)
+
+
+def device_class_weights(masks, classes, ignore_background=False):
+    """Loader.get_class_weights (S/dataset.py:360-384) with the pixel count done by cvcs_label_histogram on the device"""
+    from . import ops
+    counts = torch.zeros(classes, dtype=torch.int64, device=masks[0].device)
+    for m in masks:
+        ops.label_histogram(m.contiguous(), counts)
+    return class_weights_from_counts(counts.cpu().float(), ignore_background)
+
+
 def make_loader(spec, chunk_size, patch_size, num_classes, random_shift=False, seed=0):
     """`spec` is a dataset directory, or 'synthetic:<n_images>[:<tiles_per_image>]'."""
     if isinstance(spec, str) and spec.startswith("synthetic:"):

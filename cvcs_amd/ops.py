@@ -336,6 +336,24 @@ def argmax_stitch(logits, p, first_tile, tiles_per_row, palette, rgb, labels):
                                         _ptr(labels), Hout, Wout, _stream()), "cvcs_argmax_stitch")
 
 
+def gather_tiles(src, origins, dst):
+    """src u8 [C,H,W] (or [H,W]) resident on the device, origins int32 [n,2] (top, left) -> dst u8 [n,C,S,S] (or [n,S,S])"""
+    assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and origins.dtype == torch.int32
+    assert src.is_contiguous() and dst.is_contiguous() and origins.is_contiguous()
+    C_ = src.shape[0] if src.dim() == 3 else 1
+    H, W = src.shape[-2:]
+    n, S = dst.shape[0], dst.shape[-1]
+    assert origins.shape == (n, 2)
+    check(_lib.lib().cvcs_gather_tiles(src.data_ptr(), C_, H, W, origins.data_ptr(), n, S, dst.data_ptr(), _stream()),
+          "cvcs_gather_tiles")
+
+
+def label_histogram(labels, counts):
+    assert labels.dtype == torch.uint8 and labels.is_contiguous() and counts.dtype == torch.int64
+    check(_lib.lib().cvcs_label_histogram(labels.data_ptr(), labels.numel(), counts.numel(), counts.data_ptr(), _stream()),
+          "cvcs_label_histogram")
+
+
 # ------------------------------------------------------------------------------------------------ optimisers
 def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale, first_step):
     check(_lib.lib().cvcs_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, weight_decay,

@@ -175,6 +175,14 @@ int cvcs_crop_tiles(const uint8_t* src, int C, int H, int W, uint8_t* dst, int n
 int cvcs_argmax_stitch(const float* logits, int n, int NC, int S, int p, int first_tile, int tiles_per_row,
                        const uint8_t* palette, uint8_t* rgb, uint8_t* labels, int Hout, int Wout, void* stream);
 
+/* ---- tile producer --------------------------------------------------------------------------------------------
+ * replaces: IterableChunk's eager Python pre-crop of every patch (S/dataset.py:136-172, _random_shift :25-26) and the
+ * per-class pixel count behind the wCEL weights (S/dataset.py:346-358).  Decoded images stay resident as u8 on the
+ * device; a batch is one gather launch over n origins (int32 [n][2] = top, left; out-of-image pixels read 0).      */
+int cvcs_gather_tiles(const uint8_t* src, int C, int H, int W, const int32_t* origins, int n, int S, uint8_t* dst,
+                      void* stream);
+int cvcs_label_histogram(const uint8_t* labels, int64_t n, int K, int64_t* counts /* int64 [K], accumulated */, void* stream);
+
 /* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
  * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).
  * grad_scale multiplies the gradient first (1/world_size after the sum all-reduce).                           */

@@ -98,3 +98,30 @@ def test_checkpoint_round_trip_and_reference_layout(tmp_path):
         out = net3(img.to(DEV), None).cpu()
         ref = O.unet_forward(O.init_params("Unetv2", NC, seed=9), img.float(), "Unetv2", train=False)
     assert (out - ref).abs().max() < 1e-3 * ref.abs().max()
+
+
+def test_device_chunk_tile_producer_matches_reference_crops():
+    """tile producer (S/dataset.py:136-172): resident images + gather launches == the eager Python crops, incl. a
+    randomly shifted grid (zero fill past the border) and the class-weight histogram (S/dataset.py:346-384)."""
+    from cvcs_amd.dataset import DeviceChunk, class_weights_from_counts, device_class_weights
+    g = torch.Generator().manual_seed(5)
+    images = [torch.randint(0, 256, (3, 96, 130), dtype=torch.uint8, generator=g) for _ in range(2)]
+    masks = [torch.randint(0, 6, (96, 130), dtype=torch.uint8, generator=g) for _ in range(2)]
+    dimg, dmsk = [i.to(DEV) for i in images], [m.to(DEV) for m in masks]
+    for shift in (False, True):
+        ch = DeviceChunk(dimg, dmsk, 32, batch_size=5, random_shift=shift, shuffle=True, seed=1)
+        assert len(ch.items) == 2 * 3 * 4 and len(ch) == 5
+        seen = 0
+        for b, (im, mk, _, _) in enumerate(ch):
+            assert im.dtype == torch.uint8 and im.is_cuda and im.shape[1:] == (3, 32, 32) and mk.shape[1:] == (32, 32)
+            for j in range(im.shape[0]):
+                i, y, x = ch.items[b * 5 + j]
+                pad = 32
+                ref_i = F.pad(images[i], (pad, pad, pad, pad))[:, y + pad:y + pad + 32, x + pad:x + pad + 32]
+                ref_m = F.pad(masks[i], (pad, pad, pad, pad))[y + pad:y + pad + 32, x + pad:x + pad + 32]
+                assert torch.equal(im[j].cpu(), ref_i) and torch.equal(mk[j].cpu(), ref_m)
+                seen += 1
+        assert seen == 24
+    counts = sum(torch.bincount(m.reshape(-1).long(), minlength=6) for m in masks).float()
+    for ib in (False, True):
+        assert torch.equal(device_class_weights(dmsk, 6, ib), class_weights_from_counts(counts, ib))
