@@ -381,6 +381,15 @@ __device__ __forceinline__ void wait_vm_barrier(int k) {
   else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// sum over the 16 lanes of a row group, result in every lane (DPP butterflies: quad_perm, quad_perm, half mirror, mirror)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // lanes 1,0,3,2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // lanes 2,3,0,1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 template <typename T> __device__ __forceinline__ f32x4 mma_u(const u32x4& a, const u32x4& b, f32x4 c) {
   return Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c);
 }
@@ -532,10 +541,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
         };
         auto mma_set = [&](const FragSet& f) {
           auto row_mma = [&](int i, const u32x4& af) {
-            acc[i][0] = mma_u<T>(af, f.b0, acc[i][0]);
-            acc[i][1] = mma_u<T>(af, f.b1, acc[i][1]);
-            acc[i][2] = mma_u<T>(af, f.b2, acc[i][2]);
-            acc[i][3] = mma_u<T>(af, f.b3, acc[i][3]);
+            acc[i][0] = mma_u<T>(f.b0, af, acc[i][0]);   // A = weights, B = pixels: D[channel][pixel]
+            acc[i][1] = mma_u<T>(f.b1, af, acc[i][1]);
+            acc[i][2] = mma_u<T>(f.b2, af, acc[i][2]);
+            acc[i][3] = mma_u<T>(f.b3, af, acc[i][3]);
           };
           row_mma(0, f.a0); row_mma(1, f.a1); row_mma(2, f.a2); row_mma(3, f.a3);
         };
@@ -569,10 +578,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
             lds_read2q<AOFF + kh * RB, AOFF + (kh + 1) * RB>(a0, a1, abase[kw]);
           }
           auto row_mma = [&](int i, const u32x4& af) {
-            acc[i][0] = mma_u<T>(af, bf0, acc[i][0]);
-            acc[i][1] = mma_u<T>(af, bf1, acc[i][1]);
-            acc[i][2] = mma_u<T>(af, bf2, acc[i][2]);
-            acc[i][3] = mma_u<T>(af, bf3, acc[i][3]);
+            acc[i][0] = mma_u<T>(bf0, af, acc[i][0]);   // A = weights, B = pixels: D[channel][pixel]
+            acc[i][1] = mma_u<T>(bf1, af, acc[i][1]);
+            acc[i][2] = mma_u<T>(bf2, af, acc[i][2]);
+            acc[i][3] = mma_u<T>(bf3, af, acc[i][3]);
           };
           if constexpr (MREP == 8) {
             u32x4 a4, a5, a6, a7;
@@ -596,79 +605,85 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     if (cs + 1 < nslice) slice_body(std::integral_constant<int, 1>{}, cs + 1);
   }
 
-  // ---- epilogue: bias / ReLU.  acc[i][j][r]: image row y = wm*MREP + i, pixel x = fg*4 + r, channel = .. + fr
+  // ---- epilogue.  The MFMAs ran with A = weights, B = pixels, so acc[i][j][r] is image row y = wm*MREP + i, pixel
+  // x = fr, channel = wn*WNC + j*16 + fg*4 + r: every lane owns FOUR CONSECUTIVE CHANNELS of one pixel - a packed
+  // 8-byte (bf16) / 16-byte (f32) LDS write per 16x16 block when staging the output rows.  Per-channel BatchNorm sums run
+  // over the 16 lanes of a row group (DPP butterflies) and over i in registers.
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
-    const float bv = p.bias ? p.bias[n0 + wn * WNC + j * 16 + fr] : 0.f;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + wn * WNC + j * 16 + fg * 4);
+      bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+    }
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv;
+        float v = acc[i][j][r] + bv[r];
         if (p.relu) v = fmaxf(v, 0.f);
         acc[i][j][r] = v;
       }
   }
   int ny = p.H - ty0 - wm * MREP; ny = ny < 0 ? 0 : (ny > MREP ? MREP : ny);
   int nx = p.W - tx0;             nx = nx > 16 ? 16 : nx;
-  if (p.stat_sum && p.dbg_skip < 2) {
+  if (p.stat_sum) {
     const int nvalid = ny * nx;
     const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
     const int64_t row = (int64_t)blockIdx.x * WM + wm;
+    const bool xok = fr < nx;
 #pragma unroll
     for (int j = 0; j < NREP; ++j) {
-      float s = 0.f;
+      float s[4], q[4];
 #pragma unroll
-      for (int i = 0; i < MREP; ++i)
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (i < ny && fg * 4 + r < nx) s += acc[i][j][r];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      const float mean = s * inv;
-      float q = 0.f;
+        for (int i = 0; i < MREP; ++i)
+          if (i < ny && xok) t += acc[i][j][r];
+        s[r] = row_sum16(t);
+      }
 #pragma unroll
-      for (int i = 0; i < MREP; ++i)
+      for (int r = 0; r < 4; ++r) {
+        const float mean = s[r] * inv;
+        float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (i < ny && fg * 4 + r < nx) {
+        for (int i = 0; i < MREP; ++i)
+          if (i < ny && xok) {
             const float d = acc[i][j][r] - mean;
-            q += d * d;
+            t += d * d;
           }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (fg == 0) {
-        const int n = n0 + wn * WNC + j * 16 + fr;
-        p.stat_sum[row * p.Cout + n] = s;
-        p.stat_m2[row * p.Cout + n] = q;
+        q[r] = row_sum16(t);
+      }
+      if (fr == 0) {
+        const int n = n0 + wn * WNC + j * 16 + fg * 4;
+        *reinterpret_cast<float4*>(p.stat_sum + row * p.Cout + n) = make_float4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<float4*>(p.stat_m2 + row * p.Cout + n) = make_float4(q[0], q[1], q[2], q[3]);
       }
     }
     if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[row] = (float)nvalid;
   }
-  // ---- store: two halves of 8 image rows, transposed through LDS into whole pixel rows
+  // ---- store: two halves of 8 image rows staged through LDS as [pixel][channel] (one packed 8/16-byte LDS write per
+  // lane and 16x16 block) and written out as whole pixel rows of BN*sizeof(T) contiguous bytes
   constexpr int CPR = BN * ES / 16;
-  if (p.dbg_skip) {   // keep the accumulators alive without the staging / store
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < MREP; ++i)
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 1.2345e-30f) p.out[0] = 1;
-    return;
-  }
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if ((wm * MREP) / 8 == h) {
 #pragma unroll
       for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int lrow = (wm * MREP + i - h * 8) * 16 + fg * 4 + r;
-            const int col = wn * WNC + j * 16 + fr;
-            Elem<T>::st(reinterpret_cast<T*>(smem + lrow * OROW) + col, acc[i][j][r]);
+        for (int j = 0; j < NREP; ++j) {
+          const int lrow = (wm * MREP + i - h * 8) * 16 + fr;
+          char* dst = smem + lrow * OROW + (wn * WNC + j * 16 + fg * 4) * ES;
+          if constexpr (ES == 2) {
+            uint2 u;
+            u.x = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
+            u.y = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = u;
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           }
+        }
     }
     __syncthreads();
     for (int id = tid; id < 128 * CPR; id += NT) {
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
 template <typename T, int BN, int WM, int WN, int TPS>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
-  size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(TPS * BN * 64);
+  size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(TPS * BN * 64);   // halo double buffer + weight ring
   size_t epi = (size_t)128 * (BN * ES + 16);
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;

@@ -275,3 +275,30 @@ def test_training_is_bitwise_reproducible(variant, B, S):
         l1, p1 = run()
         assert l0 == l1
         assert torch.equal(p0, p1)
+
+
+def test_reference_default_tile_224_ragged_levels():
+    """the reference's default patch size 224 (configs/train/server.yaml:23): levels 224/112/56/28/14 exercise ragged
+    16x16 conv tiles, 14-pixel rows in wgrad and the small-map conv path.  fp32 eval logits vs the oracle, then one bf16
+    training step that must be finite and reproducible."""
+    NC = 16
+    img, lab = O.synthetic_tiles(2, 224, NC, seed=31, structured=True)
+    net = _build("Unetv2", NC, "fp32")
+    net.eval()
+    with torch.no_grad():
+        out = net(img.to(DEV), None).cpu()
+        ref = O.unet_forward(O.init_params("Unetv2", NC, seed=3), img.float(), "Unetv2", train=False)
+    assert (out - ref).abs().max() < 1e-3 * ref.abs().max()
+    losses = []
+    for _ in range(2):
+        nb = _build("Unetv2", NC, "bf16")
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        optim, _ = utils.load_optimizer({"opt": "ADAM1", "epochs": 3}, nb)
+        nb.train()
+        ls = []
+        for _ in range(2):
+            loss = crit(nb(img.to(DEV), None), lab.to(DEV))
+            optim.zero_grad(); loss.backward(); optim.step()
+            ls.append(loss.item())
+        losses.append(ls)
+    assert all(np.isfinite(l) for l in losses[0]) and losses[0] == losses[1]
