@@ -48,8 +48,9 @@ class GradientAllReducer:
         self.next = 0
         self.works = []
 
-    def ready_down_to(self, lo_floats: int):
-        """backward has finished every gradient at flat offset >= lo_floats: launch the buckets that are complete."""
+    def ready_down_to(self, lo_floats: int, extra_events=()):
+        """backward has finished every gradient at flat offset >= lo_floats: launch the buckets that are complete.
+        extra_events: events of other streams that produced part of those gradients (the weight-gradient stream)."""
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= lo_floats:
             lo, hi = self.buckets[self.next]
             self.next += 1
@@ -58,6 +59,8 @@ class GradientAllReducer:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 self.comm_stream.wait_event(ev)
+                for e in extra_events:
+                    self.comm_stream.wait_event(e)
                 with torch.cuda.stream(self.comm_stream):
                     self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             else:
