@@ -59,7 +59,9 @@ __device__ __forceinline__ void wait_vm_barrier_n(int k) {
     case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;   // unknown count: drain
   }
 }
 
@@ -238,21 +240,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 //     of the swizzle period, so the swizzled address of a transposed read depends on (k + kw) only -> 12 per-lane
 //     registers cover all nine taps, the tap row and the ring stage are instruction immediates;
 //   * per-lane DMA source offsets are computed once (no divisions per K-tile), the K-tile origin is scalar;
-//   * the transposed reads of tap t+1 are issued before the four MFMAs of tap t (three rotating register sets).
-template <int O0, int O1, int O2, int O3>
-__device__ __forceinline__ void tr_issue4(u32x2& o0, u32x2& o1, u32x2& o2, u32x2& o3, unsigned a0, unsigned a1, unsigned a2,
-                                          unsigned a3) {
-  static_assert(O0 >= 0 && O0 < 65536 && O1 < 65536 && O2 < 65536 && O3 < 65536, "ds_read offset is a 16-bit immediate");
-  asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%8\n\tds_read_b64_tr_b16 %1, %5 offset:%9\n\t"
-               "ds_read_b64_tr_b16 %2, %6 offset:%10\n\tds_read_b64_tr_b16 %3, %7 offset:%11"
-               : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
-               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "i"(O0), "i"(O1), "i"(O2), "i"(O3)
-               : "memory");
-}
-struct TrSet { u32x2 r0, r1, r2, r3; };
-__device__ __forceinline__ void tr_wait(TrSet& f) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r0), "+v"(f.r1), "+v"(f.r2), "+v"(f.r3) : : "memory");
-}
+//   * the LDS-DMA is issued from inline asm, the transposed reads are builtins: the compiler interleaves reads and MFMAs
+//     with its own fine-grained lgkmcnt waits (it would drain vmcnt before every LDS read if it saw the DMA).
 template <int I, int N, typename F>
 __device__ __forceinline__ void wg_static_for(F&& f) {
   if constexpr (I < N) {
@@ -261,12 +250,31 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
   }
 }
 
+// LDS-DMA issued from inline asm: the compiler then does not know a DMA is in flight and schedules the LDS fragment
+// reads (builtins) freely with its own fine-grained lgkmcnt waits - no vmcnt(0) in front of every read, no register
+// copies to assemble MFMA operands.  Completion is tracked by hand (counted vmcnt before the barrier).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+typedef __attribute__((ext_vector_type(4))) short s16x4v;
+typedef __attribute__((ext_vector_type(8))) short s16x8v;
+__device__ __forceinline__ bf16x8 tr_pair(const char* smem_base, unsigned off0, unsigned off1) {
+  const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(smem_base + off0));
+  const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(smem_base + off1));
+  const s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   constexpr int ROWB = 128, HP = 40;               // LDS row bytes (64 bf16), padded halo pitch in pixels
   constexpr int DY_BYTES = 32 * ROWB, X_ROWS = 3 * HP, X_BYTES = X_ROWS * ROWB;
   constexpr int STAGE = DY_BYTES + X_BYTES;        // 19456
   constexpr int XP = X_ROWS / 8;                   // 15 halo DMA pieces
-  constexpr int NS = 3;
+  constexpr int NS = 3;                            // ring stages: two K-tiles in flight (a third buys nothing: measured)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -314,12 +322,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
     const int b = kt / tiles_per_img;                 // wave-uniform scalars
     const int tr = kt - b * tiles_per_img;
     const int oy = tr / p.tiles_x, tx0 = (tr - oy * p.tiles_x) * 32;
-    char* sdy = smem + st * STAGE;
-    char* sx = sdy + DY_BYTES;
+    const unsigned sdy = lds0 + st * STAGE;
+    const unsigned sx = sdy + DY_BYTES;
     const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
     const char* src = (tx0 + kdy < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sdy + wave * 1024), 16, 0, 0);
+    dma16(src, sdy + wave * 1024);
     const int iy0 = oy - 1, ix0 = tx0 - 1;
     const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;   // may lie before the tensor: only
 #pragma unroll                                                                        // dereferenced for valid pixels
@@ -328,16 +335,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
         const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
         const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
         const char* s2 = ok ? xorg + off_x[j] : reinterpret_cast<const char*>(&g_wzero16);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2,
-                                         (__attribute__((address_space(3))) void*)(sx + (wave + 4 * j) * 1024), 16, 0, 0);
+        dma16(s2, sx + (wave + 4 * j) * 1024);
       }
     }
   };
 
-  // ---- per-lane transposed-read addresses (relative to the stage base)
+  // ---- per-lane transposed-read offsets (relative to the stage base)
   const int q = fr >> 2, pp = fr & 3;
   const int k0 = 4 * fg + q, k1 = 16 + 4 * fg + q;
-  auto taddr = [&](int row, int cc) -> unsigned { return lds0 + row * ROWB + ((cc ^ ((row >> 1) & 3)) << 5) + pp * 8; };
+  auto taddr = [&](int row, int cc) -> unsigned { return row * ROWB + ((cc ^ ((row >> 1) & 3)) << 5) + pp * 8; };
   const unsigned ad0 = taddr(k0, wm * 2), ad1 = taddr(k1, wm * 2), ad2 = taddr(k0, wm * 2 + 1), ad3 = taddr(k1, wm * 2 + 1);
   unsigned ax[3][4];
 #pragma unroll
@@ -357,50 +363,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
     constexpr int ST = decltype(st_)::value;
     int issued = 0;
     if (kt + 2 < kt_end) { issue_tile(kt + 2, (ST + 2) % NS); issued = my_pieces; }
-    constexpr int SB = ST * STAGE;
-    TrSet A;
-    tr_issue4<SB, SB, SB, SB>(A.r0, A.r1, A.r2, A.r3, ad0, ad1, ad2, ad3);
-    TrSet X, Y, Z;
-    auto issue_tap = [&](auto t_, TrSet& f) {
+    const char* sb = smem + ST * STAGE;
+    const bf16x8 af0 = tr_pair(sb, ad0, ad1);
+    const bf16x8 af1 = tr_pair(sb, ad2, ad3);
+    wg_static_for<0, 9>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
       constexpr int kh = t / 3, kw = t - kh * 3;
-      constexpr int O = SB + DY_BYTES + kh * HP * ROWB;
-      tr_issue4<O, O, O, O>(f.r0, f.r1, f.r2, f.r3, ax[kw][0], ax[kw][1], ax[kw][2], ax[kw][3]);
-    };
-    issue_tap(std::integral_constant<int, 0>{}, X);
-    tr_wait(A);
-    tr_wait(X);
-    const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(A.r0.x, A.r0.y, A.r1.x, A.r1.y));
-    const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(A.r2.x, A.r2.y, A.r3.x, A.r3.y));
-    auto mma_tap = [&](auto t_, const TrSet& f) {
-      constexpr int t = decltype(t_)::value;
-      const bf16x8 bf0 = __builtin_bit_cast(bf16x8, make_uint4(f.r0.x, f.r0.y, f.r1.x, f.r1.y));
-      const bf16x8 bf1 = __builtin_bit_cast(bf16x8, make_uint4(f.r2.x, f.r2.y, f.r3.x, f.r3.y));
+      const char* xb = sb + DY_BYTES + kh * HP * ROWB;
+      const bf16x8 bf0 = tr_pair(xb, ax[kw][0], ax[kw][1]);
+      const bf16x8 bf1 = tr_pair(xb, ax[kw][2], ax[kw][3]);
       acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
       acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
       acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
       acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
-    };
-    // taps 0..8 over three rotating register sets: reads of tap t+1 in flight during the MFMAs of tap t
-    wg_static_for<0, 3>([&](auto g_) {
-      constexpr int g = decltype(g_)::value;   // taps 3g, 3g+1, 3g+2 use X, Y, Z
-      issue_tap(std::integral_constant<int, 3 * g + 1>{}, Y);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_tap(std::integral_constant<int, 3 * g>{}, X);
-      __builtin_amdgcn_sched_barrier(0);
-      tr_wait(Y);
-      issue_tap(std::integral_constant<int, 3 * g + 2>{}, Z);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_tap(std::integral_constant<int, 3 * g + 1>{}, Y);
-      __builtin_amdgcn_sched_barrier(0);
-      tr_wait(Z);
-      if constexpr (g < 2) issue_tap(std::integral_constant<int, 3 * g + 3>{}, X);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_tap(std::integral_constant<int, 3 * g + 2>{}, Z);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (g < 2) tr_wait(X);
     });
-    wait_vm_barrier_n(issued);
+    wait_vm_barrier_n(issued);   // tile kt+1 has landed; this iteration's pieces (tile kt+2) may stay in flight
   };
   for (int kt = kt_begin; kt < kt_end; kt += 3) {
     tile_body(std::integral_constant<int, 0>{}, kt);
@@ -424,7 +401,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
         }
       }
 }
-
 
 // dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int taps,
