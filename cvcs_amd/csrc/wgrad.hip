@@ -269,18 +269,25 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* smem_base, unsigned off0, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// K-tile shape TH x TW (TH*TW = 32).  The halo tile is what crosses L2->LDS per K-tile: 3x34 pixels for 1x32, 6x10 for
+// 4x8 - the square-ish tile re-reads the input 1.9x instead of 3.2x (the deep levels of this kernel are MALL-bound and
+// the shallow ones HBM-bound on exactly that traffic).
+template <int TH, int TW>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
-  constexpr int ROWB = 128, HP = 40;               // LDS row bytes (64 bf16), padded halo pitch in pixels
-  constexpr int DY_BYTES = 32 * ROWB, X_ROWS = 3 * HP, X_BYTES = X_ROWS * ROWB;
-  constexpr int STAGE = DY_BYTES + X_BYTES;        // 19456
-  constexpr int XP = X_ROWS / 8;                   // 15 halo DMA pieces
+  static_assert(TH * TW == 32, "a K-tile is 32 output pixels");
+  constexpr int ROWB = 128;                        // LDS row bytes (64 bf16)
+  constexpr int HP = (TW + 2 + 7) / 8 * 8;         // halo pitch in pixels, a multiple of the swizzle period
+  constexpr int HR = TH + 2;
+  constexpr int DY_BYTES = 32 * ROWB, X_ROWS = HR * HP, X_BYTES = X_ROWS * ROWB;
+  constexpr int STAGE = DY_BYTES + X_BYTES;
+  constexpr int XP = X_ROWS / 8;                   // halo DMA pieces
+  constexpr int XJ = (XP + 3) / 4;                 // ... per wave
   constexpr int NS = 3;                            // ring stages: two K-tiles in flight (a third buys nothing: measured)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x;
   const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
   const int co0 = tm * 64, ci0 = tn * 64;
@@ -289,13 +296,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   int kt_end = kt_begin + p.per_slice;
   if (kt_end > p.ktiles) kt_end = p.ktiles;
 
-  f32x4 acc[9][2][2];
+  // wave w owns ALL 64 output channels x input channels [16w, 16w+16) for all nine taps: the dy fragments (4 blocks) are
+  // read once per K-tile and reused by every tap, each x fragment feeds four MFMAs - 26 transposed reads per 36 MFMAs
+  // (a 32x32 wave tile needs 40): this kernel is LDS-bandwidth-bound (fragment reads + DMA writes), not latency-bound.
+  f32x4 acc[9][4];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
   const int cin_rem = p.Cin - ci0;
@@ -304,14 +312,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
 
   // ---- per-lane DMA sources.  dy: piece `wave`, tile pixel k = wave*8 + rr.  halo: pieces wave + 4j (j < 4).
   const int kdy = wave * 8 + rr;
-  const int off_dy = (kdy * (int)p.dy_ld + co0) * 2 + swzc(kdy, pc) * 16;
-  int off_x[4], hyx[4];
+  const int kdy_y = kdy / TW, kdy_x = kdy % TW;
+  const int off_dy = ((kdy_y * p.Wo + kdy_x) * (int)p.dy_ld + co0) * 2 + swzc(kdy, pc) * 16;
+  int off_x[XJ], hyx[XJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < XJ; ++j) {
     const int r = (wave + 4 * j) * 8 + rr;
     const int hy = r / HP, hx = r - hy * HP;
     const int c = swzc(r, pc);
-    const bool ok = (wave + 4 * j) < XP && hx < 34 && c * 8 < cin_rem;
+    const bool ok = (wave + 4 * j) < XP && hx < TW + 2 && c * 8 < cin_rem;
     off_x[j] = ((hy * p.W + hx) * (int)p.x_ld + ci0) * 2 + c * 16;
     hyx[j] = ok ? ((hy << 8) | hx) : -1;
   }
@@ -321,16 +330,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   auto issue_tile = [&](int kt, int st) {
     const int b = kt / tiles_per_img;                 // wave-uniform scalars
     const int tr = kt - b * tiles_per_img;
-    const int oy = tr / p.tiles_x, tx0 = (tr - oy * p.tiles_x) * 32;
+    const int ty = tr / p.tiles_x;
+    const int oy = ty * TH, tx0 = (tr - ty * p.tiles_x) * TW;
     const unsigned sdy = lds0 + st * STAGE;
     const unsigned sx = sdy + DY_BYTES;
     const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
-    const char* src = (tx0 + kdy < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
+    const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
     dma16(src, sdy + wave * 1024);
     const int iy0 = oy - 1, ix0 = tx0 - 1;
     const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;   // may lie before the tensor: only
 #pragma unroll                                                                        // dereferenced for valid pixels
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < XJ; ++j) {
       if (wave + 4 * j < XP) {
         const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
         const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
@@ -344,15 +354,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   const int q = fr >> 2, pp = fr & 3;
   const int k0 = 4 * fg + q, k1 = 16 + 4 * fg + q;
   auto taddr = [&](int row, int cc) -> unsigned { return row * ROWB + ((cc ^ ((row >> 1) & 3)) << 5) + pp * 8; };
-  const unsigned ad0 = taddr(k0, wm * 2), ad1 = taddr(k1, wm * 2), ad2 = taddr(k0, wm * 2 + 1), ad3 = taddr(k1, wm * 2 + 1);
-  unsigned ax[3][4];
+  unsigned ad[4][2];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    ax[kw][0] = taddr(k0 + kw, wn * 2);
-    ax[kw][1] = taddr(k1 + kw, wn * 2);
-    ax[kw][2] = taddr(k0 + kw, wn * 2 + 1);
-    ax[kw][3] = taddr(k1 + kw, wn * 2 + 1);
-  }
+  for (int i = 0; i < 4; ++i) { ad[i][0] = taddr(k0, i); ad[i][1] = taddr(k1, i); }
+  const int h0 = (k0 / TW) * HP + k0 % TW, h1 = (k1 / TW) * HP + k1 % TW;   // halo rows of the two tile pixels (tap 0,0)
+  unsigned ax[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) { ax[kw][0] = taddr(h0 + kw, wave); ax[kw][1] = taddr(h1 + kw, wave); }
 
   // ---- prologue
   if (kt_begin < kt_end) issue_tile(kt_begin, 0);
@@ -364,18 +372,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
     int issued = 0;
     if (kt + 2 < kt_end) { issue_tile(kt + 2, (ST + 2) % NS); issued = my_pieces; }
     const char* sb = smem + ST * STAGE;
-    const bf16x8 af0 = tr_pair(sb, ad0, ad1);
-    const bf16x8 af1 = tr_pair(sb, ad2, ad3);
+    bf16x8 af[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tr_pair(sb, ad[i][0], ad[i][1]);
     wg_static_for<0, 9>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
       constexpr int kh = t / 3, kw = t - kh * 3;
       const char* xb = sb + DY_BYTES + kh * HP * ROWB;
-      const bf16x8 bf0 = tr_pair(xb, ax[kw][0], ax[kw][1]);
-      const bf16x8 bf1 = tr_pair(xb, ax[kw][2], ax[kw][3]);
-      acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
-      acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
-      acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
-      acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
+      const bf16x8 bf = tr_pair(xb, ax[kw][0], ax[kw][1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
     });
     wait_vm_barrier_n(issued);   // tile kt+1 has landed; this iteration's pieces (tile kt+2) may stay in flight
   };
@@ -386,20 +392,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   }
 
   const int64_t slice_stride = (int64_t)9 * p.Cout * p.Cin;
+  const int ci = ci0 + wave * 16 + fr;
+  if (ci < p.Cin) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ci = ci0 + wn * 32 + j * 16 + fr;
-        if (ci >= p.Cin) continue;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = co0 + wm * 32 + i * 16 + fg * 4 + r;
-          p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j][r];
+          const int co = co0 + i * 16 + fg * 4 + r;
+          p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][r];
         }
-      }
+  }
 }
 
 // dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order
@@ -424,12 +428,13 @@ struct WgradPlan {
   int TH, TW, HR, HC, tiles_x, tiles_y, ktiles, nslice, per_slice, tiles_mn;
 };
 
-static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
+static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, bool fast = false) {
   WgradPlan pl;
   int tw = 1;
   while (tw < Wo && tw < 32) tw <<= 1;
   pl.TW = tw;
   pl.TH = 32 / tw;
+  if (fast) { pl.TW = 8; pl.TH = 4; }   // the bf16 3x3 fast path works on 4 x 8-pixel K-tiles
   pl.HR = (pl.TH - 1) * stride + KH;
   pl.HC = (pl.TW - 1) * stride + KW;
   pl.tiles_x = (int)cdiv(Wo, pl.TW);
@@ -465,9 +470,21 @@ static int launch(const WgradArgs& a, const WgradPlan& pl, hipStream_t st) {
 
 using namespace cvcs;
 
+// bf16, 3x3 / stride 1 / pad 1, maps of at least 4 x 8 pixels, 32-bit per-image offsets
+static bool fast_shape(int dtype, int KH, int KW, int stride, int pad, int H, int W, int Ho, int Wo, int64_t x_ld, int64_t dy_ld) {
+  return dtype == CVCS_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho >= 4 && Wo >= 8 &&
+         (int64_t)H * W * x_ld * 2 < (1ll << 31) && (int64_t)Ho * Wo * dy_ld * 2 < (1ll << 31);
+}
+static bool fast_path(const cvcs_wgrad_desc* d) {
+  return fast_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->H, d->W, d->Ho, d->Wo, d->x_ld, d->dy_ld);
+}
+
+// worst case over both kernels (the slice count of the generic and of the fast plan can differ)
 extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 64 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
-  return make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride).nslice;
+  const int a = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, false).nslice;
+  const int b = (KH == 3 && KW == 3 && stride == 1 && Ho >= 4 && Wo >= 8) ? make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, true).nslice : 0;
+  return a > b ? a : b;
 }
 
 extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
@@ -488,7 +505,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0,
                  "cvcs_conv2d_wgrad: leading dimensions");
   CVCS_CHECK_ARG(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad: alignment");
-  WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride);
+  WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, fast_path(d));
   CVCS_CHECK_ARG(pl.HR * pl.HC <= 128, "cvcs_conv2d_wgrad: halo tile too large");
   WgradArgs a;
   a.x = (const char*)d->x; a.dy = (const char*)d->dy; a.ws = d->workspace;
@@ -502,15 +519,15 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   int rc;
   if (d->dtype == CVCS_F32)
     rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
-  else if (taps == 9 && d->stride == 1 && d->pad == 1 && pl.TW == 32 && pl.TH == 1 &&
-           (int64_t)d->H * d->W * d->x_ld * 2 < (1ll << 31) && (int64_t)32 * d->dy_ld * 2 < (1ll << 31)) {
+  else if (fast_path(d)) {
+    // 4 x 8-pixel K-tiles (plan already made for that shape by make_plan)
     static bool attr_done = false;
-    const int lds = 3 * (32 + 120) * 128;
+    const int lds = 3 * (32 + 6 * 16) * 128;
     if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_fast_kernel, dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wgrad_fast_kernel<4, 8>), dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(256), lds, st, a);
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(fast)");
     rc = CVCS_OK;
   } else
