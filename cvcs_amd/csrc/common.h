@@ -78,6 +78,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// One LDS-DMA wave-instruction (global_load_lds_dwordx4: lane l's 16 bytes land at lds_dst + 16*l) issued from inline
+// asm: the compiler then does not know a DMA is in flight and schedules its LDS fragment reads freely with its own
+// lgkmcnt waits (seeing the DMA, it would drain vmcnt before every LDS read).  Completion is tracked by hand: a counted
+// `s_waitcnt vmcnt(k)` + barrier before the data are read.  M0 (the LDS base) is saved and restored around the load.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace cvcs

@@ -64,6 +64,16 @@ constexpr int kBM = 128;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ (((row >> 2) & 1) << 1); }
 
+__device__ uint4 g_gzero16;   // zero word: LDS-DMA source of padding pixels (generic kernel)
+
+__device__ __forceinline__ void wait_vm_barrier_g(int k) {
+  if (k <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (k == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <typename T, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int ES = sizeof(T);
@@ -74,31 +84,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int A_BYTES = kBM * 64;
   constexpr int B_BYTES = BN * 64;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int BROWS = BN / 64;   // B rows per loader thread
+  constexpr int NSTAGE = 3;           // LDS-DMA ring: two K-steps in flight
+  constexpr int APW = kBM / 16 / 4;   // 16-row DMA pieces of the A tile per wave (2)
+  constexpr int BPW = BN / 16 / 4;    // ... of the B tile (1 | 2)
   constexpr int OROW = BN * ES + 16;  // epilogue LDS row pitch (bytes)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * kBM;
   const int n0 = blockIdx.y * BN;
-  const int lr = tid >> 2, lc = tid & 3;
+  const int rr = lane >> 2, pc = lane & 3;   // row / physical chunk of this lane inside a 16-row DMA piece
 
-  // ---- loader rows: A rows lr, lr+64 ; B rows lr + 64*j
-  int iy0[2], ix0[2];
-  int64_t pbase[2];
-  bool mvalid[2];
+  // ---- per-lane DMA sources: A pieces wave + 4i (rows = output pixels), B pieces wave + 4j (rows = output channels)
+  int iy0[APW], ix0[APW], ac[APW];
+  int64_t pbase[APW];
+  bool mvalid[APW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + lr + 64 * i;
+  for (int i = 0; i < APW; ++i) {
+    const int row = (wave + 4 * i) * 16 + rr;
+    ac[i] = swz(row, pc);            // logical chunk stored at physical chunk pc
+    const int m = m0 + row;
     mvalid[i] = m < p.M;
-    int mm = mvalid[i] ? m : 0;
-    int ox = mm % p.Wo;
-    int t = mm / p.Wo;
-    int oy = t % p.Ho;
-    int b = t / p.Ho;
+    const int mm = mvalid[i] ? m : 0;
+    const int ox = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int oy = t % p.Ho;
+    const int b = t / p.Ho;
     iy0[i] = oy * p.stride - p.pad;
     ix0[i] = ox * p.stride - p.pad;
     pbase[i] = (int64_t)b * p.H * p.W;
@@ -107,40 +122,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int nslice = p.Cin / KG;
   const int nsteps = taps * nslice;
   const int64_t wt_tap_stride = (int64_t)p.Cout * p.Cin;  // elements
-
-  uint4 ra[2], rb[BROWS];
-  auto load_regs = [&](int tap, int cs) {
+  const char* bsrc[BPW];
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int row = (wave + 4 * j) * 16 + rr;
+    bsrc[j] = p.wt + ((int64_t)(n0 + row) * p.Cin) * ES + swz(row, pc) * 16;
+  }
+  auto dma_step = [&](int tap, int cs, int stage) {
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const unsigned sa = lds0 + stage * STAGE, sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int iy = iy0[i] + kh * p.dil, ix = ix0[i] + kw * p.dil;
-      bool ok = mvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const char* src = p.in + ((pbase[i] + (int64_t)iy * p.W + ix) * p.in_ld + (int64_t)cs * KG) * ES + lc * 16;
-        ra[i] = *reinterpret_cast<const uint4*>(src);
-      }
+    for (int i = 0; i < APW; ++i) {
+      const int iy = iy0[i] + kh * p.dil, ix = ix0[i] + kw * p.dil;
+      const bool ok = mvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const char* src = ok ? p.in + ((pbase[i] + (int64_t)iy * p.W + ix) * p.in_ld + (int64_t)cs * KG) * ES + ac[i] * 16
+                           : reinterpret_cast<const char*>(&g_gzero16);
+      dma16(src, sa + (wave + 4 * i) * 1024);
     }
+    const int64_t soff = ((int64_t)tap * wt_tap_stride + (int64_t)cs * KG) * ES;
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      int n = n0 + lr + 64 * j;
-      const char* src = p.wt + ((int64_t)tap * wt_tap_stride + (int64_t)n * p.Cin + (int64_t)cs * KG) * ES + lc * 16;
-      rb[j] = *reinterpret_cast<const uint4*>(src);
-    }
-  };
-  auto write_lds = [&](int buf) {
-    char* sa = smem + buf * STAGE;
-    char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int r = lr + 64 * i;
-      *reinterpret_cast<uint4*>(sa + r * 64 + swz(r, lc) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      int r = lr + 64 * j;
-      *reinterpret_cast<uint4*>(sb + r * 64 + swz(r, lc) * 16) = rb[j];
-    }
+    for (int j = 0; j < BPW; ++j) dma16(bsrc[j] + soff, sb + (wave + 4 * j) * 1024);
   };
 
   f32x4 acc[MREP][NREP];
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  auto compute = [&](int buf) {
-    const char* sa = smem + buf * STAGE;
+  auto compute = [&](int stage) {
+    const char* sa = smem + stage * STAGE;
     const char* sb = sa + A_BYTES;
     uint4 af[MREP], bfr[NREP];
 #pragma unroll
@@ -170,20 +171,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       for (int j = 0; j < NREP; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
   };
 
-  // ---- main loop: slice-major, tap-minor (neighbouring taps re-touch the same lines in L1/L2)
-  int tap = 0, cs = 0;
-  load_regs(0, 0);
-  write_lds(0);
-  __syncthreads();
+  // ---- main loop: slice-major, tap-minor (neighbouring taps re-touch the same lines in L1/L2).  The DMA of step s+2
+  //      is issued (from asm, invisible to the compiler) before the fragment reads + MFMAs of step s; each step ends with
+  //      a counted vmcnt (this step's DMA instructions may stay in flight) and a barrier.
+  auto next = [&](int& tap, int& cs) { if (++tap == taps) { tap = 0; ++cs; } };
+  int tap2 = 0, cs2 = 0;   // the step two ahead
+  dma_step(0, 0, 0);
+  next(tap2, cs2);
+  if (nsteps > 1) { dma_step(tap2, cs2, 1); next(tap2, cs2); }
+  wait_vm_barrier_g(0);
+  int stage = 0;
   for (int s = 0; s < nsteps; ++s) {
-    int ntap = tap + 1, ncs = cs;
-    if (ntap == taps) { ntap = 0; ncs = cs + 1; }
-    const bool more = (s + 1 < nsteps);
-    if (more) load_regs(ntap, ncs);
-    compute(s & 1);
-    if (more) write_lds((s + 1) & 1);
-    __syncthreads();
-    tap = ntap; cs = ncs;
+    int issued = 0;
+    if (s + 2 < nsteps) {
+      int st2 = stage + 2; if (st2 >= NSTAGE) st2 -= NSTAGE;
+      dma_step(tap2, cs2, st2);
+      next(tap2, cs2);
+      issued = APW + BPW;
+    }
+    compute(stage);
+    wait_vm_barrier_g(issued);
+    if (++stage == NSTAGE) stage = 0;
   }
 
   // ---- epilogue: bias / ReLU
@@ -719,7 +727,7 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
 template <typename T, int BN>
 static int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
-  size_t stage = 2 * (size_t)(kBM * 64 + BN * 64);
+  size_t stage = 3 * (size_t)(kBM * 64 + BN * 64);
   size_t epi = (size_t)kBM * (BN * ES + 16);
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;

@@ -250,16 +250,6 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
   }
 }
 
-// LDS-DMA issued from inline asm: the compiler then does not know a DMA is in flight and schedules the LDS fragment
-// reads (builtins) freely with its own fine-grained lgkmcnt waits - no vmcnt(0) in front of every read, no register
-// copies to assemble MFMA operands.  Completion is tracked by hand (counted vmcnt before the barrier).
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
 __device__ __forceinline__ bf16x8 tr_pair(const char* smem_base, unsigned off0, unsigned off1) {
