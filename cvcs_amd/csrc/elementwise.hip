@@ -43,18 +43,27 @@ __device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, co
   return a;
 }
 
+// finalize workgroups are 1024 threads = kRL row-lanes x 16 channels (these kernels are latency-bound serial f64 loops
+// over the partial rows: 64 row-lanes cut the loop 4x against 16); lanes are merged in two levels, in a fixed order
+constexpr int kRL = 64;
 __device__ __forceinline__ Moments merge_lanes(Moments a, int rl, int cl) {
-  __shared__ double sh[3][16][17];
+  __shared__ double sh[3][kRL][17];
   sh[0][rl][cl] = a.n; sh[1][rl][cl] = a.mean; sh[2][rl][cl] = a.m2;
+  __syncthreads();
+  if (rl < 8) {   // level 1: lane rl merges entries rl, rl+8, ...
+    Moments t{0.0, 0.0, 0.0};
+    for (int q = rl; q < kRL; q += 8) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+    sh[0][rl][cl] = t.n; sh[1][rl][cl] = t.mean; sh[2][rl][cl] = t.m2;
+  }
   __syncthreads();
   Moments t{0.0, 0.0, 0.0};
   if (rl == 0)
-    for (int q = 0; q < 16; ++q) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+    for (int q = 0; q < 8; ++q) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
   return t;
 }
 
 // stage 1: grid (nblk, C/16); block b merges rows [b*R, (b+1)*R) -> out_sum/out_m2 [nblk][C] (sum = mean*n)
-__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
+__global__ __launch_bounds__(1024) void bn_stats_reduce_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
                                                              const float* __restrict__ scnt, int rows, int R, int C,
                                                              float* out_sum, float* out_m2, float* out_cnt) {
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
   const int r0 = blockIdx.x * R;
   int r1 = r0 + R;
   if (r1 > rows) r1 = rows;
-  Moments a = merge_rows(ssum, sm2, scnt, r0 + rl, r1, 16, C, c);
+  Moments a = merge_rows(ssum, sm2, scnt, r0 + rl, r1, kRL, C, c);
   a = merge_lanes(a, rl, cl);
   if (rl == 0) {
     out_sum[(int64_t)blockIdx.x * C + c] = (float)(a.mean * a.n);
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
                                                          const float* __restrict__ scnt, int rows, int64_t M, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum, float eps,
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     return;
   }
-  Moments a = merge_rows(ssum, sm2, scnt, rl, rows, 16, C, c);
+  Moments a = merge_rows(ssum, sm2, scnt, rl, rows, kRL, C, c);
   a = merge_lanes(a, rl, cl);
   if (rl != 0) return;
   const double mean = a.mean, m2 = a.m2;
@@ -303,20 +312,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* x, int64_t ld, 
   }
 }
 
-// column sums of up to 1024 partial rows: workgroup = 16 row-lanes x 16 channels, f64 accumulate, fixed order
+// column sums of up to 1024 partial rows: workgroup = kRL row-lanes x 16 channels, f64 accumulate, fixed order
 __device__ __forceinline__ double colsum16(const float* __restrict__ part, int rows, int C, int c, int rl, int cl, int slot) {
-  __shared__ double sh[2][16][17];
+  __shared__ double sh[2][kRL][17];
   double a = 0.0;
-  for (int r = rl; r < rows; r += 16) a += (double)part[(int64_t)r * C + c];
+  for (int r = rl; r < rows; r += kRL) a += (double)part[(int64_t)r * C + c];
   sh[slot][rl][cl] = a;
   __syncthreads();
   double t = 0.0;
   if (rl == 0)
-    for (int q = 0; q < 16; ++q) t += sh[slot][q][cl];
+    for (int q = 0; q < kRL; ++q) t += sh[slot][q][cl];
   return t;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ pdz, const float* __restrict__ pdzx,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ pdz, const float* __restrict__ pdzx,
                                                              int rows, int64_t M, int C, const float* __restrict__ gamma,
                                                              const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                                              float* ca, float* cb) {
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   cb[c] = (float)(b / (double)M);
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int rows, int C, float* out) {
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int rows, int C, float* out) {
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   const bool ok = c < C;
@@ -524,12 +533,12 @@ extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, con
       float* o_sum = workspace;
       float* o_m2 = workspace + (int64_t)nblk * C;
       float* o_cnt = workspace + (int64_t)2 * nblk * C;
-      hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2,
+      hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 16)), dim3(16 * kRL), 0, st, stat_sum, stat_m2,
                          stat_cnt, rows, R, C, o_sum, o_m2, o_cnt);
       stat_sum = o_sum; stat_m2 = o_m2; stat_cnt = o_cnt; rows = nblk;
     }
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, st, stat_sum, stat_m2, stat_cnt, rows, M, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(16 * kRL), 0, st, stat_sum, stat_m2, stat_cnt, rows, M, C,
                      gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean, save_invstd);
   CVCS_CHECK_LAUNCH("cvcs_bn_finalize");
   return CVCS_OK;
@@ -626,7 +635,7 @@ extern "C" int cvcs_bn_bwd_finalize(const float* part_dz, const float* part_dzx,
   CVCS_CHECK_ARG(part_dz && part_dzx && dgamma && dbeta && coef_a && coef_b && C > 0 && M > 0, "cvcs_bn_bwd_finalize: null argument");
   CVCS_CHECK_ARG(rows == cvcs_bn_bwd_rows(M), "cvcs_bn_bwd_finalize: rows");
   CVCS_CHECK_ARG(C % 16 == 0, "cvcs_bn_bwd_finalize: C %% 16 != 0");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)(C / 16)), dim3(256), 0, (hipStream_t)stream, part_dz, part_dzx,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)(C / 16)), dim3(16 * kRL), 0, (hipStream_t)stream, part_dz, part_dzx,
                      rows, M, C, gamma, save_invstd, dgamma, dbeta, coef_a, coef_b);
   CVCS_CHECK_LAUNCH("cvcs_bn_bwd_finalize");
   return CVCS_OK;
@@ -642,7 +651,7 @@ extern "C" int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, in
 
 extern "C" int cvcs_colsum_finalize(const float* part, int rows, int C, float* out, void* stream) {
   CVCS_CHECK_ARG(part && out && rows > 0 && C > 0, "cvcs_colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, rows, C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(16 * kRL), 0, (hipStream_t)stream, part, rows, C, out);
   CVCS_CHECK_LAUNCH("cvcs_colsum_finalize");
   return CVCS_OK;
 }

@@ -431,7 +431,7 @@ static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int
   pl.tiles_y = (int)cdiv(Ho, pl.TH);
   pl.ktiles = B * pl.tiles_x * pl.tiles_y;
   pl.tiles_mn = (Cout / 64) * (int)cdiv(Cin, 64);
-  int want = (int)cdiv(1024, pl.tiles_mn);
+  int want = (int)cdiv(512, pl.tiles_mn);   // ~2 resident workgroups per CU; fewer slices = less partial-slab traffic
   if (want > pl.ktiles) want = pl.ktiles;
   if (want < 1) want = 1;
   pl.per_slice = (int)cdiv(pl.ktiles, want);
