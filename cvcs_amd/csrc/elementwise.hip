@@ -62,21 +62,26 @@ __device__ __forceinline__ Moments merge_lanes(Moments a, int rl, int cl) {
   return t;
 }
 
-// stage 1: grid (nblk, C/16); block b merges rows [b*R, (b+1)*R) -> out_sum/out_m2 [nblk][C] (sum = mean*n)
+// stage 1: grid (nblk, C/64), 1024 threads = 16 row-lanes x 64 channels (a wave reads 256 contiguous bytes of a partial
+// row); block b merges rows [b*R, (b+1)*R) -> out_sum/out_m2 [nblk][C] (sum = mean*n), out_cnt [nblk]
 __global__ __launch_bounds__(1024) void bn_stats_reduce_kernel(const float* __restrict__ ssum, const float* __restrict__ sm2,
                                                              const float* __restrict__ scnt, int rows, int R, int C,
                                                              float* out_sum, float* out_m2, float* out_cnt) {
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.y * 16 + cl;
+  __shared__ double sh[3][16][65];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
   const int r0 = blockIdx.x * R;
   int r1 = r0 + R;
   if (r1 > rows) r1 = rows;
-  Moments a = merge_rows(ssum, sm2, scnt, r0 + rl, r1, kRL, C, c);
-  a = merge_lanes(a, rl, cl);
+  Moments a = merge_rows(ssum, sm2, scnt, r0 + rl, r1, 16, C, c);
+  sh[0][rl][cl] = a.n; sh[1][rl][cl] = a.mean; sh[2][rl][cl] = a.m2;
+  __syncthreads();
   if (rl == 0) {
-    out_sum[(int64_t)blockIdx.x * C + c] = (float)(a.mean * a.n);
-    out_m2[(int64_t)blockIdx.x * C + c] = (float)a.m2;
-    if (blockIdx.y == 0 && cl == 0) out_cnt[blockIdx.x] = (float)a.n;   // exact: pixel counts < 2^24
+    Moments t{0.0, 0.0, 0.0};
+    for (int q = 0; q < 16; ++q) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+    out_sum[(int64_t)blockIdx.x * C + c] = (float)(t.mean * t.n);
+    out_m2[(int64_t)blockIdx.x * C + c] = (float)t.m2;
+    if (blockIdx.y == 0 && cl == 0) out_cnt[blockIdx.x] = (float)t.n;   // exact: pixel counts < 2^24
   }
 }
 
@@ -533,7 +538,8 @@ extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, con
       float* o_sum = workspace;
       float* o_m2 = workspace + (int64_t)nblk * C;
       float* o_cnt = workspace + (int64_t)2 * nblk * C;
-      hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 16)), dim3(16 * kRL), 0, st, stat_sum, stat_m2,
+      CVCS_CHECK_ARG(C % 64 == 0, "cvcs_bn_finalize: the two-stage merge needs C %% 64 == 0");
+      hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 64)), dim3(1024), 0, st, stat_sum, stat_m2,
                          stat_cnt, rows, R, C, o_sum, o_m2, o_cnt);
       stat_sum = o_sum; stat_m2 = o_m2; stat_cnt = o_cnt; rows = nblk;
     }

@@ -77,18 +77,23 @@ class _CEFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        dl = ctx.crit._dl
-        dl.mul_(gout)      # d(loss)/d(logits) was produced by the forward launch; scale by the incoming gradient
+        dl = ctx.crit._dl   # d(loss)/d(logits) was produced by the forward launch
+        if not ctx.crit.unit_grad:
+            dl.mul_(gout)   # chained through further autograd ops: scale by the incoming gradient
         return dl, None, None
 
 
 class CrossEntropyLoss:
     """nn.CrossEntropyLoss(weight, ignore_index) (S/utils.py:230,238): one fused HIP launch produces the loss and
-    d(loss)/d(logits).  target: uint8 or int64 [B,H,W]."""
+    d(loss)/d(logits).  target: uint8 or int64 [B,H,W].
+    unit_grad=True (default) assumes the loss is differentiated directly, `loss.backward()` with its implicit gradient
+    of 1 as S/train.py:125 does, and skips a 2-pass multiply over the logits-sized gradient; pass unit_grad=False when the
+    loss value is scaled / combined by further autograd ops before backward."""
 
-    def __init__(self, weight=None, ignore_index=-100):
+    def __init__(self, weight=None, ignore_index=-100, unit_grad=True):
         self.weight = None if weight is None else weight.float()
         self.ignore_index = ignore_index
+        self.unit_grad = unit_grad
         self._ws = None
         self._dl = None
 

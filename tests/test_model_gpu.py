@@ -302,3 +302,17 @@ def test_reference_default_tile_224_ragged_levels():
             ls.append(loss.item())
         losses.append(ls)
     assert all(np.isfinite(l) for l in losses[0]) and losses[0] == losses[1]
+
+
+def test_loss_scaling_through_autograd_when_unit_grad_is_off():
+    """CrossEntropyLoss(unit_grad=False): (2 * loss).backward() doubles every gradient."""
+    NC = 5
+    img, lab = O.synthetic_tiles(2, 32, NC, seed=11)
+    grads = []
+    for scale, unit in ((1.0, True), (2.0, False)):
+        net = _build("Unetv2", NC, "fp32")
+        net.train()
+        loss = utils.CrossEntropyLoss(ignore_index=0, unit_grad=unit)(net(img.to(DEV), None), lab.to(DEV))
+        (loss * scale).backward()
+        grads.append(net.flat_parameters()[1].clone())
+    assert torch.allclose(grads[1], 2 * grads[0], rtol=1e-6, atol=1e-9)
