@@ -53,6 +53,9 @@ SIGNATURES = {
     "cvcs_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "cvcs_bn_finalize_workspace_floats": (_i, [_i, _i]),
     "cvcs_bn_finalize": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_moments": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "cvcs_bn_finalize_moments": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_bwd_coeffs": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "cvcs_bn_act": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "cvcs_bn_bwd_rows": (_i, [_i64]),
     "cvcs_bn_bwd_reduce": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
@@ -70,7 +73,8 @@ SIGNATURES = {
     "cvcs_head_bwd_rows": (_i, [_i64]),
     "cvcs_head_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _vp]),
     "cvcs_ce_workspace_floats": (_i, [_i64]),
-    "cvcs_ce_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "cvcs_ce_weight_sum": (_i, [_vp, _i, _i, _i, _i64, _vp, _i, _vp, _vp]),
+    "cvcs_ce_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "cvcs_argmax_confusion": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "cvcs_crop_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "cvcs_argmax_stitch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum, float eps,
                                                          int train, float* scale, float* shift, float* save_mean,
-                                                         float* save_invstd) {
+                                                         float* save_invstd, double* moments) {
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   if (!train) {
@@ -105,6 +105,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   Moments a = merge_rows(ssum, sm2, scnt, rl, rows, kRL, C, c);
   a = merge_lanes(a, rl, cl);
   if (rl != 0) return;
+  if (moments) {   // this rank's (n, sum x, sum x^2) per channel, to be summed over ranks (cvcs_bn_moments)
+    moments[c] = a.n;
+    moments[C + c] = a.n * a.mean;
+    moments[2 * C + c] = a.m2 + a.n * a.mean * a.mean;
+    return;
+  }
   const double mean = a.mean, m2 = a.m2;
   const double var = m2 / (double)M;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -116,6 +122,35 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
   running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+// scale/shift/saved statistics/running statistics from all-rank moments (n, sum x, sum x^2) [3][C] in f64
+__global__ __launch_bounds__(256) void bn_finalize_moments_kernel(const double* __restrict__ mom, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* running_mean, float* running_var, float momentum, float eps,
+                                                                float* scale, float* shift, float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = mom[c], mean = mom[C + c] / n;
+  double m2 = mom[2 * C + c] - n * mean * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = m2 / n;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restrict__ sums, double M, int C, float* ca, float* cb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  ca[c] = (float)((double)sums[c] / M);
+  cb[c] = (float)((double)sums[C + c] / M);
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply fwd
@@ -521,6 +556,23 @@ extern "C" int cvcs_bn_finalize_workspace_floats(int rows, int C) {
   return (int)cdiv(rows, R) * (2 * C + 1);
 }
 
+// merge > kDirectRows partial rows down to <= 1024 block rows in the workspace (stage 1 of the two-stage merge)
+static int bn_stage1(const char* fn, const float*& stat_sum, const float*& stat_m2, const float*& stat_cnt, int& rows, int C,
+                     float* workspace, hipStream_t st) {
+  if (rows <= kDirectRows) return CVCS_OK;
+  CVCS_CHECK_ARG(workspace != nullptr, "%s: %d partial rows need the workspace", fn, rows);
+  CVCS_CHECK_ARG(C % 64 == 0, "%s: the two-stage merge needs C %% 64 == 0", fn);
+  const int R = (int)cdiv(rows, 1024);
+  const int nblk = (int)cdiv(rows, R);
+  float* o_sum = workspace;
+  float* o_m2 = workspace + (int64_t)nblk * C;
+  float* o_cnt = workspace + (int64_t)2 * nblk * C;
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 64)), dim3(1024), 0, st, stat_sum, stat_m2,
+                     stat_cnt, rows, R, C, o_sum, o_m2, o_cnt);
+  stat_sum = o_sum; stat_m2 = o_m2; stat_cnt = o_cnt; rows = nblk;
+  return CVCS_OK;
+}
+
 extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, const float* stat_cnt, int rows, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 float momentum, float eps, int train, float* scale, float* shift, float* save_mean,
@@ -531,22 +583,46 @@ extern "C" int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, con
   if (train) {
     CVCS_CHECK_ARG(stat_sum && stat_m2 && stat_cnt && save_mean && save_invstd && M > 0 && rows > 0,
                    "cvcs_bn_finalize: train needs statistics");
-    if (rows > kDirectRows) {
-      CVCS_CHECK_ARG(workspace != nullptr, "cvcs_bn_finalize: %d partial rows need the workspace", rows);
-      const int R = (int)cdiv(rows, 1024);
-      const int nblk = (int)cdiv(rows, R);
-      float* o_sum = workspace;
-      float* o_m2 = workspace + (int64_t)nblk * C;
-      float* o_cnt = workspace + (int64_t)2 * nblk * C;
-      CVCS_CHECK_ARG(C % 64 == 0, "cvcs_bn_finalize: the two-stage merge needs C %% 64 == 0");
-      hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 64)), dim3(1024), 0, st, stat_sum, stat_m2,
-                         stat_cnt, rows, R, C, o_sum, o_m2, o_cnt);
-      stat_sum = o_sum; stat_m2 = o_m2; stat_cnt = o_cnt; rows = nblk;
-    }
+    int rc;
+    if ((rc = bn_stage1("cvcs_bn_finalize", stat_sum, stat_m2, stat_cnt, rows, C, workspace, st))) return rc;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(16 * kRL), 0, st, stat_sum, stat_m2, stat_cnt, rows, M, C,
-                     gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean, save_invstd);
+                     gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, save_mean, save_invstd,
+                     (double*)nullptr);
   CVCS_CHECK_LAUNCH("cvcs_bn_finalize");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_moments(const float* stat_sum, const float* stat_m2, const float* stat_cnt, int rows, int C,
+                               double* moments, float* workspace, void* stream) {
+  CVCS_CHECK_ARG(C > 0 && C % 16 == 0 && stat_sum && stat_m2 && stat_cnt && moments && rows > 0,
+                 "cvcs_bn_moments: null argument or C %% 16 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = bn_stage1("cvcs_bn_moments", stat_sum, stat_m2, stat_cnt, rows, C, workspace, st))) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)(C / 16)), dim3(16 * kRL), 0, st, stat_sum, stat_m2, stat_cnt, rows,
+                     (int64_t)0, C, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 1,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, moments);
+  CVCS_CHECK_LAUNCH("cvcs_bn_moments");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_finalize_moments(const double* moments, int C, const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, float momentum, float eps, float* scale, float* shift,
+                                        float* save_mean, float* save_invstd, void* stream) {
+  CVCS_CHECK_ARG(C > 0 && moments && gamma && beta && running_mean && running_var && scale && shift && save_mean && save_invstd,
+                 "cvcs_bn_finalize_moments: null argument");
+  hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, moments, C, gamma,
+                     beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+  CVCS_CHECK_LAUNCH("cvcs_bn_finalize_moments");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_bwd_coeffs(const float* sums, int64_t M, int C, float* coef_a, float* coef_b, void* stream) {
+  CVCS_CHECK_ARG(sums && coef_a && coef_b && C > 0 && M > 0, "cvcs_bn_bwd_coeffs: bad argument");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, (double)M, C,
+                     coef_a, coef_b);
+  CVCS_CHECK_LAUNCH("cvcs_bn_bwd_coeffs");
   return CVCS_OK;
 }
 

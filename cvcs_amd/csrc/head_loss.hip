@@ -167,10 +167,13 @@ __global__ __launch_bounds__(256) void ce_weight_kernel(const void* target, int 
 
 __global__ void ce_reduce_kernel(float* ws, int R, int which, float* loss_out) {
   // which 0: ws[0] = sum of partial weights.  which 1: ws[1] = numerator; loss_out = ws[1]/ws[0]
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave; fixed lane-strided order + xor-tree in f64 (deterministic)
   double a = 0.0;
   const float* part = ws + 2 + (which ? R : 0);
-  for (int r = 0; r < R; ++r) a += (double)part[r];
+  for (int r = threadIdx.x; r < R; r += 64) a += (double)part[r];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (threadIdx.x != 0) return;
   ws[which] = (float)a;
   if (which) *loss_out = (float)(a / (double)ws[0]);
 }
@@ -385,16 +388,31 @@ extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, 
 
 extern "C" int cvcs_ce_workspace_floats(int64_t P) { return 2 + 2 * ce_rows(P); }
 
+extern "C" int cvcs_ce_weight_sum(const void* target, int target_is_u8, int B, int NC, int64_t HW, const float* class_weight,
+                                  int ignore_index, float* workspace, void* stream) {
+  CVCS_CHECK_ARG(target && workspace && B > 0 && HW > 0, "cvcs_ce_weight_sum: null argument");
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_ce_weight_sum: NC=%d out of [1,%d]", NC, kMaxNC);
+  const int64_t P = (int64_t)B * HW;
+  const int R = ce_rows(P);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_weight_kernel, dim3(R), dim3(256), 0, st, target, target_is_u8, P, NC, class_weight, ignore_index, workspace);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 0, (float*)nullptr);
+  CVCS_CHECK_LAUNCH("cvcs_ce_weight_sum");
+  return CVCS_OK;
+}
+
 extern "C" int cvcs_ce_fwd_bwd(const float* logits, const void* target, int target_is_u8, int B, int NC, int64_t HW,
                                const float* class_weight, int ignore_index, float grad_scale, float* loss_out, float* dlogits,
-                               float* workspace, void* stream) {
+                               float* workspace, int external_denominator, void* stream) {
   CVCS_CHECK_ARG(logits && target && loss_out && workspace && B > 0 && HW > 0, "cvcs_ce_fwd_bwd: null argument");
   CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_ce_fwd_bwd: NC=%d out of [1,%d]", NC, kMaxNC);
   const int64_t P = (int64_t)B * HW;
   const int R = ce_rows(P);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_weight_kernel, dim3(R), dim3(256), 0, st, target, target_is_u8, P, NC, class_weight, ignore_index, workspace);
-  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 0, loss_out);
+  if (!external_denominator) {
+    hipLaunchKernelGGL(ce_weight_kernel, dim3(R), dim3(256), 0, st, target, target_is_u8, P, NC, class_weight, ignore_index, workspace);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 0, loss_out);
+  }
   if (NC <= 8)
     hipLaunchKernelGGL((ce_main_kernel<8>), dim3(R), dim3(256), 0, st, logits, target, target_is_u8, P, HW, NC, class_weight, ignore_index, grad_scale, dlogits, workspace, R);
   else if (NC <= 16)

@@ -48,6 +48,8 @@ class UNetEngine:
         self.Bf = None  # name -> f32 buffer (running stats)
         self.packed = {}
         self._saved_train = False
+        self.sync_bn = None             # parallel.SyncStats: batch-norm statistics over all ranks' tiles (None: per rank)
+        self._sync_mom = self._sync_sums = None   # its exchange buffers (allocated by enable_sync_bn)
         self.on_backward_begin = None   # data-parallel hooks (cvcs_amd.parallel): called at the start of backward,
         self.on_grad_ready = None       # and with the lowest flat-gradient offset that is complete so far
         # Weight gradients are off the critical chain of backward (dy_L -> dgrad_L -> BN backward_{L-1} -> ...): they can be
@@ -174,6 +176,12 @@ class UNetEngine:
         so, uo = (0, w) if SKIP_FIRST[d] else (w, 0)
         return View(self.cat[L], so, w), View(self.cat[L], uo, w), View(self.g_cat[L], so, w), View(self.g_cat[L], uo, w)
 
+    def enable_sync_bn(self, sync):
+        """sync: object with .world and .all_reduce(tensor) (sum over ranks, in place, ordered on the current stream)"""
+        self.sync_bn = sync
+        self._sync_mom = torch.empty(3 * 1024, dtype=torch.float64, device=self.dev)
+        self._sync_sums = torch.empty(2 * 1024, dtype=torch.float32, device=self.dev)
+
     def _conv_bn(self, x: View, conv, bnname, y, out: View, relu_after_bn: bool, train: bool, pool: View | None = None):
         """conv3x3(+bias) [-> ReLU] with fused statistics, BN finalize, BN apply [-> ReLU] [-> pool]."""
         pk = self.packed[conv]
@@ -183,9 +191,18 @@ class UNetEngine:
         stats = (self.stat_sum, self.stat_m2, self.stat_cnt) if train else None
         ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats)
         st = self.bn[bnname]
-        ops.bn_finalize(stats, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
-                        self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], train, st.scale, st.shift,
-                        st.mean if train else None, st.invstd if train else None, workspace=self.bn_ws)
+        if train and self.sync_bn is not None:
+            # batch statistics over the tiles of ALL ranks (the reference's batch is not sharded): one [3][C] f64 sum
+            mom = self._sync_mom[:3 * C_]
+            ops.bn_moments(stats, rows, C_, mom, workspace=self.bn_ws)
+            self.sync_bn.all_reduce(mom)
+            ops.bn_finalize_moments(mom, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
+                                    self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], st.scale, st.shift,
+                                    st.mean, st.invstd)
+        else:
+            ops.bn_finalize(stats, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
+                            self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], train, st.scale, st.shift,
+                            st.mean if train else None, st.invstd if train else None, workspace=self.bn_ws)
         ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -241,6 +258,14 @@ class UNetEngine:
         ops.bn_bwd_reduce(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
         ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[bnname + ".weight"], st.invstd, self.G[bnname + ".weight"],
                             self.G[bnname + ".bias"], st.ca, st.cb)
+        if self.sync_bn is not None:
+            # dgamma / dbeta stay this rank's sums (the gradient all-reduce adds them up); the two coefficients of
+            # pass 2 are means over every rank's pixels
+            sums = self._sync_sums[:2 * C_]
+            sums[:C_].copy_(self.G[bnname + ".bias"])
+            sums[C_:].copy_(self.G[bnname + ".weight"])
+            self.sync_bn.all_reduce(sums)
+            ops.bn_bwd_coeffs(sums, M * self.sync_bn.world, C_, st.ca, st.cb)
         ops.bn_bwd_apply(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, ops.view(dy), p2)
         ops.colsum_finalize(p2, rows, C_, self.G[conv + ".bias"])
 

@@ -194,6 +194,28 @@ def bn_finalize(stats, rows, M, C_, gamma, beta, rmean, rvar, train, scale, shif
           "cvcs_bn_finalize")
 
 
+def bn_moments(stats, rows, C_, moments, workspace=None):
+    """this rank's per-channel (n, sum x, sum x^2) as f64 [3*C] from the conv's partial statistics"""
+    ssum, sm2, scnt = stats
+    assert moments.dtype == torch.float64 and moments.numel() >= 3 * C_
+    if workspace is None and bn_finalize_workspace_floats(rows, C_) > 0:
+        workspace = torch.empty(bn_finalize_workspace_floats(rows, C_), dtype=torch.float32, device=moments.device)
+    check(_lib.lib().cvcs_bn_moments(ssum.data_ptr(), sm2.data_ptr(), scnt.data_ptr(), rows, C_, moments.data_ptr(),
+                                     _ptr(workspace), _stream()), "cvcs_bn_moments")
+
+
+def bn_finalize_moments(moments, C_, gamma, beta, rmean, rvar, scale, shift, save_mean, save_invstd, momentum=0.1, eps=1e-5):
+    check(_lib.lib().cvcs_bn_finalize_moments(moments.data_ptr(), C_, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
+                                              rvar.data_ptr(), momentum, eps, scale.data_ptr(), shift.data_ptr(),
+                                              save_mean.data_ptr(), save_invstd.data_ptr(), _stream()),
+          "cvcs_bn_finalize_moments")
+
+
+def bn_bwd_coeffs(sums, M, C_, ca, cb):
+    assert sums.dtype == torch.float32 and sums.numel() >= 2 * C_
+    check(_lib.lib().cvcs_bn_bwd_coeffs(sums.data_ptr(), M, C_, ca.data_ptr(), cb.data_ptr(), _stream()), "cvcs_bn_bwd_coeffs")
+
+
 def bn_act(y: View, scale, shift, relu: bool, out: View, pool: View | None = None):
     check(_lib.lib().cvcs_bn_act(y.ptr, y.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(relu), out.ptr,
                                  out.ld, 0 if pool is None else pool.ptr, 0 if pool is None else pool.ld, y.code,
@@ -298,14 +320,23 @@ def ce_workspace_floats(P: int) -> int:
     return _lib.lib().cvcs_ce_workspace_floats(P)
 
 
-def ce_fwd_bwd(logits, target, class_weight, ignore_index, grad_scale, loss_out, dlogits, workspace):
+def ce_weight_sum(target, B, NC, class_weight, ignore_index, workspace):
+    """workspace[0] <- sum of class weights over this rank's non-ignored pixels (the CE denominator)"""
+    HW = target.numel() // B
+    assert target.is_contiguous() and target.dtype in (torch.uint8, torch.int64)
+    check(_lib.lib().cvcs_ce_weight_sum(target.data_ptr(), int(target.dtype == torch.uint8), B, NC, HW, _ptr(class_weight),
+                                        ignore_index, workspace.data_ptr(), _stream()), "cvcs_ce_weight_sum")
+
+
+def ce_fwd_bwd(logits, target, class_weight, ignore_index, grad_scale, loss_out, dlogits, workspace,
+               external_denominator=False):
     B, NC = logits.shape[:2]
     HW = logits.numel() // (B * NC)
     assert logits.is_contiguous() and logits.dtype == torch.float32 and target.is_contiguous()
     assert target.dtype in (torch.uint8, torch.int64) and target.numel() == B * HW
     check(_lib.lib().cvcs_ce_fwd_bwd(logits.data_ptr(), target.data_ptr(), int(target.dtype == torch.uint8), B, NC, HW,
                                      _ptr(class_weight), ignore_index, grad_scale, loss_out.data_ptr(), _ptr(dlogits),
-                                     workspace.data_ptr(), _stream()), "cvcs_ce_fwd_bwd")
+                                     workspace.data_ptr(), int(external_denominator), _stream()), "cvcs_ce_fwd_bwd")
 
 
 def argmax_confusion(logits, labels=None, target=None, ignore_index=-1, K=16, conf=None):

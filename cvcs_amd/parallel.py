@@ -13,7 +13,11 @@ north star.  Design for MI355X / xGMI rather than a translation of torch DDP:
     overlaps the rest of backward; the optimiser launch waits on that stream, and the 1/world_size averaging is
     folded into the fused optimiser kernel (grad_scale) instead of a separate pass over the gradients.
 
-BatchNorm statistics stay per-rank (as torch DDP without SyncBN would do); the loss value logged is the rank's own.
+By default BatchNorm statistics and the cross-entropy mean stay per-rank (what torch DDP without SyncBN does).
+`DataParallel(..., exact=True)` instead reproduces the reference's single-process step on the WHOLE batch (SURVEY
+section 8e items 1-2): batch-norm moments and the two backward sums are summed over ranks per layer (tiny f64 / f32
+all-reduces in stream order), and the loss is normalised by the number of non-ignored pixels of the whole batch, so
+N ranks x B tiles give the same update as one process on N*B tiles up to floating-point summation order.
 """
 from __future__ import annotations
 
@@ -76,6 +80,17 @@ class GradientAllReducer:
         self.works = []
 
 
+class SyncStats:
+    """sum-over-ranks of small statistics tensors, ordered with the kernels of the current stream"""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, t: torch.Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
 class DataParallel:
     """Wraps a cvcs_amd network + fused optimiser for N ranks.  Usage (one process per GPU):
 
@@ -83,7 +98,8 @@ class DataParallel:
         loss = crit(net(x_shard), y_shard); opt.zero_grad(); loss.backward(); opt.step()
     """
 
-    def __init__(self, net, optimizer, bucket_mb: float = 32.0, group=None):
+    def __init__(self, net, optimizer, bucket_mb: float = 32.0, group=None, exact: bool = False, criterion=None):
+        """exact=True: SyncBN + whole-batch loss normalisation (pass the CrossEntropyLoss as `criterion`)"""
         self.net, self.opt = net, optimizer
         flat, flat_grad = net.flat_parameters()
         self.world = dist.get_world_size(group)
@@ -96,6 +112,11 @@ class DataParallel:
         net._engine.on_grad_ready = self.reducer.ready_down_to
         optimizer.grad_scale = 1.0 / self.world
         optimizer.pre_step = self.reducer.finish
+        if exact:
+            assert criterion is not None, "exact=True needs the loss object (its mean spans all ranks' pixels)"
+            sync = SyncStats(group)
+            net._engine.enable_sync_bn(sync)
+            criterion.sync = sync
 
 
 def shard_batch(global_batch: int, rank: int, world: int):

@@ -70,8 +70,18 @@ class _CEFunction(torch.autograd.Function):
         w = crit.weight
         if w is not None and w.device != dev:
             w = crit.weight = w.to(dev)
-        ops.ce_fwd_bwd(logits.contiguous(), target.contiguous(), w, crit.ignore_index, 1.0, loss,
-                       crit._dl if need_grad else None, crit._ws)
+        logits, target = logits.contiguous(), target.contiguous()
+        if crit.sync is None:
+            ops.ce_fwd_bwd(logits, target, w, crit.ignore_index, 1.0, loss, crit._dl if need_grad else None, crit._ws)
+        else:
+            # tiles of one batch on several ranks: the mean runs over the non-ignored pixels of ALL ranks.  The gradient
+            # carries a factor world (the optimiser averages the summed gradients); the returned value is the whole
+            # batch's loss, identical on every rank.
+            ops.ce_weight_sum(target, B, NC, w, crit.ignore_index, crit._ws)
+            crit.sync.all_reduce(crit._ws[:1])
+            ops.ce_fwd_bwd(logits, target, w, crit.ignore_index, float(crit.sync.world), loss,
+                           crit._dl if need_grad else None, crit._ws, external_denominator=True)
+            crit.sync.all_reduce(loss)
         ctx.crit = crit
         return loss[0]
 
@@ -94,6 +104,7 @@ class CrossEntropyLoss:
         self.weight = None if weight is None else weight.float()
         self.ignore_index = ignore_index
         self.unit_grad = unit_grad
+        self.sync = None    # parallel.SyncStats when the batch is sharded over ranks with exact=True
         self._ws = None
         self._dl = None
 
@@ -200,20 +211,29 @@ class ConfusionMatrix:
 
 
 def eval_model(net, Loader_validation, device, batch_size=1, show_progress=False, ignore_background=False,
-               num_classes=16):
+               num_classes=16, shard=None):
     """S/utils.py:59-103 with the per-tile logits D2H + CPU argmax replaced by one fused argmax+histogram launch
-    (any batch size).  Returns (flat, normalized): `flat.compute()` is the int64 confusion matrix."""
+    (any batch size).  Returns (flat, normalized): `flat.compute()` is the int64 confusion matrix.
+    shard=(rank, world[, group]): every rank evaluates the batches i with i % world == rank and the count matrices are
+    summed over ranks once at the end (integer counts: identical to the single-process matrix)."""
     net.eval()
     ignored_index = 0 if ignore_background else None
     flat = ConfusionMatrix(num_classes=num_classes, ignore_index=ignored_index, device=device)
+    i = 0
     with torch.no_grad():
         for c in range(len(Loader_validation)):
             dataset = Loader_validation.get_iterable_chunk(c)
             dl = torch.utils.data.DataLoader(dataset, batch_size=batch_size)
             for x, y, _, context in dl:
+                i += 1
+                if shard is not None and (i - 1) % shard[1] != shard[0]:
+                    continue
                 x, y = x.to(device), mask_reshape(y.to(device))
                 y_pred = net(x, None)
                 flat.update_from_logits(y_pred, y.squeeze(1) if y.dim() == 4 else y)
+    if shard is not None:
+        import torch.distributed as dist
+        dist.all_reduce(flat.conf, op=dist.ReduceOp.SUM, group=shard[2] if len(shard) > 2 else None)
     return flat, NormalizedConfusion(flat)
 
 

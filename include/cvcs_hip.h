@@ -88,6 +88,16 @@ int cvcs_bn_finalize(const float* stat_sum, const float* stat_m2, const float* s
                      float momentum, float eps, int train,
                      float* scale, float* shift, float* save_mean, float* save_invstd, float* workspace, void* stream);
 
+/* Cross-rank ("SyncBN") variant, used when tiles of ONE batch are sharded over ranks and the result must equal the
+ * reference's single-process batch statistics (S/blocks.py:14 over the whole batch): cvcs_bn_moments writes this rank's
+ * per-channel (n, sum x, sum x^2) as f64 [3][C]; the host sums them over ranks (one small all-reduce);
+ * cvcs_bn_finalize_moments then does what cvcs_bn_finalize(train=1) does, from the summed moments.             */
+int cvcs_bn_moments(const float* stat_sum, const float* stat_m2, const float* stat_cnt, int rows, int C,
+                    double* moments, float* workspace, void* stream);
+int cvcs_bn_finalize_moments(const double* moments, int C, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps,
+                             float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+
 /* y -> out = relu?(scale*y + shift), optionally also pool[p/2] = max 2x2 (nn.MaxPool2d(2,2), S/nets.py:130,135,140,145).
  * replaces: BN apply + nn.ReLU (S/blocks.py:17) (+ MaxPool2d).  relu=1: encoder order; relu=0: decoder BN apply. */
 int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C,
@@ -108,6 +118,8 @@ int cvcs_bn_bwd_reduce(const void* y, int64_t y_ld, const void* g1, int64_t g1_l
 int cvcs_bn_bwd_finalize(const float* part_dz, const float* part_dzx, int rows, int64_t M, int C,
                          const float* gamma, const float* save_invstd,
                          float* dgamma, float* dbeta, float* coef_a, float* coef_b, void* stream);
+/* SyncBN backward: coef_a/coef_b from all-rank sums [2][C] (sum dz, sum dz*xhat; f32) over M = all ranks' pixels */
+int cvcs_bn_bwd_coeffs(const float* sums, int64_t M, int C, float* coef_a, float* coef_b, void* stream);
 int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, const void* g2, int64_t g2_ld,
                       int B, int H, int W, int C, const float* scale, const float* shift,
                       const float* save_mean, const float* save_invstd, const float* coef_a, const float* coef_b,
@@ -150,11 +162,17 @@ int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int 
 /* nn.CrossEntropyLoss(weight, ignore_index) (S/utils.py:230,238; called S/train.py:122, S/utils.py:120):
  *   loss = sum_{t!=ignore} -w[t] log_softmax(z)[t] / sum_{t!=ignore} w[t];   dlogits likewise (may be NULL).
  * logits f32 NCHW [B,NC,H,W]; target u8 (target_is_u8=1) or int64 [B,H,W]; class_weight f32 [NC] or NULL.
- * workspace: cvcs_ce_workspace_floats(P) floats; loss_out: 1 float (device).                               */
+ * workspace: cvcs_ce_workspace_floats(P) floats; loss_out: 1 float (device).
+ * Sharded batches: the mean is over the non-ignored pixels of the WHOLE batch, so with tiles of one batch on several
+ * ranks call cvcs_ce_weight_sum (writes this rank's sum of w[t] to workspace[0]), sum workspace[0] over ranks, then
+ * cvcs_ce_fwd_bwd(..., external_denominator=1): loss_out = this rank's numerator / global denominator (the ranks'
+ * values add up to the reference's loss), dlogits = grad_scale * d(global loss)/d(logits).                    */
 int cvcs_ce_workspace_floats(int64_t P);
+int cvcs_ce_weight_sum(const void* target, int target_is_u8, int B, int NC, int64_t HW, const float* class_weight,
+                       int ignore_index, float* workspace, void* stream);
 int cvcs_ce_fwd_bwd(const float* logits, const void* target, int target_is_u8, int B, int NC, int64_t HW,
                     const float* class_weight, int ignore_index, float grad_scale,
-                    float* loss_out, float* dlogits, float* workspace, void* stream);
+                    float* loss_out, float* dlogits, float* workspace, int external_denominator, void* stream);
 
 /* argmax over classes (ties -> lowest index; torch.max/argmax S/utils.py:90,158) -> u8 labels [B,H,W], and
  * confusion-matrix accumulation conf[t*K + p] += 1 for target != ignore (torchmetrics MulticlassConfusionMatrix,

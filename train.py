@@ -41,7 +41,8 @@ if world > 1:
     from cvcs_amd.parallel import DataParallel, shard_batch
     net.flat_parameters()
     net(torch.zeros(1, 3, 32, 32, dtype=torch.uint8, device=device))
-    DataParallel(net, opt)
+    # exact_data_parallel: SyncBN + whole-batch loss mean, i.e. the reference's single-process step on world x batch tiles
+    DataParallel(net, opt, exact=bool(config.get("exact_data_parallel", False)), criterion=crit)
 
 training_loss_values, validation_loss_values, conf_flat = [], [], []
 last_epoch = 0
@@ -78,11 +79,13 @@ for epoch in range(last_epoch, config["epochs"]):
         scheduler.step()
     print("Running validation...", flush=True)
     validation_loss_values += utils.validation_loss(net, Loader_validation, crit, device, config["batch_size"])
-    if (epoch + 1) % config["precision_evaluation_freq"] == 0 and rank == 0:
+    if (epoch + 1) % config["precision_evaluation_freq"] == 0:
         flat, normalized = utils.eval_model(net, Loader_validation, device, batch_size=config.get("eval_batch_size", 8),
-                                            ignore_background=config["ignore_background"], num_classes=max(16, NC))
-        utils.print_metrics(flat.compute())
-        conf_flat.append(flat.compute())
+                                            ignore_background=config["ignore_background"], num_classes=max(16, NC),
+                                            shard=(rank, world) if world > 1 else None)
+        if rank == 0:
+            utils.print_metrics(flat.compute())
+            conf_flat.append(flat.compute())
     if (epoch + 1) % config["freq"] == 0 and rank == 0:
         torch.save({"epoch": epoch, "model_state_dict": net.state_dict(), "optimizer_state_dict": opt.state_dict(),
                     "scheduler_state_dict": scheduler.state_dict(), "training_loss_values": training_loss_values,
