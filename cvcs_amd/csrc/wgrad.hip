@@ -396,6 +396,151 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   }
 }
 
+// ===================================================================================================================
+// 128-channel variant of the fast path.  Experiments on the 64 x 64 kernel above (MFMAs removed / DMA removed / reads
+// removed) showed it is bound by the global->LDS fill: 16 KB of DMA per K-tile and workgroup, 7.5 TB/s chip-wide = the
+// measured LDS-DMA ceiling, with the MFMA pipes idle a third of the time.  Here a workgroup is 8 waves and owns
+// 128 output channels x 64 input channels x 9 taps: the halo tile of x (the larger, 1.9x over-fetched operand) is staged
+// once for twice the MFMA work, 10 KB of fill per 64x64x9 unit instead of 16.  Wave (wm, wn) = 64 channels of dy x 16
+// channels of x; the dy tile is kept as two 32 x 64-channel blocks so that addressing, swizzle and the conflict-free
+// transposed reads are those of the kernel above.
+template <int TH, int TW, int NS>
+__global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
+  static_assert(TH * TW == 32, "a K-tile is 32 output pixels");
+  constexpr int ROWB = 128;
+  constexpr int HP = (TW + 2 + 7) / 8 * 8;
+  constexpr int HR = TH + 2;
+  constexpr int DYH_BYTES = 32 * ROWB, DY_BYTES = 2 * DYH_BYTES, X_ROWS = HR * HP, X_BYTES = X_ROWS * ROWB;
+  constexpr int STAGE = DY_BYTES + X_BYTES;
+  constexpr int XP = X_ROWS / 8;                   // halo DMA pieces
+  constexpr int XJ = (XP + 7) / 8;                 // ... per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tile = blockIdx.x;
+  const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
+  const int co0 = tm * 128, ci0 = tn * 64;
+  const int slice = blockIdx.y;
+  const int kt_begin = slice * p.per_slice;
+  int kt_end = kt_begin + p.per_slice;
+  if (kt_end > p.ktiles) kt_end = p.ktiles;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int cin_rem = p.Cin - ci0;
+  const int rr = lane >> 3, pc = lane & 7;
+  auto swzc = [](int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); };
+
+  // ---- per-lane DMA sources.  dy: piece `wave` = channel half wm, tile pixels (wave&3)*8 + rr.  halo: pieces wave + 8j.
+  const int kdy = wn * 8 + rr;
+  const int kdy_y = kdy / TW, kdy_x = kdy % TW;
+  const int off_dy = ((kdy_y * p.Wo + kdy_x) * (int)p.dy_ld + co0 + wm * 64) * 2 + swzc(kdy, pc) * 16;
+  int off_x[XJ], hyx[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int r = (wave + 8 * j) * 8 + rr;
+    const int hy = r / HP, hx = r - hy * HP;
+    const int c = swzc(r, pc);
+    const bool ok = (wave + 8 * j) < XP && hx < TW + 2 && c * 8 < cin_rem;
+    off_x[j] = ((hy * p.W + hx) * (int)p.x_ld + ci0) * 2 + c * 16;
+    hyx[j] = ok ? ((hy << 8) | hx) : -1;
+  }
+  const int my_pieces = 1 + (XP - wave + 7) / 8;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+  auto issue_tile = [&](int kt, int st) {
+    const int b = kt / tiles_per_img;
+    const int tr = kt - b * tiles_per_img;
+    const int ty = tr / p.tiles_x;
+    const int oy = ty * TH, tx0 = (tr - ty * p.tiles_x) * TW;
+    const unsigned sdy = lds0 + st * STAGE;
+    const unsigned sx = sdy + DY_BYTES;
+    const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
+    const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
+    dma16(src, sdy + wave * 1024);
+    const int iy0 = oy - 1, ix0 = tx0 - 1;
+    const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      if (wave + 8 * j < XP) {
+        const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
+        const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
+        const char* s2 = ok ? xorg + off_x[j] : reinterpret_cast<const char*>(&g_wzero16);
+        dma16(s2, sx + (wave + 8 * j) * 1024);
+      }
+    }
+  };
+
+  const int q = fr >> 2, pp = fr & 3;
+  const int k0 = 4 * fg + q, k1 = 16 + 4 * fg + q;
+  auto taddr = [&](int row, int cc) -> unsigned { return row * ROWB + ((cc ^ ((row >> 1) & 3)) << 5) + pp * 8; };
+  unsigned ad[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ad[i][0] = wm * DYH_BYTES + taddr(k0, i); ad[i][1] = wm * DYH_BYTES + taddr(k1, i); }
+  const int h0 = (k0 / TW) * HP + k0 % TW, h1 = (k1 / TW) * HP + k1 % TW;
+  unsigned ax[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) { ax[kw][0] = taddr(h0 + kw, wn); ax[kw][1] = taddr(h1 + kw, wn); }
+
+  // ring of NS stages, NS-1 K-tiles ahead: the fetch of a K-tile (HBM / Infinity-Cache latency) has NS-2 whole
+  // iterations to land before it is waited for
+  constexpr int D = NS - 1;
+  wg_static_for<0, D>([&](auto d_) {
+    constexpr int d = decltype(d_)::value;
+    if (kt_begin + d < kt_end) issue_tile(kt_begin + d, d);
+  });
+  wait_vm_barrier_n(0);
+
+  auto tile_body = [&](auto st_, int kt) {
+    constexpr int ST = decltype(st_)::value;
+    // vmcnt: the pieces of tiles kt+2 .. kt+D may stay in flight, tile kt+1 must have landed
+    int issued = 0;
+    if (kt + D < kt_end) issue_tile(kt + D, (ST + D) % NS);
+    { int ahead = kt_end - (kt + 2); ahead = ahead < 0 ? 0 : (ahead > D - 1 ? D - 1 : ahead); issued = ahead * my_pieces; }
+    const char* sb = smem + ST * STAGE;
+    bf16x8 af[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tr_pair(sb, ad[i][0], ad[i][1]);
+    wg_static_for<0, 9>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      constexpr int kh = t / 3, kw = t - kh * 3;
+      const char* xb = sb + DY_BYTES + kh * HP * ROWB;
+      const bf16x8 bf = tr_pair(xb, ax[kw][0], ax[kw][1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
+    });
+    wait_vm_barrier_n(issued);
+  };
+  for (int kt = kt_begin; kt < kt_end; kt += NS) {
+    wg_static_for<0, NS>([&](auto s_) {
+      constexpr int s = decltype(s_)::value;
+      if (kt + s < kt_end) tile_body(std::integral_constant<int, s>{}, kt + s);
+    });
+  }
+
+  const int64_t slice_stride = (int64_t)9 * p.Cout * p.Cin;
+  const int ci = ci0 + wn * 16 + fr;
+  if (ci < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wm * 64 + i * 16 + fg * 4 + r;
+          p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][r];
+        }
+  }
+}
+
 // dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int taps,
                                     int Cout, int Cin, int Cin_real) {
@@ -418,7 +563,8 @@ struct WgradPlan {
   int TH, TW, HR, HC, tiles_x, tiles_y, ktiles, nslice, per_slice, tiles_mn;
 };
 
-static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, bool fast = false) {
+// fast: 0 = generic kernel, 1 = 64 x 64 fast path, 2 = 128 x 64 fast path (8 waves, one workgroup per CU)
+static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int fast = 0) {
   WgradPlan pl;
   int tw = 1;
   while (tw < Wo && tw < 32) tw <<= 1;
@@ -430,8 +576,9 @@ static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int
   pl.tiles_x = (int)cdiv(Wo, pl.TW);
   pl.tiles_y = (int)cdiv(Ho, pl.TH);
   pl.ktiles = B * pl.tiles_x * pl.tiles_y;
-  pl.tiles_mn = (Cout / 64) * (int)cdiv(Cin, 64);
-  int want = (int)cdiv(512, pl.tiles_mn);   // ~2 resident workgroups per CU; fewer slices = less partial-slab traffic
+  pl.tiles_mn = (fast == 2 ? Cout / 128 : Cout / 64) * (int)cdiv(Cin, 64);
+  // ~2 resident workgroups per CU (one for the 8-wave kernel); fewer slices = less partial-slab traffic
+  int want = (int)cdiv(fast == 2 ? 256 : 512, pl.tiles_mn);
   if (want > pl.ktiles) want = pl.ktiles;
   if (want < 1) want = 1;
   pl.per_slice = (int)cdiv(pl.ktiles, want);
@@ -465,16 +612,25 @@ static bool fast_shape(int dtype, int KH, int KW, int stride, int pad, int H, in
   return dtype == CVCS_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho >= 4 && Wo >= 8 &&
          (int64_t)H * W * x_ld * 2 < (1ll << 31) && (int64_t)Ho * Wo * dy_ld * 2 < (1ll << 31);
 }
-static bool fast_path(const cvcs_wgrad_desc* d) {
-  return fast_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->H, d->W, d->Ho, d->Wo, d->x_ld, d->dy_ld);
+static int fast_path(const cvcs_wgrad_desc* d) {
+  static const int force64 = getenv("CVCS_WGRAD_64") ? atoi(getenv("CVCS_WGRAD_64")) : 0;   // tuning knob
+  if (!fast_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->H, d->W, d->Ho, d->Wo, d->x_ld, d->dy_ld)) return 0;
+  return (d->Cout % 128 == 0 && !force64) ? 2 : 1;
 }
 
 // worst case over both kernels (the slice count of the generic and of the fast plan can differ)
 extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 64 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
-  const int a = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, false).nslice;
-  const int b = (KH == 3 && KW == 3 && stride == 1 && Ho >= 4 && Wo >= 8) ? make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, true).nslice : 0;
-  return a > b ? a : b;
+  int n = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 0).nslice;
+  if (KH == 3 && KW == 3 && stride == 1 && Ho >= 4 && Wo >= 8) {
+    const int b = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 1).nslice;
+    n = b > n ? b : n;
+    if (Cout % 128 == 0) {
+      const int c = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 2).nslice;
+      n = c > n ? c : n;
+    }
+  }
+  return n;
 }
 
 extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
@@ -509,7 +665,19 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   int rc;
   if (d->dtype == CVCS_F32)
     rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
-  else if (fast_path(d)) {
+  else if (fast_path(d) == 2) {
+    constexpr int kStages = 3;   // deeper rings (4-6 stages) measured no faster: the fetch is not latency-bound
+    const int lds = kStages * (64 + 6 * 16) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast128_kernel<4, 8, kStages>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad_fast128_kernel<4, 8, kStages>), dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(512), lds, st, a);
+    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(fast128)");
+    rc = CVCS_OK;
+  } else if (fast_path(d)) {
     // 4 x 8-pixel K-tiles (plan already made for that shape by make_plan)
     static bool attr_done = false;
     const int lds = 3 * (32 + 6 * 16) * 128;

@@ -183,6 +183,8 @@ WGRAD_CASES = [
     (2, 7, 64, 128, 128, 64, 3, 1, 1),   # fast path: 1x32 K-tiles, two Cin tiles, whole rows
     (3, 5, 50, 64, 64, 128, 3, 1, 1),    # fast path: ragged row tiles (50 = 32 + 18)
     (1, 33, 96, 192, 192, 64, 3, 1, 1),  # fast path: 3 Cin tiles, many K-tiles per slice
+    (2, 21, 44, 128, 128, 256, 3, 1, 1), # 128-channel fast path (8 waves): two Cout tiles x two Cin tiles, ragged 4x8 K-tiles
+    (1, 40, 72, 72, 72, 128, 3, 1, 1),   # 128-channel fast path: Cin not a multiple of 64 (absent channels zero-filled)
 ]
 
 
