@@ -402,7 +402,7 @@ template <typename T> __device__ __forceinline__ f32x4 mma_u(const u32x4& a, con
   return Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c);
 }
 
-template <typename T, int BN, int WM, int WN, int TPS>
+template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int KG = 64 / ES;
@@ -425,9 +425,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   constexpr int BPW = BGROUPS / NW;                // pieces per wave
   constexpr int APW = (21 + NW * SPS - 1) / (NW * SPS) > 1 ? 2 : 1;   // halo pieces per wave per step
   constexpr int OROW = BN * ES + 16;
+  // PIPE (the 8-wave bf16 kernel, one workgroup per CU): the step barrier sits in the MIDDLE of a step and the fragment
+  // pipeline runs across step boundaries, so no wave starts a step with an empty MFMA queue waiting for its first LDS
+  // reads (with the barrier at the step end all 8 waves do, together).  Needs a 4-slot weight ring.  Measured +1.3 %
+  // on the conv family of bench.py (the kernel is within ~10 % of the guide's best plain GEMM: the rest is not here).
+  static_assert(!PIPE || (TPS == 3 && MREP == 4 && NW == 8), "the pipelined loop is written for the 8-wave bf16 kernel");
+  constexpr int NSLOT = PIPE ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                     // [2][A_BYTES]
-  char* sB = smem + 2 * A_BYTES;       // [3][B_BYTES]
+  char* sB = smem + 2 * A_BYTES;       // [NSLOT][B_BYTES]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -511,6 +517,99 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     abase[kw] = lds0 + ((wm * MREP) * HS + fr + kw) * 64 + swz(fr + kw, fg) * 16;
   constexpr int RB = HS * 64;   // bytes between image rows of the halo tile
 
+  if constexpr (PIPE) {
+    // ---- pipelined main loop.  Global step g = cs*SPS + st uses ring slot g & 3 (a VGPR add per step; the offsets inside
+    // a slot and inside the halo buffers stay instruction immediates).  Per step:
+    //   A  issue the weight DMA of step g+2 (slot (g+2)&3, last read in step g-2: every wave is past barrier g-1)
+    //   B  tap 0 (its fragments were issued during tap 2 of the previous step); issue tap 1
+    //   C  counted vmcnt + barrier: the weights of step g+1 (and, in the last step of a slice, the next halo) have landed
+    //   D  issue this step's share of the next slice's halo (buffer PAR^1: every wave is past barrier C, i.e. done
+    //      with the previous slice)
+    //   E  tap 1; issue tap 2          F  tap 2; issue tap 0 of step g+1
+    FragSet X, Y, Z;
+    auto issue = [&](auto par_, auto tap_, unsigned bb, FragSet& f) {
+      constexpr int PAR = decltype(par_)::value;
+      constexpr int tap = decltype(tap_)::value;
+      constexpr int kh = tap / 3, kw = tap - kh * 3;
+      constexpr int BOFF = kw * TAP_BYTES;             // TPS == 3: a step is one filter row
+      constexpr int AOFF = PAR * A_BYTES;
+      lds_issue4q<BOFF, BOFF + 1024, BOFF + 2048, BOFF + 3072>(f.b0, f.b1, f.b2, f.b3, bb);
+      lds_issue4q<AOFF + kh * RB, AOFF + (kh + 1) * RB, AOFF + (kh + 2) * RB, AOFF + (kh + 3) * RB>(f.a0, f.a1, f.a2, f.a3, abase[kw]);
+    };
+    auto mma_set = [&](const FragSet& f) {
+      auto row_mma = [&](int i, const u32x4& af) {
+        acc[i][0] = mma_u<T>(f.b0, af, acc[i][0]);   // A = weights, B = pixels: D[channel][pixel]
+        acc[i][1] = mma_u<T>(f.b1, af, acc[i][1]);
+        acc[i][2] = mma_u<T>(f.b2, af, acc[i][2]);
+        acc[i][3] = mma_u<T>(f.b3, af, acc[i][3]);
+      };
+      row_mma(0, f.a0); row_mma(1, f.a1); row_mma(2, f.a2); row_mma(3, f.a3);
+    };
+    auto dma_b_slot = [&](int cs, int st, int slot) {
+      const int64_t soff = ((int64_t)(st * TPS) * wt_tap_stride + (int64_t)cs * KG) * ES;   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < BPW; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + soff),
+                                         (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + (wave + NW * j) * 1024),
+                                         16, 0, 0);
+    };
+    int g = 0;
+    issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, bbase, X);
+    auto slice_body = [&](auto par_, int cs) {
+      constexpr int PAR = decltype(par_)::value;
+      int kh_prev = 0;                               // halo pieces this wave issued in step D of the previous step
+      static_for<0, SPS>([&](auto st_) {
+        constexpr int st = decltype(st_)::value;
+        const unsigned bb = bbase + (unsigned)(g & 3) * B_BYTES;
+        int kw_ = 0;
+        {
+          constexpr int t2 = (st + 2) % SPS;
+          const int c2 = cs + (st + 2) / SPS;
+          if (c2 < nslice) { dma_b_slot(c2, t2, (g + 2) & 3); kw_ = BPW; }
+        }
+        lds_wait(X);
+        issue(par_, std::integral_constant<int, st * 3 + 1>{}, bb, Y);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(X);
+        __builtin_amdgcn_sched_barrier(0);
+        // the halo pieces of the previous step may stay in flight, except in the last step of a slice (the next step reads them)
+        wait_vm_barrier((st == SPS - 1 ? 0 : kh_prev) + kw_);
+        kh_prev = 0;
+        if constexpr (st < SPS - 1) {
+          if (cs + 1 < nslice) {
+            constexpr int APP = (NPA + SPS - 2) / (SPS - 1);   // halo pieces per wave and step, SPS-1 steps carry them
+            static_for<0, APP>([&](auto j_) {
+              constexpr int q = st * APP + decltype(j_)::value;
+              if constexpr (q < NPA) {
+                if (q * NW + wave < HGROUPS) { dma_halo(q, cs + 1, PAR ^ 1); kh_prev += 1; }
+              }
+            });
+          }
+        }
+        lds_wait(Y);
+        issue(par_, std::integral_constant<int, st * 3 + 2>{}, bb, Z);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(Y);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait(Z);
+        if (g + 1 < total) {
+          constexpr int stn = (st + 1) % SPS;
+          constexpr int PARN = (st == SPS - 1) ? (PAR ^ 1) : PAR;
+          issue(std::integral_constant<int, PARN>{}, std::integral_constant<int, stn * 3>{},
+                bbase + (unsigned)((g + 1) & 3) * B_BYTES, X);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(Z);
+        __builtin_amdgcn_sched_barrier(0);
+        ++g;
+      });
+    };
+    for (int cs = 0; cs < nslice; cs += 2) {
+      slice_body(std::integral_constant<int, 0>{}, cs);
+      if (cs + 1 < nslice) slice_body(std::integral_constant<int, 1>{}, cs + 1);
+    }
+    __syncthreads();   // every wave is done reading fragments before the staging area is overwritten
+  } else {
   // one channel slice = SPS steps, everything indexed by compile-time constants (ring slot = step % 3, halo buffer
   // = slice parity PAR): the LDS offsets are instruction immediates, the loop body carries no address arithmetic
   auto slice_body = [&](auto par_, int cs) {
@@ -613,6 +712,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     if (cs + 1 < nslice) slice_body(std::integral_constant<int, 1>{}, cs + 1);
   }
 
+  }
+
   // ---- epilogue.  The MFMAs ran with A = weights, B = pixels, so acc[i][j][r] is image row y = wm*MREP + i, pixel
   // x = fr, channel = wn*WNC + j*16 + fg*4 + r: every lane owns FOUR CONSECUTIVE CHANNELS of one pixel - a packed
   // 8-byte (bf16) / 16-byte (f32) LDS write per 16x16 block when staging the output rows.  Per-channel BatchNorm sums run
@@ -706,20 +807,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   }
 }
 
-template <typename T, int BN, int WM, int WN, int TPS>
+template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
-  size_t stage = 2 * (size_t)(21 * 1024) + 3 * (size_t)(TPS * BN * 64);   // halo double buffer + weight ring
+  constexpr int nslot = PIPE ? 4 : 3;                                        // the pipelined 8-wave kernel rings 4 slots
+  size_t stage = 2 * (size_t)(21 * 1024) + nslot * (size_t)(TPS * BN * 64);  // halo double buffer + weight ring
   size_t epi = (size_t)128 * (BN * ES + 16);
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM, WN, TPS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, BN, WM, WN, TPS, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)(a.Cout / BN));
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, WN, TPS>), grid, dim3(WM * WN * 64), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, WN, TPS, PIPE>), grid, dim3(WM * WN * 64), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d(halo)");
   return CVCS_OK;
 }
@@ -803,6 +905,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     const bool wide = d->Cout % 128 == 0;
     static const int waves = getenv("CVCS_HALO_WAVES") ? atoi(getenv("CVCS_HALO_WAVES")) : 8;   // tuning knob (4 | 8)
     if (d->dtype == CVCS_F32) return wide ? launch_halo<float, 128, 4, 2, 1>(a, st) : launch_halo<float, 64, 4, 1, 3>(a, st);
+    static const int pipe = getenv("CVCS_HALO_PIPE") ? atoi(getenv("CVCS_HALO_PIPE")) : 1;               // tuning knob
+    if (wide && waves != 4 && pipe) return launch_halo<bf16_t, 128, 4, 2, 3, true>(a, st);
     if (wide) return waves == 4 ? launch_halo<bf16_t, 128, 4, 2, 1>(a, st) : launch_halo<bf16_t, 128, 4, 2, 3>(a, st);
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }

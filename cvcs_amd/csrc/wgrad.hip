@@ -456,27 +456,35 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   const int my_pieces = 1 + (XP - wave + 7) / 8;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
 
-  auto issue_tile = [&](int kt, int st) {
+  // one DMA piece of K-tile kt into ring stage st: which = 0 -> this wave's dy piece, 1 + j -> its j-th halo piece
+  auto issue_piece = [&](int kt, int st, int which) {
     const int b = kt / tiles_per_img;
     const int tr = kt - b * tiles_per_img;
     const int ty = tr / p.tiles_x;
     const int oy = ty * TH, tx0 = (tr - ty * p.tiles_x) * TW;
     const unsigned sdy = lds0 + st * STAGE;
+    if (which == 0) {
+      const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
+      const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
+      dma16(src, sdy + wave * 1024);
+      return;
+    }
     const unsigned sx = sdy + DY_BYTES;
-    const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
-    const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
-    dma16(src, sdy + wave * 1024);
     const int iy0 = oy - 1, ix0 = tx0 - 1;
     const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      if (wave + 8 * j < XP) {
+      if (which == 1 + j && wave + 8 * j < XP) {
         const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
         const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
         const char* s2 = ok ? xorg + off_x[j] : reinterpret_cast<const char*>(&g_wzero16);
         dma16(s2, sx + (wave + 8 * j) * 1024);
       }
     }
+  };
+  auto issue_tile = [&](int kt, int st) {
+#pragma unroll
+    for (int w = 0; w < 1 + XJ; ++w) issue_piece(kt, st, w);
   };
 
   const int q = fr >> 2, pp = fr & 3;
@@ -503,7 +511,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
     constexpr int ST = decltype(st_)::value;
     // vmcnt: the pieces of tiles kt+2 .. kt+D may stay in flight, tile kt+1 must have landed
     int issued = 0;
-    if (kt + D < kt_end) issue_tile(kt + D, (ST + D) % NS);
+    // Waves 0-3 issue their DMA at the start of the iteration, their SIMD partners (waves 4-7) at its end.  A wave whose
+    // global_load_lds blocks at issue (the vector-memory pipeline backs up under real traffic: with every DMA pointed at
+    // one zero word this kernel runs 1.6x faster) cannot issue MFMAs either, and partners running the same program
+    // would block together.  Measured (bench.py, wgrad family): all at start 850, all at end 846, partners at taps
+    // 2 / 4 / 6 / after tap 8: 878 / 905 / 942 / 950 TFLOP/s.
+    const bool late = wave >= 4;
+    const bool more = kt + D < kt_end;
+    if (!late && more) issue_tile(kt + D, (ST + D) % NS);
     { int ahead = kt_end - (kt + 2); ahead = ahead < 0 ? 0 : (ahead > D - 1 ? D - 1 : ahead); issued = ahead * my_pieces; }
     const char* sb = smem + ST * STAGE;
     bf16x8 af[4];
@@ -516,6 +531,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
       const bf16x8 bf = tr_pair(xb, ax[kw][0], ax[kw][1]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
+      if constexpr (t == 8) {
+        if (late && more) issue_tile(kt + D, (ST + D) % NS);
+      }
     });
     wait_vm_barrier_n(issued);
   };
