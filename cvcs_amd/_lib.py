@@ -76,6 +76,8 @@ SIGNATURES = {
     "cvcs_ce_weight_sum": (_i, [_vp, _i, _i, _i, _i64, _vp, _i, _vp, _vp]),
     "cvcs_ce_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "cvcs_argmax_confusion": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "cvcs_label_confusion": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
+    "cvcs_vote_labels": (_i, [_vp, _i, _i64, _vp, _vp]),
     "cvcs_crop_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "cvcs_argmax_stitch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "cvcs_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),

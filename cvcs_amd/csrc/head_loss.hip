@@ -254,6 +254,42 @@ __global__ __launch_bounds__(256) void argmax_conf_kernel(const float* __restric
   }
 }
 
+// confusion matrix from label maps (networks that return labels, not logits: the Ensemble, S/utils.py:89-91)
+__global__ __launch_bounds__(256) void label_conf_kernel(const uint8_t* __restrict__ pred, const void* target, int is_u8,
+                                                        int64_t P, int ignore, int K, unsigned long long* conf) {
+  __shared__ unsigned int hist[kMaxNC * kMaxNC];
+  for (int i = threadIdx.x; i < K * K; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    const int t = load_target(target, is_u8, i);
+    const int a = pred[i];
+    if (t != ignore && (unsigned)t < (unsigned)K && a < K) atomicAdd(&hist[t * K + a], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * K; i += 256)
+    if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
+// per-pixel majority vote over M label maps [M][P]; ties -> the smallest label (torch.mode, S/utils.py:504-506)
+constexpr int kMaxVoters = 16;
+__global__ __launch_bounds__(256) void vote_kernel(const uint8_t* __restrict__ labels, int M, int64_t P, uint8_t* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    int v[kMaxVoters];
+#pragma unroll
+    for (int m = 0; m < kMaxVoters; ++m) v[m] = m < M ? labels[(int64_t)m * P + i] : -1;
+    int best = 256, best_n = 0;
+#pragma unroll
+    for (int a = 0; a < kMaxVoters; ++a) {
+      if (a >= M) continue;
+      int n = 0;
+#pragma unroll
+      for (int b = 0; b < kMaxVoters; ++b) n += (b < M && v[b] == v[a]) ? 1 : 0;
+      if (n > best_n || (n == best_n && v[a] < best)) { best_n = n; best = v[a]; }
+    }
+    out[i] = (uint8_t)best;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ inference boundary
 // crop n tiles (S x S, origin = tile origin - (S-p)/2, zero outside the image) out of one u8 CHW image
 __global__ __launch_bounds__(256) void crop_tiles_kernel(const uint8_t* __restrict__ src, int C, int H, int W, uint8_t* dst,
@@ -441,6 +477,24 @@ extern "C" int cvcs_argmax_confusion(const float* logits, int B, int NC, int64_t
   else
     hipLaunchKernelGGL((argmax_conf_kernel<32>), grid, dim3(256), 0, st, logits, P, HW, NC, labels, target, target_is_u8, ignore_index, K, c);
   CVCS_CHECK_LAUNCH("cvcs_argmax_confusion");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_label_confusion(const uint8_t* pred, const void* target, int target_is_u8, int64_t P, int ignore_index, int K,
+                                    int64_t* conf, void* stream) {
+  CVCS_CHECK_ARG(pred && target && conf && P > 0, "cvcs_label_confusion: null argument");
+  CVCS_CHECK_ARG(K >= 1 && K <= kMaxNC, "cvcs_label_confusion: K=%d out of [1,%d]", K, kMaxNC);
+  hipLaunchKernelGGL(label_conf_kernel, dim3(pix_grid(P, 1024)), dim3(256), 0, (hipStream_t)stream, pred, target, target_is_u8, P,
+                     ignore_index, K, reinterpret_cast<unsigned long long*>(conf));
+  CVCS_CHECK_LAUNCH("cvcs_label_confusion");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_vote_labels(const uint8_t* labels, int M, int64_t P, uint8_t* out, void* stream) {
+  CVCS_CHECK_ARG(labels && out && P > 0, "cvcs_vote_labels: null argument");
+  CVCS_CHECK_ARG(M >= 1 && M <= kMaxVoters, "cvcs_vote_labels: M=%d voters out of [1,%d]", M, kMaxVoters);
+  hipLaunchKernelGGL(vote_kernel, dim3(pix_grid(P, 2048)), dim3(256), 0, (hipStream_t)stream, labels, M, P, out);
+  CVCS_CHECK_LAUNCH("cvcs_vote_labels");
   return CVCS_OK;
 }
 

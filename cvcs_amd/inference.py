@@ -35,7 +35,13 @@ def segment_image(net, image_chw_u8: torch.Tensor, patch_size: int, border_corre
         n = min(batch, hi - first)
         tiles = torch.empty((n, 3, S, S), dtype=torch.uint8, device=dev)
         ops.crop_tiles(image, tiles, first, Wn, p)
-        logits = net(tiles, None)
-        ops.argmax_stitch(logits, p, first, Wn, palette, rgb, labels)
+        out = net(tiles, None)
+        if getattr(net, "returns_logits", True):
+            ops.argmax_stitch(out, p, first, Wn, palette, rgb, labels)
+        else:
+            # a label-returning network (the Ensemble, S/utils.py:157-160): stitch its labels as one-hot "logits"
+            lab = out.reshape(n, S, S)
+            onehot = torch.zeros((n, 16, S, S), dtype=torch.float32, device=dev).scatter_(1, lab.unsqueeze(1), 1.0)
+            ops.argmax_stitch(onehot, p, first, Wn, palette, rgb, labels)
     net.train(was_training)
     return rgb, labels

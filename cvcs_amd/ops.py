@@ -350,6 +350,21 @@ def argmax_confusion(logits, labels=None, target=None, ignore_index=-1, K=16, co
                                            _ptr(conf), _stream()), "cvcs_argmax_confusion")
 
 
+def label_confusion(pred, target, ignore_index, K, conf):
+    assert pred.dtype == torch.uint8 and pred.is_contiguous() and target.is_contiguous() and pred.numel() == target.numel()
+    assert target.dtype in (torch.uint8, torch.int64) and conf.dtype == torch.int64 and conf.numel() == K * K
+    check(_lib.lib().cvcs_label_confusion(pred.data_ptr(), target.data_ptr(), int(target.dtype == torch.uint8), pred.numel(),
+                                          ignore_index, K, conf.data_ptr(), _stream()), "cvcs_label_confusion")
+
+
+def vote_labels(labels, out):
+    """labels u8 [M, ...] -> out u8 [...]: per-pixel majority, ties -> smallest label"""
+    assert labels.dtype == torch.uint8 and out.dtype == torch.uint8 and labels.is_contiguous() and out.is_contiguous()
+    M = labels.shape[0]
+    assert out.numel() * M == labels.numel()
+    check(_lib.lib().cvcs_vote_labels(labels.data_ptr(), M, out.numel(), out.data_ptr(), _stream()), "cvcs_vote_labels")
+
+
 def crop_tiles(image_chw, dst, first_tile, tiles_per_row, p):
     """image u8 [C,H,W] -> dst u8 [n,C,S,S]: S-windows centred on tiles first_tile.. of side p"""
     assert image_chw.dtype == torch.uint8 and dst.dtype == torch.uint8 and image_chw.is_contiguous() and dst.is_contiguous()

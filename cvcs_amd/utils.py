@@ -8,6 +8,8 @@ keys are added: `precision` ('bf16' default | 'fp32'), `eval_batch_size`, `world
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import nets, ops
@@ -35,7 +37,8 @@ def load_device(config):
 
 def load_network(config, device):
     """S/utils.py:174-195.  `Unet` / `Unetv2` are the HIP models; the torchvision / HuggingFace wrappers of the
-    reference (`Resnet101`, `MobileNet`, `SegformerMod`, `Ensemble`) are not on the hot path and not built."""
+    reference (`Resnet101`, `MobileNet`, `SegformerMod`) are not on the hot path and not built; `Ensemble` votes over
+    HIP member networks."""
     netname = config["net"]
     classes = config["num_classes"] + 1
     precision = config.get("precision", "bf16")
@@ -43,7 +46,13 @@ def load_network(config, device):
         return nets.Urnet(classes, precision).to(device)
     elif netname == "Unetv2":
         return nets.Urnetv2(classes, precision).to(device)
-    elif netname in ("Resnet101", "MobileNet", "Ensemble", "SegformerMod"):
+    elif netname == "Ensemble":
+        try:
+            return Ensemble(classes, device, config.get("ensemble_config"), precision=precision)
+        except Exception:
+            print("Some error occured when loading ensemble!")
+            raise
+    elif netname in ("Resnet101", "MobileNet", "SegformerMod"):
         raise NotImplementedError(f"network '{netname}' wraps third-party pretrained models in the reference "
                                   "(S/nets.py:234-356) and is outside the MI355X hot path of this build")
     else:
@@ -187,6 +196,58 @@ def mask_reshape(mask: torch.Tensor):
     return mask
 
 
+class Ensemble(torch.nn.Module):
+    """S/utils.py:472-507: several trained networks vote per pixel.  `config_file` (under configs/ensemble/, or an
+    absolute path) maps network names to checkpoints; each member runs its HIP forward in eval mode, its argmax label map
+    is taken on the device (ties -> first class) and the maps are merged by a per-pixel majority vote (torch.mode: ties ->
+    smallest label) in one HIP launch.  Returns int64 labels ([H,W] for a single tile, [B,H,W] otherwise);
+    `returns_logits` is False, as in the reference."""
+
+    def __init__(self, num_classes, device, config_file, precision="bf16", config_path=None):
+        super().__init__()
+        if not config_file:
+            print("To use the ensemble you have to specify a config file.")
+            print("Add the 'ensemble_config' entry in your evaluation configuration file.")
+            raise Exception
+        self.requires_context = False
+        self.num_classes = num_classes
+        self.wrapper = False
+        self.returns_logits = False
+        self.config_path = os.path.abspath(config_path or "configs/ensemble/")
+        self.config_file = config_file
+        self.device = device
+        self.precision = precision
+        self._init_models()
+
+    def _init_models(self):
+        import yaml
+        path = self.config_file if os.path.isabs(self.config_file) else os.path.join(self.config_path, self.config_file)
+        with open(path, "r") as file:
+            checkpoints = yaml.safe_load(file)
+        items = checkpoints.items() if isinstance(checkpoints, dict) else [tuple(d.items())[0] for d in checkpoints]
+        models = []
+        for key, value in items:
+            config = {"net": key, "load_checkpoint": value, "device": "gpu", "num_classes": self.num_classes - 1,
+                      "precision": self.precision}
+            model = load_network(config, self.device)
+            load_checkpoint(config, model)
+            models.append(model)
+        assert 1 <= len(models) <= 16, "the vote kernel takes 1..16 member networks"
+        self.models = torch.nn.ModuleList(models)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, context=None):
+        B, _, H, W = x.shape
+        stack = torch.empty((len(self.models), B, H, W), dtype=torch.uint8, device=x.device)
+        for m, net in enumerate(self.models):
+            net.eval()
+            ops.argmax_confusion(net(x, None), labels=stack[m])
+        out = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
+        ops.vote_labels(stack, out)
+        out = out.long()
+        return out[0] if B == 1 else out
+
+
 # ---------------------------------------------------------------------------------------------------- evaluation
 class ConfusionMatrix:
     """device-side stand-in for torchmetrics' MulticlassConfusionMatrix (S/utils.py:76-78): rows = target,
@@ -197,6 +258,13 @@ class ConfusionMatrix:
         self.ignore_index = -1 if ignore_index is None else ignore_index
         self.conf = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=device)
         self._labels = None
+
+    def update_from_labels(self, pred, target):
+        """pred: integer label map from a network with returns_logits = False (S/utils.py:89-94)"""
+        p8 = pred.to(torch.uint8).contiguous()
+        t = target if target.dtype in (torch.uint8, torch.int64) else target.long()
+        ops.label_confusion(p8.view(-1), t.contiguous().view(-1), self.ignore_index, self.K, self.conf)
+        return p8
 
     def update_from_logits(self, logits, target):
         B, NC = logits.shape[:2]
@@ -230,7 +298,11 @@ def eval_model(net, Loader_validation, device, batch_size=1, show_progress=False
                     continue
                 x, y = x.to(device), mask_reshape(y.to(device))
                 y_pred = net(x, None)
-                flat.update_from_logits(y_pred, y.squeeze(1) if y.dim() == 4 else y)
+                tgt = y.squeeze(1) if y.dim() == 4 else y
+                if getattr(net, "returns_logits", True):
+                    flat.update_from_logits(y_pred, tgt)
+                else:   # the network already returns label indices (S/utils.py:89)
+                    flat.update_from_labels(y_pred.reshape(tgt.shape), tgt)
     if shard is not None:
         import torch.distributed as dist
         dist.all_reduce(flat.conf, op=dist.ReduceOp.SUM, group=shard[2] if len(shard) > 2 else None)

@@ -179,6 +179,13 @@ int cvcs_ce_fwd_bwd(const float* logits, const void* target, int target_is_u8, i
  * S/utils.py:76-78,93-94; ignore_index < 0: none).  conf: int64 [K*K], accumulated.                          */
 int cvcs_argmax_confusion(const float* logits, int B, int NC, int64_t HW, uint8_t* labels,
                           const void* target, int target_is_u8, int ignore_index, int K, int64_t* conf, void* stream);
+/* the same accumulation from predicted LABELS (u8 [P]) for networks with returns_logits = False (the Ensemble,
+ * S/utils.py:89-94).                                                                                        */
+int cvcs_label_confusion(const uint8_t* pred, const void* target, int target_is_u8, int64_t P, int ignore_index, int K,
+                         int64_t* conf, void* stream);
+/* per-pixel majority vote over M label maps labels[M][P] -> out[P]; ties -> smallest label.
+ * replaces: torch.mode(torch.stack(preds), dim=0) in Ensemble.forward (S/utils.py:504-507).  M <= 16.        */
+int cvcs_vote_labels(const uint8_t* labels, int M, int64_t P, uint8_t* out, void* stream);
 
 /* ---- whole-image inference boundary -----------------------------------------------------------------------------
  * replaces: GID15.__getitem__ crop / _get_padded_patch (S/dataset.py:18-23,70-96), CenterCrop + argmax + iconvert +

@@ -125,3 +125,64 @@ def test_device_chunk_tile_producer_matches_reference_crops():
     counts = sum(torch.bincount(m.reshape(-1).long(), minlength=6) for m in masks).float()
     for ib in (False, True):
         assert torch.equal(device_class_weights(dmsk, 6, ib), class_weights_from_counts(counts, ib))
+
+
+@pytest.mark.parametrize("M,NC", [(1, 5), (3, 3), (4, 2), (7, 16), (16, 4)])
+def test_vote_labels_matches_torch_mode(M, NC):
+    """per-pixel majority vote (Ensemble.forward, S/utils.py:504-507): torch.mode semantics, ties -> smallest label."""
+    g = torch.Generator().manual_seed(M * 31 + NC)
+    stack = torch.randint(0, NC, (M, 2, 37, 53), generator=g, dtype=torch.uint8)
+    out = torch.empty((2, 37, 53), dtype=torch.uint8, device=DEV)
+    ops.vote_labels(stack.to(DEV), out)
+    want, _ = torch.mode(stack.long(), dim=0)
+    assert torch.equal(out.cpu().long(), want)
+
+
+def test_label_confusion_matches_bincount():
+    g = torch.Generator().manual_seed(5)
+    K = 16
+    pred = torch.randint(0, K, (3, 41, 29), generator=g, dtype=torch.uint8)
+    tgt = torch.randint(0, K, (3, 41, 29), generator=g, dtype=torch.int64)
+    conf = torch.zeros(K, K, dtype=torch.int64, device=DEV)
+    ops.label_confusion(pred.to(DEV).view(-1), tgt.to(DEV).view(-1), 0, K, conf)
+    ops.label_confusion(pred.to(DEV).view(-1), tgt.to(torch.uint8).to(DEV).view(-1), 0, K, conf)   # accumulates
+    keep = tgt != 0
+    want = torch.bincount(tgt[keep] * K + pred.long()[keep], minlength=K * K).view(K, K)
+    assert torch.equal(conf.cpu(), 2 * want)
+
+
+def test_ensemble_votes_like_the_reference(tmp_path):
+    """utils.Ensemble (S/utils.py:472-507): members loaded from checkpoints by network name, per-member argmax, per-pixel
+    torch.mode; checked against the oracle's forward of the same weights, member by member and after the vote."""
+    import yaml
+    NC, S = 5, 64
+    img, lab = O.synthetic_tiles(2, S, NC, seed=12, structured=True)
+    members = {"Unetv2": 31, "Unet": 32}
+    cfg = {}
+    for name, seed in members.items():
+        sd = dict(O.init_params(name, NC, seed=seed))
+        for k in [k for k in sd if k.endswith("running_mean")]:   # a torch-written checkpoint carries the BN step counters
+            sd[k.replace("running_mean", "num_batches_tracked")] = torch.tensor(0)
+        torch.save({"model_state_dict": sd}, os.path.join(tmp_path, f"ck_{name}"))
+        cfg[name] = os.path.join(str(tmp_path), f"ck_{name}")
+    with open(os.path.join(tmp_path, "ens.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    ens = utils.load_network({"net": "Ensemble", "num_classes": NC - 1, "precision": "fp32",
+                              "ensemble_config": os.path.join(str(tmp_path), "ens.yaml")}, DEV)
+    assert ens.returns_logits is False and len(ens.models) == 2
+    got = ens(img.to(DEV), None).cpu()
+    assert got.dtype == torch.int64 and got.shape == (2, S, S)
+    refs = [O.unet_forward(O.init_params(name, NC, seed=seed), img.float(), name, train=False) for name, seed in members.items()]
+    want, _ = torch.mode(torch.stack([r.argmax(1) for r in refs]), dim=0)
+    # undecided pixels (top-2 logits of a member within 1e-3 relative) may flip that member's vote
+    decided = torch.ones_like(want, dtype=torch.bool)
+    for r in refs:
+        top2 = r.topk(2, dim=1).values
+        decided &= (top2[:, 0] - top2[:, 1]) > 1e-3 * r.abs().max()
+    assert decided.float().mean() > 0.9 and torch.equal(got[decided], want[decided])
+    # single tile -> [H,W] like the reference's squeeze; eval_model takes the label path
+    assert ens(img[:1].to(DEV), None).shape == (S, S)
+    from cvcs_amd import dataset
+    loader = dataset.make_loader("synthetic:2:2", 2, S, NC, seed=1)
+    flat, _ = utils.eval_model(ens, loader, DEV, batch_size=2, ignore_background=True, num_classes=16)
+    assert int(flat.compute().sum()) > 0
