@@ -316,3 +316,71 @@ def test_loss_scaling_through_autograd_when_unit_grad_is_off():
         (loss * scale).backward()
         grads.append(net.flat_parameters()[1].clone())
     assert torch.allclose(grads[1], 2 * grads[0], rtol=1e-6, atol=1e-9)
+
+
+def test_full_size_tile_train_forward_and_loss_vs_oracle():
+    """BASELINE config 2 tile size (512 x 512, NC=16): train-mode forward (batch statistics) + CE on the fp32 path against the
+    oracle on the same two tiles: logits within 1e-3 of max|logit|, labels identical where decided, loss within 1e-4."""
+    NC, B, S = 16, 2, 512
+    net = _build("Unetv2", NC, "fp32")
+    img, lab = O.synthetic_tiles(B, S, NC, seed=17, structured=True)
+    p = O.init_params("Unetv2", NC, seed=3)
+    with torch.no_grad():
+        ref = O.unet_forward(p, img.float(), "Unetv2", train=True)
+        ref_loss = O.cross_entropy(ref, lab.long(), None, 0).item()
+    net.train()
+    with torch.no_grad():
+        out = net(img.to(DEV), None)
+        loss = utils.CrossEntropyLoss(ignore_index=0)(out, lab.to(DEV)).item()
+    scale = ref.abs().max().item()
+    err = (out.cpu() - ref).abs().max().item() / scale
+    assert err < 1e-3, f"logits rel err {err:.2e}"
+    assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss), (loss, ref_loss)
+    top2 = torch.topk(ref, 2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 4 * err * scale
+    assert torch.equal(torch.argmax(out.cpu(), 1)[decided], torch.argmax(ref, 1)[decided])
+
+
+def test_full_batch_eval_is_tile_independent():
+    """BASELINE config 2 batch (32 x 512 x 512, bf16): tiles are independent units in eval mode, so the labels and logits of
+    the whole batch equal those of its two halves pushed through separately, bit for bit (a size-independent property
+    checked at the full bench size: tile -> workgroup mapping, 32-bit offsets, halo handling at batch seams)."""
+    NC, B, S = 16, 32, 512
+    net = _build("Unetv2", NC, "bf16")
+    net.eval()
+    img, _ = O.synthetic_tiles(B, S, NC, seed=23)
+    x = img.to(DEV)
+    with torch.no_grad():
+        whole = net(x, None).clone()
+        halves = torch.cat([net(x[:16], None).clone(), net(x[16:], None).clone()])
+    assert torch.isfinite(whole).all()
+    assert torch.equal(whole, halves)
+    assert not torch.equal(whole[0], whole[1])
+
+
+def test_config5_shape_1024_tiles_21_classes():
+    """BASELINE config 5 shape (1024 x 1024 tiles, 20 classes + background): two bf16 training steps are finite, lower the
+    loss on structured tiles and are bitwise reproducible; NC = 21 exercises the > 16-class head / loss / argmax kernels."""
+    NC, B, S = 21, 2, 1024
+    img, lab = O.synthetic_tiles(B, S, NC, seed=29, structured=True)
+
+    def run():
+        net = _build("Unetv2", NC, "bf16")
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
+        net.train()
+        losses = []
+        for _ in range(3):
+            loss = crit(net(img.to(DEV), None), lab.to(DEV))
+            optim.zero_grad(); loss.backward(); optim.step()
+            losses.append(loss.item())
+        net.eval()
+        with torch.no_grad():
+            labels = torch.argmax(net(img.to(DEV), None), 1)
+        return losses, labels
+
+    l0, a0 = run()
+    l1, a1 = run()
+    assert all(np.isfinite(l0)) and l0[-1] < l0[0]
+    assert l0 == l1 and torch.equal(a0, a1)
+    assert int(a0.max()) < NC
