@@ -559,21 +559,53 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   }
 }
 
-// dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int taps,
-                                    int Cout, int Cin, int Cin_real) {
-  const int64_t total = (int64_t)Cout * Cin_real * taps;
-  const int64_t slice_stride = (int64_t)taps * Cout * Cin;
-  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
-    // iterate in the ws-friendly order: ci fastest
-    const int ci = (int)(id % Cin_real);
-    const int64_t r = id / Cin_real;
-    const int co = (int)(r % Cout);
-    const int t = (int)(r / Cout);
-    const float* src = ws + ((int64_t)t * Cout + co) * Cin + ci;
-    float s = 0.f;
-    for (int k = 0; k < nslice; ++k) s += src[k * slice_stride];
-    dw[((int64_t)co * Cin_real + ci) * taps + t] = s;
+// dw[co][ci][tap] (OIHW, ci < Cin_real) = sum over slices, fixed order.  One (co, ci) pair and all TAPS taps per lane: the
+// slab reads are coalesced along ci and the TAPS results leave as one contiguous run of the OIHW tensor.  KS lanes share a
+// pair (each sums every KS-th slice; merged in fixed order through LDS) so that small layers with many slices still fill
+// the chip.
+template <int TAPS, int KS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslice,
+                                                          int Cout, int Cin, int Cin_real) {
+  constexpr int PAIRS = 256 / KS;
+  __shared__ float sh[KS > 1 ? KS : 1][PAIRS][TAPS + 1];
+  const int64_t total = (int64_t)Cout * Cin_real;
+  const int64_t tap_stride = (int64_t)Cout * Cin;
+  const int64_t slice_stride = (int64_t)TAPS * tap_stride;
+  const int pl = threadIdx.x % PAIRS, kg = threadIdx.x / PAIRS;
+  for (int64_t base = (int64_t)blockIdx.x * PAIRS; base < total; base += (int64_t)gridDim.x * PAIRS) {
+    const int64_t id = base + pl;
+    const bool ok = id < total;
+    float s[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+    if (ok) {
+      const int ci = (int)(id % Cin_real);
+      const int co = (int)(id / Cin_real);
+      const float* src = ws + (int64_t)co * Cin + ci;
+      for (int k = kg; k < nslice; k += KS) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) s[t] += src[k * slice_stride + t * tap_stride];
+      }
+    }
+    if constexpr (KS > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) sh[kg][pl][t] = s[t];
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          float a = sh[0][pl][t];
+          for (int g = 1; g < KS; ++g) a += sh[g][pl][t];
+          s[t] = a;
+        }
+      }
+    }
+    if (ok && kg == 0) {
+      float* dst = dw + id * TAPS;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) dst[t] = s[t];
+    }
   }
 }
 
@@ -709,11 +741,24 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   } else
     rc = taps == 9 ? launch<bf16_t, 9>(a, pl, st) : taps == 4 ? launch<bf16_t, 4>(a, pl, st) : launch<bf16_t, 1>(a, pl, st);
   if (rc != CVCS_OK) return rc;
-  const int64_t total = (int64_t)d->Cout * d->Cin_real * taps;
-  int blocks = (int)cdiv(total, 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, d->workspace, d->dw, pl.nslice, taps, d->Cout,
-                     d->Cin, d->Cin_real);
+  const int64_t total = (int64_t)d->Cout * d->Cin_real;
+  // lanes per (co, ci) pair: enough threads for ~64K in flight, never more than the slices there are
+  int ks = 1;
+  while (ks < 16 && total * ks < 65536 && ks * 2 <= pl.nslice) ks *= 4;
+#define LAUNCH_RED(TAPS, KS)                                                                                        \
+  hipLaunchKernelGGL((wgrad_reduce_kernel<TAPS, KS>), dim3((unsigned)(cdiv(total, 256 / KS) > 4096 ? 4096 : cdiv(total, 256 / KS))), \
+                     dim3(256), 0, st, d->workspace, d->dw, pl.nslice, d->Cout, d->Cin, d->Cin_real)
+#define LAUNCH_RED_T(TAPS)                                   \
+  do {                                                       \
+    if (ks >= 16) LAUNCH_RED(TAPS, 16);                      \
+    else if (ks >= 4) LAUNCH_RED(TAPS, 4);                   \
+    else LAUNCH_RED(TAPS, 1);                                \
+  } while (0)
+  if (taps == 9) LAUNCH_RED_T(9);
+  else if (taps == 4) LAUNCH_RED_T(4);
+  else LAUNCH_RED_T(1);
+#undef LAUNCH_RED_T
+#undef LAUNCH_RED
   CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(reduce)");
   return CVCS_OK;
 }
