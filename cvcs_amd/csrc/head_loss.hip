@@ -44,71 +44,69 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const char* x, int64_t x_
   }
 }
 
-// dx[p][k] = sum_c dl[p][c] * w[c][k]
-template <typename T>
-__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dl, int64_t P, int64_t HW,
-                                                         const float* __restrict__ w, int NC, char* dx, int64_t dx_ld) {
-  constexpr int V = 16 / sizeof(T);
-  __shared__ float sw[kMaxNC * kHeadC];
-  for (int i = threadIdx.x; i < NC * kHeadC; i += 256) sw[i] = w[i];
-  __syncthreads();
-  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * 256) {
-    const int64_t b = pidx / HW, hw = pidx - b * HW;
-    float o[kHeadC];
-#pragma unroll
-    for (int k = 0; k < kHeadC; ++k) o[k] = 0.f;
-    for (int c = 0; c < NC; ++c) {
-      const float d = dl[(b * NC + c) * HW + hw];
-#pragma unroll
-      for (int k = 0; k < kHeadC; ++k) o[k] += d * sw[c * kHeadC + k];
-    }
-    char* dst = dx + pidx * dx_ld * sizeof(T);
-#pragma unroll
-    for (int c = 0; c < kHeadC / V; ++c) *reinterpret_cast<uint4*>(dst + c * 16) = Elem<T>::pack(o + c * V);
-  }
-}
-
-// partial dW[c][k] = sum_p dl[p][c] * x[p][k], db[c] = sum_p dl[p][c]; one partial row per workgroup:
-// part[row][c*64 + k] for c < NC, then part[row][NC*64 + c].
-// A [NC x P] x [P x 64] contraction over pixels: staged 64 pixels at a time in LDS (dl as [class][pixel], x as
-// f32 [pixel][channel]) and contracted with the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, A = dl^T, B = x), wave w
-// owning channels 16w..16w+15.  LDS pitches (130 / 80 floats) make both ds_read_b32 fragment reads conflict-free.
+// Head backward, one pass over (x, dl) per 64-pixel tile:
+//   partial dW[c][k] = sum_p dl[p][c] * x[p][k], db[c] = sum_p dl[p][c]  (one partial row per workgroup:
+//                      part[row][c*64 + k] for c < NC, then part[row][NC*64 + c]; fixed-order finalize elsewhere)
+//   dx[p][k]         = sum_c dl[p][c] * w[c][k]                         (written as whole NHWC pixel rows)
+// Both are contractions on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  The tile is staged in LDS (dl as
+// [class][pixel], x as f32 [pixel][channel]; pitches 130 / 80 floats keep the ds_read_b32 fragment reads conflict-free).
+// dW: A = dl^T [class][pixel], B = x [pixel][channel], wave w owns channels 16w..16w+15.
+// dx: computed TRANSPOSED, A = w^T [channel][class] (held in registers for the whole kernel), B = dl [class][pixel], so a
+// lane ends up with four consecutive channels of one pixel - one packed 8/16-byte write into the staging tile (the x
+// tile's LDS, free by then), from which the 64 pixel rows leave as contiguous 16-byte-per-lane stores.
 constexpr int kDwTile = 64;   // pixels staged per iteration
 constexpr int kSdPitch = 130, kSxPitch = 80;
 template <typename T>
-__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl,
-                                                         int64_t P, int64_t HW, int NC, float* part) {
-  constexpr int V = 16 / sizeof(T);
-  __shared__ float sx[kDwTile * kSxPitch];
+__global__ __launch_bounds__(256) void head_bwd_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P,
+                                                      int64_t HW, const float* __restrict__ w, int NC, char* dx, int64_t dx_ld,
+                                                      float* part) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  constexpr int OROW = kHeadC * ES + 16;          // staging row: one pixel's 64 channels + 16 bytes against bank conflicts
+  static_assert(kDwTile * OROW <= kDwTile * kSxPitch * 4, "the dx staging tile reuses the x tile");
+  __shared__ __attribute__((aligned(16))) float sx[kDwTile * kSxPitch];
   __shared__ float sd[kMaxNC * kSdPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int ncb = (NC + 15) / 16;
+  const int ncb = (NC + 15) / 16;                  // class blocks of dW
+  const int nks = (NC + 3) / 4;                    // class k-steps of dx
   for (int i = tid; i < kMaxNC * kSdPitch; i += 256) sd[i] = 0.f;   // class rows >= NC stay zero
+  float wa[kMaxNC / 4];                            // A fragments of dx: w[class 4s+fg][channel 16*wave+fr]
+#pragma unroll
+  for (int s = 0; s < kMaxNC / 4; ++s) {
+    const int c = 4 * s + fg;
+    wa[s] = c < NC ? w[c * kHeadC + wave * 16 + fr] : 0.f;
+  }
   f32x4 acc[kMaxNC / 16];
 #pragma unroll
   for (int cb = 0; cb < kMaxNC / 16; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float accb = 0.f;  // threads tid < NC own db[tid]
+  float accb[kMaxNC / 4];                          // db partials: this wave's lanes cover class wave + 4k
+#pragma unroll
+  for (int k = 0; k < kMaxNC / 4; ++k) accb[k] = 0.f;
+  char* stage = reinterpret_cast<char*>(sx);
   for (int64_t p0 = (int64_t)blockIdx.x * kDwTile; p0 < P; p0 += (int64_t)gridDim.x * kDwTile) {
     __syncthreads();
     for (int id = tid; id < kDwTile * (kHeadC / V); id += 256) {
       const int r = id / (kHeadC / V), c = id - r * (kHeadC / V);
       float f[V];
-      if (p0 + r < P) Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (p0 + r) * x_ld * sizeof(T) + c * 16), f);
+      if (p0 + r < P) Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (p0 + r) * x_ld * ES + c * 16), f);
       else
 #pragma unroll
         for (int q = 0; q < V; ++q) f[q] = 0.f;
 #pragma unroll
       for (int q = 0; q < V; ++q) sx[r * kSxPitch + c * V + q] = f[q];
     }
-    for (int id = tid; id < kDwTile * NC; id += 256) {
-      const int c = id / kDwTile, r = id - c * kDwTile;
-      float v = 0.f;
-      if (p0 + r < P) {
-        const int64_t pidx = p0 + r, b = pidx / HW, hw = pidx - b * HW;
-        v = dl[(b * NC + c) * HW + hw];
+#pragma unroll
+    for (int k = 0; k < kMaxNC / 4; ++k) {
+      const int c = wave + 4 * k;                  // id = tid + 256k -> class id / 64 = wave + 4k, pixel lane
+      if (c < NC) {
+        float v = 0.f;
+        if (p0 + lane < P) {
+          const int64_t pidx = p0 + lane, b = pidx / HW, hw = pidx - b * HW;
+          v = dl[(b * NC + c) * HW + hw];
+        }
+        sd[c * kSdPitch + lane] = v;
+        accb[k] += v;
       }
-      sd[c * kSdPitch + r] = v;
     }
     __syncthreads();
 #pragma unroll 4
@@ -118,8 +116,34 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t
       for (int cb = 0; cb < kMaxNC / 16; ++cb)
         if (cb < ncb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sd[(cb * 16 + fr) * kSdPitch + 4 * s + fg], bv, acc[cb], 0, 0, 0);
     }
-    if (tid < NC)
-      for (int r = 0; r < kDwTile; ++r) accb += sd[tid * kSdPitch + r];
+    f32x4 dxa[kDwTile / 16];
+#pragma unroll
+    for (int nb = 0; nb < kDwTile / 16; ++nb) {
+      dxa[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < kMaxNC / 4; ++s)
+        if (s < nks) dxa[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], sd[(4 * s + fg) * kSdPitch + nb * 16 + fr], dxa[nb], 0, 0, 0);
+    }
+    __syncthreads();                               // every wave is done reading the x tile
+#pragma unroll
+    for (int nb = 0; nb < kDwTile / 16; ++nb) {    // D layout: row (channel) = fg*4 + r, col (pixel) = fr
+      char* dst = stage + (nb * 16 + fr) * OROW + (wave * 16 + fg * 4) * ES;
+      if constexpr (ES == 2) {
+        uint2 u;
+        u.x = (uint32_t)f32_to_bf16(dxa[nb][0]) | ((uint32_t)f32_to_bf16(dxa[nb][1]) << 16);
+        u.y = (uint32_t)f32_to_bf16(dxa[nb][2]) | ((uint32_t)f32_to_bf16(dxa[nb][3]) << 16);
+        *reinterpret_cast<uint2*>(dst) = u;
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(dxa[nb][0], dxa[nb][1], dxa[nb][2], dxa[nb][3]);
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = kHeadC * ES / 16;          // 16-byte chunks per pixel row
+    for (int id = tid; id < kDwTile * CPR; id += 256) {
+      const int r = id / CPR, c = id - r * CPR;
+      if (p0 + r < P)
+        *reinterpret_cast<uint4*>(dx + (p0 + r) * dx_ld * ES + c * 16) = *reinterpret_cast<const uint4*>(stage + r * OROW + c * 16);
+    }
   }
   float* row = part + (int64_t)blockIdx.x * (NC * kHeadC + NC);
 #pragma unroll
@@ -129,7 +153,11 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const char* x, int64_t
       const int c = cb * 16 + fg * 4 + r;   // D layout: row (class) = fg*4 + r, col (channel) = fr
       if (cb < ncb && c < NC) row[c * kHeadC + wave * 16 + fr] = acc[cb][r];
     }
-  if (tid < NC) row[NC * kHeadC + tid] = accb;
+#pragma unroll
+  for (int k = 0; k < kMaxNC / 4; ++k) {
+    const float sum = wave_sum(accb[k]);
+    if (lane == 0 && wave + 4 * k < NC) row[NC * kHeadC + wave + 4 * k] = sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ cross entropy
@@ -410,14 +438,11 @@ extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, 
                      (dx_ld * es) % 16 == 0 && dx_ld >= C, "cvcs_head_bwd: view alignment");
   const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
   hipStream_t st = (hipStream_t)stream;
-  dim3 g1(pix_grid(P)), g2((unsigned)cvcs_head_bwd_rows(P));
-  if (dtype == CVCS_F32) {
-    hipLaunchKernelGGL((head_bwd_dx_kernel<float>), g1, dim3(256), 0, st, dlogits, P, HW, w, NC, (char*)dx, dx_ld);
-    hipLaunchKernelGGL((head_bwd_dw_kernel<float>), g2, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, NC, part_dw);
-  } else {
-    hipLaunchKernelGGL((head_bwd_dx_kernel<bf16_t>), g1, dim3(256), 0, st, dlogits, P, HW, w, NC, (char*)dx, dx_ld);
-    hipLaunchKernelGGL((head_bwd_dw_kernel<bf16_t>), g2, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, NC, part_dw);
-  }
+  dim3 grid((unsigned)cvcs_head_bwd_rows(P));
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((head_bwd_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw);
+  else
+    hipLaunchKernelGGL((head_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw);
   CVCS_CHECK_LAUNCH("cvcs_head_bwd");
   return CVCS_OK;
 }

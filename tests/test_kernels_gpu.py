@@ -334,11 +334,12 @@ def test_pack_input(dtype, src_dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("NC", [5, 16, 21])
-def test_head_forward_backward(NC, dtype):
-    """nn.Conv2d(64, NC, 1) (S/nets.py:172) forward (NHWC -> NCHW f32 logits) and backward."""
+@pytest.mark.parametrize("NC,B,H,W", [(5, 2, 9, 11), (16, 2, 9, 11), (21, 2, 9, 11), (16, 3, 64, 96), (32, 1, 7, 5)])
+def test_head_forward_backward(NC, B, H, W, dtype):
+    """nn.Conv2d(64, NC, 1) (S/nets.py:172) forward (NHWC -> NCHW f32 logits) and backward (ragged last 64-pixel tile,
+    more tiles than workgroup rows, the 32-class limit)."""
     g = torch.Generator().manual_seed(12)
-    B, H, W, C = 2, 9, 11, 64
+    C = 64
     x = rq(torch.randn(B, C, H, W, generator=g), dtype)
     w = torch.randn(NC, C, generator=g) / 8
     b = torch.randn(NC, generator=g)
