@@ -741,35 +741,42 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
     const int64_t row = (int64_t)blockIdx.x * WM + wm;
     const bool xok = fr < nx;
+    // interior tiles (the wave's whole 4 x 16 patch lies inside the image: wave-uniform) take the unmasked instance -
+    // the per-element selects were a fifth of the epilogue's instructions
+    auto wave_stats = [&](auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      float s[4], q[4];
+      for (int j = 0; j < NREP; ++j) {
+        float s[4], q[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = 0.f;
+        for (int r = 0; r < 4; ++r) {
+          float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < MREP; ++i)
-          if (i < ny && xok) t += acc[i][j][r];
-        s[r] = row_sum16(t);
+          for (int i = 0; i < MREP; ++i)
+            if (FULL || (i < ny && xok)) t += acc[i][j][r];
+          s[r] = row_sum16(t);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mean = s[r] * inv;
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < MREP; ++i)
+            if (FULL || (i < ny && xok)) {
+              const float d = acc[i][j][r] - mean;
+              t += d * d;
+            }
+          q[r] = row_sum16(t);
+        }
+        if (fr == 0) {
+          const int n = n0 + wn * WNC + j * 16 + fg * 4;
+          *reinterpret_cast<float4*>(p.stat_sum + row * p.Cout + n) = make_float4(s[0], s[1], s[2], s[3]);
+          *reinterpret_cast<float4*>(p.stat_m2 + row * p.Cout + n) = make_float4(q[0], q[1], q[2], q[3]);
+        }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float mean = s[r] * inv;
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-          if (i < ny && xok) {
-            const float d = acc[i][j][r] - mean;
-            t += d * d;
-          }
-        q[r] = row_sum16(t);
-      }
-      if (fr == 0) {
-        const int n = n0 + wn * WNC + j * 16 + fg * 4;
-        *reinterpret_cast<float4*>(p.stat_sum + row * p.Cout + n) = make_float4(s[0], s[1], s[2], s[3]);
-        *reinterpret_cast<float4*>(p.stat_m2 + row * p.Cout + n) = make_float4(q[0], q[1], q[2], q[3]);
-      }
-    }
+    };
+    if (ny == MREP && nx == 16) wave_stats(std::true_type{});
+    else wave_stats(std::false_type{});
     if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[row] = (float)nvalid;
   }
   // ---- store: two halves of 8 image rows staged through LDS as [pixel][channel] (one packed 8/16-byte LDS write per
