@@ -39,7 +39,6 @@ struct ConvArgs {
   int relu, pixel_shuffle;
   int M;
   int tiles_x, tiles_y;   // halo kernel: 16x16 output tiles per image
-  int dbg_skip;           // timing experiments only (CVCS_DBG_SKIP): 1 = skip the output store, 2 = skip statistics too
 };
 
 template <typename T> struct Mma;
@@ -901,8 +900,6 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.in = (const char*)d->in; a.wt = (const char*)d->wt; a.bias = d->bias; a.out = (char*)d->out;
   a.stat_sum = d->stat_sum; a.stat_m2 = d->stat_m2; a.stat_cnt = d->stat_cnt;
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
-  static const int dbg_skip = getenv("CVCS_DBG_SKIP") ? atoi(getenv("CVCS_DBG_SKIP")) : 0;
-  a.dbg_skip = dbg_skip;
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
