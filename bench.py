@@ -67,12 +67,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # rehearsal hooks for a one-GPU box (tests/test_bench_multirank_gpu.py): every rank on cuda:0, collectives over gloo
+    if os.environ.get("CVCS_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("CVCS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from cvcs_amd import ops, utils
     cfg = {"net": a.net, "num_classes": a.classes, "precision": a.precision, "loss": "CEL", "ignore_background": True,
