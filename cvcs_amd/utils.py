@@ -27,7 +27,9 @@ def load_device(config):
     """S/utils.py:273-280 ('gpu' -> 'cuda:0'); the cpu branch no longer calls torch.cuda.get_device_name."""
     if config["device"] == "gpu":
         assert torch.cuda.is_available(), "Notebook is not configured properly!"
-        device = "cuda:0" if "LOCAL_RANK" not in __import__("os").environ else f"cuda:{__import__('os').environ['LOCAL_RANK']}"
+        # one process per GPU under torch.distributed.run; CVCS_ONE_DEVICE=1 rehearses N ranks on a one-GPU box
+        local = os.environ.get("LOCAL_RANK", "0") if os.environ.get("CVCS_ONE_DEVICE") != "1" else "0"
+        device = f"cuda:{local}"
         print("Training network on {}".format(torch.cuda.get_device_name(device=device)))
     else:
         device = torch.device("cpu")

@@ -32,7 +32,11 @@ if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(device)
-    dist.init_process_group("nccl", device_id=torch.device(device))
+    backend = os.environ.get("CVCS_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    else:
+        dist.init_process_group(backend)
 net = utils.load_network(config, device)
 print("parameters", utils.count_params(net), "| tiles/epoch", len(Loader_train.idxs) * Loader_train.tpi, flush=True)
 crit = utils.load_loss(config, device, Loader_train)
