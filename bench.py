@@ -142,13 +142,18 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "loss": round(last_loss, 5),
         }
-        if "conv_igemm" in timers:
-            c = timers["conv_igemm"]
+        if "conv3x3_halo" in timers:
+            c = timers["conv3x3_halo"]
             out["roofline"] = {"bound": "mfma", "achieved": round(c["tflops"], 2), "peak": PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3,
                                "unit": "TFLOP/s", "frac": round(c["tflops"] / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
-                               "traffic": None, "kernel": "conv3x3_halo_kernel + conv_igemm_kernel (forward, data-gradient and ConvTranspose launches)",
+                               "traffic": None, "kernel": "conv3x3_halo_kernel (every 3x3 forward and data-gradient launch)",
                                "launches_per_step": c["launches"] // a.steps, "avg_launch_us": round(c["avg_us"], 2),
                                "algorithmic_gflop_per_step": round(c["flops"] / a.steps / 1e9, 1)}
+            if "conv_igemm" in timers:   # ConvTranspose forward / data gradient on the generic implicit-GEMM kernel
+                g = timers["conv_igemm"]
+                out["other_conv"] = {"kernel": "conv_igemm_kernel (ConvTranspose forward + data gradient; HBM-bound shapes)",
+                                     "achieved": round(g["tflops"], 2), "unit": "TFLOP/s", "launches_per_step": g["launches"] // a.steps,
+                                     "avg_launch_us": round(g["avg_us"], 2), "algorithmic_gflop_per_step": round(g["flops"] / a.steps / 1e9, 1)}
             if "wgrad" in timers:
                 w = timers["wgrad"]
                 out["roofline_wgrad"] = {"bound": "mfma", "achieved": round(w["tflops"], 2), "unit": "TFLOP/s",
@@ -158,7 +163,7 @@ def main():
             # HBM traffic of the same kernel family from the rocprofv3 PMC passes of this exact workload (FETCH_SIZE
             # doubled per the gfx950 correction, WRITE_SIZE exact), collected with scripts/pmc_traffic.py
             if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and a.net == "Unetv2" and os.path.exists(PMC_FILE):
-                pm = json.load(open(PMC_FILE)).get("conv_igemm")
+                pm = json.load(open(PMC_FILE)).get("conv3x3_halo_kernel")
                 if pm:
                     out["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
                     out["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/r01_pmc_traffic_b32_s512_bf16.json)"

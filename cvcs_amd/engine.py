@@ -189,7 +189,8 @@ class UNetEngine:
         C_ = y.shape[3]
         rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1) if train else 0
         stats = (self.stat_sum, self.stat_m2, self.stat_cnt) if train else None
-        ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats)
+        ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats,
+                   cin_real=3 if conv == "encode1.0.layer.0" else None)
         st = self.bn[bnname]
         if train and self.sync_bn is not None:
             # batch statistics over the tiles of ALL ranks (the reference's batch is not sharded): one [3][C] f64 sum

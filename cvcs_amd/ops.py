@@ -131,7 +131,7 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
-           pixel_shuffle=False, stats=None):
+           pixel_shuffle=False, stats=None, cin_real=None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...)."""
     d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats)
@@ -142,7 +142,10 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         assert (out.H, out.W, out.C) == (Ho, Wo, Cout), f"output view mismatch {(out.H, out.W, out.C)} vs {(Ho, Wo, Cout)}"
     assert out.B == x.B
     if TIMERS is not None:
-        ev = TIMERS.bracket("conv_igemm", 2.0 * x.B * Ho * Wo * Cout * x.C * KH * KW)
+        # same dispatch rule as cvcs_conv2d: 3x3 / stride 1 / pad 1 on maps of at least 8 pixels -> the halo kernel
+        halo = KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1 and not pixel_shuffle and x.H >= 8 and x.W >= 8
+        # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count
+        ev = TIMERS.bracket("conv3x3_halo" if halo else "conv_igemm", 2.0 * x.B * Ho * Wo * Cout * (cin_real or x.C) * KH * KW)
         ev[0].record()
     check(_lib.lib().cvcs_conv2d(C.byref(d), _stream()), "cvcs_conv2d")
     if TIMERS is not None:
@@ -170,7 +173,7 @@ def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, works
     assert workspace.dtype == torch.float32 and \
         workspace.numel() >= wgrad_workspace_floats(x.B, dy.H, dy.W, dy.C, x.C, KH, KW, stride), "wgrad workspace too small"
     if TIMERS is not None:
-        ev = TIMERS.bracket("wgrad", 2.0 * x.B * dy.H * dy.W * dy.C * x.C * KH * KW)
+        ev = TIMERS.bracket("wgrad", 2.0 * x.B * dy.H * dy.W * dy.C * cin_real * KH * KW)
         ev[0].record()
     check(_lib.lib().cvcs_conv2d_wgrad(C.byref(d), _stream()), "cvcs_conv2d_wgrad")
     if TIMERS is not None:

@@ -13,8 +13,10 @@ import sys
 
 def family(name):
     n = re.sub(r"\(.*", "", name).replace("void cvcs::", "").replace("cvcs::", "")
-    if n.startswith(("conv3x3_halo_kernel", "conv_igemm_kernel")):
-        return "conv_igemm"
+    if n.startswith("conv3x3_halo_kernel"):
+        return "conv3x3_halo_kernel"
+    if n.startswith("conv_igemm_kernel"):
+        return "conv_igemm_kernel"
     if n.startswith(("wgrad_kernel", "wgrad_fast_kernel")):
         return "wgrad"
     return re.sub(r"<.*", "", n)

@@ -104,7 +104,7 @@ def test_fp32_path_replays_reference_golden(golden_dir, tag, variant, opt, ignor
 @pytest.mark.parametrize("variant", ["Unetv2", "Unet"])
 def test_fp32_gradients_vs_f64_oracle(variant):
     """every parameter gradient of one train step against the oracle evaluated in float64 (5e-4 of max|grad|)."""
-    NC, B, S = 5, 2, 32
+    NC, B, S = 5, 2, 64
     img, lab = O.synthetic_tiles(B, S, NC, seed=11)
     p = {k: v.double() for k, v in O.init_params(variant, NC, seed=3).items()}
     names = [k for k in p if not O.is_buffer(k)]
@@ -120,6 +120,7 @@ def test_fp32_gradients_vs_f64_oracle(variant):
     loss.backward()
     assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
     assert (pred.detach().cpu().double() - logits.detach()).abs().max() < 1e-4 * logits.abs().max()
+    worst = (0.0, "")
     for k, q in net.named_parameters():
         sc = ref[k].abs().max().item()
         if sc < 1e-12:   # conv bias in front of a train-mode BN: exactly zero in exact arithmetic
@@ -127,11 +128,14 @@ def test_fp32_gradients_vs_f64_oracle(variant):
             continue
         err = (q.grad.cpu().double() - ref[k]).abs().max().item() / sc
         # Typical error is 1-2e-5 (scripts/grad_noise_probe.py).  A ReLU / max-pool decision that sits on a rounding
-        # boundary flips one pixel's mask; with only 2048 pixels in this fixture one flip moves a weight gradient by
-        # ~1/sqrt(2048) = 2e-2 and every layer upstream of it by ~7e-3 (torch-CPU fp32 shows the same events).  The
-        # last layers cannot be downstream of a flip and are held to the tight bound.
+        # boundary flips one pixel's mask; with only 8192 pixels in this fixture (128 at the deepest level) one flip moves
+        # a weight gradient by ~1/sqrt(pixels) = 1e-2 .. 9e-2 and every layer upstream of it by a fraction of that
+        # (torch-CPU fp32 shows the same events); gradients that are sums with heavy cancellation (biases in front of
+        # ReLU + BN) amplify it.  The last layers cannot be downstream of a flip and are held to the tight bound.
         tight = k.startswith(("decode_forward4.1", "decode_forward4.0.layer.5"))
+        worst = max(worst, (err, k)) if not tight else worst
         assert err < (5e-4 if tight else 1e-1), f"{k}: rel err {err:.2e}"
+    print("largest loose-set error:", worst)
 
 
 @pytest.mark.parametrize("variant", ["Unetv2", "Unet"])
