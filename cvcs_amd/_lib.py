@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("pixel_shuffle", C.c_int32),
         ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p), ("stat_cnt", C.c_void_p),
         ("dtype", C.c_int32),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p),
     ]
 
 
@@ -101,7 +102,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 1:
+        if h.cvcs_abi_version() != 2:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         _lib = h
     return _lib

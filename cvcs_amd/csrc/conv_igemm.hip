@@ -29,6 +29,7 @@ struct ConvArgs {
   const char* in;
   const char* wt;
   const float* bias;
+  const float* pre_scale; const float* pre_shift; const float* post_scale; const float* post_shift;   // eval-mode BN folds
   char* out;
   float* stat_sum;
   float* stat_m2;
@@ -198,12 +199,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int j = 0; j < NREP; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
     const float bv = p.bias ? p.bias[n] : 0.f;
+    const float s1 = p.pre_scale ? p.pre_scale[n] : 1.f, t1 = p.pre_scale ? p.pre_shift[n] : 0.f;
+    const float s2 = p.post_scale ? p.post_scale[n] : 1.f, t2 = p.post_scale ? p.post_shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv;
+        if (p.pre_scale) v = v * s1 + t1;
         if (p.relu) v = fmaxf(v, 0.f);
+        if (p.post_scale) v = v * s2 + t2;
         acc[i][j][r] = v;
       }
   }
@@ -720,9 +725,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nb = n0 + wn * WNC + j * 16 + fg * 4;
     if (p.bias) {
-      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + wn * WNC + j * 16 + fg * 4);
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + nb);
       bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+    }
+    if (p.pre_scale || p.post_scale) {   // eval mode: BatchNorm folded into the epilogue (wave-uniform branch)
+      float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {1.f, 1.f, 1.f, 1.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.pre_scale) {
+        const float4 a = *reinterpret_cast<const float4*>(p.pre_scale + nb), c = *reinterpret_cast<const float4*>(p.pre_shift + nb);
+        s1[0] = a.x; s1[1] = a.y; s1[2] = a.z; s1[3] = a.w; t1[0] = c.x; t1[1] = c.y; t1[2] = c.z; t1[3] = c.w;
+      }
+      if (p.post_scale) {
+        const float4 a = *reinterpret_cast<const float4*>(p.post_scale + nb), c = *reinterpret_cast<const float4*>(p.post_shift + nb);
+        s2[0] = a.x; s2[1] = a.y; s2[2] = a.z; s2[3] = a.w; t2[0] = c.x; t2[1] = c.y; t2[2] = c.z; t2[3] = c.w;
+      }
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = (acc[i][j][r] + bv[r]) * s1[r] + t1[r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          acc[i][j][r] = v * s2[r] + t2[r];
+        }
+      continue;
     }
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
@@ -899,6 +925,10 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   ConvArgs a;
   a.in = (const char*)d->in; a.wt = (const char*)d->wt; a.bias = d->bias; a.out = (char*)d->out;
   a.stat_sum = d->stat_sum; a.stat_m2 = d->stat_m2; a.stat_cnt = d->stat_cnt;
+  CVCS_CHECK_ARG((d->pre_scale == nullptr) == (d->pre_shift == nullptr) && (d->post_scale == nullptr) == (d->post_shift == nullptr),
+                 "cvcs_conv2d: a folded BatchNorm needs both scale and shift");
+  CVCS_CHECK_ARG(!(d->pixel_shuffle && (d->pre_scale || d->post_scale)), "cvcs_conv2d: no BatchNorm fold with pixel_shuffle");
+  a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.post_scale = d->post_scale; a.post_shift = d->post_shift;
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
           if (p.relu) f[k] = fmaxf(f[k], 0.f);
           mx[k] = fmaxf(mx[k], f[k]);
         }
-        *reinterpret_cast<uint4*>(p.out + (pix * p.out_ld) * ES + cc * 16) = Elem<T>::pack(f);
+        if (p.out) *reinterpret_cast<uint4*>(p.out + (pix * p.out_ld) * ES + cc * 16) = Elem<T>::pack(f);
       }
       *reinterpret_cast<uint4*>(p.pool + (it * p.pool_ld) * ES + cc * 16) = Elem<T>::pack(mx);
     }
@@ -639,7 +639,8 @@ extern "C" int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int
   CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "cvcs_bn_act: bad shape");
   int rc;
   if ((rc = check_view("cvcs_bn_act", y, y_ld, C, es))) return rc;
-  if ((rc = check_view("cvcs_bn_act", out, out_ld, C, es))) return rc;
+  CVCS_CHECK_ARG(out || pool, "cvcs_bn_act: nothing to write");
+  if (out && (rc = check_view("cvcs_bn_act", out, out_ld, C, es))) return rc;
   if (pool) {
     if ((rc = check_view("cvcs_bn_act", pool, pool_ld, C, es))) return rc;
     CVCS_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "cvcs_bn_act: pooling needs even H, W");

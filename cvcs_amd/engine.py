@@ -50,6 +50,8 @@ class UNetEngine:
         self._saved_train = False
         self.sync_bn = None             # parallel.SyncStats: batch-norm statistics over all ranks' tiles (None: per rank)
         self._sync_mom = self._sync_sums = None   # its exchange buffers (allocated by enable_sync_bn)
+        self.one = torch.ones(1024, dtype=torch.float32, device=self.dev)    # identity affine of the pooling-only pass
+        self.zero = torch.zeros(1024, dtype=torch.float32, device=self.dev)
         self.on_backward_begin = None   # data-parallel hooks (cvcs_amd.parallel): called at the start of backward,
         self.on_grad_ready = None       # and with the lowest flat-gradient offset that is complete so far
         # Weight gradients are off the critical chain of backward (dy_L -> dgrad_L -> BN backward_{L-1} -> ...): they can be
@@ -187,24 +189,41 @@ class UNetEngine:
         pk = self.packed[conv]
         M = x.B * y.shape[1] * y.shape[2]
         C_ = y.shape[3]
-        rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1) if train else 0
-        stats = (self.stat_sum, self.stat_m2, self.stat_cnt) if train else None
+        st = self.bn[bnname]
+        if not train:
+            # eval mode: the BatchNorm is a fixed per-channel affine -> folded into the conv epilogue (before the ReLU in the
+            # encoder order conv->BN->ReLU, after it in the decoder order conv->ReLU->BN); the activation is written once,
+            # and only pooled layers need a second (pooling-only) pass
+            ops.bn_finalize(None, 0, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
+                            self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], False, st.scale, st.shift,
+                            None, None)
+            fold = (st.scale, st.shift)
+            ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], out, 3, 3, 1, 1, relu=True,
+                       pre_affine=fold if relu_after_bn else None, post_affine=None if relu_after_bn else fold,
+                       cin_real=3 if conv == "encode1.0.layer.0" else None)
+            if pool is not None:
+                ops.bn_act(out, self.one[:C_], self.zero[:C_], False, None, pool)
+            return
+        rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1)
+        stats = (self.stat_sum, self.stat_m2, self.stat_cnt)
         ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats,
                    cin_real=3 if conv == "encode1.0.layer.0" else None)
-        st = self.bn[bnname]
-        if train and self.sync_bn is not None:
-            # batch statistics over the tiles of ALL ranks (the reference's batch is not sharded): one [3][C] f64 sum
-            mom = self._sync_mom[:3 * C_]
-            ops.bn_moments(stats, rows, C_, mom, workspace=self.bn_ws)
-            self.sync_bn.all_reduce(mom)
-            ops.bn_finalize_moments(mom, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
-                                    self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], st.scale, st.shift,
-                                    st.mean, st.invstd)
-        else:
+        if self.sync_bn is None:
             ops.bn_finalize(stats, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
-                            self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], train, st.scale, st.shift,
-                            st.mean if train else None, st.invstd if train else None, workspace=self.bn_ws)
+                            self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], True, st.scale, st.shift,
+                            st.mean, st.invstd, workspace=self.bn_ws)
+        else:
+            self._sync_bn_finalize(stats, rows, C_, bnname, st)
         ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
+
+    def _sync_bn_finalize(self, stats, rows, C_, bnname, st):
+        # batch statistics over the tiles of ALL ranks (the reference's batch is not sharded): one [3][C] f64 sum
+        mom = self._sync_mom[:3 * C_]
+        ops.bn_moments(stats, rows, C_, mom, workspace=self.bn_ws)
+        self.sync_bn.all_reduce(mom)
+        ops.bn_finalize_moments(mom, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
+                                self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], st.scale, st.shift,
+                                st.mean, st.invstd)
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:

@@ -131,10 +131,15 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
-           pixel_shuffle=False, stats=None, cin_real=None):
+           pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...)."""
     d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats)
+    # eval-mode BatchNorm folded into the epilogue: (scale, shift) before / after the ReLU
+    if pre_affine is not None:
+        d.pre_scale, d.pre_shift = pre_affine[0].data_ptr(), pre_affine[1].data_ptr()
+    if post_affine is not None:
+        d.post_scale, d.post_shift = post_affine[0].data_ptr(), post_affine[1].data_ptr()
     assert wt.shape[0] == KH * KW and wt.shape[2] == x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
     if pixel_shuffle:
         assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"
@@ -219,9 +224,11 @@ def bn_bwd_coeffs(sums, M, C_, ca, cb):
     check(_lib.lib().cvcs_bn_bwd_coeffs(sums.data_ptr(), M, C_, ca.data_ptr(), cb.data_ptr(), _stream()), "cvcs_bn_bwd_coeffs")
 
 
-def bn_act(y: View, scale, shift, relu: bool, out: View, pool: View | None = None):
-    check(_lib.lib().cvcs_bn_act(y.ptr, y.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(relu), out.ptr,
-                                 out.ld, 0 if pool is None else pool.ptr, 0 if pool is None else pool.ld, y.code,
+def bn_act(y: View, scale, shift, relu: bool, out: View | None, pool: View | None = None):
+    """out = relu?(scale*y + shift) (+ pool = 2x2 max of it); out=None with a pool view: pooling only"""
+    check(_lib.lib().cvcs_bn_act(y.ptr, y.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(relu),
+                                 0 if out is None else out.ptr, 0 if out is None else out.ld,
+                                 0 if pool is None else pool.ptr, 0 if pool is None else pool.ld, y.code,
                                  _stream()), "cvcs_bn_act")
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 1
+#define CVCS_ABI_VERSION 2
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -55,6 +55,12 @@ typedef struct {
   int32_t pixel_shuffle;  /* 1: Cout = 4*Cr, column (dy*2+dx)*Cr+co goes to pixel (2y+dy, 2x+dx), channel co */
   float* stat_sum;  float* stat_m2;  float* stat_cnt;
   int32_t dtype;
+  /* eval-mode BatchNorm folded into the epilogue (f32 [Cout] each, NULL = none): v = acc + bias;
+   * v = v*pre_scale + pre_shift; ReLU if `relu`; v = v*post_scale + post_shift.  "pre" is the encoder order
+   * conv->BN->ReLU (S/blocks.py:13-17), "post" the decoder order conv->ReLU->BN (S/blocks.py:40-45); scale/shift come
+   * from cvcs_bn_finalize(train=0).                                                                              */
+  const float* pre_scale;   const float* pre_shift;
+  const float* post_scale;  const float* post_shift;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
@@ -98,7 +104,8 @@ int cvcs_bn_finalize_moments(const double* moments, int C, const float* gamma, c
                              float* running_mean, float* running_var, float momentum, float eps,
                              float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 
-/* y -> out = relu?(scale*y + shift), optionally also pool[p/2] = max 2x2 (nn.MaxPool2d(2,2), S/nets.py:130,135,140,145).
+/* (out may be NULL when pool is given: pooling-only pass over an already activated tensor, scale = 1, shift = 0)
+ * y -> out = relu?(scale*y + shift), optionally also pool[p/2] = max 2x2 (nn.MaxPool2d(2,2), S/nets.py:130,135,140,145).
  * replaces: BN apply + nn.ReLU (S/blocks.py:17) (+ MaxPool2d).  relu=1: encoder order; relu=0: decoder BN apply. */
 int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C,
                 const float* scale, const float* shift, int relu,

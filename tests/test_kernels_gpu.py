@@ -99,6 +99,41 @@ def test_conv2d_matches_aten(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("order", ["encoder", "decoder"])
+@pytest.mark.parametrize("H,W,Cin,Cout,pool", [(20, 36, 64, 128, True), (6, 6, 64, 64, False), (16, 16, 128, 64, True)])
+def test_conv2d_eval_mode_batchnorm_fold(H, W, Cin, Cout, pool, order, dtype):
+    """eval mode: BN (running statistics) folded into the conv epilogue - encoder order conv->BN->ReLU (S/blocks.py:13-17)
+    and decoder order conv->ReLU->BN (S/blocks.py:40-45) - plus the pooling-only pass (S/nets.py:130); halo kernel
+    (20x36, 16x16) and generic kernel (6x6 map)."""
+    g = torch.Generator().manual_seed(H * 7 + Cout)
+    B = 2
+    x = rq(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = rq(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    rm, rv = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    bn = lambda t: F.batch_norm(t, rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    ref = (bn(y).relu() if order == "encoder" else bn(y.relu())).float()
+    scale, shift = torch.empty(Cout, device=DEV), torch.empty(Cout, device=DEV)
+    ops.bn_finalize(None, 0, B * H * W, Cout, gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), False, scale, shift, None, None)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype, want_dgrad=False)
+    out = torch.empty(B, H, W, Cout, dtype=dtype, device=DEV)
+    fold = (scale, shift)
+    ops.conv2d(ops.view(to_nhwc(x, dtype)), wf, b.to(DEV), ops.view(out), 3, 3, 1, 1, relu=True,
+               pre_affine=fold if order == "encoder" else None, post_affine=fold if order == "decoder" else None)
+    torch.cuda.synchronize()
+    close(from_nhwc(out), ref, tol(dtype), "folded conv+BN")
+    if pool:
+        pl = torch.empty(B, H // 2, W // 2, Cout, dtype=dtype, device=DEV)
+        keep = out.clone()
+        ops.bn_act(ops.view(out), torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV), False, None, ops.view(pl))
+        torch.cuda.synchronize()
+        assert torch.equal(out, keep)                                   # pooling-only: the source is not rewritten
+        assert torch.equal(from_nhwc(pl), F.max_pool2d(from_nhwc(out), 2, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W", [(2, 16, 16), (4, 192, 192)])  # the second has 2304 partial rows: two-stage merge
 def test_conv2d_f32_large_mean_statistics(dtype, B, H, W):
     """raw 0..255 inputs (S/train.py:121, no normalisation): mean >> std must not cancel in the variance."""
