@@ -71,6 +71,8 @@ SIGNATURES = {
     "cvcs_pack_conv_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "cvcs_pack_convT_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "cvcs_head_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "cvcs_head_argmax": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "cvcs_label_stitch": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "cvcs_head_bwd_rows": (_i, [_i64]),
     "cvcs_head_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _vp]),
     "cvcs_ce_workspace_floats": (_i, [_i64]),

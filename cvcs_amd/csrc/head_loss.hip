@@ -44,6 +44,31 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const char* x, int64_t x_
   }
 }
 
+// head + argmax in one pass (prediction: S/utils.py:88-90, S/inference.py:45-47 without the logits round trip): the NC
+// logits of a pixel are formed exactly as in head_fwd_kernel (same order of operations -> the same labels as
+// head_fwd + argmax), only the index of the first maximum leaves the kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void head_argmax_kernel(const char* x, int64_t x_ld, int64_t P, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int NC, uint8_t* labels) {
+  __shared__ float sw[kMaxNC * kHeadC + kMaxNC];
+  for (int i = threadIdx.x; i < NC * kHeadC; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < NC; i += 256) sw[kMaxNC * kHeadC + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * 256) {
+    float xv[kHeadC];
+    load_pixel64<T>(x + pidx * x_ld * sizeof(T), xv);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < NC; ++c) {
+      float s = sw[kMaxNC * kHeadC + c];
+#pragma unroll
+      for (int k = 0; k < kHeadC; ++k) s += xv[k] * sw[c * kHeadC + k];
+      if (s > best || c == 0) { best = s; arg = c; }   // strict '>' keeps the FIRST maximum
+    }
+    labels[pidx] = (uint8_t)arg;
+  }
+}
+
 // Head backward, one pass over (x, dl) per 64-pixel tile:
 //   partial dW[c][k] = sum_p dl[p][c] * x[p][k], db[c] = sum_p dl[p][c]  (one partial row per workgroup:
 //                      part[row][c*64 + k] for c < NC, then part[row][NC*64 + c]; fixed-order finalize elsewhere)
@@ -395,6 +420,29 @@ __global__ __launch_bounds__(256) void argmax_stitch_kernel(const float* __restr
   }
 }
 
+// the same stitching from per-tile LABEL maps [n][S][S] (fused head+argmax output, or an Ensemble's vote)
+__global__ __launch_bounds__(256) void label_stitch_kernel(const uint8_t* __restrict__ tiles, int n, int S, int p, int first_tile,
+                                                          int tiles_per_row, const uint8_t* __restrict__ palette, uint8_t* rgb,
+                                                          uint8_t* labels, int Hout, int Wout) {
+  const int m = (S - p) / 2;
+  const int64_t total = (int64_t)n * p * p;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int x = (int)(id % p);
+    int64_t t = id / p;
+    const int y = (int)(t % p);
+    const int ti = (int)(t / p);
+    const int arg = tiles[((int64_t)ti * S + (y + m)) * S + (x + m)];
+    const int tile = first_tile + ti;
+    const int ty = tile / tiles_per_row, tx = tile - ty * tiles_per_row;
+    const int oy = ty * p + y, ox = tx * p + x;
+    if (oy < Hout && ox < Wout) {
+      const int64_t o = (int64_t)oy * Wout + ox;
+      if (labels) labels[o] = (uint8_t)arg;
+      if (rgb) { rgb[o * 3] = palette[arg * 3]; rgb[o * 3 + 1] = palette[arg * 3 + 1]; rgb[o * 3 + 2] = palette[arg * 3 + 2]; }
+    }
+  }
+}
+
 static inline int pix_grid(int64_t P, int cap = 256 * 16) {
   int64_t g = cdiv(P, 256);
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -419,6 +467,34 @@ extern "C" int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, i
   else
     hipLaunchKernelGGL((head_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, logits);
   CVCS_CHECK_LAUNCH("cvcs_head_fwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_head_argmax(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                                uint8_t* labels, int dtype, void* stream) {
+  CVCS_CHECK_ARG(dtype == CVCS_F32 || dtype == CVCS_BF16, "cvcs_head_argmax: bad dtype");
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(x && w && labels && B > 0 && H > 0 && W > 0, "cvcs_head_argmax: null argument");
+  CVCS_CHECK_ARG(C == kHeadC, "cvcs_head_argmax: head is built for %d input channels, got %d", kHeadC, C);
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_argmax: NC=%d out of [1,%d]", NC, kMaxNC);
+  CVCS_CHECK_ARG(((uintptr_t)x % 16) == 0 && (x_ld * es) % 16 == 0 && x_ld >= C, "cvcs_head_argmax: view alignment");
+  const int64_t P = (int64_t)B * H * W;
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((head_argmax_kernel<float>), dim3(pix_grid(P)), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, w, bias, NC, labels);
+  else
+    hipLaunchKernelGGL((head_argmax_kernel<bf16_t>), dim3(pix_grid(P)), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, w, bias, NC, labels);
+  CVCS_CHECK_LAUNCH("cvcs_head_argmax");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_label_stitch(const uint8_t* tiles, int n, int S, int p, int first_tile, int tiles_per_row, const uint8_t* palette,
+                                 uint8_t* rgb, uint8_t* labels, int Hout, int Wout, void* stream) {
+  CVCS_CHECK_ARG(tiles && n > 0 && S >= p && p > 0 && (S - p) % 2 == 0 && tiles_per_row > 0 && first_tile >= 0 && Hout > 0 &&
+                     Wout > 0, "cvcs_label_stitch: bad argument");
+  CVCS_CHECK_ARG((rgb == nullptr || palette != nullptr) && (rgb || labels), "cvcs_label_stitch: rgb needs a palette; nothing to write");
+  hipLaunchKernelGGL(label_stitch_kernel, dim3(pix_grid((int64_t)n * p * p, 4096)), dim3(256), 0, (hipStream_t)stream, tiles, n, S, p,
+                     first_tile, tiles_per_row, palette, rgb, labels, Hout, Wout);
+  CVCS_CHECK_LAUNCH("cvcs_label_stitch");
   return CVCS_OK;
 }
 

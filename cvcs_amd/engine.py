@@ -226,8 +226,8 @@ class UNetEngine:
                                 st.mean, st.invstd)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
-        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)."""
+    def _backbone(self, x: torch.Tensor, train: bool) -> View:
+        """everything in front of the 1x1 head: x NCHW u8 | f32 [B,3,S,S] -> the last decoder activation (NHWC view)"""
         B, C_, S, S2 = x.shape
         assert C_ == 3 and S == S2
         self.plan(B, S)
@@ -261,10 +261,22 @@ class UNetEngine:
             self._conv_bn(ops.view(self.cat[L]), pre + ".0", pre + ".2", self.ra[d], ops.view(self.za[d]), False, train)
             self._conv_bn(ops.view(self.za[d]), pre + ".3", pre + ".5", self.rb[d], ops.view(self.zb[d]), False, train)
             prev = ops.view(self.zb[d])
+        self._saved_train = train
+        return prev
+
+    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
+        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)."""
+        prev = self._backbone(x, train)
         hw = self.P["decode_forward4.1.weight"]
         ops.head_fwd(prev, hw.view(self.NC, 64), self.P["decode_forward4.1.bias"], self.logits)
-        self._saved_train = train
         return self.logits
+
+    def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
+        """eval-mode prediction: u8 labels [B,S,S] = argmax of the logits, head and argmax fused (no logits tensor)"""
+        prev = self._backbone(x, False)
+        hw = self.P["decode_forward4.1.weight"]
+        ops.head_argmax(prev, hw.view(self.NC, 64), self.P["decode_forward4.1.bias"], labels)
+        return labels
 
     # ------------------------------------------------------------------------------------------------ backward
     def _bn_backward(self, bnname, conv, y, g1: View, g2, mode, dy):

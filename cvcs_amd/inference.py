@@ -35,13 +35,14 @@ def segment_image(net, image_chw_u8: torch.Tensor, patch_size: int, border_corre
         n = min(batch, hi - first)
         tiles = torch.empty((n, 3, S, S), dtype=torch.uint8, device=dev)
         ops.crop_tiles(image, tiles, first, Wn, p)
-        out = net(tiles, None)
-        if getattr(net, "returns_logits", True):
-            ops.argmax_stitch(out, p, first, Wn, palette, rgb, labels)
+        if hasattr(net, "predict_labels"):          # HIP network: fused head + argmax -> per-tile label maps
+            lab = net.predict_labels(tiles)
         else:
-            # a label-returning network (the Ensemble, S/utils.py:157-160): stitch its labels as one-hot "logits"
-            lab = out.reshape(n, S, S)
-            onehot = torch.zeros((n, 16, S, S), dtype=torch.float32, device=dev).scatter_(1, lab.unsqueeze(1), 1.0)
-            ops.argmax_stitch(onehot, p, first, Wn, palette, rgb, labels)
+            out = net(tiles, None)
+            if getattr(net, "returns_logits", True):
+                ops.argmax_stitch(out, p, first, Wn, palette, rgb, labels)
+                continue
+            lab = out.reshape(n, S, S).to(torch.uint8)   # a label-returning network (the Ensemble, S/utils.py:157-160)
+        ops.label_stitch(lab.contiguous(), p, first, Wn, palette, rgb, labels)
     net.train(was_training)
     return rgb, labels

@@ -193,6 +193,17 @@ class _HipUNet(nn.Module):
             return self._engine.forward(x, train=True).clone()
         return self._engine.forward(x, train=False).clone()
 
+    @torch.no_grad()
+    def predict_labels(self, x: torch.Tensor) -> torch.Tensor:
+        """u8 labels [B,S,S] = argmax over classes of the eval-mode logits (ties -> lowest class, as torch.max /
+        torch.argmax at S/utils.py:90,158): the head and the argmax are one launch, the logits are never written.
+        Running statistics are used whatever the module's train / eval flag says."""
+        self._ensure_flat()
+        if x.dtype not in (torch.uint8, torch.float32):
+            x = x.float()
+        labels = torch.empty((x.shape[0], x.shape[2], x.shape[3]), dtype=torch.uint8, device=x.device)
+        return self._engine.forward_labels(x, labels)
+
     def state_dict(self, *args, **kwargs):
         if self._nbt_pending:
             for name, b in self.named_buffers():

@@ -316,6 +316,13 @@ def head_fwd(x: View, w, bias, logits):
                                    _stream()), "cvcs_head_fwd")
 
 
+def head_argmax(x: View, w, bias, labels):
+    """u8 labels [B,H,W] = argmax_c (w x + b)_c (ties -> lowest class): head_fwd + argmax without the logits tensor"""
+    assert labels.dtype == torch.uint8 and labels.is_contiguous() and labels.numel() == x.B * x.H * x.W
+    check(_lib.lib().cvcs_head_argmax(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), _ptr(bias), w.shape[0], labels.data_ptr(),
+                                      x.code, _stream()), "cvcs_head_argmax")
+
+
 def head_bwd_rows(P: int) -> int:
     return _lib.lib().cvcs_head_bwd_rows(P)
 
@@ -390,6 +397,15 @@ def argmax_stitch(logits, p, first_tile, tiles_per_row, palette, rgb, labels):
     assert logits.is_contiguous() and logits.dtype == torch.float32
     check(_lib.lib().cvcs_argmax_stitch(logits.data_ptr(), n, NC, S, p, first_tile, tiles_per_row, _ptr(palette), _ptr(rgb),
                                         _ptr(labels), Hout, Wout, _stream()), "cvcs_argmax_stitch")
+
+
+def label_stitch(tiles, p, first_tile, tiles_per_row, palette, rgb, labels):
+    """tiles u8 [n,S,S] (per-tile label maps) -> centre p x p of each written into the full-size rgb / label maps"""
+    n, S, _ = tiles.shape
+    Hout, Wout = (rgb.shape[0], rgb.shape[1]) if rgb is not None else labels.shape
+    assert tiles.is_contiguous() and tiles.dtype == torch.uint8
+    check(_lib.lib().cvcs_label_stitch(tiles.data_ptr(), n, S, p, first_tile, tiles_per_row, _ptr(palette), _ptr(rgb),
+                                       _ptr(labels), Hout, Wout, _stream()), "cvcs_label_stitch")
 
 
 def gather_tiles(src, origins, dst):

@@ -243,7 +243,7 @@ class Ensemble(torch.nn.Module):
         stack = torch.empty((len(self.models), B, H, W), dtype=torch.uint8, device=x.device)
         for m, net in enumerate(self.models):
             net.eval()
-            ops.argmax_confusion(net(x, None), labels=stack[m])
+            stack[m] = net.predict_labels(x)
         out = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
         ops.vote_labels(stack, out)
         out = out.long()
@@ -299,8 +299,11 @@ def eval_model(net, Loader_validation, device, batch_size=1, show_progress=False
                 if shard is not None and (i - 1) % shard[1] != shard[0]:
                     continue
                 x, y = x.to(device), mask_reshape(y.to(device))
-                y_pred = net(x, None)
                 tgt = y.squeeze(1) if y.dim() == 4 else y
+                if hasattr(net, "predict_labels"):   # HIP network: head + argmax fused, the logits never leave the chip
+                    flat.update_from_labels(net.predict_labels(x), tgt)
+                    continue
+                y_pred = net(x, None)
                 if getattr(net, "returns_logits", True):
                     flat.update_from_logits(y_pred, tgt)
                 else:   # the network already returns label indices (S/utils.py:89)

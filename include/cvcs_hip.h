@@ -161,6 +161,10 @@ int cvcs_pack_convT_weight(const float* w_iohw, int Cin, int Cout, void* w_fwd, 
  * cvcs_head_fwd replaces nn.Conv2d(64, NC, 1) (S/nets.py:172): NHWC `dtype` [P, C] -> NCHW f32 logits [B, NC, H, W]. */
 int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
                   float* logits, int dtype, void* stream);
+/* head + argmax fused (prediction, S/utils.py:88-90, S/inference.py:45-47): u8 labels [B,H,W], ties -> lowest class;
+ * identical to cvcs_head_fwd followed by cvcs_argmax_confusion(labels) without the logits round trip.        */
+int cvcs_head_argmax(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                     uint8_t* labels, int dtype, void* stream);
 /* backward of the head: dx (NHWC dtype), partial dW/db rows -> finalize with cvcs_colsum_finalize            */
 int cvcs_head_bwd_rows(int64_t P);
 int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
@@ -206,6 +210,9 @@ int cvcs_crop_tiles(const uint8_t* src, int C, int H, int W, uint8_t* dst, int n
                     int p, int S, void* stream);
 int cvcs_argmax_stitch(const float* logits, int n, int NC, int S, int p, int first_tile, int tiles_per_row,
                        const uint8_t* palette, uint8_t* rgb, uint8_t* labels, int Hout, int Wout, void* stream);
+/* the same stitching from per-tile label maps u8 [n][S][S] (cvcs_head_argmax output, or an Ensemble's vote) */
+int cvcs_label_stitch(const uint8_t* tiles, int n, int S, int p, int first_tile, int tiles_per_row,
+                      const uint8_t* palette, uint8_t* rgb, uint8_t* labels, int Hout, int Wout, void* stream);
 
 /* ---- tile producer --------------------------------------------------------------------------------------------
  * replaces: IterableChunk's eager Python pre-crop of every patch (S/dataset.py:136-172, _random_shift :25-26) and the

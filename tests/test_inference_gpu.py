@@ -186,3 +186,26 @@ def test_ensemble_votes_like_the_reference(tmp_path):
     loader = dataset.make_loader("synthetic:2:2", 2, S, NC, seed=1)
     flat, _ = utils.eval_model(ens, loader, DEV, batch_size=2, ignore_background=True, num_classes=16)
     assert int(flat.compute().sum()) > 0
+
+
+@pytest.mark.parametrize("precision,NC", [("fp32", 5), ("bf16", 16), ("bf16", 21)])
+def test_predict_labels_equals_argmax_of_logits(precision, NC):
+    """net.predict_labels (head + argmax fused, no logits tensor) == torch.argmax(net(x)) of the eval-mode logits, bit for
+    bit, ties included (same order of operations as cvcs_head_fwd); label_stitch == argmax_stitch on the same tiles."""
+    torch.manual_seed(7)
+    net = (nets.Urnetv2 if NC != 5 else nets.Urnet)(NC, precision).to(DEV)
+    net.eval()
+    img, _ = O.synthetic_tiles(3, 96, NC, seed=3)
+    x = img.to(DEV)
+    with torch.no_grad():
+        logits = net(x, None)
+    lab = net.predict_labels(x)
+    assert lab.dtype == torch.uint8 and lab.shape == (3, 96, 96)
+    assert torch.equal(lab.long(), torch.argmax(logits, 1))
+    pal = GID15Converter().palette_u8(DEV)
+    p, Wn = 64, 2
+    rgb_a = torch.zeros(2 * p, Wn * p, 3, dtype=torch.uint8, device=DEV); lab_a = torch.zeros(2 * p, Wn * p, dtype=torch.uint8, device=DEV)
+    rgb_b, lab_b = torch.zeros_like(rgb_a), torch.zeros_like(lab_a)
+    ops.argmax_stitch(logits.contiguous(), p, 1, Wn, pal, rgb_a, lab_a)
+    ops.label_stitch(lab, p, 1, Wn, pal, rgb_b, lab_b)
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(lab_a, lab_b) and int(lab_a.sum()) > 0
