@@ -1,0 +1,112 @@
+"""CPU-only: error behaviour of the boundary.  Every C-ABI entry point validates its arguments on the host before any HIP
+call (so these run without a GPU) and reports through the int status + cvcs_last_error(); the Python factories keep the
+reference's error behaviour (S/utils.py:174-221)."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from cvcs_amd import _lib, nets, utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.lib()
+
+
+def _buf(n=4096):
+    b = (C.c_char * (n + 64))()
+    a = (C.addressof(b) + 63) // 64 * 64
+    return b, a           # keep b alive; a is 64-byte aligned
+
+
+def _desc(a, **kw):
+    d = _lib.ConvDesc()
+    d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = a, 32, 1, 8, 8, 32
+    d.wt, d.bias, d.out, d.out_ld, d.Ho, d.Wo, d.Cout = a, None, a, 64, 8, 8, 64
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.relu, d.pixel_shuffle, d.dtype = 3, 3, 1, 1, 1, 0, 0, 1   # 1 = bf16
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(dtype=7), b"bad dtype"),
+    (dict(Cin=24, in_ld=24), b"Cin=24 must be a multiple of 32"),
+    (dict(Cout=48), b"Cout=48 must be a multiple of 64"),
+    (dict(Ho=7), b"geometry gives 8,8"),
+    (dict(B=0), b"bad shape"),
+    (dict(in_ld=16), b"in_ld"),
+    (dict(out_ld=60), b"out_ld"),
+    (dict(stride=0), b"bad filter geometry"),
+    (dict(pixel_shuffle=1, Cout=128), b"pixel_shuffle needs"),
+])
+def test_conv2d_rejects_bad_descriptors(lib, kw, msg):
+    keep, a = _buf()
+    rc = lib.cvcs_conv2d(C.byref(_desc(a, **kw)), None)
+    assert rc == -1 and msg in lib.cvcs_last_error(), lib.cvcs_last_error()
+
+
+def test_conv2d_rejects_misaligned_and_half_given_arguments(lib):
+    keep, a = _buf()
+    assert lib.cvcs_conv2d(C.byref(_desc(a, in_=a + 2)), None) == -1 and b"16-byte aligned" in lib.cvcs_last_error()
+    assert lib.cvcs_conv2d(C.byref(_desc(a, stat_sum=a)), None) == -1 and b"go together" in lib.cvcs_last_error()
+    assert lib.cvcs_conv2d(C.byref(_desc(a, pre_scale=a)), None) == -1 and b"both scale and shift" in lib.cvcs_last_error()
+    assert lib.cvcs_conv2d(C.byref(_desc(a, wt=None)), None) == -1 and b"null tensor" in lib.cvcs_last_error()
+
+
+def test_wgrad_rejects_unbuilt_filters_and_bad_shapes(lib):
+    keep, a = _buf()
+    d = _lib.WgradDesc()
+    d.x, d.x_ld, d.B, d.H, d.W, d.Cin = a, 64, 1, 8, 8, 64
+    d.dy, d.dy_ld, d.Ho, d.Wo, d.Cout = a, 64, 8, 8, 64
+    d.KH, d.KW, d.stride, d.pad, d.dw, d.Cin_real, d.workspace, d.dtype = 5, 5, 1, 2, a, 64, a, 1
+    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"filter 5x5 not built" in lib.cvcs_last_error()
+    d.KH = d.KW = 3
+    d.pad = 0
+    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"geometry gives 6,6" in lib.cvcs_last_error()
+    d.pad, d.Cout = 1, 32
+    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"Cout=32" in lib.cvcs_last_error()
+    assert lib.cvcs_wgrad_slices(0, 8, 8, 64, 64, 3, 3, 1) == -1
+
+
+def test_other_entry_points_reject_bad_arguments(lib):
+    keep, a = _buf()
+    assert lib.cvcs_head_fwd(a, 32, 1, 4, 4, 32, a, a, 5, a, 1, None) == -1 and b"64 input channels" in lib.cvcs_last_error()
+    assert lib.cvcs_head_argmax(a, 64, 1, 4, 4, 64, a, a, 40, a, 1, None) == -1 and b"NC=40" in lib.cvcs_last_error()
+    assert lib.cvcs_ce_fwd_bwd(a, a, 1, 1, 33, 16, None, 0, 1.0, a, a, a, 0, None) == -1 and b"NC=33" in lib.cvcs_last_error()
+    assert lib.cvcs_vote_labels(a, 0, 16, a, None) == -1 and b"voters" in lib.cvcs_last_error()
+    assert lib.cvcs_vote_labels(a, 17, 16, a, None) == -1
+    assert lib.cvcs_label_confusion(a, a, 1, 16, 0, 64, a, None) == -1 and b"K=64" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_act(a, 64, 1, 3, 4, 64, a, a, 1, a, 64, a, 64, 1, None) == -1 and b"even H, W" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_act(a, 64, 1, 4, 4, 64, a, a, 1, None, 0, None, 0, 1, None) == -1 and b"nothing to write" in lib.cvcs_last_error()
+    assert lib.cvcs_crop_tiles(a, 3, 8, 8, a, 1, 0, 1, 4, 5, None) == -1          # S - p must be even
+    assert lib.cvcs_label_stitch(a, 1, 8, 4, 0, 1, None, a, None, 8, 8, None) == -1 and b"palette" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_finalize(None, None, None, 0, 0, 60, a, a, a, a, 0.1, 1e-5, 0, a, a, None, None, None, None) == -1
+
+
+def test_factories_keep_the_reference_error_behaviour(capsys):
+    with pytest.raises(Exception):
+        utils.load_network({"net": "NoSuchNet", "num_classes": 4}, "cpu")
+    assert "Invalid network name." in capsys.readouterr().out                       # S/utils.py:193-195
+    with pytest.raises(NotImplementedError):
+        utils.load_network({"net": "Resnet101", "num_classes": 4}, "cpu")          # third-party wrapper, out of scope
+    with pytest.raises(Exception):
+        utils.load_network({"net": "Ensemble", "num_classes": 4}, "cpu")            # no ensemble_config (S/utils.py:475-478)
+    assert "specify a config file" in capsys.readouterr().out
+    net = nets.Urnetv2(5)
+    with pytest.raises(ValueError, match="Optimizer name not valid"):
+        utils.load_optimizer({"opt": "LION", "epochs": 1}, net)                     # S/utils.py:219-220
+    with pytest.raises(Exception):
+        utils.load_loss({"loss": "Dice", "num_classes": 4}, "cpu")
+    with pytest.raises(AssertionError):
+        nets.Urnetv2(5, precision="fp8")
+    with pytest.raises(RuntimeError, match="GPU only"):                             # no CPU fallback
+        net(torch.zeros(1, 3, 32, 32))
+    assert utils.load_device({"device": "cpu"}) == torch.device("cpu")
