@@ -1,0 +1,128 @@
+"""CPU-only: the host-side mirror of the reference surface that needs no GPU - metrics (S/utils.py:311-403), scheduler
+(S/utils.py:208-221), class weights (S/dataset.py:360-384), palette converter (S/converters.py), the GID-15 chunk loader
+on a tiny on-disk dataset (S/dataset.py:228-387), parameter layout (S/nets.py) - against the oracle, torch and sklearn."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cvcs_amd import converters, dataset, nets, optim, utils
+from oracle import unet_oracle as O
+
+
+def test_metrics_match_oracle_and_sklearn():
+    from sklearn.metrics import jaccard_score, precision_score, recall_score
+    rng = np.random.default_rng(0)
+    K = 16
+    t = rng.integers(0, 12, 20000)          # classes 12..15 never occur in the target -> excluded from the means
+    p = np.where(rng.random(20000) < 0.7, t, rng.integers(0, K, 20000))
+    conf = torch.from_numpy(O.confusion_matrix(p, t, K, ignore_index=0))
+    m = utils.print_metrics(conf, silent=True)
+    o = O.metrics(conf.numpy())
+    for k in ("mIoU", "precision_score", "recall_score", "dice_score", "oa_score"):
+        assert m[k] == pytest.approx(o[k], rel=1e-6), k
+    keep = t != 0
+    present = sorted(set(t[keep]))
+    sk = jaccard_score(t[keep], p[keep], labels=present, average="macro")
+    assert m["mIoU"] == pytest.approx(sk, rel=1e-6)                      # mean over classes present in the target
+    assert m["recall_score"] == pytest.approx(recall_score(t[keep], p[keep], labels=present, average="macro"), rel=1e-6)
+    vals, excluded = utils.IoU(conf, mean=False, return_excluded=True)
+    assert excluded == [0, 12, 13, 14, 15] and len(vals) == K
+    pred_present = sorted(set(p[keep]))
+    assert m["precision_score"] == pytest.approx(
+        precision_score(t[keep], p[keep], labels=pred_present, average="macro", zero_division=0), rel=1e-6)
+
+
+def test_polynomial_lr_is_torchs_schedule_and_round_trips():
+    class Opt:
+        lr = 0.005
+    for total, power in ((20, 1.0), (7, 2.0)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        topt = torch.optim.SGD([p], lr=0.005)
+        ts = torch.optim.lr_scheduler.PolynomialLR(topt, total_iters=total, power=power)
+        o = Opt(); o.lr = 0.005
+        s = optim.PolynomialLR(o, total_iters=total, power=power)
+        for _ in range(total + 4):
+            assert o.lr == pytest.approx(topt.param_groups[0]["lr"], rel=1e-12, abs=1e-18)
+            topt.step(); ts.step(); s.step()
+        o2 = Opt(); o2.lr = 0.005
+        s2 = optim.PolynomialLR(o2, total_iters=total, power=power)
+        s2.load_state_dict(s.state_dict())
+        assert o2.lr == o.lr and s2.last_epoch == s.last_epoch
+
+
+def test_class_weights_match_the_oracle():
+    counts = torch.tensor([50.0, 10.0, 0.0, 70.0, 20.0])
+    for ib in (False, True):
+        np.testing.assert_allclose(dataset.class_weights_from_counts(counts, ib).numpy(),
+                                   O.class_weights(counts.tolist(), ignore_background=ib), rtol=1e-6)
+
+
+def test_converter_round_trip_and_palette(golden_dir):
+    g = np.load(os.path.join(golden_dir, "converter_ref.npz"))     # written by the reference's own GID15Converter
+    conv = converters.GID15Converter()
+    pal = conv.palette_u8().numpy()
+    assert pal.shape == (16, 3) and (pal[g["labels"]] == g["colors"]).all()
+    assert np.allclose(conv.iconvert(torch.arange(16).reshape(4, 4)).numpy(), g["iconvert_4x4"])
+    assert all(conv.color_to_label[tuple(int(v) for v in c)] == int(l) for c, l in zip(g["colors"], g["labels"]))
+    assert torch.equal(conv.iconvert(torch.tensor([[99]]))[0, 0], torch.ones(3))     # unknown label stays white
+
+
+def test_gid15_loader_on_a_tiny_dataset(tmp_path):
+    """the reference's directory layout (Image__8bit_NirRGB / Annotation__index), patch_size 224: tiles-per-image,
+    chunking, specify(), whole-image coverage of the crops and the class-weight scan"""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    os.makedirs(tmp_path / "Image__8bit_NirRGB"); os.makedirs(tmp_path / "Annotation__index")
+    imgs, masks = [], []
+    for i in range(3):
+        im = rng.integers(0, 256, (460, 700, 3), dtype=np.uint8)
+        mk = rng.integers(0, 5, (460, 700), dtype=np.uint8)
+        Image.fromarray(im).save(tmp_path / "Image__8bit_NirRGB" / f"t{i}.png")
+        Image.fromarray(mk).save(tmp_path / "Annotation__index" / f"t{i}.png")
+        imgs.append(im); masks.append(mk)
+    ld = dataset.make_loader(str(tmp_path), 2, 224, 5)
+    assert ld.tpi == 2 * 3 and len(ld) == 2 and ld.chunks == [[0, 1], [2]]
+    chunk = ld.get_iterable_chunk(1)
+    tiles = list(chunk)
+    assert len(tiles) == 6
+    # every tile is an exact crop of image 2 at a tile-aligned origin, and together they cover all six origins
+    seen = set()
+    for img, lab, _, _ in tiles:
+        assert img.shape == (3, 224, 224) and img.dtype == torch.uint8 and lab.shape == (224, 224)
+        hits = [(ty, tx) for ty in range(2) for tx in range(3)
+                if np.array_equal(img.permute(1, 2, 0).numpy(), imgs[2][ty * 224:(ty + 1) * 224, tx * 224:(tx + 1) * 224])]
+        assert len(hits) == 1
+        ty, tx = hits[0]
+        assert np.array_equal(lab.numpy(), masks[2][ty * 224:(ty + 1) * 224, tx * 224:(tx + 1) * 224])
+        seen.add(hits[0])
+    assert len(seen) == 6
+    w = ld.get_class_weights(5, ignore_background=True)
+    counts = np.bincount(np.concatenate([m.reshape(-1) for m in masks]), minlength=5)
+    np.testing.assert_allclose(w.numpy(), O.class_weights(counts.tolist(), ignore_background=True), rtol=1e-5)
+    ld.specify([2])
+    assert ld.chunks == [[2]]
+    with pytest.raises(AssertionError):
+        dataset.make_loader(str(tmp_path), 2, 200, 5)          # S/dataset.py:268: only 224 / 256 / 512
+
+
+def test_synthetic_loader_is_deterministic_and_exercises_ignore_index():
+    a = dataset.make_loader("synthetic:2:3", 1, 64, 6, seed=5)
+    b = dataset.make_loader("synthetic:2:3", 1, 64, 6, seed=5)
+    ta, tb = list(a.get_iterable_chunk(1)), list(b.get_iterable_chunk(1))
+    assert len(ta) == 3 and all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(ta, tb))
+    labs = torch.cat([t[1].reshape(-1) for c in range(len(a)) for t in a.get_iterable_chunk(c)])
+    assert int(labs.max()) < 6 and (labs == 0).any() and (labs > 0).any()
+
+
+@pytest.mark.parametrize("variant,NC,count", [("Unetv2", 16, 31044496), ("Unet", 16, 34526096)])
+def test_parameter_count_and_state_dict_layout(variant, NC, count):
+    """31 044 496 / 34 526 096 parameters at NC = 16; state_dict keys and shapes are the reference's
+    (the oracle's parameter table is pinned by the reference's own key list in tests/golden)."""
+    net = (nets.Urnetv2 if variant == "Unetv2" else nets.Urnet)(NC)
+    assert utils.count_params(net) == count
+    sd = net.state_dict()
+    ref = O.init_params(variant, NC, seed=0)
+    assert set(k for k in sd if not k.endswith("num_batches_tracked")) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
