@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p), ("stat_cnt", C.c_void_p),
         ("dtype", C.c_int32),
         ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p),
+        ("Cin_valid", C.c_int32),
     ]
 
 

@@ -36,6 +36,7 @@ struct ConvArgs {
   float* stat_cnt;
   int64_t in_ld, out_ld;  // in elements
   int B, H, W, Cin, Ho, Wo, Cout;
+  int valid_bytes;        // bytes of a pixel row of `in` that exist (channels beyond read as zero)
   int KH, KW, stride, pad, dil;
   int relu, pixel_shuffle;
   int M;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
       const int iy = iy0[i] + kh * p.dil, ix = ix0[i] + kw * p.dil;
-      const bool ok = mvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bool ok = mvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cs * 64 + ac[i] * 16 < p.valid_bytes;
       const char* src = ok ? p.in + ((pbase[i] + (int64_t)iy * p.W + ix) * p.in_ld + (int64_t)cs * KG) * ES + ac[i] * 16
                            : reinterpret_cast<const char*>(&g_gzero16);
       dma16(src, sa + (wave + 4 * i) * 1024);
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   // halo pieces of this wave: q-th piece = DMA piece g = q*NW + wave of every slice
   constexpr int NPA = (HGROUPS + NW - 1) / NW;
   int aoff[NPA];                 // byte offset inside the image of this lane's 16 bytes, -1: padding -> zero word
+  int achk[NPA];                 // its byte offset inside a 64-byte channel slice
 #pragma unroll
   for (int q = 0; q < NPA; ++q) {
     const int g = q * NW + wave;
@@ -468,11 +470,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
     const bool ok = g < HGROUPS && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     aoff[q] = ok ? (int)((((int64_t)iy * p.W + ix) * p.in_ld) * ES + c * 16) : -1;
+    achk[q] = c * 16;
   }
   const char* img_ptr = p.in + img_base * p.in_ld * ES;
   auto dma_halo = [&](int q, int cs, int buf) {   // q compile-time after unrolling
     const int g = q * NW + wave;
-    const char* src = aoff[q] >= 0 ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES) : reinterpret_cast<const char*>(&g_zero16);
+    const char* src = (aoff[q] >= 0 && cs * 64 + achk[q] < p.valid_bytes) ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES)
+                                                                         : reinterpret_cast<const char*>(&g_zero16);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
   };
@@ -908,7 +912,9 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   const int eh = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const int ew = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   CVCS_CHECK_ARG(eh == d->Ho && ew == d->Wo, "cvcs_conv2d: Ho,Wo=%d,%d but geometry gives %d,%d", d->Ho, d->Wo, eh, ew);
-  CVCS_CHECK_ARG(d->in_ld >= d->Cin && d->in_ld * es % 16 == 0, "cvcs_conv2d: in_ld");
+  const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
+  CVCS_CHECK_ARG(cin_valid <= d->Cin && (cin_valid * es) % 16 == 0, "cvcs_conv2d: Cin_valid=%d must be <= Cin and a multiple of 16 bytes", d->Cin_valid);
+  CVCS_CHECK_ARG(d->in_ld >= cin_valid && d->in_ld * es % 16 == 0, "cvcs_conv2d: in_ld");
   const int cout_store = d->pixel_shuffle ? d->Cout / 4 : d->Cout;
   CVCS_CHECK_ARG(d->out_ld >= cout_store && d->out_ld * es % 16 == 0, "cvcs_conv2d: out_ld");
   CVCS_CHECK_ARG(((uintptr_t)d->in % 16) == 0 && ((uintptr_t)d->out % 16) == 0 && ((uintptr_t)d->wt % 16) == 0,
@@ -932,6 +938,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.valid_bytes = cin_valid * es;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;

@@ -105,7 +105,9 @@ class UNetEngine:
         self.shape = (B, S)
         self.sizes = [S >> l for l in range(5)]
         s_ = self.sizes
-        self.in0 = A(S, self.KG)
+        # the 3-channel tile as NHWC rows of 16 bytes (8 bf16 / 4 f32 channels, zero padded); the first conv contracts over
+        # one zero-padded K-group without fetching the padding (cvcs_conv_desc.Cin_valid)
+        self.in0 = A(S, 16 // torch.empty((), dtype=dt).element_size())
         self.ya, self.aa, self.yb, self.pool, self.cat, self.x5 = {}, {}, {}, {}, {}, None
         self.g_aa, self.dy_a, self.dy_b, self.g_pool, self.g_cat = {}, {}, {}, {}, {}
         for L in range(1, 6):

@@ -102,6 +102,8 @@ def _conv_desc(x: View, wt, bias, out: View, KH, KW, stride, pad, dil, relu, pix
     Ho, Wo = conv_out_hw(x.H, x.W, KH, KW, stride, pad, dil)
     d = ConvDesc()
     d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    if wt.shape[2] > x.C:     # narrow input (the 3-channel tile stored 16 bytes per pixel) under a zero-padded K-group
+        d.Cin, d.Cin_valid = wt.shape[2], x.C
     d.wt, d.bias = _ptr(wt), _ptr(bias)
     d.out, d.out_ld, d.Ho, d.Wo, d.Cout = 0 if out is None else out.ptr, 0 if out is None else out.ld, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad, d.dil = KH, KW, stride, pad, dil
@@ -140,7 +142,7 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         d.pre_scale, d.pre_shift = pre_affine[0].data_ptr(), pre_affine[1].data_ptr()
     if post_affine is not None:
         d.post_scale, d.post_shift = post_affine[0].data_ptr(), post_affine[1].data_ptr()
-    assert wt.shape[0] == KH * KW and wt.shape[2] == x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
+    assert wt.shape[0] == KH * KW and wt.shape[2] >= x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
     if pixel_shuffle:
         assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"
     else:

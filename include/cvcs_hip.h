@@ -61,6 +61,10 @@ typedef struct {
    * from cvcs_bn_finalize(train=0).                                                                              */
   const float* pre_scale;   const float* pre_shift;
   const float* post_scale;  const float* post_shift;
+  /* 0, or the number of channels the `in` rows really hold (a multiple of 16 bytes, <= Cin): channels Cin_valid..Cin-1
+   * read as zero without being fetched.  The first layer's 3-channel tile is stored 16 bytes per pixel while the
+   * contraction runs over one zero-padded K-group (`wt` is [KH*KW][Cout][Cin]).                                  */
+  int32_t Cin_valid;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */

@@ -99,6 +99,31 @@ def test_conv2d_matches_aten(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W", [(24, 40), (6, 6)])
+def test_conv2d_narrow_first_layer_input(H, W, dtype):
+    """the first layer (S/nets.py:126, 3 -> 64): the tile is stored 16 bytes per pixel (8 bf16 / 4 f32 channels) and the
+    contraction runs over one zero-padded K-group whose padding is never fetched (cvcs_conv_desc.Cin_valid); halo kernel
+    (24x40) and generic kernel (6x6).  The buffer behind the 16 bytes is poisoned: nothing beyond Cin_valid may be read."""
+    g = torch.Generator().manual_seed(H)
+    B, Cout = 2, 64
+    x = torch.randint(0, 256, (B, 3, H, W), generator=g).float()          # raw 0..255 pixels: exact in bf16
+    w = rq(torch.randn(Cout, 3, 3, 3, generator=g) / 27 ** 0.5, dtype)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    cs = 16 // torch.empty((), dtype=dtype).element_size()                  # stored channels: 8 | 4
+    buf = torch.full((B, H, W, cs + 32), float("nan"), dtype=dtype, device=DEV)
+    xin = ops.View(buf, 0, cs)
+    packed = torch.empty((B, H, W, cs), dtype=dtype, device=DEV)
+    ops.pack_input(x.to(DEV).contiguous(), packed)
+    buf[..., :cs] = packed
+    wf, _ = ops.pack_conv_weight(w.to(DEV), ops.KGROUP[ops.dtype_code(dtype)], dtype, want_dgrad=False)
+    out = torch.empty(B, H, W, Cout, dtype=dtype, device=DEV)
+    ops.conv2d(xin, wf, b.to(DEV), ops.view(out), 3, 3, 1, 1)
+    torch.cuda.synchronize()
+    close(from_nhwc(out), ref, tol(dtype), "narrow-input conv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("order", ["encoder", "decoder"])
 @pytest.mark.parametrize("H,W,Cin,Cout,pool", [(20, 36, 64, 128, True), (6, 6, 64, 64, False), (16, 16, 128, 64, True)])
 def test_conv2d_eval_mode_batchnorm_fold(H, W, Cin, Cout, pool, order, dtype):
