@@ -765,7 +765,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   }
   int ny = p.H - ty0 - wm * MREP; ny = ny < 0 ? 0 : (ny > MREP ? MREP : ny);
   int nx = p.W - tx0;             nx = nx > 16 ? 16 : nx;
-  if (p.stat_sum) {
+  // bf16: the statistics are taken from the staged output tile by the matrix cores (below); f32 (parity path): exact
+  // centred sums on the VALU
+  constexpr bool MSTATS = (ES == 2);
+  static_assert(!MSTATS || NW * 16 == BN, "MFMA statistics: one 16-channel block per wave");
+  if (p.stat_sum && !MSTATS) {
     const int nvalid = ny * nx;
     const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
     const int64_t row = (int64_t)blockIdx.x * WM + wm;
@@ -824,6 +828,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
             uint2 u;
             u.x = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
             u.y = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
+            if (MSTATS && p.stat_sum && !(i < ny && fr < nx)) u = make_uint2(0u, 0u);   // outside the image: not in the sums
             *reinterpret_cast<uint2*>(dst) = u;
           } else {
             *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
@@ -831,6 +836,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
         }
     }
     __syncthreads();
+    if constexpr (MSTATS) {
+      if (p.stat_sum) {
+        // BatchNorm partial statistics of this half tile (128 pixels x BN channels, as STORED: bf16) on the matrix cores:
+        // wave w owns channels 16w..16w+15; a transposed fragment X[32 pixels][16 channels] gives the column sums as
+        // ones^T X and the sums of squares as the diagonal of X^T X (A and B fragment layouts coincide, one set of
+        // registers serves both operands).  f32 accumulation of exact bf16 products; M2 = sum x^2 - (sum x)^2 / n per
+        // 128-pixel block, merged across blocks by Chan's formula in f64 (bn_finalize).
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const int q = fr >> 2, pp = fr & 3;
+        const char* base = smem + (wave * 16) * ES + pp * 8;
+        f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f}, ssq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+          const int r0 = pg * 32 + 4 * fg + q, r1 = r0 + 16;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + r0 * OROW));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + r1 * OROW));
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          ssum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf, ssum, 0, 0, 0);
+          ssq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, xf, ssq, 0, 0, 0);
+        }
+        int nyh = p.H - ty0 - h * 8; nyh = nyh < 0 ? 0 : (nyh > 8 ? 8 : nyh);
+        const int nvalid = nyh * nx;
+        const int64_t row = (int64_t)blockIdx.x * 2 + h;
+        if (fg == q) {                                   // lane fr of group fr>>2 holds the diagonal entry of its channel
+          const float sx = ssum[0];
+          const float s2 = pp == 0 ? ssq[0] : (pp == 1 ? ssq[1] : (pp == 2 ? ssq[2] : ssq[3]));
+          float m2 = nvalid > 0 ? s2 - sx * sx / (float)nvalid : 0.f;
+          m2 = m2 < 0.f ? 0.f : m2;
+          const int n = n0 + wave * 16 + fr;
+          p.stat_sum[row * p.Cout + n] = sx;
+          p.stat_m2[row * p.Cout + n] = m2;
+        }
+        if (blockIdx.y == 0 && tid == 0) p.stat_cnt[row] = (float)nvalid;
+      }
+    }
     for (int id = tid; id < 128 * CPR; id += NT) {
       const int lrow = id / CPR, c = id - lrow * CPR;
       const int y = ty0 + h * 8 + (lrow >> 4), x = tx0 + (lrow & 15);
@@ -889,7 +931,8 @@ static bool use_halo(const cvcs_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
          d->W >= 8;
 }
-static int halo_wm(const cvcs_conv_desc* d) { (void)d; return 4; }   // every variant splits the 16 tile rows over 4 waves
+// partial-statistics rows per 16x16 tile: bf16 = one per staged half tile (MFMA statistics), f32 = one per wave row group
+static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 2 : 4; }
 
 extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
