@@ -137,7 +137,9 @@ class UNetEngine:
         M1 = B * S * S
         rows_c = [(ops.conv_stat_rows(View(self.ya[L], 0, WIDTHS[L - 1]), WIDTHS[L - 1], 3, 3, 1, 1), WIDTHS[L - 1])
                   for L in range(1, 6)]
-        self.stat_sum = torch.empty(max(r * c for r, c in rows_c), dtype=torch.float32, device=dev)
+        # (x2: the data gradient of a decoder's first conv has 2w channels and emits column sums for the up-conv bias)
+        self.stat_sum = torch.empty(2 * max(r * c for r, c in rows_c), dtype=torch.float32, device=dev)
+        self.colsum_tmp = torch.empty(2 * max(WIDTHS), dtype=torch.float32, device=dev)
         self.stat_m2 = torch.empty_like(self.stat_sum)
         self.stat_cnt = torch.empty(max(r for r, _ in rows_c), dtype=torch.float32, device=dev)
         rows1 = ops.bn_bwd_rows(M1)
@@ -319,11 +321,23 @@ class UNetEngine:
             self._side_event = torch.cuda.Event()
             self._side_event.record(self._side)
 
-    def _conv_backward(self, conv, x: View, dy, gin: View | None, cin_real=None):
+    def _conv_backward(self, conv, x: View, dy, gin: View | None, cin_real=None, colsum_of: View | None = None, colsum_out=None):
+        """weight and data gradient of a 3x3 conv.  colsum_of: a channel range of `gin` (the up-sampled half of a concat
+        gradient) whose per-channel sum over pixels - the bias gradient of the up-conv that produced it - is wanted: the
+        dgrad launch emits the column sums of its output through the statistics epilogue, no extra pass over the tensor."""
         dyv = ops.view(dy)
         self._wgrad(x, dyv, self.G[conv + ".weight"], 3, 3, 1, 1, cin_real=cin_real)
-        if gin is not None:
+        if gin is None:
+            return
+        if colsum_of is None:
             ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1)
+            return
+        C2 = gin.C
+        rows = ops.conv_stat_rows(dyv, C2, 3, 3, 1, 1)
+        ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, stats=(self.stat_sum, self.stat_m2, self.stat_cnt))
+        ops.colsum_finalize(self.stat_sum, rows, C2, self.colsum_tmp[:C2])
+        lo = colsum_of.off - gin.off
+        colsum_out.copy_(self.colsum_tmp[lo:lo + colsum_of.C])
 
     def backward(self, dlogits: torch.Tensor):
         """dlogits: NCHW f32 [B,NC,S,S]; fills every gradient view in self.G (overwrites)."""
@@ -352,23 +366,17 @@ class UNetEngine:
             self._bn_backward(pre + ".5", pre + ".3", self.rb[d], g, None, 1, self.ddy_b[d])
             self._conv_backward(pre + ".3", ops.view(self.za[d]), self.ddy_b[d], ops.view(self.g_za[d]))
             self._bn_backward(pre + ".2", pre + ".0", self.ra[d], ops.view(self.g_za[d]), None, 1, self.ddy_a[d])
-            self._conv_backward(pre + ".0", ops.view(self.cat[L]), self.ddy_a[d], ops.view(self.g_cat[L]))
+            key = f"upscale{d}.0" if self.variant == "Unetv2" else f"upscale{d}.0.layer.1"
+            self._conv_backward(pre + ".0", ops.view(self.cat[L]), self.ddy_a[d], ops.view(self.g_cat[L]),
+                                colsum_of=gup_v, colsum_out=self.G[key + ".bias"])
             ready(pre + ".0.weight")
             prev = ops.view(self.x5) if d == 1 else ops.view(self.zb[d - 1])
             gprev = ops.view(self.g_x5) if d == 1 else ops.view(self.g_zb[d - 1])
-            M = B * gup_v.H * gup_v.W
-            prow = ops.bn_bwd_rows(M)
             if self.variant == "Unetv2":
-                key = f"upscale{d}.0"
-                ops.colsum_partial(gup_v, self.part[0][:prow * w])
-                ops.colsum_finalize(self.part[0][:prow * w], prow, w, self.G[key + ".bias"])
                 # dW[ci][co][2][2] = sum_p in[p][ci] * gup[2p+tap][co]: the "output gradient" role is played by the input
                 self._wgrad(gup_v, prev, self.G[key + ".weight"], 2, 2, 2, 0)
                 ops.conv2d(gup_v, self.packed[key]["wd"], None, gprev, 2, 2, stride=2, pad=0)
             else:
-                key = f"upscale{d}.0.layer.1"
-                ops.colsum_partial(gup_v, self.part[0][:prow * w])
-                ops.colsum_finalize(self.part[0][:prow * w], prow, w, self.G[key + ".bias"])
                 self._wgrad(ops.view(self.up_in[d]), gup_v, self.G[key + ".weight"], 3, 3, 1, 1)
                 ops.conv2d(gup_v, self.packed[key]["wd"], None, ops.view(self.g_up_in[d]), 3, 3, 1, 1)
                 ops.upsample2x_bwd(ops.view(self.g_up_in[d]), gprev)
