@@ -72,6 +72,8 @@ SIGNATURES = {
     "cvcs_pack_conv_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "cvcs_pack_convT_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "cvcs_head_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "cvcs_head_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "cvcs_head_unfold_grad": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "cvcs_head_argmax": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "cvcs_label_stitch": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "cvcs_head_bwd_rows": (_i, [_i64]),

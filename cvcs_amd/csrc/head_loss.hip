@@ -44,6 +44,25 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const char* x, int64_t x_
   }
 }
 
+// The last BatchNorm of the network is followed only by the 1x1 head: z = scale*r + shift feeds logits = W z + b, so
+// logits = (W diag(scale)) r + (b + W shift) - the BN-apply pass over the largest activation is replaced by folding the
+// affine into the NC x 64 head weights (forward), and by un-folding the weight gradient (backward):
+//   dW[c][k] = sum_p dl[p][c] z[p][k] = scale[k] * (sum_p dl[p][c] r[p][k]) + shift[k] * db[c].
+__global__ void head_fold_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, int NC, float* w_out, float* bias_out) {
+  const int c = blockIdx.x, k = threadIdx.x;   // one workgroup of 64 lanes per class
+  const float wv = w[c * kHeadC + k];
+  w_out[c * kHeadC + k] = wv * scale[k];
+  const float t = wave_sum(wv * shift[k]);
+  if (k == 0) bias_out[c] = (bias ? bias[c] : 0.f) + t;
+}
+
+__global__ void head_unfold_grad_kernel(float* dw, const float* __restrict__ db, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, int NC) {
+  const int c = blockIdx.x, k = threadIdx.x;
+  dw[c * kHeadC + k] = scale[k] * dw[c * kHeadC + k] + shift[k] * db[c];
+}
+
 // head + argmax in one pass (prediction: S/utils.py:88-90, S/inference.py:45-47 without the logits round trip): the NC
 // logits of a pixel are formed exactly as in head_fwd_kernel (same order of operations -> the same labels as
 // head_fwd + argmax), only the index of the first maximum leaves the kernel.
@@ -467,6 +486,21 @@ extern "C" int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, i
   else
     hipLaunchKernelGGL((head_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, logits);
   CVCS_CHECK_LAUNCH("cvcs_head_fwd");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_head_fold(const float* w, const float* bias, const float* scale, const float* shift, int NC, float* w_out,
+                              float* bias_out, void* stream) {
+  CVCS_CHECK_ARG(w && scale && shift && w_out && bias_out && NC >= 1 && NC <= kMaxNC, "cvcs_head_fold: bad argument");
+  hipLaunchKernelGGL(head_fold_kernel, dim3(NC), dim3(kHeadC), 0, (hipStream_t)stream, w, bias, scale, shift, NC, w_out, bias_out);
+  CVCS_CHECK_LAUNCH("cvcs_head_fold");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_head_unfold_grad(float* dw, const float* db, const float* scale, const float* shift, int NC, void* stream) {
+  CVCS_CHECK_ARG(dw && db && scale && shift && NC >= 1 && NC <= kMaxNC, "cvcs_head_unfold_grad: bad argument");
+  hipLaunchKernelGGL(head_unfold_grad_kernel, dim3(NC), dim3(kHeadC), 0, (hipStream_t)stream, dw, db, scale, shift, NC);
+  CVCS_CHECK_LAUNCH("cvcs_head_unfold_grad");
   return CVCS_OK;
 }
 

@@ -50,6 +50,8 @@ class UNetEngine:
         self._saved_train = False
         self.sync_bn = None             # parallel.SyncStats: batch-norm statistics over all ranks' tiles (None: per rank)
         self._sync_mom = self._sync_sums = None   # its exchange buffers (allocated by enable_sync_bn)
+        self.head_wf = torch.empty((num_classes, 64), dtype=torch.float32, device=self.dev)   # head with the last BN folded in
+        self.head_bf = torch.empty(num_classes, dtype=torch.float32, device=self.dev)
         self.one = torch.ones(1024, dtype=torch.float32, device=self.dev)    # identity affine of the pooling-only pass
         self.zero = torch.zeros(1024, dtype=torch.float32, device=self.dev)
         self.on_backward_begin = None   # data-parallel hooks (cvcs_amd.parallel): called at the start of backward,
@@ -188,7 +190,8 @@ class UNetEngine:
         self._sync_mom = torch.empty(3 * 1024, dtype=torch.float64, device=self.dev)
         self._sync_sums = torch.empty(2 * 1024, dtype=torch.float32, device=self.dev)
 
-    def _conv_bn(self, x: View, conv, bnname, y, out: View, relu_after_bn: bool, train: bool, pool: View | None = None):
+    def _conv_bn(self, x: View, conv, bnname, y, out: View, relu_after_bn: bool, train: bool, pool: View | None = None,
+                 apply: bool = True):
         """conv3x3(+bias) [-> ReLU] with fused statistics, BN finalize, BN apply [-> ReLU] [-> pool]."""
         pk = self.packed[conv]
         M = x.B * y.shape[1] * y.shape[2]
@@ -218,7 +221,8 @@ class UNetEngine:
                             st.mean, st.invstd, workspace=self.bn_ws)
         else:
             self._sync_bn_finalize(stats, rows, C_, bnname, st)
-        ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
+        if apply:   # apply=False: the consumer folds scale/shift into its weights (the 1x1 head)
+            ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
 
     def _sync_bn_finalize(self, stats, rows, C_, bnname, st):
         # batch statistics over the tiles of ALL ranks (the reference's batch is not sharded): one [3][C] f64 sum
@@ -263,16 +267,25 @@ class UNetEngine:
                 ops.conv2d(ops.view(self.up_in[d]), self.packed[key]["wf"], self.P[key + ".bias"], up_v, 3, 3, 1, 1)
             pre = f"decode_forward{d}.0.layer"
             self._conv_bn(ops.view(self.cat[L]), pre + ".0", pre + ".2", self.ra[d], ops.view(self.za[d]), False, train)
-            self._conv_bn(ops.view(self.za[d]), pre + ".3", pre + ".5", self.rb[d], ops.view(self.zb[d]), False, train)
-            prev = ops.view(self.zb[d])
+            # train mode: the very last BatchNorm is followed only by the 1x1 head -> its apply pass (over the largest
+            # activation) is skipped, forward() folds the affine into the head weights
+            fold_head = train and d == 4
+            self._conv_bn(ops.view(self.za[d]), pre + ".3", pre + ".5", self.rb[d], ops.view(self.zb[d]), False, train,
+                          apply=not fold_head)
+            prev = ops.view(self.rb[d]) if fold_head else ops.view(self.zb[d])
         self._saved_train = train
         return prev
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
         """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)."""
         prev = self._backbone(x, train)
-        hw = self.P["decode_forward4.1.weight"]
-        ops.head_fwd(prev, hw.view(self.NC, 64), self.P["decode_forward4.1.bias"], self.logits)
+        hw = self.P["decode_forward4.1.weight"].view(self.NC, 64)
+        hb = self.P["decode_forward4.1.bias"]
+        if train:
+            st = self.bn["decode_forward4.0.layer.5"]
+            ops.head_fold(hw, hb, st.scale, st.shift, self.head_wf, self.head_bf)
+            hw, hb = self.head_wf, self.head_bf
+        ops.head_fwd(prev, hw, hb, self.logits)
         return self.logits
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
@@ -351,11 +364,15 @@ class UNetEngine:
         NC = self.NC
         hw = self.P["decode_forward4.1.weight"]
         rows = ops.head_bwd_rows(B * S * S)
-        ops.head_bwd(ops.view(self.zb[4]), dlogits.contiguous(), hw.view(NC, 64), ops.view(self.g_zb[4]), self.head_part)
+        # the head saw r (the last ReLU output) through folded weights: dx = W^T dl is the gradient w.r.t. the BatchNorm
+        # output z either way (real W); dW comes out w.r.t. r and is un-folded below
+        ops.head_bwd(ops.view(self.rb[4]), dlogits.contiguous(), hw.view(NC, 64), ops.view(self.g_zb[4]), self.head_part)
         # head weight [NC,64,1,1] and bias [NC] are adjacent in the flat gradient buffer (registration order)
         gw, gb = self.G["decode_forward4.1.weight"], self.G["decode_forward4.1.bias"]
         assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4
         ops.colsum_finalize(self.head_part, rows, NC * 64 + NC, gw)
+        st = self.bn["decode_forward4.0.layer.5"]
+        ops.head_unfold_grad(gw, gb, st.scale, st.shift)
         ready("decode_forward4.1.weight")
         g = ops.view(self.g_zb[4])
         for d in range(4, 0, -1):

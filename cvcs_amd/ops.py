@@ -318,6 +318,16 @@ def head_fwd(x: View, w, bias, logits):
                                    _stream()), "cvcs_head_fwd")
 
 
+def head_fold(w, bias, scale, shift, w_out, bias_out):
+    check(_lib.lib().cvcs_head_fold(w.data_ptr(), _ptr(bias), scale.data_ptr(), shift.data_ptr(), w.shape[0], w_out.data_ptr(),
+                                    bias_out.data_ptr(), _stream()), "cvcs_head_fold")
+
+
+def head_unfold_grad(dw, db, scale, shift):
+    check(_lib.lib().cvcs_head_unfold_grad(dw.data_ptr(), db.data_ptr(), scale.data_ptr(), shift.data_ptr(), db.numel(),
+                                           _stream()), "cvcs_head_unfold_grad")
+
+
 def head_argmax(x: View, w, bias, labels):
     """u8 labels [B,H,W] = argmax_c (w x + b)_c (ties -> lowest class): head_fwd + argmax without the logits tensor"""
     assert labels.dtype == torch.uint8 and labels.is_contiguous() and labels.numel() == x.B * x.H * x.W

@@ -165,6 +165,12 @@ int cvcs_pack_convT_weight(const float* w_iohw, int Cin, int Cout, void* w_fwd, 
  * cvcs_head_fwd replaces nn.Conv2d(64, NC, 1) (S/nets.py:172): NHWC `dtype` [P, C] -> NCHW f32 logits [B, NC, H, W]. */
 int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
                   float* logits, int dtype, void* stream);
+/* BatchNorm in front of the head folded into it (train mode; replaces the BN-apply pass of S/blocks.py:45 for the last
+ * decoder layer): w_out[c][k] = w[c][k]*scale[k], bias_out[c] = bias[c] + sum_k w[c][k]*shift[k]; cvcs_head_unfold_grad
+ * turns the gradient w.r.t. the folded input back into dW of the real head: dw = scale*dw + shift (x) db.        */
+int cvcs_head_fold(const float* w, const float* bias, const float* scale, const float* shift, int NC, float* w_out,
+                   float* bias_out, void* stream);
+int cvcs_head_unfold_grad(float* dw, const float* db, const float* scale, const float* shift, int NC, void* stream);
 /* head + argmax fused (prediction, S/utils.py:88-90, S/inference.py:45-47): u8 labels [B,H,W], ties -> lowest class;
  * identical to cvcs_head_fwd followed by cvcs_argmax_confusion(labels) without the logits round trip.        */
 int cvcs_head_argmax(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
