@@ -348,7 +348,12 @@ class UNetEngine:
         C2 = gin.C
         rows = ops.conv_stat_rows(dyv, C2, 3, 3, 1, 1)
         ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, stats=(self.stat_sum, self.stat_m2, self.stat_cnt))
-        ops.colsum_finalize(self.stat_sum, rows, C2, self.colsum_tmp[:C2])
+        if rows > 2048:   # many partial rows: a parallel first stage (the one-launch finalize has only C/16 workgroups)
+            prow = ops.bn_bwd_rows(rows)
+            ops.colsum_partial(View(self.stat_sum[:rows * C2].view(1, rows, 1, C2), 0, C2), self.part[0][:prow * C2])
+            ops.colsum_finalize(self.part[0], prow, C2, self.colsum_tmp[:C2])
+        else:
+            ops.colsum_finalize(self.stat_sum, rows, C2, self.colsum_tmp[:C2])
         lo = colsum_of.off - gin.off
         colsum_out.copy_(self.colsum_tmp[lo:lo + colsum_of.C])
 
