@@ -32,6 +32,12 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("Cin_pad", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
@@ -70,6 +76,7 @@ SIGNATURES = {
     "cvcs_upsample2x_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_pack_input": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "cvcs_pack_conv_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "cvcs_pack_conv_weights": (_i, [_vp, _i, _i, _vp]),
     "cvcs_pack_convT_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "cvcs_head_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "cvcs_head_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -510,6 +510,35 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
   }
 }
 
+// every conv of the network in ONE launch (the per-step re-pack after the optimiser): blockIdx.y = table entry
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_item* __restrict__ items) {
+  const cvcs_pack_item it = items[blockIdx.y];
+  const float* __restrict__ w = it.w;
+  T* wf = reinterpret_cast<T*>(it.w_fwd);
+  T* wd = reinterpret_cast<T*>(it.w_dgrad);
+  const int Cout = it.Cout, Cin = it.Cin, Cin_pad = it.Cin_pad, taps = it.KH * it.KW;
+  const int64_t nf = (int64_t)taps * Cout * Cin_pad;
+  const int64_t nd = wd ? (int64_t)taps * Cin * Cout : 0;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nf + nd; id += (int64_t)gridDim.x * 256) {
+    if (id < nf) {
+      const int ci = (int)(id % Cin_pad);
+      const int64_t r = id / Cin_pad;
+      const int co = (int)(r % Cout);
+      const int t = (int)(r / Cout);
+      const float v = ci < Cin ? w[((int64_t)co * Cin + ci) * taps + t] : 0.f;
+      Elem<T>::st(wf + id, v);
+    } else {
+      const int64_t j = id - nf;
+      const int co = (int)(j % Cout);
+      const int64_t r = j / Cout;
+      const int ci = (int)(r % Cin);
+      const int tp = (int)(r / Cin);
+      Elem<T>::st(wd + j, w[((int64_t)co * Cin + ci) * taps + (taps - 1 - tp)]);
+    }
+  }
+}
+
 // ConvTranspose2d(k2,s2) weight [Cin][Cout][2][2]:
 //   forward  operand wf[n = t*Cout + co][ci] (a 1x1 conv to 4*Cout columns, pixel-shuffled by the epilogue)
 //   backward operand wd[t][ci][co]           (a 2x2 stride-2 conv over the output gradient)
@@ -824,6 +853,16 @@ extern "C" int cvcs_pack_conv_weight(const float* w, int Cout, int Cin, int KH, 
   else
     hipLaunchKernelGGL((pack_conv_weight_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH, KW, Cin_pad, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
   CVCS_CHECK_LAUNCH("cvcs_pack_conv_weight");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_pack_conv_weights(const cvcs_pack_item* items_device, int n_items, int dtype, void* stream) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_pack_conv_weights: bad dtype");
+  CVCS_CHECK_ARG(items_device && n_items > 0 && n_items <= 65535, "cvcs_pack_conv_weights: bad table");
+  dim3 grid(256, (unsigned)n_items);
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((pack_conv_weights_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, items_device);
+  else hipLaunchKernelGGL((pack_conv_weights_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, items_device);
+  CVCS_CHECK_LAUNCH("cvcs_pack_conv_weights");
   return CVCS_OK;
 }
 

@@ -48,6 +48,7 @@ class UNetEngine:
         self.Bf = None  # name -> f32 buffer (running stats)
         self.packed = {}
         self._saved_train = False
+        self._pack_table = None   # device table of (master weight, packed operands) built at first use
         self.sync_bn = None             # parallel.SyncStats: batch-norm statistics over all ranks' tiles (None: per rank)
         self._sync_mom = self._sync_sums = None   # its exchange buffers (allocated by enable_sync_bn)
         self.head_wf = torch.empty((num_classes, 64), dtype=torch.float32, device=self.dev)   # head with the last BN folded in
@@ -72,6 +73,7 @@ class UNetEngine:
         self._goff = {k: (g.data_ptr() - base) // 4 for k, g in grads.items()}
         dev, dt = self.dev, self.dtype
         self.packed = {}
+        self._pack_table = None
         for name, w in params.items():
             if w.dim() != 4 or name == "decode_forward4.1.weight":
                 continue
@@ -89,13 +91,15 @@ class UNetEngine:
                                         wd=None if first else torch.empty(kh * kw, cin, cout, dtype=dt, device=dev))
 
     def refresh_weights(self):
-        """re-pack the f32 master weights into the MFMA operand layouts (after every optimiser step)."""
+        """re-pack the f32 master weights into the MFMA operand layouts (after every optimiser step): every 3x3 conv in one
+        launch driven by a device-resident table, the four ConvTranspose layers by their own small kernels."""
+        if self._pack_table is None:
+            entries = [(self.P[k + ".weight"], pk["wf"], pk["wd"]) for k, pk in self.packed.items() if pk["kind"] == "conv"]
+            self._pack_table = ops.pack_table(entries, self.dev)
+        ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
         for key, pk in self.packed.items():
-            w = self.P[key + ".weight"]
             if pk["kind"] == "convT":
-                ops.pack_convT_weight_into(w, self.P[key + ".bias"], pk["wf"], pk["b4"], pk["wd"])
-            else:
-                ops.pack_conv_weight_into(w, pk["wf"], pk["wd"])
+                ops.pack_convT_weight_into(self.P[key + ".weight"], self.P[key + ".bias"], pk["wf"], pk["b4"], pk["wd"])
 
     # ------------------------------------------------------------------------------------------------ planning
     def plan(self, B, S):

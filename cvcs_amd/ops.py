@@ -303,6 +303,22 @@ def pack_conv_weight_into(w, wf, wd):
                                            dtype_code(wf.dtype), _stream()), "cvcs_pack_conv_weight")
 
 
+def pack_table(entries, device):
+    """entries: [(w f32 OIHW, wf, wd | None)] -> device-resident cvcs_pack_item table (uint8 tensor) for pack_conv_weights"""
+    arr = (_lib.PackItem * len(entries))()
+    for it, (w, wf, wd) in zip(arr, entries):
+        Cout, Cin, KH, KW = w.shape
+        assert w.is_contiguous() and w.dtype == torch.float32
+        it.w, it.w_fwd, it.w_dgrad = w.data_ptr(), wf.data_ptr(), _ptr(wd)
+        it.Cout, it.Cin, it.KH, it.KW, it.Cin_pad = Cout, Cin, KH, KW, wf.shape[2]
+    raw = bytes(arr)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device), len(entries)
+
+
+def pack_conv_weights(table, n, dtype):
+    check(_lib.lib().cvcs_pack_conv_weights(table.data_ptr(), n, dtype_code(dtype), _stream()), "cvcs_pack_conv_weights")
+
+
 def pack_convT_weight_into(w, bias, wf, bias4, wd):
     """w [Cin][Cout][2][2] -> wf [1][4*Cout][Cin], bias4 [4*Cout], wd [4][Cin][Cout]."""
     Cin, Cout = w.shape[:2]

@@ -154,6 +154,15 @@ int cvcs_upsample2x_bwd(const void* gout, int64_t gout_ld, int B, int H, int W, 
  * -> NHWC [B,H,W,Cpad] in `dtype`, channels >= 3 zero.                                                    */
 int cvcs_pack_input(const void* src, int src_is_u8, int B, int C, int H, int W, void* dst, int Cpad, int dtype,
                     void* stream);
+/* the same for a whole table of convs in one launch (the per-step re-pack of every layer after the optimiser
+ * step): `items` is an array of n_items entries IN DEVICE MEMORY (pointers do not change between steps).     */
+typedef struct {
+  const float* w;   void* w_fwd;   void* w_dgrad;   /* w_dgrad may be NULL */
+  int32_t Cout, Cin, KH, KW, Cin_pad;
+  int32_t reserved;
+} cvcs_pack_item;
+int cvcs_pack_conv_weights(const cvcs_pack_item* items_device, int n_items, int dtype, void* stream);
+
 /* parameter layout changes: OIHW f32 -> [KH*KW][Cout][Cin_pad] (fwd) and -> flipped/transposed [KH*KW][Cin][Cout]
  * (data-gradient operand); ConvTranspose2d IOHW -> [1][(dy*2+dx)*Cout+co][Cin] (fwd) and [4 taps][Cin][Cout] (bwd) */
 int cvcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cin_pad,
