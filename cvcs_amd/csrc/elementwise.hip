@@ -510,31 +510,47 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
   }
 }
 
-// every conv of the network in ONE launch (the per-step re-pack after the optimiser): blockIdx.y = table entry
+// every conv of the network in ONE launch (the per-step re-pack after the optimiser): blockIdx.y = table entry.
+// A workgroup moves a block of 16 output x 64 input channels x all taps through LDS: the OIHW source is read as 16
+// contiguous runs (coalesced; a thread-per-output-element gather re-fetched every line ~30x), the forward operand leaves
+// as 128-byte rows wf[t][co][ci0..ci0+63], the flipped data-gradient operand as 32-byte pieces wd[t'][ci][co0..co0+15].
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_item* __restrict__ items) {
+  constexpr int CO = 16, CI = 64, MAXT = 9;
+  __shared__ float sw[CO][CI * MAXT + 1];
   const cvcs_pack_item it = items[blockIdx.y];
   const float* __restrict__ w = it.w;
   T* wf = reinterpret_cast<T*>(it.w_fwd);
   T* wd = reinterpret_cast<T*>(it.w_dgrad);
   const int Cout = it.Cout, Cin = it.Cin, Cin_pad = it.Cin_pad, taps = it.KH * it.KW;
-  const int64_t nf = (int64_t)taps * Cout * Cin_pad;
-  const int64_t nd = wd ? (int64_t)taps * Cin * Cout : 0;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nf + nd; id += (int64_t)gridDim.x * 256) {
-    if (id < nf) {
-      const int ci = (int)(id % Cin_pad);
-      const int64_t r = id / Cin_pad;
-      const int co = (int)(r % Cout);
-      const int t = (int)(r / Cout);
-      const float v = ci < Cin ? w[((int64_t)co * Cin + ci) * taps + t] : 0.f;
-      Elem<T>::st(wf + id, v);
-    } else {
-      const int64_t j = id - nf;
-      const int co = (int)(j % Cout);
-      const int64_t r = j / Cout;
-      const int ci = (int)(r % Cin);
-      const int tp = (int)(r / Cin);
-      Elem<T>::st(wd + j, w[((int64_t)co * Cin + ci) * taps + (taps - 1 - tp)]);
+  const int nci = (Cin_pad + CI - 1) / CI, nco = Cout / CO;
+  for (int blk = blockIdx.x; blk < nco * nci; blk += gridDim.x) {
+    const int co0 = (blk / nci) * CO, ci0 = (blk % nci) * CI;
+    const int cin_here = Cin - ci0 < CI ? (Cin - ci0 < 0 ? 0 : Cin - ci0) : CI;      // real input channels in this block
+    const int run = cin_here * taps;                                                   // contiguous floats per output channel
+    __syncthreads();
+    for (int id = threadIdx.x; id < CO * CI * taps; id += 256) {
+      const int c = id / (CI * taps), r = id - c * (CI * taps);
+      sw[c][r] = r < run ? w[((int64_t)(co0 + c) * Cin + ci0) * taps + r] : 0.f;       // r = ci_local * taps + t
+    }
+    __syncthreads();
+    constexpr int V = 16 / sizeof(T);                                                  // elements per 16-byte store
+    const int cpad_here = Cin_pad - ci0 < CI ? Cin_pad - ci0 : CI;                     // a multiple of V (Cin_pad is a K-group)
+    for (int id = threadIdx.x; id < taps * CO * (cpad_here / V); id += 256) {          // wf[t][co][ci]: 16 bytes of ci per lane
+      const int cv = id % (cpad_here / V), r = id / (cpad_here / V), c = r % CO, t = r / CO;
+      float f[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) f[k] = sw[c][(cv * V + k) * taps + t];
+      *reinterpret_cast<uint4*>(wf + ((int64_t)t * Cout + co0 + c) * Cin_pad + ci0 + cv * V) = Elem<T>::pack(f);
+    }
+    if (wd) {
+      for (int id = threadIdx.x; id < taps * cin_here * (CO / V); id += 256) {         // wd[t'][ci][co]: 16 bytes of co per lane
+        const int cv = id % (CO / V), r = id / (CO / V), ci = r % cin_here, tp = r / cin_here;
+        float f[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = sw[cv * V + k][ci * taps + (taps - 1 - tp)];
+        *reinterpret_cast<uint4*>(wd + ((int64_t)tp * Cin + ci0 + ci) * Cout + co0 + cv * V) = Elem<T>::pack(f);
+      }
     }
   }
 }
@@ -859,7 +875,7 @@ extern "C" int cvcs_pack_conv_weight(const float* w, int Cout, int Cin, int KH, 
 extern "C" int cvcs_pack_conv_weights(const cvcs_pack_item* items_device, int n_items, int dtype, void* stream) {
   CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_pack_conv_weights: bad dtype");
   CVCS_CHECK_ARG(items_device && n_items > 0 && n_items <= 65535, "cvcs_pack_conv_weights: bad table");
-  dim3 grid(256, (unsigned)n_items);
+  dim3 grid(128, (unsigned)n_items);   // entries must have Cout %% 16 == 0 and at most 9 taps (checked where the table is built)
   if (dtype == CVCS_F32) hipLaunchKernelGGL((pack_conv_weights_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, items_device);
   else hipLaunchKernelGGL((pack_conv_weights_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, items_device);
   CVCS_CHECK_LAUNCH("cvcs_pack_conv_weights");

@@ -308,7 +308,8 @@ def pack_table(entries, device):
     arr = (_lib.PackItem * len(entries))()
     for it, (w, wf, wd) in zip(arr, entries):
         Cout, Cin, KH, KW = w.shape
-        assert w.is_contiguous() and w.dtype == torch.float32
+        assert w.is_contiguous() and w.dtype == torch.float32 and Cout % 16 == 0 and KH * KW <= 9
+        assert wf.shape[2] % 16 == 0 and wf.data_ptr() % 16 == 0 and (wd is None or wd.data_ptr() % 16 == 0)
         it.w, it.w_fwd, it.w_dgrad = w.data_ptr(), wf.data_ptr(), _ptr(wd)
         it.Cout, it.Cin, it.KH, it.KW, it.Cin_pad = Cout, Cin, KH, KW, wf.shape[2]
     raw = bytes(arr)

@@ -486,3 +486,26 @@ def test_optimizers_match_torch():
                 ops.adam_step(p, gr.to(DEV), s1, s2, 0.005, 0.9, 0.999, 1e-8, 0.0, 1.0, i + 1)
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=2e-5, atol=2e-6, err_msg=kind)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batched_weight_pack_equals_per_layer_pack(dtype):
+    """cvcs_pack_conv_weights (one launch over a device table, LDS-tiled) == cvcs_pack_conv_weight per layer, bit for bit:
+    forward operand [tap][Cout][Cin_pad] and flipped data-gradient operand [tap'][Cin][Cout]; first layer (3 real channels
+    in one zero-padded K-group, no dgrad operand), channel counts that are not multiples of the 64-channel block."""
+    g = torch.Generator().manual_seed(8)
+    kg = ops.KGROUP[ops.dtype_code(dtype)]
+    shapes = [(64, 3, kg, False), (64, 64, 64, True), (128, 192, 192, True), (256, 128, 128, True), (16, 40, 64, True)]
+    entries, want = [], []
+    for cout, cin, cpad, dgrad in shapes:
+        w = torch.randn(cout, cin, 3, 3, generator=g).to(DEV)
+        wf, wd = ops.pack_conv_weight(w, cpad, dtype, want_dgrad=dgrad)
+        wf2 = torch.full_like(wf, 7.0)
+        wd2 = torch.full_like(wd, 7.0) if dgrad else None
+        entries.append((w, wf2, wd2)); want.append((wf, wd))
+    table, n = ops.pack_table(entries, DEV)
+    ops.pack_conv_weights(table, n, dtype)
+    torch.cuda.synchronize()
+    for (w, wf2, wd2), (wf, wd) in zip(entries, want):
+        assert torch.equal(wf2, wf), tuple(w.shape)
+        assert wd is None or torch.equal(wd2, wd), tuple(w.shape)
