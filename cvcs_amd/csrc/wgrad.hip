@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
     int issued = 0;
     if (kt + 2 < kt_end) { issue_tile(kt + 2, (ST + 2) % NS); issued = my_pieces; }
     const char* sb = smem + ST * STAGE;
+    if (wave * 16 < cin_rem) {   // a wave whose 16 input channels do not exist (the first layer stores 8) only moves data
     bf16x8 af[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = tr_pair(sb, ad[i][0], ad[i][1]);
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
     });
+    }
     wait_vm_barrier_n(issued);   // tile kt+1 has landed; this iteration's pieces (tile kt+2) may stay in flight
   };
   for (int kt = kt_begin; kt < kt_end; kt += 3) {
