@@ -204,6 +204,119 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const char* x, int64_t x_
   }
 }
 
+// bf16 variant of the pass above (the throughput path).  The x tile stays bf16 in LDS as it is in memory (a 16-byte copy per
+// lane instead of eight 4-byte LDS writes), dW runs on the bf16 MFMA: B = x [32 pixels][16 channels] by transposed LDS
+// reads (ds_read_b64_tr_b16), A = dl^T [16 classes][32 pixels] from the f32 dl tile in LDS (two 16-byte reads per lane and
+// K-step, in exactly the pixel order the transposed reads deliver), split into a bf16 head and a bf16 remainder (dl = hi + lo
+// to 2^-17: two MFMAs, products exact to that) - x is exactly bf16 already.  dx stays on the exact-f32 MFMA.
+constexpr int kXPitch = kHeadC * 2 + 16;   // bytes: a pixel row of the bf16 x / dx tile
+constexpr int kSdPitch4 = 68;              // floats: a class row of the dl tile (16-byte aligned rows, conflict-free b128 reads)
+__global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P,
+                                                           int64_t HW, const float* __restrict__ w, int NC, char* dx,
+                                                           int64_t dx_ld, float* part) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  __shared__ __attribute__((aligned(16))) char sx[kDwTile * kXPitch];
+  __shared__ __attribute__((aligned(16))) float sd[kMaxNC * kSdPitch4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ncb = (NC + 15) / 16;
+  const int nks = (NC + 3) / 4;
+  for (int i = tid; i < kMaxNC * kSdPitch4; i += 256) sd[i] = 0.f;   // class rows >= NC stay zero
+  float wa[kMaxNC / 4];                            // A fragments of dx: w[class 4s+fg][channel 16*wave+fr]
+#pragma unroll
+  for (int s = 0; s < kMaxNC / 4; ++s) {
+    const int c = 4 * s + fg;
+    wa[s] = c < NC ? w[c * kHeadC + wave * 16 + fr] : 0.f;
+  }
+  f32x4 acc[kMaxNC / 16];
+#pragma unroll
+  for (int cb = 0; cb < kMaxNC / 16; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float accb[kMaxNC / 4];                          // db partials: this wave's lanes cover class wave + 4k
+#pragma unroll
+  for (int k = 0; k < kMaxNC / 4; ++k) accb[k] = 0.f;
+  const int q = fr >> 2, pp = fr & 3;
+  const char* xfrag = sx + (wave * 16) * 2 + pp * 8;      // transposed-read base: channel block of this wave
+  for (int64_t p0 = (int64_t)blockIdx.x * kDwTile; p0 < P; p0 += (int64_t)gridDim.x * kDwTile) {
+    // a 64-pixel tile never straddles two images (HW is a multiple of 64) nor the end of the tensor
+    const int64_t b = p0 / HW, hw0 = p0 - b * HW;
+    const float* dlb = dl + b * NC * HW + hw0;
+    __syncthreads();
+    for (int id = tid; id < kDwTile * 8; id += 256) {
+      const int r = id >> 3, c = id & 7;
+      *reinterpret_cast<uint4*>(sx + r * kXPitch + c * 16) = *reinterpret_cast<const uint4*>(x + (p0 + r) * x_ld * 2 + c * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxNC / 4; ++k) {
+      const int c = wave + 4 * k;                  // item tid + 256k: class wave + 4k, pixel lane
+      if (c < NC) {
+        const float v = dlb[(int64_t)c * HW + lane];
+        sd[c * kSdPitch4 + lane] = v;
+        accb[k] += v;
+      }
+    }
+    __syncthreads();
+    // dW: A = dl^T [16 classes][32 pixels] from the LDS tile, element i of k-group fg <-> pixel 4fg+i | 16+4fg+i-4 (the
+    // order the transposed x reads deliver), split into bf16 head + remainder; B = x [32 pixels][16 channels]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = ks * 32 + 4 * fg + q, r1 = r0 + 16;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xfrag + r0 * kXPitch));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xfrag + r1 * kXPitch));
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int cb = 0; cb < kMaxNC / 16; ++cb)
+        if (cb < ncb) {
+          const float4 a0 = *reinterpret_cast<const float4*>(sd + (cb * 16 + fr) * kSdPitch4 + ks * 32 + 4 * fg);
+          const float4 a1 = *reinterpret_cast<const float4*>(sd + (cb * 16 + fr) * kSdPitch4 + ks * 32 + 16 + 4 * fg);
+          const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const uint4 head = Elem<bf16_t>::pack(f);
+          float hf[8], rem[8];
+          Elem<bf16_t>::unpack(head, hf);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rem[k] = f[k] - hf[k];
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, head), xf, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Elem<bf16_t>::pack(rem)), xf, acc[cb], 0, 0, 0);
+        }
+    }
+    // dx = w^T dl on the f32 MFMA
+    f32x4 dxa[kDwTile / 16];
+#pragma unroll
+    for (int nb = 0; nb < kDwTile / 16; ++nb) {
+      dxa[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < kMaxNC / 4; ++s)
+        if (s < nks) dxa[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], sd[(4 * s + fg) * kSdPitch4 + nb * 16 + fr], dxa[nb], 0, 0, 0);
+    }
+    __syncthreads();                               // every wave is done reading the x tile: reuse it as the dx staging tile
+#pragma unroll
+    for (int nb = 0; nb < kDwTile / 16; ++nb) {    // D layout: row (channel) = fg*4 + r, col (pixel) = fr
+      uint2 u;
+      u.x = (uint32_t)f32_to_bf16(dxa[nb][0]) | ((uint32_t)f32_to_bf16(dxa[nb][1]) << 16);
+      u.y = (uint32_t)f32_to_bf16(dxa[nb][2]) | ((uint32_t)f32_to_bf16(dxa[nb][3]) << 16);
+      *reinterpret_cast<uint2*>(sx + (nb * 16 + fr) * kXPitch + (wave * 16 + fg * 4) * 2) = u;
+    }
+    __syncthreads();
+    for (int id = tid; id < kDwTile * 8; id += 256) {
+      const int r = id >> 3, c = id & 7;
+      *reinterpret_cast<uint4*>(dx + (p0 + r) * dx_ld * 2 + c * 16) = *reinterpret_cast<const uint4*>(sx + r * kXPitch + c * 16);
+    }
+  }
+  float* row = part + (int64_t)blockIdx.x * (NC * kHeadC + NC);
+#pragma unroll
+  for (int cb = 0; cb < kMaxNC / 16; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cb * 16 + fg * 4 + r;   // D layout: row (class) = fg*4 + r, col (channel) = fr
+      if (cb < ncb && c < NC) row[c * kHeadC + wave * 16 + fr] = acc[cb][r];
+    }
+#pragma unroll
+  for (int k = 0; k < kMaxNC / 4; ++k) {
+    const float sum = wave_sum(accb[k]);
+    if (lane == 0 && wave + 4 * k < NC) row[NC * kHeadC + wave + 4 * k] = sum;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ cross entropy
 // workspace layout (floats): [0] = sum of target weights, [1] = loss numerator, [2..2+R) partial weights,
 // [2+R..2+2R) partial numerators, R = ce_rows(P).
@@ -551,6 +664,8 @@ extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, 
   dim3 grid((unsigned)cvcs_head_bwd_rows(P));
   if (dtype == CVCS_F32)
     hipLaunchKernelGGL((head_bwd_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw);
+  else if (HW % kDwTile == 0)   // tiles of 64 pixels inside one image (every tile side that is a multiple of 16)
+    hipLaunchKernelGGL(head_bwd_bf16_kernel, grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw);
   else
     hipLaunchKernelGGL((head_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw);
   CVCS_CHECK_LAUNCH("cvcs_head_bwd");
