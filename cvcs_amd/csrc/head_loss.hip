@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64
 // [2+R..2+2R) partial numerators, R = ce_rows(P).
 __host__ __device__ inline int ce_rows(int64_t P) {
   int64_t r = (P + 1023) / 1024;
-  return (int)(r < 1 ? 1 : (r > 1024 ? 1024 : r));
+  return (int)(r < 1 ? 1 : (r > 4096 ? 4096 : r));
 }
 
 __device__ __forceinline__ int load_target(const void* t, int is_u8, int64_t i) {
@@ -374,30 +374,27 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const float* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / HW, hw = i - b * HW;
     const float* zp = logits + b * NC * HW + hw;
-    float z[NCMAX];
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < NCMAX; ++c)
-      if (c < NC) { z[c] = zp[c * HW]; m = fmaxf(m, z[c]); }
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCMAX; ++c)
-      if (c < NC) se += expf(z[c] - m);
-    const float lse = m + logf(se);
     const int t = load_target(target, is_u8, i);
     const bool valid = (t != ignore) && ((unsigned)t < (unsigned)NC);
     const float wt = valid ? (cw ? cw[t] : 1.f) : 0.f;
-    float zt = 0.f;
+    float z[NCMAX];
+    float m = -INFINITY, zt = 0.f;
 #pragma unroll
     for (int c = 0; c < NCMAX; ++c)
-      if (c < NC && c == t) zt = z[c];
+      if (c < NC) { z[c] = zp[c * HW]; m = fmaxf(m, z[c]); zt = (c == t) ? z[c] : zt; }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < NC) { z[c] = expf(z[c] - m); se += z[c]; }   // z[c] now holds exp(z_c - max): reused by the gradient
+    const float lse = m + logf(se);
+    const float inv_se = 1.f / se;
     if (valid) num += wt * (lse - zt);
     if (dlogits) {
       float* dp = dlogits + b * NC * HW + hw;
       const float f = wt * gmul;
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c)
-        if (c < NC) dp[c * HW] = f * (expf(z[c] - lse) - ((c == t) ? 1.f : 0.f));
+        if (c < NC) dp[c * HW] = f * (z[c] * inv_se - ((c == t) ? 1.f : 0.f));
     }
   }
   num = block_sum_256(num, sbuf);
