@@ -460,7 +460,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   // halo pieces of this wave: q-th piece = DMA piece g = q*NW + wave of every slice
   constexpr int NPA = (HGROUPS + NW - 1) / NW;
   int aoff[NPA];                 // byte offset inside the image of this lane's 16 bytes, -1: padding -> zero word
-  int achk[NPA];                 // its byte offset inside a 64-byte channel slice
 #pragma unroll
   for (int q = 0; q < NPA; ++q) {
     const int g = q * NW + wave;
@@ -469,14 +468,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     const int c = swz(hx, pc);   // logical chunk stored at physical chunk pc: the halo swizzle is keyed on the COLUMN hx
     const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
     const bool ok = g < HGROUPS && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    aoff[q] = ok ? (int)((((int64_t)iy * p.W + ix) * p.in_ld) * ES + c * 16) : -1;
-    achk[q] = c * 16;
+    // a narrow input (Cin_valid < Cin) has a single channel slice (checked by the host): its absent chunks are padding too
+    aoff[q] = (ok && c * 16 < p.valid_bytes) ? (int)((((int64_t)iy * p.W + ix) * p.in_ld) * ES + c * 16) : -1;
   }
   const char* img_ptr = p.in + img_base * p.in_ld * ES;
   auto dma_halo = [&](int q, int cs, int buf) {   // q compile-time after unrolling
     const int g = q * NW + wave;
-    const char* src = (aoff[q] >= 0 && cs * 64 + achk[q] < p.valid_bytes) ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES)
-                                                                         : reinterpret_cast<const char*>(&g_zero16);
+    const char* src = aoff[q] >= 0 ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES) : reinterpret_cast<const char*>(&g_zero16);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
   };
@@ -815,6 +813,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   // ---- store: two halves of 8 image rows staged through LDS as [pixel][channel] (one packed 8/16-byte LDS write per
   // lane and 16x16 block) and written out as whole pixel rows of BN*sizeof(T) contiguous bytes
   constexpr int CPR = BN * ES / 16;
+  // statistics from the staged tile: pixels outside the image are staged as zeros (only border tiles pay the selects)
+  const bool zero_oob = MSTATS && p.stat_sum != nullptr && !(ny == MREP && nx == 16);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if ((wm * MREP) / 8 == h) {
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
             uint2 u;
             u.x = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
             u.y = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
-            if (MSTATS && p.stat_sum && !(i < ny && fr < nx)) u = make_uint2(0u, 0u);   // outside the image: not in the sums
+            if (zero_oob && !(i < ny && fr < nx)) u = make_uint2(0u, 0u);   // outside the image: not in the sums
             *reinterpret_cast<uint2*>(dst) = u;
           } else {
             *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
@@ -957,6 +957,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   CVCS_CHECK_ARG(eh == d->Ho && ew == d->Wo, "cvcs_conv2d: Ho,Wo=%d,%d but geometry gives %d,%d", d->Ho, d->Wo, eh, ew);
   const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
   CVCS_CHECK_ARG(cin_valid <= d->Cin && (cin_valid * es) % 16 == 0, "cvcs_conv2d: Cin_valid=%d must be <= Cin and a multiple of 16 bytes", d->Cin_valid);
+  CVCS_CHECK_ARG(cin_valid == d->Cin || d->Cin == kg, "cvcs_conv2d: a narrow input (Cin_valid < Cin) takes exactly one K-group (Cin = %d)", kg);
   CVCS_CHECK_ARG(d->in_ld >= cin_valid && d->in_ld * es % 16 == 0, "cvcs_conv2d: in_ld");
   const int cout_store = d->pixel_shuffle ? d->Cout / 4 : d->Cout;
   CVCS_CHECK_ARG(d->out_ld >= cout_store && d->out_ld * es % 16 == 0, "cvcs_conv2d: out_ld");
