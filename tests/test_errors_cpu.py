@@ -110,3 +110,20 @@ def test_factories_keep_the_reference_error_behaviour(capsys):
     with pytest.raises(RuntimeError, match="GPU only"):                             # no CPU fallback
         net(torch.zeros(1, 3, 32, 32))
     assert utils.load_device({"device": "cpu"}) == torch.device("cpu")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """no CPU fallback: without libcvcs_hip.so the first op raises CvcsError naming the build command (tier rule 3)"""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libcvcs_hip.so"))
+    with pytest.raises(_lib.CvcsError, match="There is no CPU fallback"):
+        _lib.lib()
+    from cvcs_amd import ops
+    with pytest.raises(_lib.CvcsError):
+        ops.bn_bwd_rows(10)
+
+
+def test_check_turns_a_status_into_an_exception(lib):
+    assert lib.cvcs_conv2d(None, None) == -1
+    with pytest.raises(_lib.CvcsError, match="null descriptor"):
+        _lib.check(-1, "cvcs_conv2d")
