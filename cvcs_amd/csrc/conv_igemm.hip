@@ -815,6 +815,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   constexpr int CPR = BN * ES / 16;
   // statistics from the staged tile: pixels outside the image are staged as zeros (only border tiles pay the selects)
   const bool zero_oob = MSTATS && p.stat_sum != nullptr && !(ny == MREP && nx == 16);
+  f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f}, ssq = (f32x4){0.f, 0.f, 0.f, 0.f};   // MFMA statistics, both half tiles
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if ((wm * MREP) / 8 == h) {
@@ -842,12 +843,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
         // wave w owns channels 16w..16w+15; a transposed fragment X[32 pixels][16 channels] gives the column sums as
         // ones^T X and the sums of squares as the diagonal of X^T X (A and B fragment layouts coincide, one set of
         // registers serves both operands).  f32 accumulation of exact bf16 products; M2 = sum x^2 - (sum x)^2 / n per
-        // 128-pixel block, merged across blocks by Chan's formula in f64 (bn_finalize).
+        // 256-pixel tile (accumulated over the two staged halves), merged across tiles by Chan's formula in f64 (bn_finalize).
         typedef __attribute__((ext_vector_type(4))) short s16x4;
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const int q = fr >> 2, pp = fr & 3;
         const char* base = smem + (wave * 16) * ES + pp * 8;
-        f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f}, ssq = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
         for (int pg = 0; pg < 4; ++pg) {
@@ -858,19 +858,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
           ssum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf, ssum, 0, 0, 0);
           ssq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, xf, ssq, 0, 0, 0);
         }
-        int nyh = p.H - ty0 - h * 8; nyh = nyh < 0 ? 0 : (nyh > 8 ? 8 : nyh);
-        const int nvalid = nyh * nx;
-        const int64_t row = (int64_t)blockIdx.x * 2 + h;
-        if (fg == q) {                                   // lane fr of group fr>>2 holds the diagonal entry of its channel
-          const float sx = ssum[0];
-          const float s2 = pp == 0 ? ssq[0] : (pp == 1 ? ssq[1] : (pp == 2 ? ssq[2] : ssq[3]));
-          float m2 = nvalid > 0 ? s2 - sx * sx / (float)nvalid : 0.f;
-          m2 = m2 < 0.f ? 0.f : m2;
-          const int n = n0 + wave * 16 + fr;
-          p.stat_sum[row * p.Cout + n] = sx;
-          p.stat_m2[row * p.Cout + n] = m2;
+        if (h == 1) {                                      // one row per 16x16 tile: both halves are in the accumulators
+          int nyt = p.H - ty0; nyt = nyt > 16 ? 16 : nyt;
+          const int nvalid = nyt * nx;
+          const int64_t row = blockIdx.x;
+          if (fg == q) {                                   // lane fr of group fr>>2 holds the diagonal entry of its channel
+            const float sx = ssum[0];
+            const float s2 = pp == 0 ? ssq[0] : (pp == 1 ? ssq[1] : (pp == 2 ? ssq[2] : ssq[3]));
+            float m2 = s2 - sx * sx / (float)nvalid;
+            m2 = m2 < 0.f ? 0.f : m2;
+            const int n = n0 + wave * 16 + fr;
+            p.stat_sum[row * p.Cout + n] = sx;
+            p.stat_m2[row * p.Cout + n] = m2;
+          }
+          if (blockIdx.y == 0 && tid == 0) p.stat_cnt[row] = (float)nvalid;
         }
-        if (blockIdx.y == 0 && tid == 0) p.stat_cnt[row] = (float)nvalid;
       }
     }
     for (int id = tid; id < 128 * CPR; id += NT) {
@@ -931,8 +933,8 @@ static bool use_halo(const cvcs_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
          d->W >= 8;
 }
-// partial-statistics rows per 16x16 tile: bf16 = one per staged half tile (MFMA statistics), f32 = one per wave row group
-static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 2 : 4; }
+// partial-statistics rows per 16x16 tile: bf16 = one (MFMA statistics over the staged tile), f32 = one per wave row group
+static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 1 : 4; }
 
 extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
