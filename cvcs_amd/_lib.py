@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("dtype", C.c_int32),
         ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p),
         ("Cin_valid", C.c_int32),
+        ("pool_out", C.c_void_p), ("pool_ld", C.c_int64),
     ]
 
 

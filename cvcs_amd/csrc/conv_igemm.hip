@@ -30,6 +30,8 @@ struct ConvArgs {
   const char* wt;
   const float* bias;
   const float* pre_scale; const float* pre_shift; const float* post_scale; const float* post_shift;   // eval-mode BN folds
+  char* pool;             // halo kernel: fused 2x2 max-pool output (NULL = none)
+  int64_t pool_ld;
   char* out;
   float* stat_sum;
   float* stat_m2;
@@ -883,6 +885,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
       char* dst = p.out + ((img_base + (int64_t)y * p.W + x) * p.out_ld + n0) * ES + c * 16;
       *reinterpret_cast<uint4*>(dst) = v;
     }
+    if (p.pool) {
+      // fused MaxPool2d(2,2): the staged half tile (8 rows x 16 pixels) holds whole 2x2 windows -> 4 x 8 pooled pixels
+      const int HP = p.H >> 1, WP = p.W >> 1;
+      for (int id = tid; id < 32 * CPR; id += NT) {
+        const int pr = id / CPR, c = id - pr * CPR;
+        const int py = pr >> 3, px = pr & 7;
+        const int oy = ((ty0 + h * 8) >> 1) + py, ox = (tx0 >> 1) + px;
+        if (oy >= HP || ox >= WP) continue;
+        constexpr int V = 16 / ES;
+        float mx[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) mx[k] = -INFINITY;
+#pragma unroll
+        for (int wdw = 0; wdw < 4; ++wdw) {
+          const int lrow = (2 * py + (wdw >> 1)) * 16 + 2 * px + (wdw & 1);
+          float f[V];
+          Elem<T>::unpack(*reinterpret_cast<const uint4*>(smem + lrow * OROW + c * 16), f);
+#pragma unroll
+          for (int k = 0; k < V; ++k) mx[k] = fmaxf(mx[k], f[k]);
+        }
+        char* dst = p.pool + ((((int64_t)b * HP + oy) * WP + ox) * p.pool_ld + n0) * ES + c * 16;
+        *reinterpret_cast<uint4*>(dst) = Elem<T>::pack(mx);
+      }
+    }
     __syncthreads();
   }
 }
@@ -981,6 +1007,12 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
                  "cvcs_conv2d: a folded BatchNorm needs both scale and shift");
   CVCS_CHECK_ARG(!(d->pixel_shuffle && (d->pre_scale || d->post_scale)), "cvcs_conv2d: no BatchNorm fold with pixel_shuffle");
   a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift; a.post_scale = d->post_scale; a.post_shift = d->post_shift;
+  a.pool = (char*)d->pool_out; a.pool_ld = d->pool_ld;
+  if (d->pool_out) {
+    CVCS_CHECK_ARG(use_halo(d) && d->Ho % 2 == 0 && d->Wo % 2 == 0, "cvcs_conv2d: fused pooling needs a 3x3/s1/p1 conv on an even map of at least 8 pixels");
+    CVCS_CHECK_ARG(((uintptr_t)d->pool_out % 16) == 0 && d->pool_ld >= d->Cout && (d->pool_ld * es) % 16 == 0, "cvcs_conv2d: pool_out view");
+    CVCS_CHECK_ARG(!d->stat_sum, "cvcs_conv2d: fused pooling is an eval-mode feature (no statistics)");
+  }
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;

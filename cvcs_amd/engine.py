@@ -209,10 +209,11 @@ class UNetEngine:
                             self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], False, st.scale, st.shift,
                             None, None)
             fold = (st.scale, st.shift)
+            fuse_pool = pool is not None and x.H >= 8 and x.W >= 8      # the halo kernel pools in its epilogue
             ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], out, 3, 3, 1, 1, relu=True,
                        pre_affine=fold if relu_after_bn else None, post_affine=None if relu_after_bn else fold,
-                       cin_real=3 if conv == "encode1.0.layer.0" else None)
-            if pool is not None:
+                       cin_real=3 if conv == "encode1.0.layer.0" else None, pool=pool if fuse_pool else None)
+            if pool is not None and not fuse_pool:
                 ops.bn_act(out, self.one[:C_], self.zero[:C_], False, None, pool)
             return
         rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1)

@@ -133,7 +133,7 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
-           pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None):
+           pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...)."""
     d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats)
@@ -142,6 +142,9 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         d.pre_scale, d.pre_shift = pre_affine[0].data_ptr(), pre_affine[1].data_ptr()
     if post_affine is not None:
         d.post_scale, d.post_shift = post_affine[0].data_ptr(), post_affine[1].data_ptr()
+    if pool is not None:      # fused 2x2 max-pool of the written values (eval mode)
+        assert (pool.B, pool.H, pool.W, pool.C) == (x.B, Ho // 2, Wo // 2, Cout) and pool.t.dtype == x.t.dtype
+        d.pool_out, d.pool_ld = pool.ptr, pool.ld
     assert wt.shape[0] == KH * KW and wt.shape[2] >= x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
     if pixel_shuffle:
         assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"

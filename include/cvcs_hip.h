@@ -65,6 +65,11 @@ typedef struct {
    * read as zero without being fetched.  The first layer's 3-channel tile is stored 16 bytes per pixel while the
    * contraction runs over one zero-padded K-group (`wt` is [KH*KW][Cout][Cin]).                                  */
   int32_t Cin_valid;
+  /* optional fused nn.MaxPool2d(2,2) (S/nets.py:130,135,140,145) of the values written to `out` (after bias / folded
+   * BatchNorm / ReLU): pool_out [B, Ho/2, Wo/2, Cout] NHWC in `dtype`, leading dimension pool_ld elements; NULL = none.
+   * Eval mode only needs it (in train mode the pooling is part of the BatchNorm-apply pass); 3x3 / stride 1 / pad 1
+   * convolutions on maps of at least 8 pixels with even Ho, Wo.                                                   */
+  void* pool_out;   int64_t pool_ld;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */

@@ -145,10 +145,15 @@ def test_conv2d_eval_mode_batchnorm_fold(H, W, Cin, Cout, pool, order, dtype):
     wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype, want_dgrad=False)
     out = torch.empty(B, H, W, Cout, dtype=dtype, device=DEV)
     fold = (scale, shift)
+    fused = torch.full((B, H // 2, W // 2, Cout + 64), 7.0, dtype=dtype, device=DEV) if pool and H >= 8 else None
     ops.conv2d(ops.view(to_nhwc(x, dtype)), wf, b.to(DEV), ops.view(out), 3, 3, 1, 1, relu=True,
-               pre_affine=fold if order == "encoder" else None, post_affine=fold if order == "decoder" else None)
+               pre_affine=fold if order == "encoder" else None, post_affine=fold if order == "decoder" else None,
+               pool=None if fused is None else ops.View(fused, 64, Cout))
     torch.cuda.synchronize()
     close(from_nhwc(out), ref, tol(dtype), "folded conv+BN")
+    if fused is not None:     # MaxPool2d(2,2) fused into the epilogue of the halo kernel: exactly the pooled stored values
+        assert torch.equal(from_nhwc(fused[..., 64:]), F.max_pool2d(from_nhwc(out), 2, 2))
+        assert (fused[..., :64].float() == 7.0).all()
     if pool:
         pl = torch.empty(B, H // 2, W // 2, Cout, dtype=dtype, device=DEV)
         keep = out.clone()
