@@ -13,6 +13,7 @@ One process per GPU; for N > 1 launch through `python -m torch.distributed.run -
 import argparse
 import json
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 import sys
 import time
 

@@ -5,6 +5,7 @@ Same YAML keys (source/scripts/configs/train/README.txt); `train` / `validation`
 Under `torch.distributed.run` every rank trains on its shard of each batch (cvcs_amd.parallel.DataParallel).
 """
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 import sys
 from pathlib import Path
 
