@@ -317,26 +317,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   const int my_pieces = 1 + (XP - wave + 3) / 4;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
 
-  auto issue_tile = [&](int kt, int st) {
-    const int b = kt / tiles_per_img;                 // wave-uniform scalars
-    const int tr = kt - b * tiles_per_img;
-    const int ty = tr / p.tiles_x;
-    const int oy = ty * TH, tx0 = (tr - ty * p.tiles_x) * TW;
+  // K-tiles are issued strictly in sequence: the coordinates of the next one are kept incrementally (no divisions per issue)
+  int ib, ity, itx;
+  {
+    ib = kt_begin / tiles_per_img;
+    const int tr = kt_begin - ib * tiles_per_img;
+    ity = tr / p.tiles_x;
+    itx = tr - ity * p.tiles_x;
+  }
+  // byte offsets of the current tile ROW (tx0 = 0) inside dy and x, recomputed only when the row changes
+  int64_t dy_row, x_row;
+  auto set_row = [&]() {
+    dy_row = ((((int64_t)ib * p.Ho + ity * TH) * p.Wo) * p.dy_ld) * 2;
+    x_row = ((((int64_t)ib * p.H + ity * TH - 1) * p.W - 1) * p.x_ld) * 2;
+  };
+  set_row();
+  const char* zsrc = reinterpret_cast<const char*>(&g_wzero16);
+  asm volatile("" : "+s"(zsrc));   // keep the zero word's address in SGPRs (otherwise re-materialised pc-relative per use)
+  auto issue_tile = [&](int st) {
+    const int oy = ity * TH, tx0 = itx * TW;
     const unsigned sdy = lds0 + st * STAGE;
     const unsigned sx = sdy + DY_BYTES;
-    const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
-    const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
+    const char* dyrow = p.dy + dy_row + (int64_t)(tx0 * (int)p.dy_ld * 2);
+    const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : zsrc;
     dma16(src, sdy + wave * 1024);
     const int iy0 = oy - 1, ix0 = tx0 - 1;
-    const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;   // may lie before the tensor: only
-#pragma unroll                                                                        // dereferenced for valid pixels
+    const char* xorg = p.x + x_row + (int64_t)(tx0 * (int)p.x_ld * 2);   // may lie before the tensor: only dereferenced for valid pixels
+#pragma unroll
     for (int j = 0; j < XJ; ++j) {
       if (wave + 4 * j < XP) {
         const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
         const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
-        const char* s2 = ok ? xorg + off_x[j] : reinterpret_cast<const char*>(&g_wzero16);
+        const char* s2 = ok ? xorg + off_x[j] : zsrc;
         dma16(s2, sx + (wave + 4 * j) * 1024);
       }
+    }
+    if (++itx == p.tiles_x) {
+      itx = 0;
+      if (++ity == p.tiles_y) { ity = 0; ++ib; }
+      set_row();
     }
   };
 
@@ -353,14 +372,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
   for (int kw = 0; kw < 3; ++kw) { ax[kw][0] = taddr(h0 + kw, wave); ax[kw][1] = taddr(h1 + kw, wave); }
 
   // ---- prologue
-  if (kt_begin < kt_end) issue_tile(kt_begin, 0);
-  if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
+  if (kt_begin < kt_end) issue_tile(0);
+  if (kt_begin + 1 < kt_end) issue_tile(1);
   wait_vm_barrier_n(0);
 
   auto tile_body = [&](auto st_, int kt) {
     constexpr int ST = decltype(st_)::value;
     int issued = 0;
-    if (kt + 2 < kt_end) { issue_tile(kt + 2, (ST + 2) % NS); issued = my_pieces; }
+    if (kt + 2 < kt_end) { issue_tile((ST + 2) % NS); issued = my_pieces; }
     const char* sb = smem + ST * STAGE;
     if (wave * 16 < cin_rem) {   // a wave whose 16 input channels do not exist (the first layer stores 8) only moves data
     bf16x8 af[4];
@@ -458,35 +477,48 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   const int my_pieces = 1 + (XP - wave + 7) / 8;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
 
-  // one DMA piece of K-tile kt into ring stage st: which = 0 -> this wave's dy piece, 1 + j -> its j-th halo piece
-  auto issue_piece = [&](int kt, int st, int which) {
-    const int b = kt / tiles_per_img;
-    const int tr = kt - b * tiles_per_img;
-    const int ty = tr / p.tiles_x;
-    const int oy = ty * TH, tx0 = (tr - ty * p.tiles_x) * TW;
+  // K-tiles are issued strictly in sequence (each wave issues every tile once): the coordinates of the next one are kept
+  // incrementally - two integer divisions per issue were a third of this kernel's scalar instruction stream, which is as
+  // long as its MFMA stream (SQ_ACTIVE_INST_ANY 47 % of the wave time)
+  int ib, ity, itx;
+  {
+    ib = kt_begin / tiles_per_img;
+    const int tr = kt_begin - ib * tiles_per_img;
+    ity = tr / p.tiles_x;
+    itx = tr - ity * p.tiles_x;
+  }
+  // byte offsets of the current tile ROW (tx0 = 0) inside dy and x, recomputed only when the row changes
+  int64_t dy_row, x_row;
+  auto set_row = [&]() {
+    dy_row = ((((int64_t)ib * p.Ho + ity * TH) * p.Wo) * p.dy_ld) * 2;
+    x_row = ((((int64_t)ib * p.H + ity * TH - 1) * p.W - 1) * p.x_ld) * 2;
+  };
+  set_row();
+  const char* zsrc = reinterpret_cast<const char*>(&g_wzero16);
+  asm volatile("" : "+s"(zsrc));   // keep the zero word's address in SGPRs (otherwise re-materialised pc-relative per use)
+  auto issue_tile = [&](int st) {
+    const int oy = ity * TH, tx0 = itx * TW;
     const unsigned sdy = lds0 + st * STAGE;
-    if (which == 0) {
-      const char* dyrow = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + tx0) * p.dy_ld) * 2;
-      const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : reinterpret_cast<const char*>(&g_wzero16);
-      dma16(src, sdy + wave * 1024);
-      return;
-    }
     const unsigned sx = sdy + DY_BYTES;
+    const char* dyrow = p.dy + dy_row + (int64_t)(tx0 * (int)p.dy_ld * 2);
+    const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : zsrc;
+    dma16(src, sdy + wave * 1024);
     const int iy0 = oy - 1, ix0 = tx0 - 1;
-    const char* xorg = p.x + ((((int64_t)b * p.H + iy0) * p.W + ix0) * p.x_ld) * 2;
+    const char* xorg = p.x + x_row + (int64_t)(tx0 * (int)p.x_ld * 2);   // may lie before the tensor: only dereferenced for valid pixels
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      if (which == 1 + j && wave + 8 * j < XP) {
+      if (wave + 8 * j < XP) {
         const int hy = hyx[j] >> 8, hx = hyx[j] & 255;
         const bool ok = hyx[j] >= 0 && (unsigned)(iy0 + hy) < (unsigned)p.H && (unsigned)(ix0 + hx) < (unsigned)p.W;
-        const char* s2 = ok ? xorg + off_x[j] : reinterpret_cast<const char*>(&g_wzero16);
+        const char* s2 = ok ? xorg + off_x[j] : zsrc;
         dma16(s2, sx + (wave + 8 * j) * 1024);
       }
     }
-  };
-  auto issue_tile = [&](int kt, int st) {
-#pragma unroll
-    for (int w = 0; w < 1 + XJ; ++w) issue_piece(kt, st, w);
+    if (++itx == p.tiles_x) {
+      itx = 0;
+      if (++ity == p.tiles_y) { ity = 0; ++ib; }
+      set_row();
+    }
   };
 
   const int q = fr >> 2, pp = fr & 3;
@@ -505,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   constexpr int D = NS - 1;
   wg_static_for<0, D>([&](auto d_) {
     constexpr int d = decltype(d_)::value;
-    if (kt_begin + d < kt_end) issue_tile(kt_begin + d, d);
+    if (kt_begin + d < kt_end) issue_tile(d);
   });
   wait_vm_barrier_n(0);
 
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
     // 2 / 4 / 6 / after tap 8: 878 / 905 / 942 / 950 TFLOP/s.
     const bool late = wave >= 4;
     const bool more = kt + D < kt_end;
-    if (!late && more) issue_tile(kt + D, (ST + D) % NS);
+    if (!late && more) issue_tile((ST + D) % NS);
     { int ahead = kt_end - (kt + 2); ahead = ahead < 0 ? 0 : (ahead > D - 1 ? D - 1 : ahead); issued = ahead * my_pieces; }
     const char* sb = smem + ST * STAGE;
     bf16x8 af[4];
@@ -534,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
       if constexpr (t == 8) {
-        if (late && more) issue_tile(kt + D, (ST + D) % NS);
+        if (late && more) issue_tile((ST + D) % NS);
       }
     });
     wait_vm_barrier_n(issued);
