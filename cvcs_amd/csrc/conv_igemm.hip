@@ -877,13 +877,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
         }
       }
     }
-    for (int id = tid; id < 128 * CPR; id += NT) {
-      const int lrow = id / CPR, c = id - lrow * CPR;
-      const int y = ty0 + h * 8 + (lrow >> 4), x = tx0 + (lrow & 15);
-      if (y >= p.H || x >= p.W) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(smem + lrow * OROW + c * 16);
-      char* dst = p.out + ((img_base + (int64_t)y * p.W + x) * p.out_ld + n0) * ES + c * 16;
-      *reinterpret_cast<uint4*>(dst) = v;
+    {
+      // whole pixel rows out: a lane keeps its (pixel column, 16-byte chunk) and walks down the half tile RPI image rows at
+      // a time - one 64-bit address per half tile, all LDS reads in flight before the first store
+      constexpr int RPT = NT / CPR;            // staged rows per iteration (16 | 32)
+      constexpr int ITERS = 128 / RPT, RPI = RPT / 16;
+      static_assert(RPT % 16 == 0 && ITERS * RPT == 128, "store walk");
+      const int lrow0 = tid / CPR, c = tid - lrow0 * CPR;
+      const int x = tx0 + (lrow0 & 15), y0 = ty0 + h * 8 + (lrow0 >> 4);
+      char* dst = p.out + ((img_base + (int64_t)y0 * p.W + x) * p.out_ld + n0) * ES + c * 16;
+      const int64_t dstep = (int64_t)RPI * p.W * p.out_ld * ES;
+      uint4 v[ITERS];
+#pragma unroll
+      for (int k = 0; k < ITERS; ++k) v[k] = *reinterpret_cast<const uint4*>(smem + (lrow0 + k * RPT) * OROW + c * 16);
+#pragma unroll
+      for (int k = 0; k < ITERS; ++k)
+        if (y0 + k * RPI < p.H && x < p.W) *reinterpret_cast<uint4*>(dst + k * dstep) = v[k];
     }
     if (p.pool) {
       // fused MaxPool2d(2,2): the staged half tile (8 rows x 16 pixels) holds whole 2x2 windows -> 4 x 8 pooled pixels

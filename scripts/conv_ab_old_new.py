@@ -10,7 +10,7 @@ from cvcs_amd import ops, _lib
 old = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libconv_old.so"))
 
 class OldDesc(C.Structure):
-    _fields_ = _lib.ConvDesc._fields_[:24]      # the descriptor before the eval-fold / Cin_valid fields
+    _fields_ = _lib.ConvDesc._fields_ if os.environ.get("OLD_SAME_ABI") == "1" else _lib.ConvDesc._fields_[:24]   # [:24]: the descriptor before the eval-fold / Cin_valid fields
 
 old.cvcs_conv2d.restype = C.c_int
 old.cvcs_conv2d.argtypes = [C.POINTER(OldDesc), C.c_void_p]
