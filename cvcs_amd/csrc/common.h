@@ -39,6 +39,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, h);
 }
 
+// two floats -> one dword of two bf16 (low half = a) with ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, h);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kPer16 = 4;
@@ -64,10 +72,10 @@ template <> struct Elem<bf16_t> {
   }
   __device__ static __forceinline__ uint4 pack(const float* f) {
     uint4 u;
-    u.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-    u.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-    u.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    u.x = pack2_bf16(f[0], f[1]);
+    u.y = pack2_bf16(f[2], f[3]);
+    u.z = pack2_bf16(f[4], f[5]);
+    u.w = pack2_bf16(f[6], f[7]);
     return u;
   }
 };

@@ -749,19 +749,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = (acc[i][j][r] + bv[r]) * s1[r] + t1[r];
-          if (p.relu) v = fmaxf(v, 0.f);
+          v = fmaxf(v, p.relu ? 0.f : -INFINITY);      // one max against a wave-uniform bound instead of a select
           acc[i][j][r] = v * s2[r] + t2[r];
         }
       continue;
     }
+    // wave-uniform variants (a per-element select on a runtime flag costs as much as the operation itself; data-gradient
+    // launches have neither bias nor ReLU and skip the pass)
+    if (p.relu) {
 #pragma unroll
-    for (int i = 0; i < MREP; ++i)
+      for (int i = 0; i < MREP; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv[r];
-        if (p.relu) v = fmaxf(v, 0.f);
-        acc[i][j][r] = v;
-      }
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r] + bv[r], 0.f);
+    } else if (p.bias) {
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[r];
+    }
   }
   int ny = p.H - ty0 - wm * MREP; ny = ny < 0 ? 0 : (ny > MREP ? MREP : ny);
   int nx = p.W - tx0;             nx = nx > 16 ? 16 : nx;
@@ -829,8 +834,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
           char* dst = smem + lrow * OROW + (wn * WNC + j * 16 + fg * 4) * ES;
           if constexpr (ES == 2) {
             uint2 u;
-            u.x = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
-            u.y = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
+            u.x = pack2_bf16(acc[i][j][0], acc[i][j][1]);
+            u.y = pack2_bf16(acc[i][j][2], acc[i][j][3]);
             if (zero_oob && !(i < ny && fr < nx)) u = make_uint2(0u, 0u);   // outside the image: not in the sums
             *reinterpret_cast<uint2*>(dst) = u;
           } else {

@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const char* x, int64_t x_
       char* dst = stage + (nb * 16 + fr) * OROW + (wave * 16 + fg * 4) * ES;
       if constexpr (ES == 2) {
         uint2 u;
-        u.x = (uint32_t)f32_to_bf16(dxa[nb][0]) | ((uint32_t)f32_to_bf16(dxa[nb][1]) << 16);
-        u.y = (uint32_t)f32_to_bf16(dxa[nb][2]) | ((uint32_t)f32_to_bf16(dxa[nb][3]) << 16);
+        u.x = pack2_bf16(dxa[nb][0], dxa[nb][1]);
+        u.y = pack2_bf16(dxa[nb][2], dxa[nb][3]);
         *reinterpret_cast<uint2*>(dst) = u;
       } else {
         *reinterpret_cast<float4*>(dst) = make_float4(dxa[nb][0], dxa[nb][1], dxa[nb][2], dxa[nb][3]);
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64
 #pragma unroll
     for (int nb = 0; nb < kDwTile / 16; ++nb) {    // D layout: row (channel) = fg*4 + r, col (pixel) = fr
       uint2 u;
-      u.x = (uint32_t)f32_to_bf16(dxa[nb][0]) | ((uint32_t)f32_to_bf16(dxa[nb][1]) << 16);
-      u.y = (uint32_t)f32_to_bf16(dxa[nb][2]) | ((uint32_t)f32_to_bf16(dxa[nb][3]) << 16);
+      u.x = pack2_bf16(dxa[nb][0], dxa[nb][1]);
+      u.y = pack2_bf16(dxa[nb][2], dxa[nb][3]);
       *reinterpret_cast<uint2*>(sx + (nb * 16 + fr) * kXPitch + (wave * 16 + fg * 4) * 2) = u;
     }
     __syncthreads();
