@@ -994,6 +994,178 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   CVCS_PROBE_AT(6);
 }
 
+// ===================================================================================================================
+// Non-overlapping taps ("pointwise") kernel, bf16: 1x1 / stride 1 (the ConvTranspose2d(k2,s2) forward as a GEMM with a
+// pixel-shuffling store) and 2x2 / stride 2 / pad 0 (its data gradient).  The generic kernel above spent ~150
+// instructions of address arithmetic, fragment reads and element-wise staging per 16 MFMAs on these (0.42 PFLOP/s); here
+// every per-lane source address is computed once (TAPS <= 4 base pointers per DMA row, +64 bytes per channel slice), the
+// loop body is DMA issue + 8 ds_read_b128 + 16 MFMAs + a counted wait and barrier, and the epilogue is the halo kernel's
+// (packed staging of the whole 256 x 128 tile, LDS reads in flight before the stores).
+// Workgroup: 256 output pixels (linear index) x 128 channels, 8 waves (4 x 2, 64 pixels x 64 channels each), K-slice of
+// 32 channels per step through a 3-stage LDS-DMA ring of 24 KiB (two workgroups per CU).
+template <int TAPS>
+__global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
+  using T = bf16_t;
+  constexpr int ES = 2, KG = 32, BN = 128, BM = 256, NW = 8, NT = 512;
+  constexpr int A_BYTES = BM * 64, STAGE = A_BYTES + BN * 64;   // 16 KiB of pixel rows + 8 KiB of weight rows per K-slice
+  constexpr int NS = 3;
+  constexpr int OROW = BN * ES + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int rr = lane >> 2, pc = lane & 3;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int nslice = p.Cin / KG;
+  const int nsteps = TAPS * nslice;
+  const int64_t wt_tap_bytes = (int64_t)p.Cout * p.Cin * ES;
+
+  f32x4 bias0[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bias0[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + j * 16 + fg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- DMA sources.  Pixel rows: pieces wave and wave + 8 (16 rows each); a row beyond M re-reads row M-1 (never stored).
+  // Byte offsets from p.in fit 32 bits (checked by the host).
+  unsigned asrc[2][TAPS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + NW * i) * 16 + rr;
+    int m = m0 + row; m = m < p.M ? m : p.M - 1;
+    const int ox = m % p.Wo, t = m / p.Wo;
+    const int oy = t % p.Ho, b = t / p.Ho;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int iy = oy * p.stride + (tp >> 1), ix = ox * p.stride + (tp & 1);
+      asrc[i][tp] = (unsigned)(((((int64_t)b * p.H + iy) * p.W + ix) * p.in_ld) * ES) + swz(row, pc) * 16;
+    }
+  }
+  const char* bsrc = p.wt + ((int64_t)(n0 + wave * 16 + rr) * p.Cin) * ES + swz(wave * 16 + rr, pc) * 16;
+  unsigned acur[2] = {asrc[0][0], asrc[1][0]};
+  const char* bcur = bsrc;
+  int cs2 = 0, t2 = 0;   // (slice, tap) of the next DMA step
+  auto dma_step = [&](int stage) {
+    char* sa = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + acur[i]),
+                                       (__attribute__((address_space(3))) void*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bcur,
+                                     (__attribute__((address_space(3))) void*)(sa + A_BYTES + wave * 1024), 16, 0, 0);
+    // advance to the next (tap, slice): slices innermost
+    acur[0] += 64; acur[1] += 64; bcur += 64;
+    if (++cs2 == nslice) {
+      cs2 = 0; ++t2;
+      if constexpr (TAPS > 1) {
+#pragma unroll
+        for (int tp = 1; tp < TAPS; ++tp)
+          if (t2 == tp) { acur[0] = asrc[0][tp]; acur[1] = asrc[1][tp]; }
+        bcur = bsrc + (int64_t)t2 * wt_tap_bytes;
+      }
+    }
+  };
+  dma_step(0);
+  if (nsteps > 1) dma_step(1);
+  wait_vm_barrier(0);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][j] = bias0[j];
+
+  // fragment bases (rows r0 + 16k share the swizzle bit of r0: one register per stage + immediates 1024*k)
+  const int ra = wm * 64 + fr, rb = wn * 64 + fr;
+  const unsigned abase = lds0 + ra * 64 + swz(ra, fg) * 16;
+  const unsigned wbase = lds0 + A_BYTES + rb * 64 + swz(rb, fg) * 16;
+  auto step = [&](auto st_, int s) {
+    constexpr int ST = decltype(st_)::value;
+    int k = 0;
+    if (s + 2 < nsteps) { dma_step((ST + 2) % NS); k = 3; }   // that stage was last read in step s-1: every wave is past its barrier
+    FragSet f;
+    lds_issue4q<0, 1024, 2048, 3072>(f.b0, f.b1, f.b2, f.b3, wbase + ST * STAGE);
+    lds_issue4q<0, 1024, 2048, 3072>(f.a0, f.a1, f.a2, f.a3, abase + ST * STAGE);
+    lds_wait(f);
+    auto row_mma = [&](int i, const u32x4& af) {
+      acc[i][0] = mma_u<T>(f.b0, af, acc[i][0]);   // A = weights, B = pixels: D[channel][pixel]
+      acc[i][1] = mma_u<T>(f.b1, af, acc[i][1]);
+      acc[i][2] = mma_u<T>(f.b2, af, acc[i][2]);
+      acc[i][3] = mma_u<T>(f.b3, af, acc[i][3]);
+    };
+    row_mma(0, f.a0); row_mma(1, f.a1); row_mma(2, f.a2); row_mma(3, f.a3);
+    wait_vm_barrier(k);
+  };
+  for (int s = 0; s < nsteps; s += NS) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < nsteps) step(std::integral_constant<int, 2>{}, s + 2);
+  }
+
+  // ---- epilogue: acc[i][j][r] = pixel row wm*64 + i*16 + fr, channel wn*64 + j*16 + fg*4 + r (bias already inside)
+  auto stage = [&](auto relu_) {
+    constexpr bool RELU = decltype(relu_)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+        uint2 u;
+        u.x = pack2_bf16(v[0], v[1]);
+        u.y = pack2_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2*>(smem + (wm * 64 + i * 16 + fr) * OROW + (wn * 64 + j * 16 + fg * 4) * ES) = u;
+      }
+  };
+  if (p.relu) stage(std::true_type{}); else stage(std::false_type{});   // wave-uniform
+  __syncthreads();
+  {
+    constexpr int CPR = BN * ES / 16;   // 16
+    constexpr int RPT = NT / CPR;       // 32 staged rows per iteration
+    constexpr int LS = RPT * OROW;
+    const int lrow0 = tid / CPR, c = tid - lrow0 * CPR;
+    const unsigned lbase = lds0 + lrow0 * OROW + c * 16;
+    u32x4 v[8];
+    lds_issue4q<0, LS, 2 * LS, 3 * LS>(v[0], v[1], v[2], v[3], lbase);
+    lds_issue4q<4 * LS, 5 * LS, 6 * LS, 7 * LS>(v[4], v[5], v[6], v[7], lbase);
+    // destination of this lane's 8 channels: with the pixel-shuffling store, channel n of the GEMM is quadrant q = n / Cr
+    // (dy = q >> 1, dx = q & 1) and channel n % Cr of the 2x upsampled map
+    const int n = n0 + c * 8;
+    int q = 0, co = n;
+    if (p.pixel_shuffle) { const int Cr = p.Cout >> 2; q = n / Cr; co = n - q * Cr; }
+    int m = m0 + lrow0;
+    int ox = m % p.Wo, t = m / p.Wo;
+    int oy = t % p.Ho, b = t / p.Ho;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (m < p.M) {
+        const int64_t pix = p.pixel_shuffle ? ((int64_t)b * (2 * p.Ho) + 2 * oy + (q >> 1)) * (2 * p.Wo) + 2 * ox + (q & 1) : (int64_t)m;
+        *reinterpret_cast<u32x4*>(p.out + (pix * p.out_ld + co) * ES) = v[k];
+      }
+      m += RPT; ox += RPT;
+      while (ox >= p.Wo) { ox -= p.Wo; ++oy; }
+      while (oy >= p.Ho) { oy -= p.Ho; ++b; }
+    }
+  }
+}
+
+template <int TAPS>
+static int launch_taps(const ConvArgs& a, hipStream_t st) {
+  const size_t lds = 3 * (size_t)(256 * 64 + 128 * 64);   // the ring; the staged output tile (256 x 272 B) aliases it
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_taps_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)cdiv(a.M, 256), (unsigned)(a.Cout / 128));
+  hipLaunchKernelGGL((conv_taps_kernel<TAPS>), grid, dim3(512), lds, st, a);
+  CVCS_CHECK_LAUNCH("cvcs_conv2d(taps)");
+  return CVCS_OK;
+}
+
 template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
@@ -1116,5 +1288,13 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
+  // bf16 1x1/s1 and 2x2/s2 convolutions without padding (the ConvTranspose2d forward and data gradient) take the
+  // non-overlapping-taps kernel
+  static const int taps_on = getenv("CVCS_CONV_TAPS") ? atoi(getenv("CVCS_CONV_TAPS")) : 1;   // tuning knob
+  const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1, k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
+  if (taps_on && (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !d->stat_sum &&
+      !d->pre_scale && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&
+      (!d->pixel_shuffle || (d->Cout / 4) % 8 == 0) && (int64_t)d->B * d->H * d->W * d->in_ld * es < (1ll << 32))
+    return k1 ? launch_taps<1>(a, st) : launch_taps<4>(a, st);
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

@@ -191,7 +191,7 @@ def test_conv2d_f32_large_mean_statistics(dtype, B, H, W):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 4, 4, 128, 64), (1, 7, 5, 256, 128)])
+@pytest.mark.parametrize("shape", [(2, 4, 4, 128, 64), (1, 7, 5, 256, 128), (2, 20, 24, 128, 64), (1, 32, 32, 512, 256)])
 def test_conv_transpose_forward_and_dgrad(shape, dtype):
     """nn.ConvTranspose2d(k2,s2) (S/nets.py:150,156,162,168) = 1x1 conv + pixel shuffle; its data gradient =
     2x2 stride-2 conv."""
