@@ -150,9 +150,9 @@ def main():
                                "traffic": None, "kernel": "conv3x3_halo_kernel (every 3x3 forward and data-gradient launch)",
                                "launches_per_step": c["launches"] // a.steps, "avg_launch_us": round(c["avg_us"], 2),
                                "algorithmic_gflop_per_step": round(c["flops"] / a.steps / 1e9, 1)}
-            if "conv_igemm" in timers:   # ConvTranspose forward / data gradient on the generic implicit-GEMM kernel
+            if "conv_igemm" in timers:   # ConvTranspose forward / data gradient on the non-overlapping-taps kernel
                 g = timers["conv_igemm"]
-                out["other_conv"] = {"kernel": "conv_igemm_kernel (ConvTranspose forward + data gradient; HBM-bound shapes)",
+                out["other_conv"] = {"kernel": "conv_taps_kernel (ConvTranspose forward + data gradient: short-K GEMMs, the shallow levels HBM-bound)",
                                      "achieved": round(g["tflops"], 2), "unit": "TFLOP/s", "launches_per_step": g["launches"] // a.steps,
                                      "avg_launch_us": round(g["avg_us"], 2), "algorithmic_gflop_per_step": round(g["flops"] / a.steps / 1e9, 1)}
             if "wgrad" in timers:

@@ -1278,7 +1278,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   if (use_halo(d)) {
-    static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 0;   // tuning knob
+    static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 64;   // tuning knob
     const bool wide = d->Cout % 128 == 0 && !(d->dtype == CVCS_BF16 && d->Cin <= narrow_cin);
     static const int waves = getenv("CVCS_HALO_WAVES") ? atoi(getenv("CVCS_HALO_WAVES")) : 8;   // tuning knob (4 | 8)
     if (d->dtype == CVCS_F32) return wide ? launch_halo<float, 128, 4, 2, 1>(a, st) : launch_halo<float, 64, 4, 1, 3>(a, st);
