@@ -425,13 +425,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(WgradArgs p) {
 // once for twice the MFMA work, 10 KB of fill per 64x64x9 unit instead of 16.  Wave (wm, wn) = 64 channels of dy x 16
 // channels of x; the dy tile is kept as two 32 x 64-channel blocks so that addressing, swizzle and the conflict-free
 // transposed reads are those of the kernel above.
-template <int TH, int TW, int NS>
+// S2 = the 2x2 / stride 2 / pad 0 geometry (ConvTranspose2d(k2,s2) weight gradient): four taps, the x tile is the 8 x 16
+// fine pixels under the 4 x 8 K-tile, stored DE-INTERLEAVED - LDS block (fy, kw) holds the eight pixels (fy, 2kx + kw) -
+// so that the eight tile pixels of a transposed read are eight consecutive LDS rows for every tap, exactly as in the
+// 3x3 case (stride-2 rows would all start on the same 32 banks), and a tap is an immediate offset of kh*2048 + kw*1024.
+template <int TH, int TW, int NS, bool S2 = false>
 __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   static_assert(TH * TW == 32, "a K-tile is 32 output pixels");
   constexpr int ROWB = 128;
   constexpr int HP = (TW + 2 + 7) / 8 * 8;
   constexpr int HR = TH + 2;
-  constexpr int DYH_BYTES = 32 * ROWB, DY_BYTES = 2 * DYH_BYTES, X_ROWS = HR * HP, X_BYTES = X_ROWS * ROWB;
+  constexpr int NTAPS = S2 ? 4 : 9;
+  static_assert(!S2 || (TH == 4 && TW == 8), "the stride-2 layout is written for 4 x 8 K-tiles");
+  constexpr int DYH_BYTES = 32 * ROWB, DY_BYTES = 2 * DYH_BYTES, X_ROWS = S2 ? 128 : HR * HP, X_BYTES = X_ROWS * ROWB;
   constexpr int STAGE = DY_BYTES + X_BYTES;
   constexpr int XP = X_ROWS / 8;                   // halo DMA pieces
   constexpr int XJ = (XP + 7) / 8;                 // ... per wave
@@ -449,9 +455,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   int kt_end = kt_begin + p.per_slice;
   if (kt_end > p.ktiles) kt_end = p.ktiles;
 
-  f32x4 acc[9][4];
+  f32x4 acc[NTAPS][4];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -468,9 +474,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
 #pragma unroll
   for (int j = 0; j < XJ; ++j) {
     const int r = (wave + 8 * j) * 8 + rr;
-    const int hy = r / HP, hx = r - hy * HP;
+    // tile-relative source pixel of LDS row r.  3x3: halo row r / HP, column r % HP; stride 2: block (fy, kw) = piece index
+    const int hy = S2 ? (wave + 8 * j) >> 1 : r / HP, hx = S2 ? 2 * rr + ((wave + 8 * j) & 1) : r - (r / HP) * HP;
     const int c = swzc(r, pc);
-    const bool ok = (wave + 8 * j) < XP && hx < TW + 2 && c * 8 < cin_rem;
+    const bool ok = (wave + 8 * j) < XP && (S2 || hx < TW + 2) && c * 8 < cin_rem;
     off_x[j] = ((hy * p.W + hx) * (int)p.x_ld + ci0) * 2 + c * 16;
     hyx[j] = ok ? ((hy << 8) | hx) : -1;
   }
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   int64_t dy_row, x_row;
   auto set_row = [&]() {
     dy_row = ((((int64_t)ib * p.Ho + ity * TH) * p.Wo) * p.dy_ld) * 2;
-    x_row = ((((int64_t)ib * p.H + ity * TH - 1) * p.W - 1) * p.x_ld) * 2;
+    x_row = S2 ? ((((int64_t)ib * p.H + ity * TH * 2) * p.W) * p.x_ld) * 2 : ((((int64_t)ib * p.H + ity * TH - 1) * p.W - 1) * p.x_ld) * 2;
   };
   set_row();
   const char* zsrc = reinterpret_cast<const char*>(&g_wzero16);
@@ -503,8 +510,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
     const char* dyrow = p.dy + dy_row + (int64_t)(tx0 * (int)p.dy_ld * 2);
     const char* src = (oy + kdy_y < p.Ho && tx0 + kdy_x < p.Wo) ? dyrow + off_dy : zsrc;
     dma16(src, sdy + wave * 1024);
-    const int iy0 = oy - 1, ix0 = tx0 - 1;
-    const char* xorg = p.x + x_row + (int64_t)(tx0 * (int)p.x_ld * 2);   // may lie before the tensor: only dereferenced for valid pixels
+    const int iy0 = S2 ? 2 * oy : oy - 1, ix0 = S2 ? 2 * tx0 : tx0 - 1;
+    const char* xorg = p.x + x_row + (int64_t)((S2 ? 2 * tx0 : tx0) * (int)p.x_ld * 2);   // may lie before the tensor: only dereferenced for valid pixels
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       if (wave + 8 * j < XP) {
@@ -527,10 +534,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
   unsigned ad[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { ad[i][0] = wm * DYH_BYTES + taddr(k0, i); ad[i][1] = wm * DYH_BYTES + taddr(k1, i); }
-  const int h0 = (k0 / TW) * HP + k0 % TW, h1 = (k1 / TW) * HP + k1 % TW;
-  unsigned ax[3][2];
+  // LDS rows of the two tile pixels at tap (0,0): 3x3 = halo row; stride 2 = ky*32 + kx (blocks (2ky+kh, kw) of 8 rows)
+  const int h0 = S2 ? (k0 / TW) * 32 + k0 % TW : (k0 / TW) * HP + k0 % TW, h1 = S2 ? (k1 / TW) * 32 + k1 % TW : (k1 / TW) * HP + k1 % TW;
+  constexpr int NAX = S2 ? 1 : 3;
+  unsigned ax[NAX][2];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) { ax[kw][0] = taddr(h0 + kw, wn); ax[kw][1] = taddr(h1 + kw, wn); }
+  for (int kw = 0; kw < NAX; ++kw) { ax[kw][0] = taddr(h0 + kw, wn); ax[kw][1] = taddr(h1 + kw, wn); }
 
   // ring of NS stages, NS-1 K-tiles ahead: the fetch of a K-tile (HBM / Infinity-Cache latency) has NS-2 whole
   // iterations to land before it is waited for
@@ -558,14 +567,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
     bf16x8 af[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = tr_pair(sb, ad[i][0], ad[i][1]);
-    wg_static_for<0, 9>([&](auto t_) {
+    wg_static_for<0, NTAPS>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
-      constexpr int kh = t / 3, kw = t - kh * 3;
-      const char* xb = sb + DY_BYTES + kh * HP * ROWB;
-      const bf16x8 bf = tr_pair(xb, ax[kw][0], ax[kw][1]);
+      constexpr int kh = S2 ? t / 2 : t / 3, kw = S2 ? t % 2 : t - kh * 3;
+      const char* xb = sb + DY_BYTES + (S2 ? kh * 2048 + kw * 1024 : kh * HP * ROWB);
+      const bf16x8 bf = tr_pair(xb, ax[S2 ? 0 : kw][0], ax[S2 ? 0 : kw][1]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
-      if constexpr (t == 8) {
+      if constexpr (t == NTAPS - 1) {
         if (late && more) issue_tile((ST + D) % NS);
       }
     });
@@ -578,11 +587,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_fast128_kernel(WgradArgs p) {
     });
   }
 
-  const int64_t slice_stride = (int64_t)9 * p.Cout * p.Cin;
+  const int64_t slice_stride = (int64_t)NTAPS * p.Cout * p.Cin;
   const int ci = ci0 + wn * 16 + fr;
   if (ci < p.Cin) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -696,8 +705,16 @@ static bool fast_shape(int dtype, int KH, int KW, int stride, int pad, int H, in
   return dtype == CVCS_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Ho >= 4 && Wo >= 8 &&
          (int64_t)H * W * x_ld * 2 < (1ll << 31) && (int64_t)Ho * Wo * dy_ld * 2 < (1ll << 31);
 }
+// bf16, 2x2 / stride 2 / pad 0 (the ConvTranspose2d weight gradient), 128-channel tiles
+static bool s2_shape(const cvcs_wgrad_desc* d) {
+  static const int on = getenv("CVCS_WGRAD_S2") ? atoi(getenv("CVCS_WGRAD_S2")) : 1;   // tuning knob
+  return on && d->dtype == CVCS_BF16 && d->KH == 2 && d->KW == 2 && d->stride == 2 && d->pad == 0 && d->Ho >= 4 && d->Wo >= 8 &&
+         d->Cout % 128 == 0 && d->H == 2 * d->Ho && d->W == 2 * d->Wo &&
+         (int64_t)d->H * d->W * d->x_ld * 2 < (1ll << 31) && (int64_t)d->Ho * d->Wo * d->dy_ld * 2 < (1ll << 31);
+}
 static int fast_path(const cvcs_wgrad_desc* d) {
   static const int force64 = getenv("CVCS_WGRAD_64") ? atoi(getenv("CVCS_WGRAD_64")) : 0;   // tuning knob
+  if (s2_shape(d)) return 2;
   if (!fast_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->H, d->W, d->Ho, d->Wo, d->x_ld, d->dy_ld)) return 0;
   return (d->Cout % 128 == 0 && !force64) ? 2 : 1;
 }
@@ -713,6 +730,10 @@ extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int K
       const int c = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 2).nslice;
       n = c > n ? c : n;
     }
+  }
+  if (KH == 2 && KW == 2 && stride == 2 && Ho >= 4 && Wo >= 8 && Cout % 128 == 0) {
+    const int c = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 2).nslice;
+    n = c > n ? c : n;
   }
   return n;
 }
@@ -749,7 +770,18 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   int rc;
   if (d->dtype == CVCS_F32)
     rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
-  else if (fast_path(d) == 2) {
+  else if (s2_shape(d)) {
+    const int lds = 3 * (64 + 128) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast128_kernel<4, 8, 3, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad_fast128_kernel<4, 8, 3, true>), dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(512), lds, st, a);
+    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(s2)");
+    rc = CVCS_OK;
+  } else if (fast_path(d) == 2) {
     constexpr int kStages = 3;   // deeper rings (4-6 stages) measured no faster: the fetch is not latency-bound
     const int lds = kStages * (64 + 6 * 16) * 128;
     static bool attr_done = false;

@@ -250,6 +250,9 @@ WGRAD_CASES = [
     (1, 33, 96, 192, 192, 64, 3, 1, 1),  # fast path: 3 Cin tiles, many K-tiles per slice
     (2, 21, 44, 128, 128, 256, 3, 1, 1), # 128-channel fast path (8 waves): two Cout tiles x two Cin tiles, ragged 4x8 K-tiles
     (1, 40, 72, 72, 72, 128, 3, 1, 1),   # 128-channel fast path: Cin not a multiple of 64 (absent channels zero-filled)
+    (2, 16, 32, 64, 64, 128, 2, 2, 0),   # stride-2 fast path (ConvTranspose weight gradient): whole 4x8 K-tiles
+    (1, 24, 20, 128, 128, 256, 2, 2, 0), # stride-2 fast path: ragged K-tiles (Wo = 10), two Cout x two Cin tiles
+    (3, 16, 16, 72, 72, 128, 2, 2, 0),   # stride-2 fast path: Cin not a multiple of 64
 ]
 
 
