@@ -416,8 +416,14 @@ __device__ unsigned long long g_probe[8 * 32768];
 #define CVCS_PROBE_AT(i) do { } while (0)
 #endif
 
+// PACKED (the narrow bf16 kernel with one tap per step): the two halo buffers are 324 rows each instead of 21 whole DMA
+// pieces (the last piece writes its four real rows only: its other lanes are masked off) and the ring holds one tap per
+// slot - 53,760 bytes of LDS, THREE workgroups per CU.
+template <typename T, int BN, int WM, int WN, int TPS>
+constexpr bool halo_packed() { return sizeof(T) == 2 && BN == 64 && WM * WN == 4 && TPS == 1; }
+
 template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 3 : 2)) void conv3x3_halo_kernel(ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int KG = 64 / ES;
   constexpr int NW = WM * WN;          // waves per workgroup (4 | 8)
@@ -428,7 +434,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   static_assert(NREP == 4 && (MREP == 4 || MREP == 8), "fragment blocks are written for NREP = 4, MREP = 4 | 8");
   constexpr int HS = 18, HROWS = HS * HS;
   constexpr int HGROUPS = (HROWS + 15) / 16;       // 21 DMA pieces of 16 rows
-  constexpr int A_BYTES = HGROUPS * 1024;          // 21504
+  constexpr bool PACKED = halo_packed<T, BN, WM, WN, TPS>();
+  constexpr int A_BYTES = PACKED ? HROWS * 64 : HGROUPS * 1024;   // 20736 | 21504
   // a STEP covers TPS consecutive taps (one filter row when TPS = 3): fewer barriers per MFMA for narrow BN
   static_assert(TPS == 1 || TPS == 3, "taps per step (ring slot = step % 3 needs 9/TPS % 3 == 0)");
   constexpr int SPS = 9 / TPS;                     // steps per channel slice
@@ -504,6 +511,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(ConvArgs 
   auto dma_halo = [&](int q, int cs, int buf) {   // q compile-time after unrolling
     const int g = q * NW + wave;
     const char* src = aoff[q] >= 0 ? img_ptr + aoff[q] + (int64_t)cs * (KG * ES) : reinterpret_cast<const char*>(&g_zero16);
+    if (PACKED && g == HGROUPS - 1 && g * 16 + rr >= HROWS) return;   // packed buffers: the rows past 323 belong to the neighbour
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + g * 1024), 16, 0, 0);
   };
@@ -1170,7 +1178,7 @@ template <typename T, int BN, int WM, int WN, int TPS, bool PIPE = false>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int ES = sizeof(T);
   constexpr int nslot = PIPE ? 4 : 3;                                        // the pipelined 8-wave kernel rings 4 slots
-  size_t stage = 2 * (size_t)(21 * 1024) + nslot * (size_t)(TPS * BN * 64);  // halo double buffer + weight ring
+  size_t stage = 2 * (size_t)(halo_packed<T, BN, WM, WN, TPS>() ? 324 * 64 : 21 * 1024) + nslot * (size_t)(TPS * BN * 64);  // halo double buffer + weight ring
   size_t epi = (size_t)(ES == 2 ? 256 : 128) * (BN * ES + 16);   // staged tile: whole (bf16) | half (f32)
   size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
@@ -1285,6 +1293,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     static const int pipe = getenv("CVCS_HALO_PIPE") ? atoi(getenv("CVCS_HALO_PIPE")) : 1;               // tuning knob
     if (wide && waves != 4 && pipe) return launch_halo<bf16_t, 128, 4, 2, 3, true>(a, st);
     if (wide) return waves == 4 ? launch_halo<bf16_t, 128, 4, 2, 1>(a, st) : launch_halo<bf16_t, 128, 4, 2, 3>(a, st);
+    static const int narrow3 = getenv("CVCS_HALO_NARROW3") ? atoi(getenv("CVCS_HALO_NARROW3")) : 1;   // tuning knob (0: two workgroups per CU, a filter row per barrier)
+    if (narrow3) return launch_halo<bf16_t, 64, 4, 1, 1>(a, st);   // three workgroups per CU, one tap per barrier
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
