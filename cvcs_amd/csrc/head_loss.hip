@@ -9,6 +9,7 @@
 // Reference ops replaced: nn.Conv2d(64, NC, 1) (S/nets.py:172), nn.CrossEntropyLoss(weight, ignore_index)
 // (S/utils.py:230,238; S/train.py:122), torch.max/argmax (S/utils.py:90,158), MulticlassConfusionMatrix.update
 // (S/utils.py:93-94) and the backward of the first two (S/train.py:125).
+#include <stdlib.h>
 #include "common.h"
 
 namespace cvcs {
@@ -643,8 +644,9 @@ extern "C" int cvcs_label_stitch(const uint8_t* tiles, int n, int S, int p, int 
 }
 
 extern "C" int cvcs_head_bwd_rows(int64_t P) {
+  static const int cap = getenv("CVCS_HEAD_ROWS") ? atoi(getenv("CVCS_HEAD_ROWS")) : 1024;   // tuning knob: resident workgroups
   int64_t r = cdiv(P, kDwTile);
-  return (int)(r < 1 ? 1 : (r > 1024 ? 1024 : r));
+  return (int)(r < 1 ? 1 : (r > cap ? cap : r));
 }
 
 extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
