@@ -6,7 +6,8 @@ north star.  Design for MI355X / xGMI rather than a translation of torch DDP:
   * every parameter gradient already lives in ONE flat f32 buffer laid out in forward order, and the HIP backward
     produces it strictly back-to-front - so a "bucket" is just a contiguous slice [lo, hi) of that buffer and becomes
     ready the moment backward has passed offset lo; no per-parameter hooks, no gradient copies, no re-bucketing;
-  * buckets are large (default 32 MiB = 8 Mi floats; the 124 MB of Urnetv2 gradients go out as 4 collectives):
+  * buckets are large (default 32 MiB = 8 Mi floats; the 124 MB of Urnetv2 gradients go out as 4 collectives plus a
+    4 MiB one for the front of the buffer, the only slice whose all-reduce cannot overlap backward):
     xGMI is point-to-point (7 links x ~153 GB/s per GPU) and RCCL's ring/tree all-reduce is per-link bound, so few
     large messages beat many small ones;
   * each bucket's all-reduce (RCCL, backend "nccl") is issued on a dedicated HIP stream as soon as it is ready and
@@ -25,15 +26,25 @@ import torch
 import torch.distributed as dist
 
 
-def plan_buckets(total_floats: int, bucket_floats: int):
+def plan_buckets(total_floats: int, bucket_floats: int, tail_floats: int | None = None):
     """contiguous [lo, hi) slices covering [0, total), built from the END of the buffer (backward order);
-    returned in the order they become ready."""
+    returned in the order they become ready.
+
+    The slice that starts at offset 0 becomes ready only when backward is over, so its all-reduce is the one nothing
+    overlaps: it is kept SMALL (tail_floats, default an eighth of a bucket).  In a U-Net the front of the buffer is
+    the cheap-to-send, expensive-to-compute part anyway (levels 1-3 hold 4 % of the parameters and half of the backward
+    time), so the big slices before it are long done by then."""
     assert total_floats > 0 and bucket_floats > 0
+    if tail_floats is None:
+        tail_floats = max(1, bucket_floats // 8)
+    tail = min(tail_floats, total_floats) if total_floats > bucket_floats else 0
     out, hi = [], total_floats
-    while hi > 0:
-        lo = max(0, hi - bucket_floats)
+    while hi > tail:
+        lo = max(tail, hi - bucket_floats)
         out.append((lo, hi))
         hi = lo
+    if tail:
+        out.append((0, tail))
     return out
 
 

@@ -11,13 +11,15 @@ from cvcs_amd.parallel import GradientAllReducer, plan_buckets, shard_batch
 
 
 def test_plan_buckets_cover_back_to_front():
-    b = plan_buckets(1000, 300)
+    b = plan_buckets(1000, 300, tail_floats=0)
     assert b == [(700, 1000), (400, 700), (100, 400), (0, 100)]
     assert plan_buckets(10, 100) == [(0, 10)]
+    # the slice that is ready last (it starts at offset 0) is the small one: nothing overlaps its all-reduce
+    assert plan_buckets(1000, 300, tail_floats=50) == [(700, 1000), (400, 700), (100, 400), (50, 100), (0, 50)]
     total = 31044496 + 64  # Urnetv2 parameters (+ alignment padding)
     bk = plan_buckets(total, 8 << 20)
     assert bk[0][1] == total and bk[-1][0] == 0 and all(a[0] == b_[1] for a, b_ in zip(bk, bk[1:]))
-    assert len(bk) == 4
+    assert len(bk) == 5 and bk[-1] == (0, 1 << 20) and all(hi - lo <= 8 << 20 for lo, hi in bk)
 
 
 def test_shard_batch():
