@@ -667,7 +667,11 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
       {
         constexpr int t2 = (st + 2) % SPS;
         const int c2 = cs + (st + 2) / SPS;
+#ifdef CVCS_PROBE_SKIP_W   // scripts/wg_timeline_probe.py experiment: fetch the weights of one step in three only (results are garbage)
+        if (c2 < nslice && t2 % 3 == 0) { dma_b(c2, t2, (st + 2) % 3); k += BPW; }
+#else
         if (c2 < nslice) { dma_b(c2, t2, (st + 2) % 3); k += BPW; }   // SPS % 3 == 0: ring slot = st % 3
+#endif
       }
       if constexpr (TPS == 3 && MREP == 4) {
         // software-pipelined taps: the fragment reads of tap t+1 are in flight while the 16 MFMAs of tap t issue;

@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cvcs_amd import _lib
-lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libconv_probe.so"))
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PROBE_LIB", "libconv_probe.so")))
 lib.cvcs_conv2d.restype = C.c_int
 lib.cvcs_conv2d.argtypes = [C.POINTER(_lib.ConvDesc), C.c_void_p]
 lib.cvcs_probe_read.argtypes = [C.c_void_p, C.c_size_t]
@@ -41,6 +41,12 @@ for (B, S, Cin, Cout, stats) in ((32, 512, 64, 64, 0), (32, 512, 64, 64, 1), (32
     mid = slice(n // 4, 3 * n // 4)   # steady state
     conc = life.sum() / span_us
     us = span_us
+    h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h0.record()
+    for _ in range(10): lib.cvcs_conv2d(C.byref(d), st)
+    h1.record(); torch.cuda.synchronize()
+    hot_us = h0.elapsed_time(h1) * 100
+    print(f"[hot: {hot_us:.0f} us/launch over 10] ", end="")
     print(f"S={S} {Cin}->{Cout} stats={stats}: kernel {us:.0f} us, tick {tick_us*1e3:.2f} ns, WG life {life[mid].mean():.2f} us "
           f"(setup {((t[mid,7]-t[mid,0])*tick_us).mean():.2f}, DMA issue {((t[mid,1]-t[mid,7])*tick_us).mean():.2f}, wait for the first slice {ph[mid,1].mean():.2f}, main loop {ph[mid,2].mean():.2f}, epilogue {ph[mid,3].mean():.2f}); resident WGs {conc:.0f} "
           f"of grid {rows}x{Cout // (128 if Cout % 128 == 0 else 64)}", flush=True)
