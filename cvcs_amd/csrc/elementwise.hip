@@ -707,8 +707,9 @@ extern "C" int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int
 }
 
 extern "C" int cvcs_bn_bwd_rows(int64_t M) {
+  static const int cap = getenv("CVCS_BN_BWD_ROWS") ? atoi(getenv("CVCS_BN_BWD_ROWS")) : 1024;   // tuning knob: workgroups (= partial rows)
   int64_t r = cdiv(M, 256);
-  return (int)(r < 1 ? 1 : (r > 1024 ? 1024 : r));
+  return (int)(r < 1 ? 1 : (r > cap ? cap : r));
 }
 
 static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld, const void* g1, int64_t g1_ld,
