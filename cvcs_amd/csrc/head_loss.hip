@@ -209,9 +209,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const char* x, int64_t x_
 // lane instead of eight 4-byte LDS writes), dW runs on the bf16 MFMA: B = x [32 pixels][16 channels] by transposed LDS
 // reads (ds_read_b64_tr_b16), A = dl^T [16 classes][32 pixels] from the f32 dl tile in LDS (two 16-byte reads per lane and
 // K-step, in exactly the pixel order the transposed reads deliver), split into a bf16 head and a bf16 remainder (dl = hi + lo
-// to 2^-17: two MFMAs, products exact to that) - x is exactly bf16 already.  dx stays on the exact-f32 MFMA.
+// to 2^-17: two MFMAs, products exact to that) - x is exactly bf16 already.  dx runs on the bf16 MFMA too, with both of ITS
+// operands split (below).
 constexpr int kXPitch = kHeadC * 2 + 16;   // bytes: a pixel row of the bf16 x / dx tile
 constexpr int kSdPitch4 = 68;              // floats: a class row of the dl tile (16-byte aligned rows, conflict-free b128 reads)
+constexpr int kSdpPitch = kMaxNC + 4;      // floats: a pixel row of the pixel-major copy of the dl tile (16-byte aligned rows)
 __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P,
                                                            int64_t HW, const float* __restrict__ w, int NC, char* dx,
                                                            int64_t dx_ld, float* part) {
@@ -219,16 +221,32 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   __shared__ __attribute__((aligned(16))) char sx[kDwTile * kXPitch];
   __shared__ __attribute__((aligned(16))) float sd[kMaxNC * kSdPitch4];
+  __shared__ __attribute__((aligned(16))) float sdp[kDwTile * kSdpPitch];   // the same dl tile, pixel-major (dx B operand)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int ncb = (NC + 15) / 16;
-  const int nks = (NC + 3) / 4;
   for (int i = tid; i < kMaxNC * kSdPitch4; i += 256) sd[i] = 0.f;   // class rows >= NC stay zero
-  float wa[kMaxNC / 4];                            // A fragments of dx: w[class 4s+fg][channel 16*wave+fr]
+  for (int i = tid; i < kDwTile * kSdpPitch; i += 256) sdp[i] = 0.f;
+  // dx = w^T dl on the bf16 MFMA with both operands split into a bf16 head and a bf16 remainder (exact to 2^-17, the
+  // result is stored as bf16): one K = 32 instruction contracts 16 classes TWICE - k-groups 0,1 hold the heads of dl,
+  // k-groups 2,3 the remainders of the same classes, against the same w values - so w_head x (dl_head + dl_rem) is one
+  // MFMA and w_rem x (...) a second (the exact-f32 MFMA took 16 instructions of 32 cycles per 64-pixel tile, and a
+  // third of this kernel's time).  A fragment: lane (fr = channel, fg) holds classes cb*16 + (fg & 1)*8 + 0..7.
+  bf16x8 wah[kMaxNC / 16], wal[kMaxNC / 16];
 #pragma unroll
-  for (int s = 0; s < kMaxNC / 4; ++s) {
-    const int c = 4 * s + fg;
-    wa[s] = c < NC ? w[c * kHeadC + wave * 16 + fr] : 0.f;
+  for (int cb = 0; cb < kMaxNC / 16; ++cb) {
+    float f[8], hf[8], rem[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cb * 16 + (fg & 1) * 8 + i;
+      f[i] = c < NC ? w[c * kHeadC + wave * 16 + fr] : 0.f;
+    }
+    const uint4 head = Elem<bf16_t>::pack(f);
+    Elem<bf16_t>::unpack(head, hf);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rem[i] = f[i] - hf[i];
+    wah[cb] = __builtin_bit_cast(bf16x8, head);
+    wal[cb] = __builtin_bit_cast(bf16x8, Elem<bf16_t>::pack(rem));
   }
   f32x4 acc[kMaxNC / 16];
 #pragma unroll
@@ -253,6 +271,7 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64
       if (c < NC) {
         const float v = dlb[(int64_t)c * HW + lane];
         sd[c * kSdPitch4 + lane] = v;
+        sdp[lane * kSdpPitch + c] = v;
         accb[k] += v;
       }
     }
@@ -280,14 +299,30 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64
           acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Elem<bf16_t>::pack(rem)), xf, acc[cb], 0, 0, 0);
         }
     }
-    // dx = w^T dl on the f32 MFMA
+    // dx = w^T dl (see the A fragments above): B fragment of lane (fr = pixel, fg) = eight classes of its pixel from the
+    // pixel-major tile, heads in k-groups 0,1 and remainders in k-groups 2,3
     f32x4 dxa[kDwTile / 16];
 #pragma unroll
     for (int nb = 0; nb < kDwTile / 16; ++nb) {
       dxa[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < kMaxNC / 4; ++s)
-        if (s < nks) dxa[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], sd[(4 * s + fg) * kSdPitch4 + nb * 16 + fr], dxa[nb], 0, 0, 0);
+      for (int cb = 0; cb < kMaxNC / 16; ++cb)
+        if (cb < ncb) {
+          const float* src = sdp + (nb * 16 + fr) * kSdpPitch + cb * 16 + (fg & 1) * 8;
+          const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+          const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const uint4 head = Elem<bf16_t>::pack(f);
+          float hf[8], rem[8];
+          Elem<bf16_t>::unpack(head, hf);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rem[k] = f[k] - hf[k];
+          const uint4 lo = Elem<bf16_t>::pack(rem);
+          const bool hi_lane = fg < 2;
+          const uint4 sel = make_uint4(hi_lane ? head.x : lo.x, hi_lane ? head.y : lo.y, hi_lane ? head.z : lo.z, hi_lane ? head.w : lo.w);
+          const bf16x8 bfrag = __builtin_bit_cast(bf16x8, sel);
+          dxa[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wah[cb], bfrag, dxa[nb], 0, 0, 0);
+          dxa[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wal[cb], bfrag, dxa[nb], 0, 0, 0);
+        }
     }
     __syncthreads();                               // every wave is done reading the x tile: reuse it as the dx staging tile
 #pragma unroll
