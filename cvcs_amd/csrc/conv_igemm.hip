@@ -451,7 +451,6 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
   // reads (with the barrier at the step end all 8 waves do, together).  Needs a 4-slot weight ring.  Measured +1.3 %
   // on the conv family of bench.py (the kernel is within ~10 % of the guide's best plain GEMM: the rest is not here).
   static_assert(!PIPE || (TPS == 3 && MREP == 4 && NW == 8), "the pipelined loop is written for the 8-wave bf16 kernel");
-  constexpr int NSLOT = PIPE ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;                     // [2][A_BYTES]
   char* sB = smem + 2 * A_BYTES;       // [NSLOT][B_BYTES]
@@ -915,7 +914,6 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
         // registers serves both operands).  f32 accumulation of exact bf16 products; M2 = sum x^2 - (sum x)^2 / n per
         // 256-pixel tile, merged across tiles by Chan's formula in f64 (bn_finalize).
         typedef __attribute__((ext_vector_type(4))) short s16x4;
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
         const int q = fr >> 2, pp = fr & 3;
         const char* base = smem + (wave * 16) * ES + pp * 8;
         const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));

@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const char* x, int64
                                                            int64_t HW, const float* __restrict__ w, int NC, char* dx,
                                                            int64_t dx_ld, float* part) {
   typedef __attribute__((ext_vector_type(4))) short s16x4;
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
   __shared__ __attribute__((aligned(16))) char sx[kDwTile * kXPitch];
   __shared__ __attribute__((aligned(16))) float sd[kMaxNC * kSdPitch4];
   __shared__ __attribute__((aligned(16))) float sdp[kDwTile * kSdpPitch];   // the same dl tile, pixel-major (dx B operand)
