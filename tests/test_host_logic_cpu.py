@@ -126,3 +126,38 @@ def test_parameter_count_and_state_dict_layout(variant, NC, count):
     ref = O.init_params(variant, NC, seed=0)
     assert set(k for k in sd if not k.endswith("num_batches_tracked")) == set(ref)
     assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+
+
+def test_host_only_c_abi_sizing_functions():
+    """the sizing entry points of the C-ABI are pure host code (no device call): partial-statistics rows of a conv launch
+    (include/cvcs_hip.h cvcs_conv_stat_rows), split-K slices of a weight gradient (cvcs_wgrad_slices), the row counts of
+    the two-pass reductions - checked for every layer shape of the bench workload and for ragged ones."""
+    import ctypes as C
+    from cvcs_amd import _lib
+    lib = _lib.lib()
+    for dtype, per_tile in ((_lib.BF16, 1), (_lib.F32, 4)):
+        for (B, H, W, Cin, Cout) in ((32, 512, 512, 64, 64), (32, 256, 256, 128, 128), (2, 40, 24, 64, 128), (1, 17, 33, 64, 64)):
+            d = _lib.ConvDesc()
+            d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, H, W, Cout
+            d.KH, d.KW, d.stride, d.pad, d.dil, d.dtype = 3, 3, 1, 1, 1, dtype
+            tiles = B * -(-H // 16) * -(-W // 16)
+            assert lib.cvcs_conv_stat_rows(C.byref(d)) == tiles * per_tile   # one row per 16x16 tile (bf16) / per wave row group (f32)
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 2, 8, 8, 128, 8, 8, 256
+        d.KH, d.KW, d.stride, d.pad, d.dil, d.dtype = 1, 1, 1, 0, 1, dtype
+        assert lib.cvcs_conv_stat_rows(C.byref(d)) == 2 * -(-2 * 8 * 8 // 128)     # generic kernel: two rows per 128-pixel tile
+    bad = _lib.ConvDesc()
+    assert lib.cvcs_conv_stat_rows(C.byref(bad)) < 0
+    # every layer of Unetv2 at B=32, S=512 (3x3 convs and the four 2x2/s2 ConvTranspose gradients): at least one slice, never
+    # more slices than K-tiles, and the workspace of the deepest layer stays small (few slices where there are many tiles)
+    for (S, Cin, Cout, K, stride) in ((512, 32, 64, 3, 1), (512, 64, 64, 3, 1), (512, 128, 64, 3, 1), (256, 128, 128, 3, 1),
+                                      (64, 512, 512, 3, 1), (32, 1024, 1024, 3, 1), (32, 512, 1024, 2, 2), (256, 64, 128, 2, 2)):
+        n = lib.cvcs_wgrad_slices(32, S, S, Cout, Cin, K, K, stride)
+        assert 1 <= n <= 32 * S * S // 32
+        if Cin * Cout >= 512 * 512:
+            assert n <= 8
+    assert lib.cvcs_wgrad_slices(0, 8, 8, 64, 64, 3, 3, 1) < 0 and lib.cvcs_wgrad_slices(1, 8, 8, 32, 64, 3, 3, 1) < 0
+    for M in (1, 255, 256, 257, 1 << 23):
+        assert lib.cvcs_bn_bwd_rows(M) == min(1024, max(1, -(-M // 256)))
+        assert lib.cvcs_head_bwd_rows(M) == min(1024, max(1, -(-M // 64)))
+        assert lib.cvcs_ce_workspace_floats(M) == 2 + 2 * min(4096, max(1, -(-M // 1024)))
