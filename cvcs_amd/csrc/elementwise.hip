@@ -293,8 +293,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
           s0[k] += dz;
           s1[k] += dz * xh;
         } else {
+#ifdef CVCS_PROBE_BN_COPY   // scripts/bn_probe.py ablation: the same traffic with (almost) no arithmetic
+          float d = gv[w][k] + yv[w][k];
+          (void)xh; (void)dz;
+#else
           float d = sc[k] * (dz - ca[k] - xh * cb[k]);
           if (p.mode == 1) d = (yv[w][k] > 0.f) ? d : 0.f;                  // decoder: ReLU before BN
+#endif
           out[k] = d;
           s0[k] += d;
         }
