@@ -30,6 +30,10 @@ class ConvDesc(C.Structure):
         ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p),
         ("Cin_valid", C.c_int32),
         ("pool_out", C.c_void_p), ("pool_ld", C.c_int64),
+        ("bwd_y", C.c_void_p), ("bwd_y_ld", C.c_int64),
+        ("bwd_scale", C.c_void_p), ("bwd_shift", C.c_void_p), ("bwd_mean", C.c_void_p), ("bwd_invstd", C.c_void_p),
+        ("bwd_mode", C.c_int32),
+        ("bwd_part_dz", C.c_void_p), ("bwd_part_dzx", C.c_void_p),
     ]
 
 
@@ -115,7 +119,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 2:
+        if h.cvcs_abi_version() != 3:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -43,6 +43,11 @@ struct ConvArgs {
   int relu, pixel_shuffle;
   int M;
   int tiles_x, tiles_y;   // halo kernel: 16x16 output tiles per image
+  // halo kernel (bf16): fused first pass of the BatchNorm backward that consumes `out` (NULL bwd_y = none)
+  const char* bwd_y; int64_t bwd_y_ld;
+  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
+  float* bwd_p0; float* bwd_p1;
+  int bwd_mode;
 };
 
 template <typename T> struct Mma;
@@ -853,6 +858,26 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
   // statistics from the staged tile: pixels outside the image are staged as zeros (only border tiles pay the selects)
   const bool zero_oob = MSTATS && p.stat_sum != nullptr && !(ny == MREP && nx == 16);
   f32x4 ssum = (f32x4){0.f, 0.f, 0.f, 0.f}, ssq = (f32x4){0.f, 0.f, 0.f, 0.f};   // MFMA statistics, both half tiles
+  // fused BatchNorm-backward reduce (bf16, below): the saved activation is fetched NOW, before the tile is staged, so that the
+  // HBM latency runs under the staging and the store walk instead of at the end of the workgroup's life (fetched there, the
+  // nine launches that carry it ran 22 % longer: the wide kernel has no second workgroup on its CU to hide behind)
+  // (not in the three-workgroup narrow kernel: its 168 registers do not hold eight more pieces across the staging without
+  // spilling inside the main loop, and its two neighbour workgroups cover the latency anyway - it fetches in the store walk)
+  constexpr bool BW_EARLY = (ES == 2) && !PACKED;
+  constexpr int BW_ITERS = (ES == 2) ? 8 : 1;
+  u32x4 bwd_yv[BW_ITERS];
+  if constexpr (BW_EARLY) {
+    if (p.bwd_y) {
+      constexpr int RPT_ = NT / CPR, RPI_ = RPT_ / 16;
+      const int lr = tid / CPR, cq = tid - lr * CPR;
+      const int xq = tx0 + (lr & 15), yq = ty0 + (lr >> 4);
+      const char* ysrc = p.bwd_y + ((img_base + (int64_t)yq * p.W + xq) * p.bwd_y_ld + n0) * ES + cq * 16;
+      const int64_t ystep = (int64_t)RPI_ * p.W * p.bwd_y_ld * ES;
+#pragma unroll
+      for (int k = 0; k < BW_ITERS; ++k)
+        bwd_yv[k] = (yq + k * RPI_ < p.H && xq < p.W) ? *reinterpret_cast<const u32x4*>(ysrc + k * ystep) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
 #pragma unroll 1
   for (int h = 0; h < NPASS; ++h) {
     if (NPASS == 1 || (wm * MREP) / PR == h) {
@@ -965,13 +990,78 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
       }
-      if (ty0 + 16 <= p.H && tx0 + 16 <= p.W) {
+      const bool full = ty0 + 16 <= p.H && tx0 + 16 <= p.W;
+      if (full) {
 #pragma unroll
         for (int k = 0; k < ITERS; ++k) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
       } else {
 #pragma unroll
         for (int k = 0; k < ITERS; ++k)
           if (y0 + k * RPI < p.H && x < p.W) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
+      }
+      if constexpr (ES == 2) {
+        if (p.bwd_y) {
+          // ---- fused first pass of the BatchNorm backward that consumes this output (cvcs_bn_bwd_reduce): the lane still holds
+          // its ITERS (pixel, 8-channel) pieces of the gradient AS STORED; the saved activation comes in with the store's own
+          // address pattern.  dz = g (mode 1) | g * [scale*y + shift > 0] (mode 0); sums of dz and dz * xhat per channel.
+          float sc[8], sh[8], ia[8], ib[8];      // xhat = y * ia + ib
+          {
+            const int nb = n0 + c * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(p.bwd_scale + nb), a1 = *reinterpret_cast<const float4*>(p.bwd_scale + nb + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bwd_shift + nb), b1 = *reinterpret_cast<const float4*>(p.bwd_shift + nb + 4);
+            const float4 m0 = *reinterpret_cast<const float4*>(p.bwd_mean + nb), m1 = *reinterpret_cast<const float4*>(p.bwd_mean + nb + 4);
+            const float4 i0 = *reinterpret_cast<const float4*>(p.bwd_invstd + nb), i1 = *reinterpret_cast<const float4*>(p.bwd_invstd + nb + 4);
+            const float scv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, shv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const float muv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, isv[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = scv[e]; sh[e] = shv[e]; ia[e] = isv[e]; ib[e] = -muv[e] * isv[e]; }
+          }
+          float s0[8], s1[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+          const bool masked = p.bwd_mode == 0;   // wave-uniform
+          static_assert(ITERS == BW_ITERS, "the activation pieces fetched before staging follow the store walk");
+          const char* ysrc = p.bwd_y + ((img_base + (int64_t)y0 * p.W + x) * p.bwd_y_ld + n0) * ES + c * 16;
+          const int64_t ystep = (int64_t)RPI * p.W * p.bwd_y_ld * ES;
+#pragma unroll
+          for (int k0 = 0; k0 < ITERS; k0 += 4) {
+            if constexpr (!BW_EARLY) {     // four rows at a time, their loads in flight together
+#pragma unroll
+              for (int k = k0; k < k0 + 4; ++k)
+                bwd_yv[k] = (full || (y0 + k * RPI < p.H && x < p.W)) ? *reinterpret_cast<const u32x4*>(ysrc + k * ystep) : (u32x4){0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int k = k0; k < k0 + 4; ++k) {
+              const bool ok = full || (y0 + k * RPI < p.H && x < p.W);
+              float gf[8], yf[8];
+              Elem<T>::unpack(make_uint4(v[k].x, v[k].y, v[k].z, v[k].w), gf);
+              Elem<T>::unpack(make_uint4(bwd_yv[k].x, bwd_yv[k].y, bwd_yv[k].z, bwd_yv[k].w), yf);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float dz = ok ? gf[e] : 0.f;
+                if (masked) dz = (yf[e] * sc[e] + sh[e] > 0.f) ? dz : 0.f;
+                s0[e] += dz;
+                s1[e] += dz * (yf[e] * ia[e] + ib[e]);
+              }
+            }
+          }
+          // lanes that share the chunk c (NT / CPR row lanes) are merged through the staging area, which every lane has
+          // finished reading (the barrier below) - [row lane][BN] floats, twice
+          __syncthreads();
+          float* r0 = reinterpret_cast<float*>(smem);
+          float* r1 = r0 + (NT / CPR) * BN;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { r0[lrow0 * BN + c * 8 + e] = s0[e]; r1[lrow0 * BN + c * 8 + e] = s1[e]; }
+          __syncthreads();
+          if (tid < BN) {
+            float a = 0.f, b2 = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < NT / CPR; ++q) { a += r0[q * BN + tid]; b2 += r1[q * BN + tid]; }
+            const int64_t o = (int64_t)blockIdx.x * p.Cout + n0 + tid;
+            p.bwd_p0[o] = a;
+            p.bwd_p1[o] = b2;
+          }
+        }
       }
     }
     if (p.pool) {
@@ -1279,6 +1369,16 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     CVCS_CHECK_ARG(use_halo(d) && d->Ho % 2 == 0 && d->Wo % 2 == 0, "cvcs_conv2d: fused pooling needs a 3x3/s1/p1 conv on an even map of at least 8 pixels");
     CVCS_CHECK_ARG(((uintptr_t)d->pool_out % 16) == 0 && d->pool_ld >= d->Cout && (d->pool_ld * es) % 16 == 0, "cvcs_conv2d: pool_out view");
     CVCS_CHECK_ARG(!d->stat_sum, "cvcs_conv2d: fused pooling is an eval-mode feature (no statistics)");
+  }
+  a.bwd_y = (const char*)d->bwd_y; a.bwd_y_ld = d->bwd_y_ld; a.bwd_scale = d->bwd_scale; a.bwd_shift = d->bwd_shift;
+  a.bwd_mean = d->bwd_mean; a.bwd_invstd = d->bwd_invstd; a.bwd_p0 = d->bwd_part_dz; a.bwd_p1 = d->bwd_part_dzx; a.bwd_mode = d->bwd_mode;
+  if (d->bwd_y) {
+    CVCS_CHECK_ARG(use_halo(d) && d->dtype == CVCS_BF16, "cvcs_conv2d: the fused BatchNorm-backward reduce is built for bf16 3x3 / stride 1 / pad 1 launches");
+    CVCS_CHECK_ARG(d->bwd_scale && d->bwd_shift && d->bwd_mean && d->bwd_invstd && d->bwd_part_dz && d->bwd_part_dzx,
+                   "cvcs_conv2d: bwd_y needs its four per-channel vectors and both partial-sum buffers");
+    CVCS_CHECK_ARG(d->bwd_mode == 0 || d->bwd_mode == 1, "cvcs_conv2d: bwd_mode");
+    CVCS_CHECK_ARG(((uintptr_t)d->bwd_y % 16) == 0 && d->bwd_y_ld >= d->Cout && (d->bwd_y_ld * es) % 16 == 0, "cvcs_conv2d: bwd_y view");
+    CVCS_CHECK_ARG(!d->stat_sum && !d->pool_out && !d->pre_scale && !d->post_scale, "cvcs_conv2d: bwd_y excludes statistics, pooling and the folds");
   }
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;

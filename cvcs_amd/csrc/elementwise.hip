@@ -767,7 +767,7 @@ extern "C" int cvcs_bn_bwd_finalize(const float* part_dz, const float* part_dzx,
                                     const float* save_invstd, float* dgamma, float* dbeta, float* coef_a, float* coef_b,
                                     void* stream) {
   CVCS_CHECK_ARG(part_dz && part_dzx && dgamma && dbeta && coef_a && coef_b && C > 0 && M > 0, "cvcs_bn_bwd_finalize: null argument");
-  CVCS_CHECK_ARG(rows == cvcs_bn_bwd_rows(M), "cvcs_bn_bwd_finalize: rows");
+  CVCS_CHECK_ARG(rows >= 1 && rows <= 4096, "cvcs_bn_bwd_finalize: rows=%d out of [1,4096]", rows);
   CVCS_CHECK_ARG(C % 16 == 0, "cvcs_bn_bwd_finalize: C %% 16 != 0");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)(C / 16)), dim3(16 * kRL), 0, (hipStream_t)stream, part_dz, part_dzx,
                      rows, M, C, gamma, save_invstd, dgamma, dbeta, coef_a, coef_b);

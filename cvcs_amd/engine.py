@@ -63,6 +63,11 @@ class UNetEngine:
         # mostly just share the matrix pipes); off by default because it blurs per-kernel timing attribution
         # (CVCS_OVERLAP_WGRAD=1 switches it on).
         self.overlap_wgrad = os.environ.get("CVCS_OVERLAP_WGRAD", "0") == "1"
+        # the data gradient of the conv above an enc_L.0 / dec_L.0 block also takes the first pass of that block's BatchNorm backward
+        self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"
+        # ... where that launch runs the three-workgroup narrow kernel (64-channel blocks: +0.6 % on the step); on the wide kernel,
+        # one workgroup per CU, nothing hides the longer epilogue and the step got 0.6 % slower (tuning knobs)
+        self.fuse_bn_bwd_c = (int(os.environ.get("CVCS_FUSE_BN_BWD_MINC", "0")), int(os.environ.get("CVCS_FUSE_BN_BWD_MAXC", "64")))
         self._side = None
         self._side_event = None
 
@@ -301,17 +306,38 @@ class UNetEngine:
         return labels
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _bn_backward(self, bnname, conv, y, g1: View, g2, mode, dy):
-        """two-pass BN(+ReLU)(+pool) backward; fills dgamma, dbeta, conv-bias gradient; writes dy."""
+    def _fused_reduce(self, bnname, y, mode):
+        """argument of ops.conv2d(bn_bwd=...) for the data-gradient launch whose output is the gradient this BatchNorm
+        consumes - or None where the reduce pass stays its own launch (f32, maps under 8 pixels, CVCS_FUSE_BN_BWD=0)"""
+        yv = ops.view(y)
+        if not self.fuse_bn_bwd or self.dtype != torch.bfloat16 or yv.H < 8 or yv.W < 8:
+            return None
+        if not (self.fuse_bn_bwd_c[0] <= yv.C <= self.fuse_bn_bwd_c[1]):
+            return None
+        st = self.bn[bnname]
+        return (yv, st.scale, st.shift, st.mean, st.invstd, mode, self.stat_sum, self.stat_m2)
+
+    def _bn_backward(self, bnname, conv, y, g1: View, g2, mode, dy, fused=False):
+        """two-pass BN(+ReLU)(+pool) backward; fills dgamma, dbeta, conv-bias gradient; writes dy.
+        fused: the first pass was taken by the launch that produced g1 (one partial row per 16x16 tile in
+        stat_sum / stat_m2); only the row reduction is left of it."""
         st = self.bn[bnname]
         yv = ops.view(y)
         M = yv.B * yv.H * yv.W
         C_ = yv.C
         rows = ops.bn_bwd_rows(M)
         p0, p1, p2 = (p[:rows * C_] for p in self.part)
-        ops.bn_bwd_reduce(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
-        ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[bnname + ".weight"], st.invstd, self.G[bnname + ".weight"],
-                            self.G[bnname + ".bias"], st.ca, st.cb)
+        if fused:
+            trows = yv.B * ((yv.H + 15) // 16) * ((yv.W + 15) // 16)
+            rows1 = ops.bn_bwd_rows(trows)
+            for src, dst in ((self.stat_sum, p0), (self.stat_m2, p1)):
+                ops.colsum_partial(View(src[:trows * C_].view(1, trows, 1, C_), 0, C_), dst[:rows1 * C_])
+            ops.bn_bwd_finalize(p0, p1, rows1, M, C_, self.P[bnname + ".weight"], st.invstd, self.G[bnname + ".weight"],
+                                self.G[bnname + ".bias"], st.ca, st.cb)
+        else:
+            ops.bn_bwd_reduce(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
+            ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[bnname + ".weight"], st.invstd, self.G[bnname + ".weight"],
+                                self.G[bnname + ".bias"], st.ca, st.cb)
         if self.sync_bn is not None:
             # dgamma / dbeta stay this rank's sums (the gradient all-reduce adds them up); the two coefficients of
             # pass 2 are means over every rank's pixels
@@ -339,7 +365,8 @@ class UNetEngine:
             self._side_event = torch.cuda.Event()
             self._side_event.record(self._side)
 
-    def _conv_backward(self, conv, x: View, dy, gin: View | None, cin_real=None, colsum_of: View | None = None, colsum_out=None):
+    def _conv_backward(self, conv, x: View, dy, gin: View | None, cin_real=None, colsum_of: View | None = None, colsum_out=None,
+                       bn_bwd=None):
         """weight and data gradient of a 3x3 conv.  colsum_of: a channel range of `gin` (the up-sampled half of a concat
         gradient) whose per-channel sum over pixels - the bias gradient of the up-conv that produced it - is wanted: the
         dgrad launch emits the column sums of its output through the statistics epilogue, no extra pass over the tensor."""
@@ -348,8 +375,9 @@ class UNetEngine:
         if gin is None:
             return
         if colsum_of is None:
-            ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1)
+            ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, bn_bwd=bn_bwd)
             return
+        assert bn_bwd is None
         C2 = gin.C
         rows = ops.conv_stat_rows(dyv, C2, 3, 3, 1, 1)
         ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, stats=(self.stat_sum, self.stat_m2, self.stat_cnt))
@@ -391,8 +419,9 @@ class UNetEngine:
             pre = f"decode_forward{d}.0.layer"
             _, up_v, gskip_v, gup_v = self._skip_up(d)
             self._bn_backward(pre + ".5", pre + ".3", self.rb[d], g, None, 1, self.ddy_b[d])
-            self._conv_backward(pre + ".3", ops.view(self.za[d]), self.ddy_b[d], ops.view(self.g_za[d]))
-            self._bn_backward(pre + ".2", pre + ".0", self.ra[d], ops.view(self.g_za[d]), None, 1, self.ddy_a[d])
+            fz = self._fused_reduce(pre + ".2", self.ra[d], 1)
+            self._conv_backward(pre + ".3", ops.view(self.za[d]), self.ddy_b[d], ops.view(self.g_za[d]), bn_bwd=fz)
+            self._bn_backward(pre + ".2", pre + ".0", self.ra[d], ops.view(self.g_za[d]), None, 1, self.ddy_a[d], fused=fz is not None)
             key = f"upscale{d}.0" if self.variant == "Unetv2" else f"upscale{d}.0.layer.1"
             self._conv_backward(pre + ".0", ops.view(self.cat[L]), self.ddy_a[d], ops.view(self.g_cat[L]),
                                 colsum_of=gup_v, colsum_out=self.G[key + ".bias"])
@@ -418,9 +447,11 @@ class UNetEngine:
             else:
                 g1, g2 = self._skip_up(5 - L)[2], ops.view(self.g_pool[L])
             self._bn_backward(f"encode{L}.{base + 1}.layer.1", cb, self.yb[L], g1, g2, 0, self.dy_b[L])
-            self._conv_backward(cb, ops.view(self.aa[L]), self.dy_b[L], ops.view(self.g_aa[L]))
+            fz = self._fused_reduce(f"encode{L}.{base}.layer.1", self.ya[L], 0)
+            self._conv_backward(cb, ops.view(self.aa[L]), self.dy_b[L], ops.view(self.g_aa[L]), bn_bwd=fz)
             ready(cb + ".weight")
-            self._bn_backward(f"encode{L}.{base}.layer.1", ca, self.ya[L], ops.view(self.g_aa[L]), None, 0, self.dy_a[L])
+            self._bn_backward(f"encode{L}.{base}.layer.1", ca, self.ya[L], ops.view(self.g_aa[L]), None, 0, self.dy_a[L],
+                              fused=fz is not None)
             if L == 1:
                 self._conv_backward(ca, ops.view(self.in0), self.dy_a[L], None, cin_real=3)
             else:

@@ -133,10 +133,22 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
-           pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None):
+           pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None,
+           bn_bwd=None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
-    stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...)."""
+    stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...).
+    bn_bwd = (y view, scale, shift, mean, invstd, mode, part_dz, part_dzx): the launch also takes the first pass of the
+    BatchNorm backward that consumes `out` (bf16 3x3 / stride 1 / pad 1; one partial row per 16x16 tile)."""
     d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats)
+    if bn_bwd is not None:
+        yv, bsc, bsh, bmu, bis, bmode, p0, p1 = bn_bwd
+        rows = conv_stat_rows(x, Cout, KH, KW, stride, pad)
+        assert (yv.B, yv.H, yv.W, yv.C) == (x.B, Ho, Wo, Cout) and yv.t.dtype == x.t.dtype
+        assert p0.numel() >= rows * Cout and p1.numel() >= rows * Cout and p0.dtype == torch.float32
+        d.bwd_y, d.bwd_y_ld = yv.ptr, yv.ld
+        d.bwd_scale, d.bwd_shift, d.bwd_mean, d.bwd_invstd = bsc.data_ptr(), bsh.data_ptr(), bmu.data_ptr(), bis.data_ptr()
+        d.bwd_mode = bmode
+        d.bwd_part_dz, d.bwd_part_dzx = p0.data_ptr(), p1.data_ptr()
     # eval-mode BatchNorm folded into the epilogue: (scale, shift) before / after the ReLU
     if pre_affine is not None:
         d.pre_scale, d.pre_shift = pre_affine[0].data_ptr(), pre_affine[1].data_ptr()

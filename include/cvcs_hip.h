@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 2
+#define CVCS_ABI_VERSION 3
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -70,6 +70,17 @@ typedef struct {
    * Eval mode only needs it (in train mode the pooling is part of the BatchNorm-apply pass); 3x3 / stride 1 / pad 1
    * convolutions on maps of at least 8 pixels with even Ho, Wo.                                                   */
   void* pool_out;   int64_t pool_ld;
+  /* optional fused FIRST pass of the BatchNorm backward that consumes this launch's output (cvcs_bn_bwd_reduce without its
+   * own sweep over the tensors; bf16 3x3 / stride 1 / pad 1 launches, i.e. the data gradient of the conv ABOVE a
+   * conv->BN->ReLU (mode 0) or conv->ReLU->BN (mode 1) block, S/blocks.py:13-17 / :40-45).  `out` is the gradient g w.r.t.
+   * that block's output; bwd_y [B, Ho, Wo, Cout] is the block's saved conv output (mode 1: after the ReLU), leading
+   * dimension bwd_y_ld; the four per-channel vectors are those of cvcs_bn_bwd_reduce.  Written: one partial row per
+   * 16x16 output tile (cvcs_conv_stat_rows rows x Cout floats each) of sum(dz) and sum(dz * xhat) taken over the values
+   * as STORED (bf16), which cvcs_colsum_partial + cvcs_bn_bwd_finalize reduce.  NULL bwd_y = none.                 */
+  const void* bwd_y;   int64_t bwd_y_ld;
+  const float* bwd_scale;  const float* bwd_shift;  const float* bwd_mean;  const float* bwd_invstd;
+  int32_t bwd_mode;
+  float* bwd_part_dz;  float* bwd_part_dzx;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
@@ -123,7 +134,8 @@ int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C,
 /* BatchNorm(+ReLU)(+MaxPool) backward, two passes over (y, g):
  *   mode 0 (encoder, a = relu(bn(y))): dz = (g1 + unpool(g2)) * (a > 0);  mode 1 (decoder, z = bn(r), r = relu(conv)):
  *   dz = g1, and the ReLU mask (r > 0) is applied to the result.
- * pass 1 -> partial sums of dz and dz*xhat ([rows][C] each, rows = cvcs_bn_bwd_rows(B*H*W));
+ * pass 1 -> partial sums of dz and dz*xhat ([rows][C] each, rows = cvcs_bn_bwd_rows(B*H*W); or taken by the conv
+ *           launch that produced g1 - cvcs_conv_desc.bwd_y - and reduced to at most 1024 rows by cvcs_colsum_partial);
  * cvcs_bn_bwd_finalize -> dgamma, dbeta and the two per-channel coefficients;
  * pass 2 -> dy (gradient w.r.t. the conv output) and partial column sums of dy (conv bias gradient).        */
 int cvcs_bn_bwd_rows(int64_t M);

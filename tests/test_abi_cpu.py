@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.cvcs_abi_version() == 2
+    assert lib.cvcs_abi_version() == 3
     # argument validation happens on the host, before any HIP call: usable without a GPU
     assert lib.cvcs_conv2d(None, None) == -1
     assert b"null descriptor" in lib.cvcs_last_error()

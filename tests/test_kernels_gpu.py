@@ -236,6 +236,44 @@ def test_conv_dgrad_through_flipped_weights(dtype):
     close(from_nhwc(gin), x.grad.float(), tol(dtype), "dgrad")
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 32, 48, 64, 64), (1, 24, 40, 128, 128), (2, 20, 36, 128, 64), (1, 16, 16, 64, 256)])
+def test_conv_launch_takes_the_first_pass_of_the_batchnorm_backward(shape, mode):
+    """cvcs_conv_desc.bwd_y: the data-gradient launch above a conv->BN->ReLU (mode 0) / conv->ReLU->BN (mode 1) block
+    (S/blocks.py:13-17, :40-45) also sums dz and dz * xhat of that block over the gradient it stores - compared with
+    cvcs_bn_bwd_reduce on the stored output, and the output itself with the plain launch (bit for bit)."""
+    B, H, W, Cin, Cout = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(31 + mode)
+    gy = rq(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = rq(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype)
+    xin = ops.view(to_nhwc(gy, dtype))
+    y = torch.randn(B, H, W, Cout, generator=g)
+    if mode == 1:
+        y = y.relu()
+    y = y.to(dtype).to(DEV)
+    scale, shift, mean, invstd = (torch.randn(Cout, generator=g).to(DEV) for _ in range(4))
+    invstd = invstd.abs() + 0.5
+    plain = torch.empty(B, H, W, Cout, dtype=dtype, device=DEV)
+    ops.conv2d(xin, wf, None, ops.view(plain), 3, 3, 1, 1)
+    rows = ops.bn_bwd_rows(B * H * W)
+    r0, r1 = torch.zeros(rows * Cout, device=DEV), torch.zeros(rows * Cout, device=DEV)
+    ops.bn_bwd_reduce(ops.view(y), ops.view(plain), None, scale, shift, mean, invstd, mode, r0, r1)
+    trows = ops.conv_stat_rows(xin, Cout, 3, 3, 1, 1)
+    assert trows == B * ((H + 15) // 16) * ((W + 15) // 16)
+    p0, p1 = torch.full((trows * Cout,), float("nan"), device=DEV), torch.full((trows * Cout,), float("nan"), device=DEV)
+    fused = torch.empty_like(plain)
+    ops.conv2d(xin, wf, None, ops.view(fused), 3, 3, 1, 1, bn_bwd=(ops.view(y), scale, shift, mean, invstd, mode, p0, p1))
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain)
+    for got, ref, what in ((p0, r0, "sum dz"), (p1, r1, "sum dz*xhat")):
+        a = got.view(trows, Cout).double().sum(0).cpu()
+        b = ref.view(rows, Cout).double().sum(0).cpu()
+        assert torch.isfinite(a).all()
+        close(a, b, 1e-4, what)
+
+
 WGRAD_CASES = [
     # B, H, W, Cin(stored), Cin_real, Cout, K, stride, pad
     (2, 8, 40, 64, 64, 64, 3, 1, 1),     # TW=32 strips, ragged width
