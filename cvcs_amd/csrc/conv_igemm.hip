@@ -1389,7 +1389,10 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (use_halo(d)) {
     static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 64;   // tuning knob
-    const bool wide = d->Cout % 128 == 0 && !(d->dtype == CVCS_BF16 && d->Cin <= narrow_cin);
+    // a launch that carries the fused BatchNorm-backward reduce needs neighbours on its CU to hide the longer epilogue: up to
+    // narrow_bwd output channels it takes the three-workgroup narrow tiles (two column tiles for 128 channels)
+    static const int narrow_bwd = getenv("CVCS_HALO_NARROW_BWD") ? atoi(getenv("CVCS_HALO_NARROW_BWD")) : 128;    // tuning knob
+    const bool wide = d->Cout % 128 == 0 && !(d->dtype == CVCS_BF16 && (d->Cin <= narrow_cin || (d->bwd_y && d->Cout <= narrow_bwd)));
     static const int waves = getenv("CVCS_HALO_WAVES") ? atoi(getenv("CVCS_HALO_WAVES")) : 8;   // tuning knob (4 | 8)
     if (d->dtype == CVCS_F32) return wide ? launch_halo<float, 128, 4, 2, 1>(a, st) : launch_halo<float, 64, 4, 1, 3>(a, st);
     static const int pipe = getenv("CVCS_HALO_PIPE") ? atoi(getenv("CVCS_HALO_PIPE")) : 1;               // tuning knob

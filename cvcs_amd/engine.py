@@ -65,9 +65,9 @@ class UNetEngine:
         self.overlap_wgrad = os.environ.get("CVCS_OVERLAP_WGRAD", "0") == "1"
         # the data gradient of the conv above an enc_L.0 / dec_L.0 block also takes the first pass of that block's BatchNorm backward
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"
-        # ... where that launch runs the three-workgroup narrow kernel (64-channel blocks: +0.6 % on the step); on the wide kernel,
-        # one workgroup per CU, nothing hides the longer epilogue and the step got 0.6 % slower (tuning knobs)
-        self.fuse_bn_bwd_c = (int(os.environ.get("CVCS_FUSE_BN_BWD_MINC", "0")), int(os.environ.get("CVCS_FUSE_BN_BWD_MAXC", "64")))
+        # ... where that launch runs the three-workgroup narrow kernel (64- and 128-channel blocks: +0.6 % on the step each); on the
+        # wide kernel, one workgroup per CU, nothing hides the longer epilogue and the step got 0.6 % slower (tuning knobs)
+        self.fuse_bn_bwd_c = (int(os.environ.get("CVCS_FUSE_BN_BWD_MINC", "0")), int(os.environ.get("CVCS_FUSE_BN_BWD_MAXC", "128")))
         self._side = None
         self._side_event = None
 
