@@ -147,9 +147,15 @@ def main():
             c = timers["conv3x3_halo"]
             out["roofline"] = {"bound": "mfma", "achieved": round(c["tflops"], 2), "peak": PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3,
                                "unit": "TFLOP/s", "frac": round(c["tflops"] / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
-                               "traffic": None, "kernel": "conv3x3_halo_kernel (every 3x3 forward and data-gradient launch)",
+                               "traffic": None, "kernel": "conv3x3_halo_kernel (every 3x3 forward and data-gradient launch that is a convolution only; "
+                                                          "the launches that also carry a BatchNorm-backward reduce pass are reported as fused_conv)",
                                "launches_per_step": c["launches"] // a.steps, "avg_launch_us": round(c["avg_us"], 2),
                                "algorithmic_gflop_per_step": round(c["flops"] / a.steps / 1e9, 1)}
+            if "conv3x3_halo_bn_bwd" in timers:   # same kernel, plus the fused first pass of the BatchNorm backward below it
+                f = timers["conv3x3_halo_bn_bwd"]
+                out["fused_conv"] = {"kernel": "conv3x3_halo_kernel + fused BatchNorm-backward reduce (64- and 128-channel blocks; conv FLOPs only)",
+                                     "achieved": round(f["tflops"], 2), "unit": "TFLOP/s", "launches_per_step": f["launches"] // a.steps,
+                                     "avg_launch_us": round(f["avg_us"], 2), "algorithmic_gflop_per_step": round(f["flops"] / a.steps / 1e9, 1)}
             if "conv_igemm" in timers:   # ConvTranspose forward / data gradient on the non-overlapping-taps kernel
                 g = timers["conv_igemm"]
                 out["other_conv"] = {"kernel": "conv_taps_kernel (ConvTranspose forward + data gradient: short-K GEMMs, the shallow levels HBM-bound)",

@@ -167,7 +167,10 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         # same dispatch rule as cvcs_conv2d: 3x3 / stride 1 / pad 1 on maps of at least 8 pixels -> the halo kernel
         halo = KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1 and not pixel_shuffle and x.H >= 8 and x.W >= 8
         # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count
-        ev = TIMERS.bracket("conv3x3_halo" if halo else "conv_igemm", 2.0 * x.B * Ho * Wo * Cout * (cin_real or x.C) * KH * KW)
+        # launches that also carry the first pass of a BatchNorm backward are timed as their own family: their duration is not
+        # that of a convolution alone
+        fam = ("conv3x3_halo_bn_bwd" if bn_bwd is not None else "conv3x3_halo") if halo else "conv_igemm"
+        ev = TIMERS.bracket(fam, 2.0 * x.B * Ho * Wo * Cout * (cin_real or x.C) * KH * KW)
         ev[0].record()
     check(_lib.lib().cvcs_conv2d(C.byref(d), _stream()), "cvcs_conv2d")
     if TIMERS is not None:
