@@ -111,6 +111,10 @@ def lib():
     """Load (once) and return the ctypes handle; raises CvcsError if the HIP library is not built."""
     global _lib
     if _lib is None:
+        # torch first: its wheel bundles its own libamdhip64, and the HIP runtime that is loaded FIRST is the one this library
+        # binds to - loaded before torch, the system runtime and torch's would coexist in the process and the launches of
+        # this library would not see torch's device ("no ROCm-capable device is detected")
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise CvcsError(f"{LIB_PATH} not found: build it with `make -C cvcs_amd/csrc` "
                             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
