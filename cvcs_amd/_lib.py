@@ -60,6 +60,8 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "cvcs_last_error": (C.c_char_p, []),
     "cvcs_abi_version": (_i, []),
+    "cvcs_sizeof_conv_desc": (_i, []),
+    "cvcs_sizeof_wgrad_desc": (_i, []),
     "cvcs_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "cvcs_wgrad_slices": (_i, [_i] * 8),
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
@@ -125,6 +127,8 @@ def lib():
             fn.argtypes = args
         if h.cvcs_abi_version() != 3:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
+        if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
+            raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")
         _lib = h
     return _lib
 

@@ -33,6 +33,10 @@ enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
 
 const char* cvcs_last_error(void);
 int cvcs_abi_version(void);
+/* sizeof(cvcs_conv_desc) / sizeof(cvcs_wgrad_desc) as this library was compiled: a binding in another language checks its
+ * own struct declaration against them when it loads the library (cvcs_amd/_lib.py does)                            */
+int cvcs_sizeof_conv_desc(void);
+int cvcs_sizeof_wgrad_desc(void);
 /* number of split-K slices cvcs_conv2d_wgrad will use; workspace = slices*KH*KW*Cout*Cin floats */
 int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride);
 

@@ -33,6 +33,9 @@ def test_header_and_binding_agree(lib):
 
 def test_version_and_error_channel(lib):
     assert lib.cvcs_abi_version() == 3
+    import ctypes as C
+    from cvcs_amd import _lib
+    assert lib.cvcs_sizeof_conv_desc() == C.sizeof(_lib.ConvDesc) and lib.cvcs_sizeof_wgrad_desc() == C.sizeof(_lib.WgradDesc)
     # argument validation happens on the host, before any HIP call: usable without a GPU
     assert lib.cvcs_conv2d(None, None) == -1
     assert b"null descriptor" in lib.cvcs_last_error()
