@@ -12,5 +12,7 @@ rm -f $(find "$R/pF" "$R/pW" -name "*counter_collection.csv")
 python scripts/trace_summary.py $(find "$R/pA" -name "*kernel_trace.csv") > "$R/pA_summary.txt"
 rm -f $(find "$R/pA" -name "*kernel_trace.csv")
 cp "$R/pmc_traffic_new.json" profiles/r01_pmc_traffic_b32_s512_bf16.json   # bench.py quotes roofline.traffic from this file
+# (on a gpurun box only gpurun_out/ travels back: copy gpurun_out/pmc_traffic_new.json, pA/*kernel_stats.csv, pA_summary.txt and
+#  the bench lines into profiles/ in the repository afterwards)
 python bench.py > "$R/bench_new.log" 2>&1
 tail -1 "$R/bench_new.log" | cut -c1-200
