@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const float* __restrict__ 
                                                      float grad_scale, float* dlogits, float* ws, int R) {
   __shared__ float sbuf[4];
   const float den = ws[0];
-  const float gmul = grad_scale / den;
+  // every pixel ignored: the loss is 0/0 = NaN as in torch, but its gradient is ZERO (F.cross_entropy with an all-ignored
+  // target returns grad == 0; the reference's step S/train.py:121-126 then leaves the weights finite)
+  const float gmul = den > 0.f ? grad_scale / den : 0.f;
   float num = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / HW, hw = i - b * HW;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const float* __restrict__ 
       const float f = wt * gmul;
 #pragma unroll
       for (int c = 0; c < NCMAX; ++c)
-        if (c < NC) dp[c * HW] = f * (z[c] * inv_se - ((c == t) ? 1.f : 0.f));
+        if (c < NC) dp[c * HW] = valid ? f * (z[c] * inv_se - ((c == t) ? 1.f : 0.f)) : 0.f;   // (0 * inf/NaN logits stay 0)
     }
   }
   num = block_sum_256(num, sbuf);

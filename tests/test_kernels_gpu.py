@@ -493,6 +493,30 @@ def test_cross_entropy(NC, ignore, weighted, tdtype):
     close(dz.cpu(), zr.grad, 1e-5, "dlogits")
 
 
+def test_cross_entropy_all_pixels_ignored():
+    """every target == ignore_index: torch returns a NaN loss and a ZERO gradient (the reference's step S/train.py:121-126
+    then leaves the weights finite) - so must the fused launch, also with an external (sharded) denominator of 0."""
+    g = torch.Generator().manual_seed(1)
+    B, NC, H, W = 2, 5, 9, 11
+    z = torch.randn(B, NC, H, W, generator=g)
+    t = torch.zeros(B, H, W, dtype=torch.int64)
+    zr = z.clone().requires_grad_(True)
+    ref = F.cross_entropy(zr, t, ignore_index=0)
+    ref.backward()
+    assert torch.isnan(ref) and zr.grad.abs().max().item() == 0.0
+    P = B * H * W
+    for ext in (False, True):
+        loss = torch.zeros(1, device=DEV)
+        dz = torch.full((B, NC, H, W), 7.0, device=DEV)
+        ws = torch.zeros(ops.ce_workspace_floats(P), device=DEV)
+        if ext:
+            ops.ce_weight_sum(t.to(DEV), B, NC, None, 0, ws)
+        ops.ce_fwd_bwd(z.to(DEV), t.to(DEV), None, 0, 1.0, loss, dz, ws, external_denominator=ext)
+        torch.cuda.synchronize()
+        assert torch.isnan(loss).all() or ext, loss        # 0/0 like torch (sharded: this rank's share of a global mean)
+        assert dz.abs().max().item() == 0.0
+
+
 def test_argmax_and_confusion():
     """torch.max(dim=0) first-max ties (S/utils.py:90) + MulticlassConfusionMatrix(16, ignore_index=0) (S/utils.py:76-78)."""
     from oracle import unet_oracle as O
