@@ -1,34 +1,43 @@
 #!/usr/bin/env python3
 """bench.py - tiles/s of the per-tile TRAIN step (forward + loss + backward + optimiser) on N MI355X.
 
-Workload (BASELINE.json metric "512x512 tiles/sec (train fwd+bwd)"): the reference's own model `Unetv2`
-(source/scripts/nets.py:117-199; NC = 15+1 as in configs/train/server.yaml:36) at the shape of BASELINE
-configs[1]: batch 32 per GPU, 512x512 tiles, bf16 MFMA convolutions with f32 accumulation / f32 master weights,
-CrossEntropyLoss(ignore_index=0) + SGD2 - the exact step of source/scripts/train.py:121-126, through the same
-factory API (load_network / load_loss / load_optimizer).  Synthetic u8 tiles and labels are resident in HBM before
-the timed region.  BASELINE's "ResNet50-UNet" has no definition in the reference; see DESIGN.md.
+Workload (BASELINE.json metric "512x512 tiles/sec (train fwd+bwd)", configs[1] "ResNet50-UNet bf16, 512x512 tiles, batch 32,
+1xMI355X"): `Resnet50Unet` (ResNet-50 v1.5 encoder + bilinear-upsample U-Net decoder, NC = 15+1 classes as in the
+reference's configs/train/server.yaml:36) through the reference's factory API (load_network / load_loss / load_optimizer,
+source/scripts/utils.py:174-242), batch 32 per GPU, 512x512 u8 tiles, bf16 MFMA convolutions with f32 accumulation and f32
+master weights, CrossEntropyLoss(ignore_index=0) + SGD2 - the exact step of source/scripts/train.py:121-126.  Synthetic u8
+tiles and labels are resident in HBM before the timed region.
+`--net Unetv2` measures the reference's own U-Net at the same shape (the round-1 headline; kept as a second record).
 
-One process per GPU; for N > 1 launch through `python -m torch.distributed.run --nproc-per-node N ...` (RCCL).
+One process per GPU.  For N > 1 the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RCCL); a plain `python bench.py --gpus N` spawns exactly that as a CHILD process before anything touches the GPU.
 """
 import argparse
 import json
 import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b32_s512_bf16.json")  # scripts/pmc_traffic.py output
+PEAK_F32_TFLOPS = 157.3
+PMC_FILES = {"Resnet50Unet": "r02_pmc_traffic_resnet50unet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json"}
+FAMILY_KERNEL = {
+    "conv3x3_halo": "conv3x3_halo_kernel (3x3 / stride 1 forward and data-gradient launches; strided 3x3 data gradients run it on the zero-dilated gradient, counted at their algorithmic FLOPs)",
+    "conv3x3_halo_bn_bwd": "conv3x3_halo_kernel + fused BatchNorm-backward reduce pass (conv FLOPs only)",
+    "conv_taps": "conv_taps_kernel (non-overlapping taps: 1x1 forward / data gradient, ConvTranspose forward / data gradient)",
+    "conv_igemm": "conv_igemm_kernel (generic gather: strided convs, the 7x1 virtual-pixel stem, 1x1 with < 128 output channels)",
+    "wgrad": "wgrad_* kernels (all weight gradients, split-K reduce included)",
+    "wgrad_1x1": "wgrad_gemm_kernel (1x1 weight gradients as one transposed GEMM)",
+}
 
 
-def cpu_baseline(nc, tile, tiles, steps):
-    """the CPU oracle (torch fp32 restatement of the reference step) on a bounded sample of the same workload."""
-    from oracle import unet_oracle as O
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # honour a cgroup CPU quota (the GPU box gives 16 CPUs of a 256-thread host)
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -36,37 +45,63 @@ def cpu_baseline(nc, tile, tiles, steps):
             cores = max(1, min(cores, int(int(q) / int(p))))
     except Exception:
         pass
-    torch.set_num_threads(min(cores, 32))
+    return cores
+
+
+def cpu_baseline(net, nc, tile, tiles, steps):
+    """the CPU oracle (torch fp32 restatement of the same train step) on a bounded sample of the same workload"""
+    import torch
+    from oracle import resnet_unet_oracle as R
+    from oracle import unet_oracle as O
+    torch.set_num_threads(min(host_cores(), 32))
     img, lab = O.synthetic_tiles(tiles, tile, nc, seed=1234)
-    tr = O.OracleTrainer("Unetv2", nc, opt="SGD2", ignore_index=0, seed=0)
+    if net == "Unetv2":
+        tr, what = O.OracleTrainer("Unetv2", nc, opt="SGD2", ignore_index=0, seed=0), "oracle.unet_oracle (torch-CPU fp32 Unetv2"
+    else:
+        arch = {"Resnet50Unet": "resnet50", "Resnet18Unet": "resnet18", "Resnet34Unet": "resnet34"}[net]
+        tr, what = R.OracleTrainer(arch, nc, opt="SGD2", ignore_index=0, seed=0), f"oracle.resnet_unet_oracle (torch-CPU fp32 {net}"
     tr.step(img, lab)  # warm-up
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step(img, lab)
     dt = time.perf_counter() - t0
     return {"value": round(tiles * steps / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle OracleTrainer (torch-CPU fp32 Unetv2 NC={nc}, CE ignore_index=0, SGD2): {steps} train steps "
-                      f"of {tiles} tiles {tile}x{tile} after 1 warm-up step"}
+            "sample": f"{what} NC={nc}, CE ignore_index=0, SGD2): {steps} train steps of {tiles} tiles {tile}x{tile} after 1 warm-up step"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a child (this process has not touched the
+    GPU, and it does not exec - it waits and exits with the child's code)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
-    ap.add_argument("--net", default="Unetv2")
+    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # rehearsal hooks for a one-GPU box (tests/test_bench_multirank_gpu.py): every rank on cuda:0, collectives over gloo
     if os.environ.get("CVCS_BENCH_ONE_DEVICE") == "1":
@@ -92,7 +127,7 @@ def main():
     opt, sched = utils.load_optimizer(cfg, net)
     if world > 1:
         from cvcs_amd.parallel import DataParallel
-        net(torch.zeros(1, 3, 32, 32, dtype=torch.uint8, device=dev))  # materialise the flat buffers / engine
+        net.flat_parameters()   # materialise the flat buffers / engine
         DataParallel(net, opt)
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randint(0, 256, (a.batch, 3, a.tile, a.tile), dtype=torch.uint8, generator=g).to(dev)
@@ -117,13 +152,17 @@ def main():
     fence()
     if not a.no_kernel_timers:
         ops.TIMERS = ops.KernelTimers()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = step()
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     timers = ops.TIMERS.summary() if ops.TIMERS is not None else {}
     ops.TIMERS = None
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     last_loss = loss.item()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -131,53 +170,60 @@ def main():
         dt = t.item()
 
     if rank == 0:
+        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        model = {"Resnet50Unet": "ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder 256/128/64/64/64, 1x1 head)",
+                 "Resnet18Unet": "ResNet18-UNet", "Resnet34Unet": "ResNet34-UNet",
+                 "Unetv2": "Unetv2 (the reference's own U-Net, source/scripts/nets.py:117-199)", "Unet": "Unet (reference)"}[a.net]
         out = {
             "metric": "512x512 tiles/sec (train fwd+bwd)" if a.tile == 512 else f"{a.tile}x{a.tile} tiles/sec (train fwd+bwd)",
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "tiles/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"{a.net} (reference U-Net, NC={NC}) train step: fwd + CE(ignore_index=0) + bwd + SGD2, "
+            "config": {"workload": f"{model}, NC={NC}, train step: fwd + CE(ignore_index=0) + bwd + SGD2, "
                                    f"{a.tile}x{a.tile} u8 tiles, batch {a.batch}/GPU, {a.precision} MFMA convs, f32 accumulate/master",
                        "global_batch": world * a.batch, "tile": a.tile, "num_classes": NC,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "loss": round(last_loss, 5),
+            "median_ms_per_step": round(statistics.median(per_step), 3),
         }
-        if "conv3x3_halo" in timers:
-            c = timers["conv3x3_halo"]
-            out["roofline"] = {"bound": "mfma", "achieved": round(c["tflops"], 2), "peak": PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3,
-                               "unit": "TFLOP/s", "frac": round(c["tflops"] / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
-                               "traffic": None, "kernel": "conv3x3_halo_kernel (every 3x3 forward and data-gradient launch that is a convolution only; "
-                                                          "the launches that also carry a BatchNorm-backward reduce pass are reported as fused_conv)",
-                               "launches_per_step": c["launches"] // a.steps, "avg_launch_us": round(c["avg_us"], 2),
-                               "algorithmic_gflop_per_step": round(c["flops"] / a.steps / 1e9, 1)}
-            if "conv3x3_halo_bn_bwd" in timers:   # same kernel, plus the fused first pass of the BatchNorm backward below it
-                f = timers["conv3x3_halo_bn_bwd"]
-                out["fused_conv"] = {"kernel": "conv3x3_halo_kernel + fused BatchNorm-backward reduce (64- and 128-channel blocks; conv FLOPs only)",
-                                     "achieved": round(f["tflops"], 2), "unit": "TFLOP/s", "launches_per_step": f["launches"] // a.steps,
-                                     "avg_launch_us": round(f["avg_us"], 2), "algorithmic_gflop_per_step": round(f["flops"] / a.steps / 1e9, 1)}
-            if "conv_igemm" in timers:   # ConvTranspose forward / data gradient on the non-overlapping-taps kernel
-                g = timers["conv_igemm"]
-                out["other_conv"] = {"kernel": "conv_taps_kernel (ConvTranspose forward + data gradient: short-K GEMMs, the shallow levels HBM-bound)",
-                                     "achieved": round(g["tflops"], 2), "unit": "TFLOP/s", "launches_per_step": g["launches"] // a.steps,
-                                     "avg_launch_us": round(g["avg_us"], 2), "algorithmic_gflop_per_step": round(g["flops"] / a.steps / 1e9, 1)}
-            if "wgrad" in timers:
-                w = timers["wgrad"]
-                out["roofline_wgrad"] = {"bound": "mfma", "achieved": round(w["tflops"], 2), "unit": "TFLOP/s",
-                                         "frac": round(w["tflops"] / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
-                                         "launches_per_step": w["launches"] // a.steps, "avg_launch_us": round(w["avg_us"], 2),
-                                         "algorithmic_gflop_per_step": round(w["flops"] / a.steps / 1e9, 1)}
-            # HBM traffic of the same kernel family from the rocprofv3 PMC passes of this exact workload (FETCH_SIZE
-            # doubled per the gfx950 correction, WRITE_SIZE exact), collected with scripts/pmc_traffic.py
-            if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and a.net == "Unetv2" and os.path.exists(PMC_FILE):
-                pm = json.load(open(PMC_FILE)).get("conv3x3_halo_kernel")
+        if timers:
+            # kernel families (HIP-event brackets on the launch stream inside the timed region); scopes: enc / dec
+            fams = {}
+            for kind, t in timers.items():
+                fam = kind.split(":")[0]
+                f = fams.setdefault(fam, dict(ms=0.0, flops=0.0, launches=0))
+                f["ms"] += t["total_ms"]; f["flops"] += t["flops"]; f["launches"] += t["launches"]
+
+            def line(f, kernel):
+                tf = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
+                return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tf / peak, 4), "launches_per_step": f["launches"] // a.steps,
+                        "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
+                        "algorithmic_gflop_per_step": round(f["flops"] / a.steps / 1e9, 1),
+                        "ms_per_step": round(f["ms"] / a.steps, 3)}
+            dom = max((k for k in fams if k.startswith("conv")), key=lambda k: fams[k]["ms"])
+            out["roofline"] = line(fams[dom], FAMILY_KERNEL.get(dom, dom))
+            out["roofline"]["traffic"] = None
+            out["kernel_families"] = {k: line(f, FAMILY_KERNEL.get(k, k)) for k, f in fams.items() if k != dom}
+            # the 3x3 ENCODER convolutions (the set the north star's >= 50 % target is written for), forward + data gradient
+            enc = [t for kind, t in timers.items() if kind.startswith("conv3x3_halo") and kind.endswith(":enc")]
+            if enc:
+                e = dict(ms=sum(t["total_ms"] for t in enc), flops=sum(t["flops"] for t in enc), launches=sum(t["launches"] for t in enc))
+                out["roofline_encoder"] = line(e, "conv3x3_halo_kernel, encoder 3x3 convolutions only (forward + data gradient)")
+            pmc = os.path.join(ROOT, "profiles", PMC_FILES.get(a.net, ""))
+            if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and os.path.isfile(pmc):
+                kern = {"conv3x3_halo": "conv3x3_halo_kernel", "conv_taps": "conv_taps_kernel", "conv_igemm": "conv_igemm_kernel"}.get(dom)
+                pm = json.load(open(pmc)).get(kern)
                 if pm:
                     out["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
-                    out["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/r01_pmc_traffic_b32_s512_bf16.json)"
-            tot = sum(t["total_ms"] for t in timers.values())
+                    out["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{PMC_FILES[a.net]})"
+            tot = sum(f["ms"] for f in fams.values())
             out["mfma_kernels_share_of_step"] = round(tot / (1e3 * dt), 3)
+            out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in fams.values()) / a.steps / 1e9, 1)
+            out["step_tflops"] = round(sum(f["flops"] for f in fams.values()) / dt / 1e12, 1)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(NC, a.tile, 2, 2)
+            out["cpu_baseline"] = cpu_baseline(a.net, NC, a.tile, 2, 2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -34,6 +34,8 @@ class ConvDesc(C.Structure):
         ("bwd_scale", C.c_void_p), ("bwd_shift", C.c_void_p), ("bwd_mean", C.c_void_p), ("bwd_invstd", C.c_void_p),
         ("bwd_mode", C.c_int32),
         ("bwd_part_dz", C.c_void_p), ("bwd_part_dzx", C.c_void_p),
+        ("aniso", C.c_int32), ("stride_w", C.c_int32), ("pad_w", C.c_int32),
+        ("in_row_pitch", C.c_int64), ("in_img_pitch", C.c_int64),
     ]
 
 
@@ -51,6 +53,8 @@ class WgradDesc(C.Structure):
         ("dw", C.c_void_p), ("Cin_real", C.c_int32),
         ("workspace", C.c_void_p),
         ("dtype", C.c_int32),
+        ("aniso", C.c_int32), ("stride_w", C.c_int32), ("pad_w", C.c_int32),
+        ("x_row_pitch", C.c_int64), ("x_img_pitch", C.c_int64),
     ]
 
 
@@ -66,6 +70,15 @@ SIGNATURES = {
     "cvcs_wgrad_slices": (_i, [_i] * 8),
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "cvcs_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
+    "cvcs_wgrad_workspace_floats": (_i64, [C.POINTER(WgradDesc)]),
+    "cvcs_bn_add_act": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp]),
+    "cvcs_relu_bwd_sum": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_maxpool3x3s2_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_maxpool3x3s2_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_dilate2x": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_pack_input_stem": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cvcs_pack_stem_weight": (_i, [_vp, _i, _vp, _i, _vp]),
+    "cvcs_unpack_stem_wgrad": (_i, [_vp, _i, _vp, _vp]),
     "cvcs_bn_finalize_workspace_floats": (_i, [_i, _i]),
     "cvcs_bn_finalize": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_moments": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -107,11 +120,86 @@ SIGNATURES = {
 }
 
 _lib = None
+_recording = None          # the Recording that is capturing launches right now (None: plain eager calls)
+_QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_conv_stat_rows",
+            "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
+            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats"}
+pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
+
+
+class Recording:
+    """A launch plan: the sequence of C-ABI launches (function, arguments without the stream) that one pass of a network
+    issues for one input shape, captured while it runs eagerly ONCE and replayed every later step with no Python between
+    the launches but this loop.  Every pointer in it is a persistent engine buffer; descriptors are kept alive by the
+    argument tuples.  ("HIP streams and graphs instead of a tracing compiler": this is the host-side launch list; the same
+    replay runs under a HIP-graph capture unchanged.)  Host callbacks (data-parallel bucket hooks) are recorded in place."""
+
+    def __init__(self):
+        self.items = []     # (fn, args, tag) | (None, callable, None)
+
+    def __enter__(self):
+        global _recording
+        assert _recording is None, "recordings do not nest"
+        lib()               # make sure the library is loaded before the proxy is consulted
+        _recording = self
+        return self
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = None
+        return False
+
+    def host(self, fn):
+        """run fn() now and at this point of every replay"""
+        self.items.append((None, fn, None))
+        fn()
+
+    def replay(self, stream: int, timers=None):
+        for fn, args, tag in self.items:
+            if fn is None:
+                args()
+                continue
+            if timers is not None and tag is not None:
+                ev = timers.bracket(*tag)
+                ev[0].record()
+                rc = fn(*args, stream)
+                ev[1].record()
+            else:
+                rc = fn(*args, stream)
+            if rc != 0:
+                check(rc, fn.__name__)
+
+
+class _Proxy:
+    def __init__(self, h):
+        self._h = h
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name in _QUERIES:
+            return fn
+
+        def call(*args):
+            global pending_tag
+            tag, pending_tag = pending_tag, None
+            _recording.items.append((fn, args[:-1], tag))
+            return fn(*args)
+        return call
+
+
+_proxy = None
 
 
 def lib():
-    """Load (once) and return the ctypes handle; raises CvcsError if the HIP library is not built."""
-    global _lib
+    """Load (once) and return the ctypes handle; raises CvcsError if the HIP library is not built.  While a Recording is
+    open the handle is a proxy that also appends every launch to it."""
+    if _recording is not None and _lib is not None:
+        return _proxy
+    return _load()
+
+
+def _load():
+    global _lib, _proxy
     if _lib is None:
         # torch first: its wheel bundles its own libamdhip64, and the HIP runtime that is loaded FIRST is the one this library
         # binds to - loaded before torch, the system runtime and torch's would coexist in the process and the launches of
@@ -125,15 +213,16 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 3:
+        if h.cvcs_abi_version() != 4:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")
         _lib = h
+        _proxy = _Proxy(h)
     return _lib
 
 
 def check(rc: int, what: str = ""):
     if rc != 0:
-        msg = lib().cvcs_last_error().decode(errors="replace")
+        msg = _load().cvcs_last_error().decode(errors="replace")
         raise CvcsError(f"{what or 'cvcs'} failed ({rc}): {msg}")

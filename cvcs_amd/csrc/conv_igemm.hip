@@ -48,6 +48,9 @@ struct ConvArgs {
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
   float* bwd_p0; float* bwd_p1;
   int bwd_mode;
+  // generic kernel: W-axis stride / padding (== stride / pad unless cvcs_conv_desc.aniso) and the pitches of `in` (elements)
+  int stride_w, pad_w;
+  int64_t in_row_pitch, in_img_pitch;
 };
 
 template <typename T> struct Mma;
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int oy = t % p.Ho;
     const int b = t / p.Ho;
     iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
-    pbase[i] = (int64_t)b * p.H * p.W;
+    ix0[i] = ox * p.stride_w - p.pad_w;
+    pbase[i] = (int64_t)b * p.in_img_pitch;
   }
   const int taps = p.KH * p.KW;
   const int nslice = p.Cin / KG;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int i = 0; i < APW; ++i) {
       const int iy = iy0[i] + kh * p.dil, ix = ix0[i] + kw * p.dil;
       const bool ok = mvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cs * 64 + ac[i] * 16 < p.valid_bytes;
-      const char* src = ok ? p.in + ((pbase[i] + (int64_t)iy * p.W + ix) * p.in_ld + (int64_t)cs * KG) * ES + ac[i] * 16
+      const char* src = ok ? p.in + (pbase[i] + (int64_t)iy * p.in_row_pitch + (int64_t)ix * p.in_ld + (int64_t)cs * KG) * ES + ac[i] * 16
                            : reinterpret_cast<const char*>(&g_gzero16);
       dma16(src, sa + (wave + 4 * i) * 1024);
     }
@@ -1321,7 +1324,8 @@ static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 1 :
 
 extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
-  if (use_halo(d)) return d->B * (int)cdiv(d->H, 16) * (int)cdiv(d->W, 16) * halo_wm(d);
+  if (use_halo(d) && !d->aniso && !d->in_row_pitch && !d->in_img_pitch)
+    return d->B * (int)cdiv(d->H, 16) * (int)cdiv(d->W, 16) * halo_wm(d);
   return (int)(cdiv((int64_t)d->B * d->Ho * d->Wo, kBM) * 2);
 }
 
@@ -1337,13 +1341,21 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "cvcs_conv2d: bad filter geometry");
   // output extent must match the filter geometry (every gathered pixel is range-checked in the kernel, but the
   // host refuses inconsistent shapes so that no tile silently reads the wrong window)
+  const bool aniso = d->aniso != 0;
+  const int stride_w = aniso ? d->stride_w : d->stride, pad_w = aniso ? d->pad_w : d->pad;
+  CVCS_CHECK_ARG(stride_w >= 1 && pad_w >= 0, "cvcs_conv2d: bad W-axis stride / padding");
+  const bool pitched = d->in_row_pitch != 0 || d->in_img_pitch != 0;
   const int eh = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
-  const int ew = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  const int ew = (d->W + 2 * pad_w - d->dil * (d->KW - 1) - 1) / stride_w + 1;
   CVCS_CHECK_ARG(eh == d->Ho && ew == d->Wo, "cvcs_conv2d: Ho,Wo=%d,%d but geometry gives %d,%d", d->Ho, d->Wo, eh, ew);
   const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
   CVCS_CHECK_ARG(cin_valid <= d->Cin && (cin_valid * es) % 16 == 0, "cvcs_conv2d: Cin_valid=%d must be <= Cin and a multiple of 16 bytes", d->Cin_valid);
   CVCS_CHECK_ARG(cin_valid == d->Cin || d->Cin == kg, "cvcs_conv2d: a narrow input (Cin_valid < Cin) takes exactly one K-group (Cin = %d)", kg);
-  CVCS_CHECK_ARG(d->in_ld >= cin_valid && d->in_ld * es % 16 == 0, "cvcs_conv2d: in_ld");
+  // (explicit pitches: consecutive pixels may overlap, in_ld < Cin - the caller vouches for the margins of its buffer)
+  CVCS_CHECK_ARG((pitched || d->in_ld >= cin_valid) && d->in_ld * es % 16 == 0, "cvcs_conv2d: in_ld");
+  const int64_t row_pitch = d->in_row_pitch ? d->in_row_pitch : (int64_t)d->W * d->in_ld;
+  const int64_t img_pitch = d->in_img_pitch ? d->in_img_pitch : (int64_t)d->H * row_pitch;
+  CVCS_CHECK_ARG(row_pitch * es % 16 == 0 && img_pitch * es % 16 == 0 && row_pitch > 0 && img_pitch >= row_pitch, "cvcs_conv2d: input pitches");
   const int cout_store = d->pixel_shuffle ? d->Cout / 4 : d->Cout;
   CVCS_CHECK_ARG(d->out_ld >= cout_store && d->out_ld * es % 16 == 0, "cvcs_conv2d: out_ld");
   CVCS_CHECK_ARG(((uintptr_t)d->in % 16) == 0 && ((uintptr_t)d->out % 16) == 0 && ((uintptr_t)d->wt % 16) == 0,
@@ -1386,8 +1398,10 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.valid_bytes = cin_valid * es;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
+  a.stride_w = stride_w; a.pad_w = pad_w; a.in_row_pitch = row_pitch; a.in_img_pitch = img_pitch;
   hipStream_t st = (hipStream_t)stream;
-  if (use_halo(d)) {
+  const bool plain = !aniso && !pitched;   // the specialised kernels assume the isotropic, densely packed case
+  if (plain && use_halo(d)) {
     static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 64;   // tuning knob
     // a launch that carries the fused BatchNorm-backward reduce needs neighbours on its CU to hide the longer epilogue: up to
     // narrow_bwd output channels it takes the three-workgroup narrow tiles (two column tiles for 128 channels)
@@ -1407,7 +1421,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   // non-overlapping-taps kernel
   static const int taps_on = getenv("CVCS_CONV_TAPS") ? atoi(getenv("CVCS_CONV_TAPS")) : 1;   // tuning knob
   const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1, k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
-  if (taps_on && (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !d->stat_sum &&
+  if (plain && taps_on && (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !d->stat_sum &&
       !d->pre_scale && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&
       (!d->pixel_shuffle || (d->Cout / 4) % 8 == 0) && (int64_t)d->B * d->H * d->W * d->in_ld * es < (1ll << 32))
     return k1 ? launch_taps<1>(a, st) : launch_taps<4>(a, st);

@@ -1,0 +1,406 @@
+// HBM-bound kernels of the residual (ResNet-encoder) networks on gfx950: the block tail (BatchNorm apply + shortcut add +
+// ReLU) and its backward, the stem's 3x3 / stride 2 max-pooling, zero-dilation for strided data gradients, and the
+// boundary packing of the 7x7 / stride 2 stem (virtual-pixel layout, see cvcs_conv_desc.aniso in include/cvcs_hip.h).
+//
+// The reference has no residual network (its factory S/utils.py:174-195 is the seam these models plug into; BASELINE.json
+// configs 1, 2, 5 name them).  Same conventions as elementwise.hip: one 16-byte chunk (8 bf16 / 4 f32 channels of one
+// pixel) per lane and access, lanes of a wave on consecutive chunks, no atomics (gather formulations), grid-stride loops.
+#include "common.h"
+
+namespace cvcs {
+
+static inline unsigned res_grid(int64_t total) {
+  int64_t g = cdiv(total, 256);
+  return (unsigned)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
+}
+
+// ------------------------------------------------------------------------------------------------ block tail forward
+// a thread keeps ONE 16-byte channel chunk for its whole life (the four per-channel vectors are loaded once, not per pixel)
+// and walks pixels with the grid stride; a workgroup covers min(C/V, 256) chunks x 256/that pixels per step.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_add_act_kernel(const char* y1, int64_t y1_ld, const float* __restrict__ s1,
+                                                        const float* __restrict__ b1, const char* y2, int64_t y2_ld,
+                                                        const float* __restrict__ s2, const float* __restrict__ b2, int64_t M,
+                                                        int C, char* out, int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int ccw = CC < 256 ? CC : 256;
+  const int PL = 256 / ccw;
+  const int cl = threadIdx.x % ccw, pl = threadIdx.x / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  if (cc >= CC) return;
+  float a1[V], c1[V], a2[V], c2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int c = cc * V + k;
+    a1[k] = s1[c]; c1[k] = b1[c];
+    a2[k] = s2 ? s2[c] : 1.f; c2[k] = s2 ? b2[c] : 0.f;
+  }
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
+    float a[V], b[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y1 + pix * y1_ld * ES + cc * 16), a);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y2 + pix * y2_ld * ES + cc * 16), b);
+#pragma unroll
+    for (int k = 0; k < V; ++k) a[k] = fmaxf((a[k] * a1[k] + c1[k]) + (b[k] * a2[k] + c2[k]), 0.f);
+    *reinterpret_cast<uint4*>(out + pix * out_ld * ES + cc * 16) = Elem<T>::pack(a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ block tail backward
+struct SumArgs {
+  const char* out; const char* g[3]; char* dz;
+  int64_t out_ld, g_ld[3], dz_ld;
+  int half[3];
+  int B, H, W, C;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_sum_kernel(SumArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = p.C / V;
+  const int64_t total = (int64_t)p.B * p.H * p.W * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;
+    const int x = (int)(pix % p.W);
+    const int64_t t = pix / p.W;
+    const int y = (int)(t % p.H);
+    const int64_t b = t / p.H;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (!p.g[j]) continue;
+      int64_t gp = pix;
+      if (p.half[j]) {
+        if ((x | y) & 1) continue;   // a stride-2 1x1 shortcut only saw the even pixels
+        gp = (b * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+      }
+      float f[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.g[j] + gp * p.g_ld[j] * ES + cc * 16), f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] += f[k];
+    }
+    if (p.out) {
+      float o[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.out + pix * p.out_ld * ES + cc * 16), o);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] = o[k] > 0.f ? s[k] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(p.dz + pix * p.dz_ld * ES + cc * 16) = Elem<T>::pack(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ MaxPool2d(3, 2, 1)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const char* x, int64_t x_ld, int B, int H, int W, int C, char* out,
+                                                          int64_t out_ld, uint8_t* idx) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t op = id / CC;
+    const int ox = (int)(op % Wo);
+    const int64_t t = op / Wo;
+    const int oy = (int)(t % Ho);
+    const int64_t b = t / Ho;
+    float best[V];
+    int arg[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; arg[k] = -1; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy - 1 + kh;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = 2 * ox - 1 + kw;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float f[V];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((b * H + iy) * W + ix) * x_ld * ES + cc * 16), f);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if (f[k] > best[k] || arg[k] < 0) { best[k] = f[k]; arg[k] = kh * 3 + kw; }   // strict '>': FIRST maximum in scan order
+      }
+    }
+    *reinterpret_cast<uint4*>(out + op * out_ld * ES + cc * 16) = Elem<T>::pack(best);
+    uint8_t* ip = idx + op * C + cc * V;
+    if constexpr (V == 8) {
+      uint2 w;
+      w.x = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+      w.y = (unsigned)arg[4] | ((unsigned)arg[5] << 8) | ((unsigned)arg[6] << 16) | ((unsigned)arg[7] << 24);
+      *reinterpret_cast<uint2*>(ip) = w;
+    } else {
+      *reinterpret_cast<unsigned*>(ip) = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const char* g0, int64_t g0_ld, const char* g1, int64_t g1_ld,
+                                                          const uint8_t* __restrict__ idx, int B, int H, int W, int C, char* dx,
+                                                          int64_t dx_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)B * H * W * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;
+    const int x = (int)(pix % W);
+    const int64_t t = pix / W;
+    const int y = (int)(t % H);
+    const int64_t b = t / H;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+    // windows (oy, ox) that contain (y, x): 2*oy - 1 <= y <= 2*oy + 1
+    const int oy0 = y >> 1, oy1 = (y + 1) >> 1, ox0 = x >> 1, ox1 = (x + 1) >> 1;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      if (oy >= Ho) continue;
+      const int kh = y - (2 * oy - 1);
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        if (ox >= Wo) continue;
+        const int want = kh * 3 + (x - (2 * ox - 1));
+        const int64_t op = (b * Ho + oy) * Wo + ox;
+        const uint8_t* ip = idx + op * C + cc * V;
+        unsigned iw[2];
+        if constexpr (V == 8) { const uint2 w = *reinterpret_cast<const uint2*>(ip); iw[0] = w.x; iw[1] = w.y; }
+        else { iw[0] = *reinterpret_cast<const unsigned*>(ip); iw[1] = 0; }
+        float f[V];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(g0 + op * g0_ld * ES + cc * 16), f);
+        if (g1) {
+          float f1[V];
+          Elem<T>::unpack(*reinterpret_cast<const uint4*>(g1 + op * g1_ld * ES + cc * 16), f1);
+#pragma unroll
+          for (int k = 0; k < V; ++k) f[k] += f1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if ((int)((iw[k >> 2] >> ((k & 3) * 8)) & 0xff) == want) s[k] += f[k];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + pix * dx_ld * ES + cc * 16) = Elem<T>::pack(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ zero dilation x2
+template <typename T>
+__global__ __launch_bounds__(256) void dilate2x_kernel(const char* in, int64_t in_ld, int B, int H, int W, int C, char* out,
+                                                      int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int64_t total = (int64_t)B * (2 * H) * (2 * W) * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;
+    const int x = (int)(pix % (2 * W));
+    const int64_t t = pix / (2 * W);
+    const int y = (int)(t % (2 * H));
+    const int64_t b = t / (2 * H);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!((x | y) & 1)) v = *reinterpret_cast<const uint4*>(in + ((b * H + (y >> 1)) * W + (x >> 1)) * in_ld * ES + cc * 16);
+    *reinterpret_cast<uint4*>(out + pix * out_ld * ES + cc * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ stem boundary
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void pack_input_stem_kernel(const S* __restrict__ src, int B, int H, int W, T* dst) {
+  const int WP = W + 8;
+  const int64_t total = (int64_t)B * H * WP;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int xp = (int)(id % WP);
+    const int64_t t = id / WP;
+    const int y = (int)(t % H);
+    const int64_t b = t / H;
+    const int x = xp - 3;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)x < (unsigned)W) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (float)src[((b * 3 + c) * H + y) * W + x];
+    }
+    T* d = dst + id * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Elem<T>::st(d + c, v[c]);
+  }
+}
+
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, int Cout, T* wf) {
+  // wf[kh][co][kw*4 + c], kw in 0..7 (kw = 7 and c = 3 are zero)
+  const int total = 7 * Cout * 32;
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+    const int v = id % 32;
+    const int co = (id / 32) % Cout;
+    const int kh = id / (32 * Cout);
+    const int kw = v >> 2, c = v & 3;
+    const float val = (kw < 7 && c < 3) ? w[((co * 3 + c) * 7 + kh) * 7 + kw] : 0.f;
+    Elem<T>::st(wf + id, val);
+  }
+}
+
+__global__ void unpack_stem_wgrad_kernel(const float* __restrict__ tmp, int Cout, float* __restrict__ dw) {
+  // tmp[co][v = kw*4 + c][kh]  ->  dw[co][c][kh][kw]
+  const int total = Cout * 3 * 49;
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+    const int kw = id % 7;
+    const int kh = (id / 7) % 7;
+    const int c = (id / 49) % 3;
+    const int co = id / 147;
+    dw[id] = tmp[(co * 32 + kw * 4 + c) * 7 + kh];
+  }
+}
+
+static int res_check_view(const char* fn, const void* ptr, int64_t ld, int C, int es) {
+  CVCS_CHECK_ARG(ptr != nullptr, "%s: null tensor", fn);
+  CVCS_CHECK_ARG(((uintptr_t)ptr % 16) == 0 && ld >= C && (ld * es) % 16 == 0, "%s: view must be 16-byte aligned with ld >= C", fn);
+  return CVCS_OK;
+}
+
+}  // namespace cvcs
+
+using namespace cvcs;
+
+#define RES_DT_OK(dt) ((dt) == CVCS_F32 || (dt) == CVCS_BF16)
+
+extern "C" int cvcs_bn_add_act(const void* y1, int64_t y1_ld, const float* s1, const float* b1, const void* y2, int64_t y2_ld,
+                               const float* s2, const float* b2, int64_t M, int C, void* out, int64_t out_ld, int dtype,
+                               void* stream) {
+  const char* fn = "cvcs_bn_add_act";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(M > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
+  CVCS_CHECK_ARG(s1 && b1 && ((s2 == nullptr) == (b2 == nullptr)), "%s: scale / shift vectors", fn);
+  int rc;
+  if ((rc = res_check_view(fn, y1, y1_ld, C, es)) || (rc = res_check_view(fn, y2, y2_ld, C, es)) ||
+      (rc = res_check_view(fn, out, out_ld, C, es)))
+    return rc;
+  const int CC = C / (16 / es), ccw = CC < 256 ? CC : 256;
+  CVCS_CHECK_ARG(256 % ccw == 0 && CC % ccw == 0, "%s: C/%d must divide 256 or be a multiple of 256", fn, 16 / es);
+  int64_t gx = cdiv(M, (256 / ccw) * 4);   // ~4 pixels per thread
+  const dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 8192 ? 8192 : gx)), (unsigned)(CC / ccw));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((bn_add_act_kernel<float>), grid, dim3(256), 0, st, (const char*)y1, y1_ld, s1, b1, (const char*)y2, y2_ld, s2, b2, M, C, (char*)out, out_ld);
+  else
+    hipLaunchKernelGGL((bn_add_act_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)y1, y1_ld, s1, b1, (const char*)y2, y2_ld, s2, b2, M, C, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_relu_bwd_sum(const void* out, int64_t out_ld, const void* g0, int64_t g0_ld, int g0_half, const void* g1,
+                                 int64_t g1_ld, int g1_half, const void* g2, int64_t g2_ld, int g2_half, int B, int H, int W,
+                                 int C, void* dz, int64_t dz_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_relu_bwd_sum";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
+  CVCS_CHECK_ARG(g0 != nullptr, "%s: g0 is required", fn);
+  CVCS_CHECK_ARG(!(g0_half || (g1 && g1_half) || (g2 && g2_half)) || (H % 2 == 0 && W % 2 == 0), "%s: a half-resolution gradient needs even H, W", fn);
+  int rc;
+  if (out && (rc = res_check_view(fn, out, out_ld, C, es))) return rc;
+  if ((rc = res_check_view(fn, g0, g0_ld, C, es)) || (rc = res_check_view(fn, dz, dz_ld, C, es))) return rc;
+  if (g1 && (rc = res_check_view(fn, g1, g1_ld, C, es))) return rc;
+  if (g2 && (rc = res_check_view(fn, g2, g2_ld, C, es))) return rc;
+  SumArgs a;
+  a.out = (const char*)out; a.out_ld = out_ld; a.dz = (char*)dz; a.dz_ld = dz_ld;
+  a.g[0] = (const char*)g0; a.g[1] = (const char*)g1; a.g[2] = (const char*)g2;
+  a.g_ld[0] = g0_ld; a.g_ld[1] = g1_ld; a.g_ld[2] = g2_ld;
+  a.half[0] = g0_half; a.half[1] = g1_half; a.half[2] = g2_half;
+  a.B = B; a.H = H; a.W = W; a.C = C;
+  const dim3 grid(res_grid((int64_t)B * H * W * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((relu_bwd_sum_kernel<float>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((relu_bwd_sum_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_maxpool3x3s2_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
+                                     uint8_t* idx, int dtype, void* stream) {
+  const char* fn = "cvcs_maxpool3x3s2_fwd";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0 && idx && ((uintptr_t)idx % 8) == 0, "%s: bad shape / idx", fn);
+  int rc;
+  if ((rc = res_check_view(fn, x, x_ld, C, es)) || (rc = res_check_view(fn, out, out_ld, C, es))) return rc;
+  const dim3 grid(res_grid((int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((maxpool3_fwd_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, B, H, W, C, (char*)out, out_ld, idx);
+  else hipLaunchKernelGGL((maxpool3_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)x, x_ld, B, H, W, C, (char*)out, out_ld, idx);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_maxpool3x3s2_bwd(const void* g0, int64_t g0_ld, const void* g1, int64_t g1_ld, const uint8_t* idx, int B,
+                                     int H, int W, int C, void* dx, int64_t dx_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_maxpool3x3s2_bwd";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0 && idx && ((uintptr_t)idx % 8) == 0, "%s: bad shape / idx", fn);
+  int rc;
+  if ((rc = res_check_view(fn, g0, g0_ld, C, es)) || (rc = res_check_view(fn, dx, dx_ld, C, es))) return rc;
+  if (g1 && (rc = res_check_view(fn, g1, g1_ld, C, es))) return rc;
+  const dim3 grid(res_grid((int64_t)B * H * W * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((maxpool3_bwd_kernel<float>), grid, dim3(256), 0, st, (const char*)g0, g0_ld, (const char*)g1, g1_ld, idx, B, H, W, C, (char*)dx, dx_ld);
+  else hipLaunchKernelGGL((maxpool3_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)g0, g0_ld, (const char*)g1, g1_ld, idx, B, H, W, C, (char*)dx, dx_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_dilate2x(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld, int dtype,
+                             void* stream) {
+  const char* fn = "cvcs_dilate2x";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
+  int rc;
+  if ((rc = res_check_view(fn, in, in_ld, C, es)) || (rc = res_check_view(fn, out, out_ld, C, es))) return rc;
+  const dim3 grid(res_grid((int64_t)B * 4 * H * W * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((dilate2x_kernel<float>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
+  else hipLaunchKernelGGL((dilate2x_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_pack_input_stem(const void* src, int src_is_u8, int B, int H, int W, void* dst, int dtype, void* stream) {
+  const char* fn = "cvcs_pack_input_stem";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  CVCS_CHECK_ARG(src && dst && B > 0 && H > 0 && W > 0 && W % 2 == 0 && ((uintptr_t)dst % 16) == 0, "%s: bad arguments", fn);
+  const dim3 grid(res_grid((int64_t)B * H * (W + 8)));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) {
+    if (src_is_u8) hipLaunchKernelGGL((pack_input_stem_kernel<float, uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)src, B, H, W, (float*)dst);
+    else hipLaunchKernelGGL((pack_input_stem_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, B, H, W, (float*)dst);
+  } else {
+    if (src_is_u8) hipLaunchKernelGGL((pack_input_stem_kernel<bf16_t, uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)src, B, H, W, (bf16_t*)dst);
+    else hipLaunchKernelGGL((pack_input_stem_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const float*)src, B, H, W, (bf16_t*)dst);
+  }
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void* stream) {
+  const char* fn = "cvcs_pack_stem_weight";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype) && w && w_fwd && Cout > 0, "%s: bad arguments", fn);
+  const dim3 grid((unsigned)cdiv(7 * Cout * 32, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<float>), grid, dim3(256), 0, st, w, Cout, (float*)w_fwd);
+  else hipLaunchKernelGGL((pack_stem_weight_kernel<bf16_t>), grid, dim3(256), 0, st, w, Cout, (bf16_t*)w_fwd);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_unpack_stem_wgrad(const float* tmp, int Cout, float* dw, void* stream) {
+  const char* fn = "cvcs_unpack_stem_wgrad";
+  CVCS_CHECK_ARG(tmp && dw && Cout > 0, "%s: bad arguments", fn);
+  hipLaunchKernelGGL(unpack_stem_wgrad_kernel, dim3((unsigned)cdiv(Cout * 147, 256)), dim3(256), 0, (hipStream_t)stream, tmp, Cout, dw);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}

@@ -28,6 +28,8 @@ struct WgradArgs {
   int64_t x_ld, dy_ld;
   int B, H, W, Cin, Ho, Wo, Cout;
   int KW, stride, pad;
+  int stride_w, pad_w;        // generic kernel: W axis (== stride / pad unless cvcs_wgrad_desc.aniso)
+  int64_t x_row_pitch, x_img_pitch;   // generic kernel: pitches of `x` in elements
   int TH, TW, HR, HC;         // K-tile and halo-tile extents
   int tiles_x, tiles_y;       // K-tiles per image
   int ktiles, per_slice;      // total K-tiles, K-tiles per slice
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   constexpr int RPP = 1024 / ROWB;         // rows per DMA piece (8 | 4)
   constexpr int CPR = ROWB / 16;           // 16-byte chunks per row (8 | 16)
   constexpr int DY_BYTES = 32 * ROWB;
-  constexpr int X_BYTES = 128 * ROWB;
+  constexpr int X_BYTES = 160 * ROWB;      // kXRows halo rows
   constexpr int STAGE = DY_BYTES + X_BYTES;
   constexpr int DYP = 32 / RPP;            // dy pieces per K-tile (4 | 8)
   constexpr int D = NS - 1;                // prefetch distance in K-tiles
@@ -129,14 +131,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sdy + pi * 1024), 16, 0, 0);
     }
-    const int iy_base = ty0 * p.stride - p.pad, ix_base = tx0 * p.stride - p.pad;
+    const int iy_base = ty0 * p.stride - p.pad, ix_base = tx0 * p.stride_w - p.pad_w;
     for (int pi = wave; pi < xpieces; pi += 4) {
       const int r = pi * RPP + rr;
       const int c = swz_chunk(r, pc);
       const int iy = iy_base + r / p.HC, ix = ix_base + r % p.HC;
       const char* src = reinterpret_cast<const char*>(&g_wzero16);
       if (r < hrows && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c * (16 / ES) < cin_rem)
-        src = p.x + ((((int64_t)b * p.H + iy) * p.W + ix) * p.x_ld + ci0) * ES + c * 16;
+        src = p.x + ((int64_t)b * p.x_img_pitch + (int64_t)iy * p.x_row_pitch + (int64_t)ix * p.x_ld + ci0) * ES + c * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sx + pi * 1024), 16, 0, 0);
     }
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
                addr(dyb, k1, wm * 2 + 1));
       const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(a0l.x, a0l.y, a0h.x, a0h.y));
       const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a1l.x, a1l.y, a1h.x, a1h.y));
-      const int hb0 = ((k0 / p.TW) * p.stride) * p.HC + (k0 % p.TW) * p.stride;
-      const int hb1 = ((k1 / p.TW) * p.stride) * p.HC + (k1 % p.TW) * p.stride;
+      const int hb0 = ((k0 / p.TW) * p.stride) * p.HC + (k0 % p.TW) * p.stride_w;
+      const int hb1 = ((k1 / p.TW) * p.stride) * p.HC + (k1 % p.TW) * p.stride_w;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int kh = t / p.KW, kw = t - kh * p.KW;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           af[i] = *reinterpret_cast<const float*>(sdy + k * ROWB + (wm * 32 + i * 16 + fr) * 4);
-        const int hb = ((k / p.TW) * p.stride) * p.HC + (k % p.TW) * p.stride;
+        const int hb = ((k / p.TW) * p.stride) * p.HC + (k % p.TW) * p.stride_w;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int kh = t / p.KW, kw = t - kh * p.KW;
@@ -652,20 +654,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+constexpr int kXRows = 160;   // halo-tile capacity of the generic kernel in LDS rows (3x3 / stride 2 needs 9 x 17 = 153)
 struct WgradPlan {
   int TH, TW, HR, HC, tiles_x, tiles_y, ktiles, nslice, per_slice, tiles_mn;
 };
 
 // fast: 0 = generic kernel, 1 = 64 x 64 fast path, 2 = 128 x 64 fast path (8 waves, one workgroup per CU)
-static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int fast = 0) {
+static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int fast = 0, int stride_w = 0) {
   WgradPlan pl;
+  if (stride_w <= 0) stride_w = stride;
   int tw = 1;
   while (tw < Wo && tw < 32) tw <<= 1;
   pl.TW = tw;
   pl.TH = 32 / tw;
   if (fast) { pl.TW = 8; pl.TH = 4; }   // the bf16 3x3 fast path works on 4 x 8-pixel K-tiles
+  // the halo tile of a K-tile has to fit kXRows LDS rows: strided / tall filters take the 32-pixel rectangle with the
+  // smallest halo (3x3 / stride 2: 8 x 4 pixels -> 17 x 9 rows)
+  if (!fast && ((pl.TH - 1) * stride + KH) * ((pl.TW - 1) * stride_w + KW) > kXRows) {
+    int best = 1 << 30;
+    for (int t = 1; t <= 32; t <<= 1) {
+      const int h = ((32 / t - 1) * stride + KH) * ((t - 1) * stride_w + KW);
+      if (h < best) { best = h; pl.TW = t; pl.TH = 32 / t; }
+    }
+  }
   pl.HR = (pl.TH - 1) * stride + KH;
-  pl.HC = (pl.TW - 1) * stride + KW;
+  pl.HC = (pl.TW - 1) * stride_w + KW;
   pl.tiles_x = (int)cdiv(Wo, pl.TW);
   pl.tiles_y = (int)cdiv(Ho, pl.TH);
   pl.ktiles = B * pl.tiles_x * pl.tiles_y;
@@ -683,7 +696,7 @@ template <typename T, int NT>
 static int launch(const WgradArgs& a, const WgradPlan& pl, hipStream_t st) {
   constexpr int ES = sizeof(T);
   constexpr int NS = ES == 2 ? 3 : 2;   // bf16: two K-tiles in flight; f32 (parity path): one
-  const size_t lds = (size_t)NS * (32 + 128) * 64 * ES;
+  const size_t lds = (size_t)NS * (32 + kXRows) * 64 * ES;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, NT, NS>),
@@ -738,6 +751,16 @@ extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int K
   return n;
 }
 
+// exact workspace size of one descriptor (covers the anisotropic / pitched case, which cvcs_wgrad_slices cannot express)
+extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
+  if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 64 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
+  const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
+  int n;
+  if (special) n = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, 0, d->aniso ? d->stride_w : d->stride).nslice;
+  else n = cvcs_wgrad_slices(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride);
+  return (int64_t)n * d->KH * d->KW * d->Cout * d->Cin;
+}
+
 extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   CVCS_CHECK_ARG(d != nullptr, "cvcs_conv2d_wgrad: null descriptor");
   CVCS_CHECK_ARG(d->dtype == CVCS_F32 || d->dtype == CVCS_BF16, "cvcs_conv2d_wgrad: bad dtype");
@@ -747,30 +770,37 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->Cin > 0 && d->Cin % (16 / es) == 0, "cvcs_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, 16 / es);
   CVCS_CHECK_ARG(d->Cin_real > 0 && d->Cin_real <= d->Cin, "cvcs_conv2d_wgrad: Cin_real");
   const int taps = d->KH * d->KW;
-  CVCS_CHECK_ARG((d->KH == 3 && d->KW == 3) || (d->KH == 2 && d->KW == 2) || (d->KH == 1 && d->KW == 1),
-                 "cvcs_conv2d_wgrad: filter %dx%d not built (3x3, 2x2, 1x1)", d->KH, d->KW);
-  CVCS_CHECK_ARG(d->stride >= 1 && d->stride <= 2 && d->pad >= 0, "cvcs_conv2d_wgrad: stride/pad");
+  CVCS_CHECK_ARG((d->KH == 3 && d->KW == 3) || (d->KH == 2 && d->KW == 2) || (d->KH == 1 && d->KW == 1) || (d->KH == 7 && d->KW == 1),
+                 "cvcs_conv2d_wgrad: filter %dx%d not built (3x3, 2x2, 1x1, 7x1)", d->KH, d->KW);
+  const bool aniso = d->aniso != 0, pitched = d->x_row_pitch != 0 || d->x_img_pitch != 0;
+  const int stride_w = aniso ? d->stride_w : d->stride, pad_w = aniso ? d->pad_w : d->pad;
+  CVCS_CHECK_ARG(d->stride >= 1 && d->stride <= 2 && d->pad >= 0 && stride_w >= 1 && stride_w <= 2 && pad_w >= 0, "cvcs_conv2d_wgrad: stride/pad");
   const int eh = (d->H + 2 * d->pad - (d->KH - 1) - 1) / d->stride + 1;
-  const int ew = (d->W + 2 * d->pad - (d->KW - 1) - 1) / d->stride + 1;
+  const int ew = (d->W + 2 * pad_w - (d->KW - 1) - 1) / stride_w + 1;
   CVCS_CHECK_ARG(eh == d->Ho && ew == d->Wo, "cvcs_conv2d_wgrad: Ho,Wo=%d,%d but geometry gives %d,%d", d->Ho, d->Wo, eh, ew);
-  CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0,
+  CVCS_CHECK_ARG((pitched || d->x_ld >= d->Cin) && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0,
                  "cvcs_conv2d_wgrad: leading dimensions");
   CVCS_CHECK_ARG(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad: alignment");
-  WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, fast_path(d));
-  CVCS_CHECK_ARG(pl.HR * pl.HC <= 128, "cvcs_conv2d_wgrad: halo tile too large");
+  const int64_t row_pitch = d->x_row_pitch ? d->x_row_pitch : (int64_t)d->W * d->x_ld;
+  const int64_t img_pitch = d->x_img_pitch ? d->x_img_pitch : (int64_t)d->H * row_pitch;
+  CVCS_CHECK_ARG(row_pitch * es % 16 == 0 && img_pitch * es % 16 == 0 && row_pitch > 0 && img_pitch >= row_pitch, "cvcs_conv2d_wgrad: pitches of x");
+  const int fastp = (aniso || pitched) ? 0 : fast_path(d);
+  WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, fastp, stride_w);
+  CVCS_CHECK_ARG(pl.HR * pl.HC <= (fastp ? 128 : kXRows), "cvcs_conv2d_wgrad: halo tile too large");
   WgradArgs a;
   a.x = (const char*)d->x; a.dy = (const char*)d->dy; a.ws = d->workspace;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.stride_w = stride_w; a.pad_w = pad_w; a.x_row_pitch = row_pitch; a.x_img_pitch = img_pitch;
   a.TH = pl.TH; a.TW = pl.TW; a.HR = pl.HR; a.HC = pl.HC;
   a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ktiles = pl.ktiles; a.per_slice = pl.per_slice;
   a.ntile_n = (int)cdiv(d->Cin, 64);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (d->dtype == CVCS_F32)
-    rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
-  else if (s2_shape(d)) {
+    rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 7 ? launch<float, 7>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
+  else if (fastp && s2_shape(d)) {
     const int lds = 3 * (64 + 128) * 128;
     static bool attr_done = false;
     if (!attr_done) {
@@ -781,7 +811,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     hipLaunchKernelGGL((wgrad_fast128_kernel<4, 8, 3, true>), dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(512), lds, st, a);
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(s2)");
     rc = CVCS_OK;
-  } else if (fast_path(d) == 2) {
+  } else if (fastp == 2) {
     constexpr int kStages = 3;   // deeper rings (4-6 stages) measured no faster: the fetch is not latency-bound
     const int lds = kStages * (64 + 6 * 16) * 128;
     static bool attr_done = false;
@@ -793,7 +823,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     hipLaunchKernelGGL((wgrad_fast128_kernel<4, 8, kStages>), dim3((unsigned)pl.tiles_mn, (unsigned)pl.nslice), dim3(512), lds, st, a);
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(fast128)");
     rc = CVCS_OK;
-  } else if (fast_path(d)) {
+  } else if (fastp) {
     // 4 x 8-pixel K-tiles (plan already made for that shape by make_plan)
     static bool attr_done = false;
     const int lds = 3 * (32 + 6 * 16) * 128;
@@ -805,7 +835,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(fast)");
     rc = CVCS_OK;
   } else
-    rc = taps == 9 ? launch<bf16_t, 9>(a, pl, st) : taps == 4 ? launch<bf16_t, 4>(a, pl, st) : launch<bf16_t, 1>(a, pl, st);
+    rc = taps == 9 ? launch<bf16_t, 9>(a, pl, st) : taps == 7 ? launch<bf16_t, 7>(a, pl, st) : taps == 4 ? launch<bf16_t, 4>(a, pl, st) : launch<bf16_t, 1>(a, pl, st);
   if (rc != CVCS_OK) return rc;
   const int64_t total = (int64_t)d->Cout * d->Cin_real;
   // lanes per (co, ci) pair: enough threads for ~64K in flight, never more than the slices there are
@@ -821,6 +851,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     else LAUNCH_RED(TAPS, 1);                                \
   } while (0)
   if (taps == 9) LAUNCH_RED_T(9);
+  else if (taps == 7) LAUNCH_RED_T(7);
   else if (taps == 4) LAUNCH_RED_T(4);
   else LAUNCH_RED_T(1);
 #undef LAUNCH_RED_T

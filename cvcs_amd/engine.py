@@ -203,6 +203,7 @@ class UNetEngine:
                  apply: bool = True):
         """conv3x3(+bias) [-> ReLU] with fused statistics, BN finalize, BN apply [-> ReLU] [-> pool]."""
         pk = self.packed[conv]
+        ops.SCOPE = "enc" if conv.startswith("encode") else "dec"
         M = x.B * y.shape[1] * y.shape[2]
         C_ = y.shape[3]
         st = self.bn[bnname]
@@ -265,6 +266,7 @@ class UNetEngine:
             else:
                 self._conv_bn(ops.view(self.aa[L]), cb, f"encode{L}.{base + 1}.layer.1", self.yb[L], ops.view(self.x5), True, train)
         prev = ops.view(self.x5)
+        ops.SCOPE = "dec"
         for d in range(1, 5):
             L = 5 - d
             _, up_v, _, _ = self._skip_up(d)
@@ -371,6 +373,7 @@ class UNetEngine:
         gradient) whose per-channel sum over pixels - the bias gradient of the up-conv that produced it - is wanted: the
         dgrad launch emits the column sums of its output through the statistics epilogue, no extra pass over the tensor."""
         dyv = ops.view(dy)
+        ops.SCOPE = "enc" if conv.startswith("encode") else "dec"
         self._wgrad(x, dyv, self.G[conv + ".weight"], 3, 3, 1, 1, cin_real=cin_real)
         if gin is None:
             return

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .engine import WIDTHS, UNetEngine
+from .resnet_engine import ARCHS as RESNET_ARCHS, DECODER_CHANNELS, ResNetUNetEngine
 
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
@@ -101,7 +102,7 @@ class _HipUNet(nn.Module):
         self.returns_logits = True
         self.num_classes = num_classes
         self.precision = precision
-        self._spec = unet_param_spec(self.variant, num_classes)
+        self._spec = self._build_spec()
         self._engine = None
         self._flat = None
         self._flat_grad = None
@@ -127,6 +128,12 @@ class _HipUNet(nn.Module):
                 holder.register_buffer(leaf, torch.ones(shape))
             else:
                 holder.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+
+    def _build_spec(self):
+        return unet_param_spec(self.variant, self.num_classes)
+
+    def _build_engine(self, dev):
+        return UNetEngine(self.variant, self.num_classes, PRECISIONS[self.precision], dev)
 
     # ------------------------------------------------------------------------------------------------ flat storage
     def _ensure_flat(self):
@@ -159,7 +166,7 @@ class _HipUNet(nn.Module):
             self._flat_grad = torch.zeros_like(flat)
             self._engine = None
         if self._engine is None:
-            eng = UNetEngine(self.variant, self.num_classes, PRECISIONS[self.precision], dev)
+            eng = self._build_engine(dev)
             P, G, off = OrderedDict(), OrderedDict(), 0
             for name, p in params.items():
                 n = p.numel()
@@ -225,3 +232,75 @@ class Urnet(_HipUNet):
 class Urnetv2(_HipUNet):
     """U-Net with ConvTranspose2d(k2,s2) up-sampling (S/nets.py:117-199)."""
     variant = "Unetv2"
+
+
+# ---------------------------------------------------------------------------------------------------- ResNet-encoder U-Nets
+def resnet_unet_param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS):
+    """(name, shape, kind) in forward order.  Encoder names are torchvision's ResNet names under `encoder.` (ImageNet /
+    torchvision checkpoints map one to one); decoder / head names follow the common `decoder.blocks.N.convK.{0,1}` /
+    `segmentation_head.0` scheme.  No conv of the encoder or decoder has a bias (each is followed by a BatchNorm)."""
+    kind, depths, widths = RESNET_ARCHS[arch]
+    spec = []
+
+    def conv(p, cin, cout, k, bias=False):
+        spec.append((p + ".weight", (cout, cin, k, k), "conv_w"))
+        if bias:
+            spec.append((p + ".bias", (cout,), "conv_b"))
+
+    def bn(p, c):
+        spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b"), (p + ".running_mean", (c,), "rm"),
+                     (p + ".running_var", (c,), "rv"), (p + ".num_batches_tracked", (), "nbt")])
+
+    conv("encoder.conv1", 3, 64, 7)
+    bn("encoder.bn1", 64)
+    cin = 64
+    for s, (n, w) in enumerate(zip(depths, widths), start=1):
+        for b in range(n):
+            p = f"encoder.layer{s}.{b}"
+            stride = 2 if (b == 0 and s > 1) else 1
+            if kind == "basic":
+                conv(p + ".conv1", cin, w, 3); bn(p + ".bn1", w)
+                conv(p + ".conv2", w, w, 3); bn(p + ".bn2", w)
+            else:
+                mid = w // 4
+                conv(p + ".conv1", cin, mid, 1); bn(p + ".bn1", mid)
+                conv(p + ".conv2", mid, mid, 3); bn(p + ".bn2", mid)
+                conv(p + ".conv3", mid, w, 1); bn(p + ".bn3", w)
+            if stride != 1 or cin != w:
+                conv(p + ".downsample.0", cin, w, 1); bn(p + ".downsample.1", w)
+            cin = w
+    skips = [widths[2], widths[1], widths[0], 64, 0]
+    for i, (dc, sk) in enumerate(zip(decoder_channels, skips)):
+        p = f"decoder.blocks.{i}"
+        conv(p + ".conv1.0", cin + sk, dc, 3); bn(p + ".conv1.1", dc)
+        conv(p + ".conv2.0", dc, dc, 3); bn(p + ".conv2.1", dc)
+        cin = dc
+    conv("segmentation_head.0", cin, num_classes, 1, bias=True)
+    return spec
+
+
+class ResnetUnet(_HipUNet):
+    """U-Net with a ResNet encoder (BASELINE.json configs 1, 2, 5) behind the reference's nn.Module contract
+    (S/nets.py:12-33) and factory seam (S/utils.py:174-195): ResNet v1.5 encoder, bilinear-upsample decoder of
+    (conv3x3 -> BN -> ReLU) pairs over [up-sampled | encoder feature], 1x1 head.  Input: the raw 0..255 tile, as every
+    network of the reference gets it (S/train.py:121).  The tile side must be a multiple of 32."""
+    arch = "resnet50"
+    variant = "ResnetUnet"
+
+    def _build_spec(self):
+        return resnet_unet_param_spec(self.arch, self.num_classes)
+
+    def _build_engine(self, dev):
+        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev)
+
+
+class Resnet18Unet(ResnetUnet):
+    arch = "resnet18"
+
+
+class Resnet34Unet(ResnetUnet):
+    arch = "resnet34"
+
+
+class Resnet50Unet(ResnetUnet):
+    arch = "resnet50"

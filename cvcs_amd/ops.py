@@ -54,6 +54,7 @@ class KernelTimers:
 
 
 TIMERS: KernelTimers | None = None
+SCOPE = ""   # set by the engines around a layer's launches: timer kinds become "<kernel family>:<scope>" (enc | dec)
 
 
 def _ptr(t) -> int:
@@ -97,12 +98,22 @@ def conv_out_hw(H, W, KH, KW, stride, pad, dil=1):
     return ((H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1)
 
 
-def _conv_desc(x: View, wt, bias, out: View, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats):
+def _conv_desc(x: View, wt, bias, out: View, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats, virt=None):
     Cout = wt.shape[1]
-    Ho, Wo = conv_out_hw(x.H, x.W, KH, KW, stride, pad, dil)
     d = ConvDesc()
-    d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
-    if wt.shape[2] > x.C:     # narrow input (the 3-channel tile stored 16 bytes per pixel) under a zero-padded K-group
+    if virt is not None:
+        # virtual-pixel input (the 7x7/s2 stem as a 7x1 filter over (kw, c) pairs, cvcs_conv_desc.aniso): `x` is the
+        # [B, H, W+8, 4] tensor of ops.pack_input_stem; a virtual pixel = 32 elements starting every 8
+        assert (KH, KW, stride, pad, dil) == (7, 1, 2, 3, 1) and x.C == 4 and x.off == 0 and wt.shape[2] == 32
+        Wv = (x.W - 8) // 2
+        Ho, Wo = conv_out_hw(x.H, Wv, 7, 1, 2, 3)[0], Wv
+        d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, 8, x.B, x.H, Wv, 32
+        d.aniso, d.stride_w, d.pad_w = 1, 1, 0
+        d.in_row_pitch, d.in_img_pitch = x.W * 4, x.H * x.W * 4
+    else:
+        Ho, Wo = conv_out_hw(x.H, x.W, KH, KW, stride, pad, dil)
+        d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    if virt is None and wt.shape[2] > x.C:     # narrow input (the 3-channel tile stored 16 bytes per pixel) under a zero-padded K-group
         d.Cin, d.Cin_valid = wt.shape[2], x.C
     d.wt, d.bias = _ptr(wt), _ptr(bias)
     d.out, d.out_ld, d.Ho, d.Wo, d.Cout = 0 if out is None else out.ptr, 0 if out is None else out.ld, Ho, Wo, Cout
@@ -123,9 +134,10 @@ class _Shape:
         return 0
 
 
-def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
+def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None) -> int:
     """number of partial-statistics rows cvcs_conv2d writes for this geometry"""
-    d, _, _, _ = _conv_desc(x, _Shape(KH * KW, Cout, x.C), None, None, KH, KW, stride, pad, dil, False, False, None)
+    d, _, _, _ = _conv_desc(x, _Shape(KH * KW, Cout, 32 if virt else x.C), None, None, KH, KW, stride, pad, dil, False, False, None,
+                            virt=virt)
     n = _lib.lib().cvcs_conv_stat_rows(C.byref(d))
     if n < 0:
         raise _lib.CvcsError("cvcs_conv_stat_rows: bad shape")
@@ -134,12 +146,12 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1) -> int:
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
            pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None,
-           bn_bwd=None):
+           bn_bwd=None, virt=None, flops=None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...).
     bn_bwd = (y view, scale, shift, mean, invstd, mode, part_dz, part_dzx): the launch also takes the first pass of the
     BatchNorm backward that consumes `out` (bf16 3x3 / stride 1 / pad 1; one partial row per 16x16 tile)."""
-    d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats)
+    d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats, virt=virt)
     if bn_bwd is not None:
         yv, bsc, bsh, bmu, bis, bmode, p0, p1 = bn_bwd
         rows = conv_stat_rows(x, Cout, KH, KW, stride, pad)
@@ -157,23 +169,31 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     if pool is not None:      # fused 2x2 max-pool of the written values (eval mode)
         assert (pool.B, pool.H, pool.W, pool.C) == (x.B, Ho // 2, Wo // 2, Cout) and pool.t.dtype == x.t.dtype
         d.pool_out, d.pool_ld = pool.ptr, pool.ld
-    assert wt.shape[0] == KH * KW and wt.shape[2] >= x.C and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
+    assert wt.shape[0] == KH * KW and (virt is not None or wt.shape[2] >= x.C) and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
     if pixel_shuffle:
         assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"
     else:
         assert (out.H, out.W, out.C) == (Ho, Wo, Cout), f"output view mismatch {(out.H, out.W, out.C)} vs {(Ho, Wo, Cout)}"
     assert out.B == x.B
-    if TIMERS is not None:
-        # same dispatch rule as cvcs_conv2d: 3x3 / stride 1 / pad 1 on maps of at least 8 pixels -> the halo kernel
-        halo = KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1 and not pixel_shuffle and x.H >= 8 and x.W >= 8
-        # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count
-        # launches that also carry the first pass of a BatchNorm backward are timed as their own family: their duration is not
-        # that of a convolution alone
-        fam = ("conv3x3_halo_bn_bwd" if bn_bwd is not None else "conv3x3_halo") if halo else "conv_igemm"
-        ev = TIMERS.bracket(fam, 2.0 * x.B * Ho * Wo * Cout * (cin_real or x.C) * KH * KW)
+    # same dispatch rule as cvcs_conv2d: 3x3 / stride 1 / pad 1 on maps of at least 8 pixels -> the halo kernel
+    halo = KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1 and not pixel_shuffle and x.H >= 8 and x.W >= 8
+    taps = (not halo and x.code == BF16 and virt is None and pad == 0 and dil == 1 and Cout % 128 == 0 and stats is None and
+            pre_affine is None and post_affine is None and ((KH, KW, stride) == (1, 1, 1) or (KH, KW, stride) == (2, 2, 2)))
+    # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count; `flops` overrides
+    # (a zero-dilated strided data gradient multiplies four times the pixels its convolution has).
+    # launches that also carry the first pass of a BatchNorm backward are timed as their own family: their duration is not
+    # that of a convolution alone
+    fam = ("conv3x3_halo_bn_bwd" if bn_bwd is not None else "conv3x3_halo") if halo else ("conv_taps" if taps else "conv_igemm")
+    if SCOPE:
+        fam = f"{fam}:{SCOPE}"
+    tag = (fam, float(flops) if flops is not None else 2.0 * x.B * Ho * Wo * Cout * (cin_real or (x.C if virt is None else 21)) * KH * KW)
+    if _lib._recording is not None:
+        _lib.pending_tag = tag
+    elif TIMERS is not None:
+        ev = TIMERS.bracket(*tag)
         ev[0].record()
     check(_lib.lib().cvcs_conv2d(C.byref(d), _stream()), "cvcs_conv2d")
-    if TIMERS is not None:
+    if TIMERS is not None and _lib._recording is None:
         ev[1].record()
 
 
@@ -184,24 +204,48 @@ def wgrad_workspace_floats(B, Ho, Wo, Cout, Cin, KH, KW, stride) -> int:
     return n * KH * KW * Cout * Cin
 
 
-def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, workspace: torch.Tensor, cin_real=None):
-    """dw[Cout][Cin_real][KH][KW] (f32, contiguous) = sum_p dy[p] (x) x[pix(p, tap)]."""
+def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None):
     d = WgradDesc()
-    d.x, d.x_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    if virt is not None:   # the stem's weight gradient over virtual pixels (see _conv_desc)
+        assert (KH, KW, stride, pad) == (7, 1, 2, 3) and x.C == 4 and x.off == 0
+        Wv = (x.W - 8) // 2
+        d.x, d.x_ld, d.B, d.H, d.W, d.Cin = x.ptr, 8, x.B, x.H, Wv, 32
+        d.aniso, d.stride_w, d.pad_w = 1, 1, 0
+        d.x_row_pitch, d.x_img_pitch = x.W * 4, x.H * x.W * 4
+    else:
+        d.x, d.x_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
     d.dy, d.dy_ld, d.Ho, d.Wo, d.Cout = dy.ptr, dy.ld, dy.H, dy.W, dy.C
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-    cin_real = x.C if cin_real is None else cin_real
+    d.dtype = x.code
+    return d
+
+
+def wgrad_workspace_floats_for(x: View, dy: View, KH, KW, stride, pad, virt=None) -> int:
+    """exact split-K workspace (floats) of one weight-gradient launch"""
+    d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt)
+    n = _lib.lib().cvcs_wgrad_workspace_floats(C.byref(d))
+    if n < 0:
+        raise _lib.CvcsError("cvcs_wgrad_workspace_floats: bad shape")
+    return n
+
+
+def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, workspace: torch.Tensor, cin_real=None, virt=None):
+    """dw[Cout][Cin_real][KH][KW] (f32, contiguous) = sum_p dy[p] (x) x[pix(p, tap)]."""
+    d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt)
+    cin_real = d.Cin if cin_real is None else cin_real
     d.dw, d.Cin_real = dw.data_ptr(), cin_real
     d.workspace = workspace.data_ptr()
-    d.dtype = x.code
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.C * cin_real * KH * KW
     assert workspace.dtype == torch.float32 and \
-        workspace.numel() >= wgrad_workspace_floats(x.B, dy.H, dy.W, dy.C, x.C, KH, KW, stride), "wgrad workspace too small"
-    if TIMERS is not None:
-        ev = TIMERS.bracket("wgrad", 2.0 * x.B * dy.H * dy.W * dy.C * cin_real * KH * KW)
+        workspace.numel() >= _lib.lib().cvcs_wgrad_workspace_floats(C.byref(d)), "wgrad workspace too small"
+    tag = ("wgrad", 2.0 * x.B * dy.H * dy.W * dy.C * (21 if virt is not None else cin_real) * KH * KW)
+    if _lib._recording is not None:
+        _lib.pending_tag = tag
+    elif TIMERS is not None:
+        ev = TIMERS.bracket(*tag)
         ev[0].record()
     check(_lib.lib().cvcs_conv2d_wgrad(C.byref(d), _stream()), "cvcs_conv2d_wgrad")
-    if TIMERS is not None:
+    if TIMERS is not None and _lib._recording is None:
         ev[1].record()
 
 
@@ -283,6 +327,67 @@ def colsum_finalize(part, rows, C_, out):
 def colsum_partial(x: View, part):
     check(_lib.lib().cvcs_colsum_partial(x.ptr, x.ld, x.B * x.H * x.W, x.C, part.data_ptr(), x.code, _stream()),
           "cvcs_colsum_partial")
+
+
+# ------------------------------------------------------------------------------------------------ residual networks
+def bn_add_act(y1: View, s1, b1, y2: View, s2, b2, out: View):
+    """out = relu(s1*y1 + b1 + (s2*y2 + b2 | y2)): the tail of a residual block in one pass"""
+    M = y1.B * y1.H * y1.W
+    assert (y2.B, y2.H, y2.W, y2.C) == (y1.B, y1.H, y1.W, y1.C) == (out.B, out.H, out.W, out.C)
+    check(_lib.lib().cvcs_bn_add_act(y1.ptr, y1.ld, s1.data_ptr(), b1.data_ptr(), y2.ptr, y2.ld, _ptr(s2), _ptr(b2), M, y1.C,
+                                     out.ptr, out.ld, y1.code, _stream()), "cvcs_bn_add_act")
+
+
+def relu_bwd_sum(out: View | None, grads, dz: View):
+    """dz = (sum of up to three gradients) * (out > 0); grads = [(view, half_resolution: bool)]"""
+    assert 1 <= len(grads) <= 3
+    g = list(grads) + [(None, False)] * (3 - len(grads))
+    for v, half in grads:
+        want = (dz.B, dz.H // 2, dz.W // 2, dz.C) if half else (dz.B, dz.H, dz.W, dz.C)
+        assert (v.B, v.H, v.W, v.C) == want and v.t.dtype == dz.t.dtype, "gradient view mismatch"
+    a = []
+    for v, half in g:
+        a += [0 if v is None else v.ptr, 0 if v is None else v.ld, int(half)]
+    check(_lib.lib().cvcs_relu_bwd_sum(0 if out is None else out.ptr, 0 if out is None else out.ld, *a, dz.B, dz.H, dz.W, dz.C,
+                                       dz.ptr, dz.ld, dz.code, _stream()), "cvcs_relu_bwd_sum")
+
+
+def maxpool3x3s2_fwd(x: View, out: View, idx: torch.Tensor):
+    assert idx.dtype == torch.uint8 and idx.is_contiguous() and idx.numel() == out.B * out.H * out.W * out.C
+    assert (out.H, out.W, out.C) == ((x.H + 1) // 2, (x.W + 1) // 2, x.C)
+    check(_lib.lib().cvcs_maxpool3x3s2_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, idx.data_ptr(), x.code, _stream()),
+          "cvcs_maxpool3x3s2_fwd")
+
+
+def maxpool3x3s2_bwd(g0: View, g1: View | None, idx: torch.Tensor, dx: View):
+    assert (g0.H, g0.W, g0.C) == ((dx.H + 1) // 2, (dx.W + 1) // 2, dx.C) and idx.numel() == g0.B * g0.H * g0.W * g0.C
+    check(_lib.lib().cvcs_maxpool3x3s2_bwd(g0.ptr, g0.ld, 0 if g1 is None else g1.ptr, 0 if g1 is None else g1.ld, idx.data_ptr(),
+                                           dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dx.code, _stream()), "cvcs_maxpool3x3s2_bwd")
+
+
+def dilate2x(x: View, out: View):
+    assert (out.B, out.H, out.W, out.C) == (x.B, 2 * x.H, 2 * x.W, x.C)
+    check(_lib.lib().cvcs_dilate2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, x.code, _stream()), "cvcs_dilate2x")
+
+
+def pack_input_stem(src: torch.Tensor, dst: torch.Tensor):
+    """src NCHW u8|f32 [B,3,H,W] -> dst [B,H,W+8,4] (real column x at x+3; margins and channel 3 zero)"""
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype in (torch.uint8, torch.float32)
+    B, C_, H, W = src.shape
+    assert C_ == 3 and tuple(dst.shape) == (B, H, W + 8, 4)
+    check(_lib.lib().cvcs_pack_input_stem(src.data_ptr(), int(src.dtype == torch.uint8), B, H, W, dst.data_ptr(),
+                                          dtype_code(dst.dtype), _stream()), "cvcs_pack_input_stem")
+
+
+def pack_stem_weight(w: torch.Tensor, wf: torch.Tensor):
+    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape[1:]) == (3, 7, 7) and tuple(wf.shape) == (7, w.shape[0], 32)
+    check(_lib.lib().cvcs_pack_stem_weight(w.data_ptr(), w.shape[0], wf.data_ptr(), dtype_code(wf.dtype), _stream()),
+          "cvcs_pack_stem_weight")
+
+
+def unpack_stem_wgrad(tmp: torch.Tensor, dw: torch.Tensor):
+    assert tmp.dtype == torch.float32 and dw.dtype == torch.float32 and dw.is_contiguous() and tmp.numel() == dw.shape[0] * 32 * 7
+    check(_lib.lib().cvcs_unpack_stem_wgrad(tmp.data_ptr(), dw.shape[0], dw.data_ptr(), _stream()), "cvcs_unpack_stem_wgrad")
 
 
 # ------------------------------------------------------------------------------------------------ bilinear

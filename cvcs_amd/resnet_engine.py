@@ -1,0 +1,421 @@
+"""Launch plan of the ResNet-encoder U-Nets (BASELINE.json configs 1, 2, 5: "ResNet18-UNet", "ResNet50-UNet") on the HIP
+kernels.
+
+The reference has no such model (its factory S/utils.py:174-195 is the seam they plug into, see nets.ResnetUnet); the
+architecture (the CPU checker states it in plain torch) is: ResNet v1.5 encoder (7x7/s2 stem, 3x3/s2
+max-pool, BasicBlock / Bottleneck stages) and a bilinear-upsample decoder of (conv3x3 -> BN -> ReLU) pairs with the encoder
+features concatenated, 1x1 head.
+
+MI355X-first choices:
+  * launch plan, not a module tree: the first pass for an input shape runs eagerly under `_lib.Recording`, every later
+    step REPLAYS the recorded list of C-ABI launches (about a thousand per training step for ResNet-50) with no Python in
+    between - the host side of a step is one loop over pre-built argument tuples;
+  * activations NHWC bf16 (f32 on the parity path); `torch.cat` never runs: encoder features and the up-sampled decoder
+    tensor are written by their producers into channel ranges of one buffer;
+  * BatchNorm batch statistics come out of the conv epilogues; the block tail (BN apply + shortcut (+ its BN) + add +
+    ReLU) is one pass; its backward (sum of up to three incoming gradients x ReLU mask) is one pass that also scatters
+    the half-resolution gradient of a stride-2 projection shortcut;
+  * the 7x7/s2 stem runs as a 7x1 filter over "virtual pixels" (64-byte windows of the 4-channel padded tile): seven
+    K-steps instead of 49 and no im2col buffer (cvcs_conv_desc.aniso);
+  * strided 3x3 data gradients = zero-dilated gradient through the stride-1 halo kernel; strided 1x1 data gradients are
+    computed at half resolution and scattered by the consumer;
+  * eval mode folds every BatchNorm into its conv's epilogue.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from .engine import _BN
+from .ops import View
+
+ARCHS = {
+    "resnet18": ("basic", (2, 2, 2, 2), (64, 128, 256, 512)),
+    "resnet34": ("basic", (3, 4, 6, 3), (64, 128, 256, 512)),
+    "resnet50": ("bottleneck", (3, 4, 6, 3), (256, 512, 1024, 2048)),
+}
+DECODER_CHANNELS = (256, 128, 64, 64, 64)
+
+
+class Act:
+    """an activation and the gradients its consumers produce for it during backward: [(view, half_resolution)]"""
+
+    def __init__(self, v: View):
+        self.v = v
+        self.grads = []
+
+
+class Unit:
+    """one conv (+ BatchNorm): input view, conv output y, geometry"""
+
+    def __init__(self, x, y, conv, bn, k, stride, pad, virt=False):
+        self.x, self.y, self.conv, self.bn, self.k, self.stride, self.pad, self.virt = x, y, conv, bn, k, stride, pad, virt
+
+
+class ResNetUNetEngine:
+    def __init__(self, arch: str, num_classes: int, dtype: torch.dtype, device, decoder_channels=DECODER_CHANNELS):
+        assert arch in ARCHS
+        self.arch, self.NC, self.dtype, self.dev = arch, num_classes, dtype, torch.device(device)
+        self.kind, self.depths, self.widths = ARCHS[arch]
+        self.dec = tuple(decoder_channels)
+        assert self.dec[-1] == 64, "the 1x1 head kernels take 64 input channels"
+        self.code = ops.dtype_code(dtype)
+        self.P = self.G = self.Bf = None
+        self.shape = None
+        self.on_backward_begin = None    # data-parallel hooks (cvcs_amd.parallel)
+        self.on_grad_ready = None
+        self.sync_bn = None
+        self._bufs = {}
+        self._rec = {}                   # "fwd_train" | "fwd_eval" | "bwd" -> _lib.Recording
+        self._tape = None
+        self._saved_train = False
+        self._last_act = {}
+        self.keep_all = False            # tests: every backward intermediate in its own buffer (no scratch reuse) + a registry
+        self.bwd_units = {}
+
+    # ------------------------------------------------------------------------------------------------ binding
+    def bind(self, params, grads, buffers):
+        self.P, self.G, self.Bf = params, grads, buffers
+        base = min(g.data_ptr() for g in grads.values())
+        self._goff = {k: (g.data_ptr() - base) // 4 for k, g in grads.items()}
+        dev, dt = self.dev, self.dtype
+        self.packed = {}
+        entries = []
+        for name, w in params.items():
+            if w.dim() != 4 or name in ("encoder.conv1.weight", "segmentation_head.0.weight"):
+                continue
+            cout, cin, kh, kw = w.shape
+            pk = dict(wf=torch.empty(kh * kw, cout, cin, dtype=dt, device=dev), wd=torch.empty(kh * kw, cin, cout, dtype=dt, device=dev))
+            self.packed[name[:-len(".weight")]] = pk
+            entries.append((w, pk["wf"], pk["wd"]))
+        self._pack_table = ops.pack_table(entries, dev)
+        self.stem_wf = torch.empty(7, 64, 32, dtype=dt, device=dev)
+        self.stem_dw_tmp = torch.empty(64 * 32 * 7, dtype=torch.float32, device=dev)
+        self.bn = {n[:-len(".weight")]: _BN(p.numel(), dev) for n, p in params.items() if p.dim() == 1 and n.endswith(".weight")}
+        cmax = max(max(self.widths), 64)
+        self.one = torch.ones(cmax, dtype=torch.float32, device=dev)
+        self.zero = torch.zeros(cmax, dtype=torch.float32, device=dev)
+        self._rec, self._bufs, self.shape = {}, {}, None
+
+    def enable_sync_bn(self, sync):
+        raise NotImplementedError("exact (SyncBN) data-parallel mode is built for the reference's U-Nets only so far; "
+                                  "ResNet-UNets train with per-rank BatchNorm statistics (torch-DDP semantics)")
+
+    def refresh_weights(self):
+        ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
+        ops.pack_stem_weight(self.P["encoder.conv1.weight"], self.stem_wf)
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype=None):
+        key = (name, tuple(shape), dtype or self.dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+        return t
+
+    def _act(self, name, B, H, W, C_):
+        return self._buf(name, (B, H, W, C_))
+
+    def _scratch(self, tag, n, dtype=torch.float32):
+        return self._buf(f"scratch.{tag}", (int(n),), dtype)
+
+    # ------------------------------------------------------------------------------------------------ forward pieces
+    def _unit(self, x: View, conv, bn, k, stride, pad, train, act_out: View | None, relu=True, virt=False) -> Unit:
+        """conv (+ batch statistics) -> BatchNorm finalize [-> apply (+ReLU) into act_out].  act_out None: the caller applies
+        the BatchNorm itself (block tail).  Eval mode: the BatchNorm is folded into the conv epilogue; y then holds bn(conv)."""
+        B = x.B
+        w = self.P[conv + ".weight"]
+        cout = w.shape[0]
+        ops.SCOPE = "enc" if conv.startswith("encoder.") else "dec"
+        if virt:
+            Ho, Wo = x.H // 2, (x.W - 8) // 2
+            wf = self.stem_wf
+            kh, kw = 7, 1
+        else:
+            Ho, Wo = ops.conv_out_hw(x.H, x.W, k, k, stride, pad)
+            wf = self.packed[conv]["wf"]
+            kh = kw = k
+        st = self.bn[bn]
+        M = B * Ho * Wo
+        if not train:
+            ops.bn_finalize(None, 0, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
+                            self.Bf[bn + ".running_var"], False, st.scale, st.shift, None, None)
+            out = act_out if act_out is not None else ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
+            ops.conv2d(x, wf, None, out, kh, kw, stride, pad, relu=relu and act_out is not None, pre_affine=(st.scale, st.shift),
+                       virt=virt or None)
+            return Unit(x, out, conv, bn, k, stride, pad, virt)
+        y = ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
+        rows = ops.conv_stat_rows(x, cout, kh, kw, stride, pad, virt=virt or None)
+        stats = (self._scratch("stat_sum", rows * cout), self._scratch("stat_m2", rows * cout), self._scratch("stat_cnt", rows))
+        ops.conv2d(x, wf, None, y, kh, kw, stride, pad, stats=stats, virt=virt or None)
+        need = ops.bn_finalize_workspace_floats(rows, cout)
+        ops.bn_finalize(stats, rows, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
+                        self.Bf[bn + ".running_var"], True, st.scale, st.shift, st.mean, st.invstd,
+                        workspace=self._scratch("bn_ws", max(need, 4)))
+        if act_out is not None:
+            ops.bn_act(y, st.scale, st.shift, relu, act_out)
+        u = Unit(x, y, conv, bn, k, stride, pad, virt)
+        self.units[conv] = (u, act_out)     # persistent views of this shape's plan (layer-wise parity tests read them)
+        if act_out is not None and relu:
+            self.relu_order.append(act_out)
+        return u
+
+    def _tail(self, u3: Unit, ud: Unit | None, h: Act, out: View, train):
+        s3 = self.bn[u3.bn]
+        C_ = out.C
+        if train:
+            if ud is not None:
+                sd = self.bn[ud.bn]
+                ops.bn_add_act(u3.y, s3.scale, s3.shift, ud.y, sd.scale, sd.shift, out)
+            else:
+                ops.bn_add_act(u3.y, s3.scale, s3.shift, h.v, None, None, out)
+        else:   # the BatchNorms are already inside the conv epilogues
+            ops.bn_add_act(u3.y, self.one[:C_], self.zero[:C_], ud.y if ud is not None else h.v, None, None, out)
+
+    def _block(self, h: Act, p, stride, out: View, train, tape) -> Act:
+        B = h.v.B
+        has_ds = (p + ".downsample.0.weight") in self.P
+        if self.kind == "basic":
+            w = self.P[p + ".conv1.weight"].shape[0]
+            Ho, Wo = h.v.H // stride, h.v.W // stride
+            a1 = Act(ops.view(self._act(p + ".a1", B, Ho, Wo, w)))
+            u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 3, stride, 1, train, a1.v)
+            ut = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, 1, 1, train, None)
+            chain = [(u1, h, a1)]
+            last_in = a1
+        else:
+            mid = self.P[p + ".conv1.weight"].shape[0]
+            Ho, Wo = h.v.H // stride, h.v.W // stride
+            a1 = Act(ops.view(self._act(p + ".a1", B, h.v.H, h.v.W, mid)))
+            a2 = Act(ops.view(self._act(p + ".a2", B, Ho, Wo, mid)))
+            u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 1, 1, 0, train, a1.v)
+            u2 = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, stride, 1, train, a2.v)
+            ut = self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
+            chain = [(u1, h, a1), (u2, a1, a2)]
+            last_in = a2
+        ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
+        self._tail(ut, ud, h, out, train)
+        self.relu_order.append(out)
+        o = Act(out)
+        if train:
+            def bwd():
+                dz = ops.view(self._act(p + ".dz", out.B, out.H, out.W, out.C))
+                ops.relu_bwd_sum(o.v, o.grads, dz)
+                dy = self._unit_bwd(ut, dz, 2)
+                last_in.grads.append(self._dgrad(ut, dy, p + ".g_t"))
+                for (u, xin, aout) in reversed(chain):
+                    assert len(aout.grads) == 1
+                    dy = self._unit_bwd(u, aout.grads[0][0], 0)
+                    xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
+                if ud is not None:
+                    dyd = self._unit_bwd(ud, dz, 2)
+                    h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
+                else:
+                    h.grads.append((dz, False))
+                self._ready(p + ".conv1.weight")
+            tape.append(bwd)
+        return o
+
+    # ------------------------------------------------------------------------------------------------ backward pieces
+    def _unit_bwd(self, u: Unit, g: View, mode) -> View:
+        """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
+        output) in a scratch buffer that lives until the next _unit_bwd"""
+        st = self.bn[u.bn]
+        y = u.y
+        M, C_ = y.B * y.H * y.W, y.C
+        rows = ops.bn_bwd_rows(M)
+        p0, p1, p2 = (self._scratch(f"bnb{i}", rows * C_) for i in range(3))
+        ops.bn_bwd_reduce(y, g, None, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
+        ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
+                            st.ca, st.cb)
+        dy = ops.view(self._scratch(u.conv + ".dy" if self.keep_all else "dy", M * C_, self.dtype).view(y.B, y.H, y.W, C_))
+        if self.keep_all:
+            self.bwd_units[u.conv] = dict(unit=u, g=g, mode=mode, dy=dy)
+        ops.bn_bwd_apply(y, g, None, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, dy, p2)
+        if u.virt:
+            need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
+            ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch("wg_ws", need), cin_real=32, virt=True)
+            ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
+        else:
+            need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad)
+            ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch("wg_ws", need))
+        return dy
+
+    def _dgrad(self, u: Unit, dy: View, name):
+        """data gradient of a unit's conv -> (view, half_resolution)"""
+        wd = self.packed[u.conv]["wd"]
+        x = u.x
+        B, cin = x.B, x.C
+        ops.SCOPE = "enc" if u.conv.startswith("encoder.") else "dec"
+        if u.k == 1:
+            # stride 2: the gradient exists at the even pixels only - computed at half resolution, scattered by the consumer
+            gx = ops.view(self._act(name, B, dy.H, dy.W, cin))
+            ops.conv2d(dy, wd, None, gx, 1, 1)
+            if self.keep_all:
+                self.bwd_units[u.conv]["gx"] = gx
+            return gx, u.stride == 2
+        gx = ops.view(self._act(name, B, x.H, x.W, cin))
+        if u.stride == 1:
+            ops.conv2d(dy, wd, None, gx, 3, 3, 1, 1)
+        else:
+            # 3x3 / stride 2 / pad 1: dx = conv3x3/s1/p1(zero-dilated dy, flipped weights) - on the halo kernel
+            dil = ops.view(self._scratch("dilated", B * x.H * x.W * dy.C, self.dtype).view(B, x.H, x.W, dy.C))
+            ops.dilate2x(dy, dil)
+            ops.conv2d(dil, wd, None, gx, 3, 3, 1, 1, flops=2.0 * B * dy.H * dy.W * dy.C * cin * 9)
+        if self.keep_all:
+            self.bwd_units[u.conv]["gx"] = gx
+        return gx, False
+
+    def _ready(self, name):
+        off = self._goff[name]   # (the hook is looked up at replay time: a data-parallel wrapper may be attached later)
+        _lib._recording.host(lambda: self.on_grad_ready(off, []) if self.on_grad_ready is not None else None)
+
+    # ------------------------------------------------------------------------------------------------ the network
+    def _backbone(self, B, S, train):
+        """issues every launch between the packed input and the last decoder activation; returns that activation and, in
+        train mode, fills self._tape with the backward closures (run in reverse by backward())"""
+        tape = []
+        self.units, self.relu_order = {}, []     # relu_order: every ReLU output in execution order (tests)
+        self.refresh_weights()
+        dec, widths = self.dec, self.widths
+        skipc = [widths[2], widths[1], widths[0], 64, 0]
+        # decoder input buffers: [up-sampled | skip] channel ranges; the encoder writes its features into the skip ranges
+        cat, cin = [], widths[3]
+        for i in range(5):
+            s = S >> (4 - i)
+            cat.append(self._act(f"cat{i}", B, s, s, cin + skipc[i]))
+            cin = dec[i]
+        upc = [widths[3]] + list(dec[:4])                    # channels of the up-sampled part of cat[i]
+        skip_view = lambda i: View(cat[i], upc[i], skipc[i])  # noqa: E731
+        in4 = ops.view(self._buf("in4", (B, S, S + 8, 4)))
+        f1 = Act(skip_view(3))
+        u0 = self._unit(in4, "encoder.conv1", "encoder.bn1", 7, 2, 3, train, f1.v, virt=True)
+        p0 = Act(ops.view(self._act("pool0", B, S // 4, S // 4, 64)))
+        idx = self._buf("pool0.idx", (B * (S // 4) * (S // 4) * 64,), torch.uint8)
+        ops.maxpool3x3s2_fwd(f1.v, p0.v, idx)
+        if train:
+            def stem_bwd():
+                dx = ops.view(self._act("pool0.dx", B, S // 2, S // 2, 64))
+                g = [v for v, _ in p0.grads]
+                ops.maxpool3x3s2_bwd(g[0], g[1] if len(g) > 1 else None, idx, dx)
+                f1.grads.append((dx, False))
+                dz = ops.view(self._act("stem.dz", B, S // 2, S // 2, 64))
+                ops.relu_bwd_sum(f1.v, f1.grads, dz)
+                self._unit_bwd(u0, dz, 0)
+                self._ready("encoder.conv1.weight")
+            tape.append(stem_bwd)
+        h = p0
+        feats = {}
+        for s, n in enumerate(self.depths, start=1):
+            for b in range(n):
+                p = f"encoder.layer{s}.{b}"
+                stride = 2 if (b == 0 and s > 1) else 1
+                hs = h.v.H // stride
+                w = widths[s - 1]
+                if b == n - 1 and s < 4:
+                    out = skip_view(3 - s)          # stage 1 -> cat[2], stage 2 -> cat[1], stage 3 -> cat[0]
+                else:
+                    out = ops.view(self._act(p + ".out", B, hs, hs, w))
+                h = self._block(h, p, stride, out, train, tape)
+            feats[s] = h
+        # decoder
+        for i in range(5):
+            s = S >> (4 - i)
+            up = View(cat[i], 0, upc[i])
+            ops.upsample2x_fwd(h.v, up)
+            pre = f"decoder.blocks.{i}"
+            a1 = Act(ops.view(self._act(pre + ".a1", B, s, s, dec[i])))
+            a2 = Act(ops.view(self._act(pre + ".a2", B, s, s, dec[i])))
+            xin = ops.view(cat[i])
+            u1 = self._unit(xin, pre + ".conv1.0", pre + ".conv1.1", 3, 1, 1, train, a1.v)
+            u2 = self._unit(a1.v, pre + ".conv2.0", pre + ".conv2.1", 3, 1, 1, train, a2.v)
+            if train:
+                def dec_bwd(i=i, s=s, pre=pre, u1=u1, u2=u2, a1=a1, a2=a2, prev=h):
+                    assert len(a2.grads) == 1
+                    dy = self._unit_bwd(u2, a2.grads[0][0], 0)
+                    g1, _ = self._dgrad(u2, dy, pre + ".g_a1")
+                    dy = self._unit_bwd(u1, g1, 0)
+                    gcat, _ = self._dgrad(u1, dy, pre + ".g_cat")
+                    gprev = ops.view(self._act(pre + ".g_prev", B, s // 2, s // 2, upc[i]))
+                    ops.upsample2x_bwd(View(gcat.t, 0, upc[i]), gprev)
+                    prev.grads.append((gprev, False))
+                    if skipc[i]:
+                        skip_act = f1 if i == 3 else feats[3 - i]
+                        skip_act.grads.append((View(gcat.t, upc[i], skipc[i]), False))
+                    self._ready(pre + ".conv1.0.weight")
+                tape.append(dec_bwd)
+            h = a2
+        if train:
+            self._tape = tape
+        self._last = h
+        return h
+
+    def _plan(self, B, S):
+        if self.shape != (B, S):
+            assert S % 32 == 0, "tile side must be a multiple of 32 (the encoder reduces the resolution 32 times)"
+            self.shape = (B, S)
+            self._rec, self._bufs = {}, {}
+            self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
+
+    def _run(self, key, fn):
+        """first time: run fn() eagerly while recording its launches; afterwards replay the recording"""
+        rec = self._rec.get(key)
+        if rec is None:
+            with _lib.Recording() as rec:
+                fn()
+            self._rec[key] = rec
+        else:
+            rec.replay(torch.cuda.current_stream().cuda_stream, ops.TIMERS)
+
+    def _forward_backbone(self, x, train):
+        B, C_, S, S2 = x.shape
+        assert C_ == 3 and S == S2
+        self._plan(B, S)
+        ops.pack_input_stem(x.contiguous(), self._buf("in4", (B, S, S + 8, 4)))
+        key = "fwd_train" if train else "fwd_eval"
+        if train and "fwd_train" not in self._rec:
+            self._rec.pop("bwd", None)
+        self._run(key, lambda: self._backbone(B, S, train))
+        if key not in self._last_act:
+            self._last_act[key] = self._last
+        self._saved_train = train
+        return self._last_act[key]
+
+    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
+        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)"""
+        if self.shape != (x.shape[0], x.shape[2]):
+            self._last_act = {}
+        h = self._forward_backbone(x, train)
+        ops.head_fwd(h.v, self.P["segmentation_head.0.weight"].view(self.NC, 64), self.P["segmentation_head.0.bias"], self.logits)
+        return self.logits
+
+    def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
+        if self.shape != (x.shape[0], x.shape[2]):
+            self._last_act = {}
+        h = self._forward_backbone(x, False)
+        ops.head_argmax(h.v, self.P["segmentation_head.0.weight"].view(self.NC, 64), self.P["segmentation_head.0.bias"], labels)
+        return labels
+
+    def backward(self, dlogits: torch.Tensor):
+        """dlogits: NCHW f32 [B,NC,S,S]; fills every gradient view in self.G (overwrites)"""
+        assert self._saved_train, "backward needs a preceding forward in train mode"
+        if self.on_backward_begin is not None:
+            self.on_backward_begin()
+        B, S = self.shape
+        NC = self.NC
+        h = self._last_act["fwd_train"]
+        rows = ops.head_bwd_rows(B * S * S)
+        part = self._scratch("head_part", rows * (NC * 64 + NC))
+        gh = ops.view(self._act("head.gx", B, S, S, 64))
+        ops.head_bwd(h.v, dlogits.contiguous(), self.P["segmentation_head.0.weight"].view(NC, 64), gh, part)
+        gw, gb = self.G["segmentation_head.0.weight"], self.G["segmentation_head.0.bias"]
+        assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4
+        ops.colsum_finalize(part, rows, NC * 64 + NC, gw)
+        if self.on_grad_ready is not None:
+            self.on_grad_ready(self._goff["segmentation_head.0.weight"], [])
+
+        def run_tape():
+            h.grads = [(gh, False)]
+            for fn in reversed(self._tape):
+                fn()
+        self._run("bwd", run_tape)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 3
+#define CVCS_ABI_VERSION 4
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -85,6 +85,16 @@ typedef struct {
   const float* bwd_scale;  const float* bwd_shift;  const float* bwd_mean;  const float* bwd_invstd;
   int32_t bwd_mode;
   float* bwd_part_dz;  float* bwd_part_dzx;
+  /* ---- ABI 4: anisotropic geometry and explicit input pitches (generic gather kernel only; all 0 = the isotropic,
+   * densely packed case above).  aniso = 1: the W axis uses stride_w / pad_w instead of stride / pad (H keeps stride / pad).
+   * in_row_pitch / in_img_pitch (elements, 0 = W*in_ld / H*row pitch): pixel (b, y, x) of `in` lives at
+   * b*in_img_pitch + y*in_row_pitch + x*in_ld, and in_ld may then be SMALLER than Cin - consecutive "pixels" overlap.
+   * This is how the 7x7 / stride 2 stem of the ResNet encoders runs without an im2col buffer: the 3-channel tile is stored
+   * 4 channels per pixel with a 3-pixel left margin, a "virtual pixel" is the 64-byte window of 8 real pixels starting at
+   * real column 2*xo - 3 (in_ld = 8 elements = two real pixels), and the stem is a KH = 7, KW = 1 convolution with
+   * stride (2, 1) over 32 virtual channels = (kw, c) pairs - seven K-steps instead of 49.                          */
+  int32_t aniso, stride_w, pad_w;
+  int64_t in_row_pitch, in_img_pitch;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
@@ -96,7 +106,7 @@ int cvcs_conv_stat_rows(const cvcs_conv_desc* d);
  * `dw` is f32 in the reference's parameter layout OIHW [Cout][Cin_real][KH][KW]; Cin_real <= Cin lets the
  * zero-padded first layer drop its padding.  A ConvTranspose2d(k2,s2) weight [Cin_T][Cout_T][2][2] is the same
  * call with dy := the layer's input, x := the gradient of its output, KH=KW=2, stride=2, pad=0.
- * Filters built: 3x3, 2x2, 1x1.  workspace: cvcs_wgrad_slices(...) * KH*KW*Cout*Cin floats.               */
+ * Filters built: 3x3, 2x2, 1x1 (and 7x1, see `aniso`).  workspace: cvcs_wgrad_slices(...) * KH*KW*Cout*Cin floats.               */
 typedef struct {
   const void* x;    int64_t x_ld;   int32_t B, H, W, Cin;
   const void* dy;   int64_t dy_ld;  int32_t Ho, Wo, Cout;
@@ -104,8 +114,14 @@ typedef struct {
   float* dw;        int32_t Cin_real;
   float* workspace;
   int32_t dtype;
+  /* ABI 4: as in cvcs_conv_desc (generic kernel only): separate W stride / padding, explicit pitches of `x`; filters
+   * 7x1 are built for this case (the stem's weight gradient over virtual channels).                              */
+  int32_t aniso, stride_w, pad_w;
+  int64_t x_row_pitch, x_img_pitch;
 } cvcs_wgrad_desc;
 int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
+/* exact workspace size (floats) of one descriptor; covers the anisotropic / pitched case cvcs_wgrad_slices cannot express */
+int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d);
 
 /* ---- BatchNorm2d ---------------------------------------------------------------------------------------
  * replaces: nn.BatchNorm2d (S/blocks.py:14,42,45) forward in train / eval mode and its backward.
@@ -137,7 +153,8 @@ int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C,
 
 /* BatchNorm(+ReLU)(+MaxPool) backward, two passes over (y, g):
  *   mode 0 (encoder, a = relu(bn(y))): dz = (g1 + unpool(g2)) * (a > 0);  mode 1 (decoder, z = bn(r), r = relu(conv)):
- *   dz = g1, and the ReLU mask (r > 0) is applied to the result.
+ *   dz = g1, and the ReLU mask (r > 0) is applied to the result;  mode 2 (no ReLU on either side: the last BatchNorm of a
+ *   residual block, whose ReLU comes after the add - cvcs_relu_bwd_sum): dz = g1.
  * pass 1 -> partial sums of dz and dz*xhat ([rows][C] each, rows = cvcs_bn_bwd_rows(B*H*W); or taken by the conv
  *           launch that produced g1 - cvcs_conv_desc.bwd_y - and reduced to at most 1024 rows by cvcs_colsum_partial);
  * cvcs_bn_bwd_finalize -> dgamma, dbeta and the two per-channel coefficients;
@@ -261,6 +278,44 @@ int cvcs_label_stitch(const uint8_t* tiles, int n, int S, int p, int first_tile,
 int cvcs_gather_tiles(const uint8_t* src, int C, int H, int W, const int32_t* origins, int n, int S, uint8_t* dst,
                       void* stream);
 int cvcs_label_histogram(const uint8_t* labels, int64_t n, int K, int64_t* counts /* int64 [K], accumulated */, void* stream);
+
+/* ---- residual networks (ResNet-encoder U-Nets of BASELINE.json configs 1, 2, 5; no counterpart in the reference, whose
+ * factory S/utils.py:174-195 is the seam these models plug into) ------------------------------------------------------
+ * cvcs_bn_add_act: the tail of a residual block, out = relu(s1*y1 + b1 + (s2 ? s2*y2 + b2 : y2)): BatchNorm apply of the
+ * main branch + the identity (s2 = NULL: y2 is the block input as stored) or the BatchNorm of the 1x1 projection
+ * shortcut + the add + the ReLU in one pass.  All views NHWC `dtype`, C % (16/sizeof) == 0.                          */
+int cvcs_bn_add_act(const void* y1, int64_t y1_ld, const float* s1, const float* b1,
+                    const void* y2, int64_t y2_ld, const float* s2, const float* b2,
+                    int64_t M, int C, void* out, int64_t out_ld, int dtype, void* stream);
+/* backward of that tail: dz = (g0 + g1 + g2) * (out > 0) - the gradient w.r.t. the block output arrives from up to three
+ * consumers (next block's first conv, next block's shortcut, a decoder skip); g1 / g2 may be NULL.  A gradient with
+ * gN_half = 1 lives at HALF resolution [B, H/2, W/2, C] and contributes to pixel (2y, 2x) only: the data gradient of a
+ * 1x1 / stride 2 projection shortcut, scattered on the fly.  `out` NULL: no ReLU mask (plain sum).                  */
+int cvcs_relu_bwd_sum(const void* out, int64_t out_ld,
+                      const void* g0, int64_t g0_ld, int g0_half,
+                      const void* g1, int64_t g1_ld, int g1_half,
+                      const void* g2, int64_t g2_ld, int g2_half,
+                      int B, int H, int W, int C, void* dz, int64_t dz_ld, int dtype, void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem and its backward.  idx (u8 [B,Ho,Wo,C]) = window position
+ * kh*3+kw of the FIRST maximum in scan order (what ATen's max_pool2d_with_indices keeps); backward gathers: every input
+ * pixel sums the gradients of the (at most four) windows whose idx points at it - no atomics, bitwise reproducible.
+ * g1 (optional) is a second gradient of the pooled tensor added on the fly (two consumers of the pooled map).       */
+int cvcs_maxpool3x3s2_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
+                          uint8_t* idx, int dtype, void* stream);
+int cvcs_maxpool3x3s2_bwd(const void* g0, int64_t g0_ld, const void* g1, int64_t g1_ld, const uint8_t* idx,
+                          int B, int H, int W, int C, void* dx, int64_t dx_ld, int dtype, void* stream);
+/* zero-dilation x2: out[b, 2y, 2x] = in[b, y, x], zero elsewhere (out is [B, 2H, 2W, C]).  The data gradient of a
+ * 3x3 / stride 2 / pad 1 convolution is the 3x3 / stride 1 / pad 1 convolution of the dilated output gradient with the
+ * flipped weights - it then runs on the halo kernel like every other data gradient.                                 */
+int cvcs_dilate2x(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld, int dtype,
+                  void* stream);
+/* stem boundary: u8 | f32 NCHW [B,3,H,W] -> [B, H, W + 8, 4] `dtype` (real column x at index x + 3, margins and the
+ * 4th channel zero) - the layout the virtual-pixel stem convolution reads (cvcs_conv_desc.aniso).                    */
+int cvcs_pack_input_stem(const void* src, int src_is_u8, int B, int H, int W, void* dst, int dtype, void* stream);
+/* stem weight OIHW f32 [Cout][3][7][7] -> [7 (kh)][Cout][32] `dtype`, virtual channel kw*4 + c (others zero); and the
+ * way back for its gradient: tmp f32 [Cout][32][7] (what cvcs_conv2d_wgrad writes for the 7x1 virtual filter) -> OIHW */
+int cvcs_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void* stream);
+int cvcs_unpack_stem_wgrad(const float* tmp, int Cout, float* dw, void* stream);
 
 /* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
  * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).
