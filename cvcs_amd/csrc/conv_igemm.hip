@@ -1207,6 +1207,39 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
   }
 
   // ---- epilogue: acc[i][j][r] = pixel row wm*64 + i*16 + fr, channel wn*64 + j*16 + fg*4 + r (bias already inside)
+  // BatchNorm partial statistics (1x1 convolutions of the residual blocks): one row per 64-pixel wave block, (count, sum,
+  // M2 centred on the block's own mean) of the f32 accumulators, as the generic kernel emits them; the 16 lanes that share
+  // a channel quadruple (fg) are merged with xor-shuffles.
+  if (p.stat_sum) {
+    const int rbase = m0 + wm * 64;
+    int nvalid = p.M - rbase;
+    nvalid = nvalid < 0 ? 0 : (nvalid > 64 ? 64 : nvalid);
+    const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
+    const int64_t srow = (int64_t)blockIdx.x * 4 + wm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += (i * 16 + fr < nvalid) ? acc[i][j][r] : 0.f;
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        const float mean = s * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dlt = acc[i][j][r] - mean;
+          q += (i * 16 + fr < nvalid) ? dlt * dlt : 0.f;
+        }
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+        if (fr == 0) {
+          const int n = n0 + wn * 64 + j * 16 + fg * 4 + r;
+          p.stat_sum[srow * p.Cout + n] = s;
+          p.stat_m2[srow * p.Cout + n] = q;
+        }
+      }
+    if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[srow] = (float)nvalid;
+  }
   auto stage = [&](auto relu_) {
     constexpr bool RELU = decltype(relu_)::value;
 #pragma unroll
@@ -1319,6 +1352,17 @@ static bool use_halo(const cvcs_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
          d->W >= 8;
 }
+// bf16 1x1/s1 and 2x2/s2 convolutions without padding (1x1 forward / data gradient of the residual blocks, the
+// ConvTranspose2d forward and data gradient) take the non-overlapping-taps kernel
+static bool use_taps(const cvcs_conv_desc* d) {
+  static const int taps_on = getenv("CVCS_CONV_TAPS") ? atoi(getenv("CVCS_CONV_TAPS")) : 1;   // tuning knob
+  if (!taps_on || d->dtype != CVCS_BF16 || d->aniso || d->in_row_pitch || d->in_img_pitch) return false;
+  const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1, k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
+  const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
+  return (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !(d->stat_sum && d->relu) &&
+         !d->pre_scale && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&
+         (!d->pixel_shuffle || ((d->Cout / 4) % 8 == 0 && !d->stat_sum)) && (int64_t)d->B * d->H * d->W * d->in_ld * 2 < (1ll << 32);
+}
 // partial-statistics rows per 16x16 tile: bf16 = one (MFMA statistics over the staged tile), f32 = one per wave row group
 static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 1 : 4; }
 
@@ -1326,6 +1370,11 @@ extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
   if (use_halo(d) && !d->aniso && !d->in_row_pitch && !d->in_img_pitch)
     return d->B * (int)cdiv(d->H, 16) * (int)cdiv(d->W, 16) * halo_wm(d);
+  // (the statistics pointers of the descriptor are not set by every caller of this query: the row count is that of the
+  //  launch WITH statistics)
+  cvcs_conv_desc q = *d;
+  q.stat_sum = q.stat_m2 = q.stat_cnt = reinterpret_cast<float*>(16);
+  if (use_taps(&q)) return (int)(cdiv((int64_t)d->B * d->Ho * d->Wo, 256) * 4);
   return (int)(cdiv((int64_t)d->B * d->Ho * d->Wo, kBM) * 2);
 }
 
@@ -1417,13 +1466,6 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
-  // bf16 1x1/s1 and 2x2/s2 convolutions without padding (the ConvTranspose2d forward and data gradient) take the
-  // non-overlapping-taps kernel
-  static const int taps_on = getenv("CVCS_CONV_TAPS") ? atoi(getenv("CVCS_CONV_TAPS")) : 1;   // tuning knob
-  const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1, k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
-  if (plain && taps_on && (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !d->stat_sum &&
-      !d->pre_scale && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&
-      (!d->pixel_shuffle || (d->Cout / 4) % 8 == 0) && (int64_t)d->B * d->H * d->W * d->in_ld * es < (1ll << 32))
-    return k1 ? launch_taps<1>(a, st) : launch_taps<4>(a, st);
+  if (use_taps(d)) return (d->KH == 1) ? launch_taps<1>(a, st) : launch_taps<4>(a, st);
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

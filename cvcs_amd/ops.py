@@ -177,8 +177,9 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     assert out.B == x.B
     # same dispatch rule as cvcs_conv2d: 3x3 / stride 1 / pad 1 on maps of at least 8 pixels -> the halo kernel
     halo = KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1 and not pixel_shuffle and x.H >= 8 and x.W >= 8
-    taps = (not halo and x.code == BF16 and virt is None and pad == 0 and dil == 1 and Cout % 128 == 0 and stats is None and
-            pre_affine is None and post_affine is None and ((KH, KW, stride) == (1, 1, 1) or (KH, KW, stride) == (2, 2, 2)))
+    taps = (not halo and x.code == BF16 and virt is None and pad == 0 and dil == 1 and Cout % 128 == 0 and
+            not (stats is not None and relu) and pre_affine is None and post_affine is None and
+            ((KH, KW, stride) == (1, 1, 1) or (KH, KW, stride) == (2, 2, 2)))
     # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count; `flops` overrides
     # (a zero-dilated strided data gradient multiplies four times the pixels its convolution has).
     # launches that also carry the first pass of a BatchNorm backward are timed as their own family: their duration is not

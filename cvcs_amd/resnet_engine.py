@@ -23,6 +23,8 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -70,6 +72,7 @@ class ResNetUNetEngine:
         self._tape = None
         self._saved_train = False
         self._last_act = {}
+        self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
         self.keep_all = False            # tests: every backward intermediate in its own buffer (no scratch reuse) + a registry
         self.bwd_units = {}
 
@@ -202,11 +205,21 @@ class ResNetUNetEngine:
                 dz = ops.view(self._act(p + ".dz", out.B, out.H, out.W, out.C))
                 ops.relu_bwd_sum(o.v, o.grads, dz)
                 dy = self._unit_bwd(ut, dz, 2)
-                last_in.grads.append(self._dgrad(ut, dy, p + ".g_t"))
-                for (u, xin, aout) in reversed(chain):
+                fz = None
+                if self.kind == "basic" and self._fusable(ut, chain[-1][0]):
+                    gx, half, fz = self._dgrad(ut, dy, p + ".g_t", fuse_into=chain[-1][0])
+                    last_in.grads.append((gx, half))
+                else:
+                    last_in.grads.append(self._dgrad(ut, dy, p + ".g_t"))
+                for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
                     assert len(aout.grads) == 1
-                    dy = self._unit_bwd(u, aout.grads[0][0], 0)
-                    xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
+                    dy = self._unit_bwd(u, aout.grads[0][0], 0, fused=fz)
+                    fz = None
+                    if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
+                        gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
+                        xin.grads.append((gx, half))
+                    else:
+                        xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
                 if ud is not None:
                     dyd = self._unit_bwd(ud, dz, 2)
                     h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
@@ -217,17 +230,34 @@ class ResNetUNetEngine:
         return o
 
     # ------------------------------------------------------------------------------------------------ backward pieces
-    def _unit_bwd(self, u: Unit, g: View, mode) -> View:
+    def _fusable(self, producer: Unit, consumer: Unit):
+        """can the data-gradient launch of `producer` (whose output is the gradient of `consumer`'s activation) also take the
+        reduce pass of consumer's BatchNorm backward?  (cvcs_conv_desc.bwd_y: bf16 3x3 / stride 1 launches on the three-
+        workgroup narrow tiles, i.e. up to 128 channels - on the wide kernel the longer epilogue is exposed)"""
+        y = consumer.y
+        return (self.fuse_bn_bwd and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
+                y.H >= 8 and y.W >= 8 and y.C <= 128)
+
+    def _unit_bwd(self, u: Unit, g: View, mode, fused=None) -> View:
         """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
-        output) in a scratch buffer that lives until the next _unit_bwd"""
+        output) in a scratch buffer that lives until the next _unit_bwd.  fused = (part_dz, part_dzx, rows): the reduce pass
+        was taken by the launch that produced g (one partial row per 16x16 tile)"""
         st = self.bn[u.bn]
         y = u.y
         M, C_ = y.B * y.H * y.W, y.C
         rows = ops.bn_bwd_rows(M)
         p0, p1, p2 = (self._scratch(f"bnb{i}", rows * C_) for i in range(3))
-        ops.bn_bwd_reduce(y, g, None, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
-        ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
-                            st.ca, st.cb)
+        if fused is not None:
+            f0, f1, trows = fused
+            rows1 = ops.bn_bwd_rows(trows)
+            for src, dst in ((f0, p0), (f1, p1)):
+                ops.colsum_partial(View(src[:trows * C_].view(1, trows, 1, C_), 0, C_), dst[:rows1 * C_])
+            ops.bn_bwd_finalize(p0, p1, rows1, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"],
+                                self.G[u.bn + ".bias"], st.ca, st.cb)
+        else:
+            ops.bn_bwd_reduce(y, g, None, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
+            ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
+                                st.ca, st.cb)
         dy = ops.view(self._scratch(u.conv + ".dy" if self.keep_all else "dy", M * C_, self.dtype).view(y.B, y.H, y.W, C_))
         if self.keep_all:
             self.bwd_units[u.conv] = dict(unit=u, g=g, mode=mode, dy=dy)
@@ -241,8 +271,19 @@ class ResNetUNetEngine:
             ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch("wg_ws", need))
         return dy
 
-    def _dgrad(self, u: Unit, dy: View, name):
-        """data gradient of a unit's conv -> (view, half_resolution)"""
+    def _dgrad(self, u: Unit, dy: View, name, fuse_into: Unit | None = None):
+        """data gradient of a unit's conv -> (view, half_resolution).  fuse_into: the unit whose activation this gradient
+        belongs to (mode-0 BatchNorm backward): its reduce pass rides on this launch; returns (view, half, fused partials)"""
+        if fuse_into is not None:
+            yv, st = fuse_into.y, self.bn[fuse_into.bn]
+            trows = ops.conv_stat_rows(dy, yv.C, 3, 3, 1, 1)
+            f0, f1 = self._scratch("fz0", trows * yv.C), self._scratch("fz1", trows * yv.C)
+            gx = ops.view(self._act(name, yv.B, yv.H, yv.W, yv.C))
+            ops.SCOPE = "enc" if u.conv.startswith("encoder.") else "dec"
+            ops.conv2d(dy, self.packed[u.conv]["wd"], None, gx, 3, 3, 1, 1, bn_bwd=(yv, st.scale, st.shift, st.mean, st.invstd, 0, f0, f1))
+            if self.keep_all:
+                self.bwd_units[u.conv]["gx"] = gx
+            return gx, False, (f0, f1, trows)
         wd = self.packed[u.conv]["wd"]
         x = u.x
         B, cin = x.B, x.C
@@ -333,8 +374,11 @@ class ResNetUNetEngine:
                 def dec_bwd(i=i, s=s, pre=pre, u1=u1, u2=u2, a1=a1, a2=a2, prev=h):
                     assert len(a2.grads) == 1
                     dy = self._unit_bwd(u2, a2.grads[0][0], 0)
-                    g1, _ = self._dgrad(u2, dy, pre + ".g_a1")
-                    dy = self._unit_bwd(u1, g1, 0)
+                    if self._fusable(u2, u1):
+                        g1, _, fz = self._dgrad(u2, dy, pre + ".g_a1", fuse_into=u1)
+                    else:
+                        (g1, _), fz = self._dgrad(u2, dy, pre + ".g_a1"), None
+                    dy = self._unit_bwd(u1, g1, 0, fused=fz)
                     gcat, _ = self._dgrad(u1, dy, pre + ".g_cat")
                     gprev = ops.view(self._act(pre + ".g_prev", B, s // 2, s // 2, upc[i]))
                     ops.upsample2x_bwd(View(gcat.t, 0, upc[i]), gprev)

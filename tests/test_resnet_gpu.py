@@ -134,6 +134,47 @@ def test_strided_and_pointwise_convs(dtype, k, stride, pad, cin, cout, S):
         close(from_nhwc(gx), xq.grad, tol(dtype), "data gradient (1x1)")
 
 
+@pytest.mark.parametrize("cin,cout,S,off", [(256, 128, 24, 64), (64, 256, 20, 0), (128, 128, 17, 32), (256, 64, 12, 0)])
+def test_pointwise_conv_statistics_and_gemm_weight_gradient(cin, cout, S, off):
+    """bf16 1x1 convolutions of the bottlenecks: forward on the non-overlapping-taps kernel WITH the BatchNorm statistics
+    epilogue (cout % 128 == 0; else the generic kernel), weight gradient as one transposed GEMM (wgrad_gemm_kernel; pixel
+    counts that are no multiple of the 32-pixel K-tile, input read through a channel-range view of a wider buffer)"""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout)
+    B = 3
+    x = torch.randn(B, cin, S, S, generator=g) + 0.5
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    xq, wq = rq(x, dtype), rq(w, dtype).requires_grad_(True)
+    ref = F.conv2d(xq, wq)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(rq(dy, dtype))
+    wide = torch.zeros(B, S, S, cin + off + 32, dtype=dtype, device=DEV)
+    wide[..., off:off + cin] = to_nhwc(x, dtype)
+    xv = View(wide, off, cin)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), cin, dtype)
+    y = torch.empty(B, S, S, cout, dtype=dtype, device=DEV)
+    rows = ops.conv_stat_rows(xv, cout, 1, 1)
+    stats = tuple(torch.zeros(n, device=DEV) for n in (rows * cout, rows * cout, rows))
+    ops.conv2d(xv, wf, None, ops.view(y), 1, 1, stats=stats)
+    torch.cuda.synchronize()
+    close(from_nhwc(y), ref.detach(), 2e-2, "forward")
+    cnt = stats[2].cpu().double()
+    M = B * S * S
+    assert cnt.sum().item() == M
+    ssum, sm2 = stats[0].cpu().double().view(rows, cout), stats[1].cpu().double().view(rows, cout)
+    mean = ssum.sum(0) / M
+    bmean = ssum / cnt.clamp_min(1)[:, None]
+    var = (sm2.sum(0) + (cnt[:, None] * (bmean - mean) ** 2).sum(0)) / M
+    close(mean.float(), ref.detach().mean(dim=(0, 2, 3)), 1e-2, "statistics: mean")
+    close(var.float(), ref.detach().var(dim=(0, 2, 3), unbiased=False), 1e-2, "statistics: variance")
+    dyd = to_nhwc(dy, dtype)
+    dw = torch.empty(cout, cin, 1, 1, device=DEV)
+    ws = torch.empty(ops.wgrad_workspace_floats_for(xv, ops.view(dyd), 1, 1, 1, 0), device=DEV)
+    ops.conv2d_wgrad(xv, ops.view(dyd), dw, 1, 1, 1, 0, ws)
+    torch.cuda.synchronize()
+    close(dw.cpu(), wq.grad, 1e-4, "weight gradient (exact bf16 products, f32 accumulate)")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H,W", [(16, 16), (13, 10)])
 def test_maxpool3x3s2_forward_indices_and_backward(dtype, H, W):
@@ -270,8 +311,8 @@ def test_fp32_train_steps_match_oracle(arch, B, S, NC):
     f32 rounding of zero is decided one way or the other by ANY two f32 implementations, and one such decision moves single
     gradient elements by O(1).  So the float64 oracle is evaluated with the HIP path's own ReLU decisions (read back from
     its stored activations), the decisions that differ from the oracle's own are COUNTED, and each must sit on a
-    pre-activation below 1e-4 of its tensor's max - i.e. be a float64 near-zero, not an error (measured: 2-14 of 2-12 million
-    decisions in step 1, |x|/max|x| <= 1e-6; up to 2e-5 after two optimiser steps of accumulated difference)."""
+    pre-activation below 1e-5 of its tensor's max (measured: 2-14 of 2-12 million decisions, |x|/max|x| <= 1e-6) - i.e. be a
+    float64 near-zero, not an error."""
     net = _build(arch, NC, "fp32")
     tr = R.OracleTrainer(arch, NC, "SGD2", ignore_index=0, seed=3)
     crit = utils.CrossEntropyLoss(ignore_index=0)
@@ -279,7 +320,9 @@ def test_fp32_train_steps_match_oracle(arch, B, S, NC):
     img, lab = O.synthetic_tiles(B, S, NC, seed=5, structured=True)
     net.train()
     for step in range(3):
-        p_before = {k: v.detach().clone() for k, v in tr.p.items()}
+        # the float64 yardstick is evaluated at the HIP network's OWN current parameters (after step 1 they differ from the
+        # oracle trainer's by one update with gradients that differ by the counted ReLU decisions)
+        p_before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
         want_loss, want_logits, want_grads = tr.step(img, lab)
         logits = net(img.to(DEV), None)
         loss = crit(logits, lab.to(DEV))
@@ -294,7 +337,7 @@ def test_fp32_train_steps_match_oracle(arch, B, S, NC):
         assert abs(loss.item() - want_loss) <= 1e-4 * max(1.0, abs(want_loss)), (step, loss.item(), want_loss)
         _, g64, flips = _f64_gradients(arch, p_before, img, lab, masks)
         nflip, nrelu = sum(n for n, _ in flips), sum(m.numel() for m in masks)
-        assert all(mx <= 1e-4 for _, mx in flips), flips
+        assert all(mx <= 1e-5 for _, mx in flips), [f for f in flips if f[0]]
         e_hip = sorted((rel_l2(grads[k].double(), g64[k]), k) for k in g64)
         e_cpu = sorted((rel_l2(want_grads[k].double(), g64[k]), k) for k in g64)
         print(f"step {step}: {nflip} of {nrelu} ReLU decisions differ from the float64 oracle's own (largest |x|/max|x| "
