@@ -44,6 +44,7 @@ class SyntheticLoader:
         self.patch_size, self.NC, self.tpi = patch_size, num_classes, tiles_per_image
         self.chunk_size, self.seed = chunk_size, seed
         self.idxs = list(range(n_images))
+        self.epoch = 0
         self._gen_chunks()
         g = torch.Generator().manual_seed(99)
         self.base = torch.randint(30, 226, (num_classes, 3), generator=g).float()
@@ -56,7 +57,11 @@ class SyntheticLoader:
         return len(self.chunks)
 
     def shuffle(self):
-        random.shuffle(self.idxs)
+        """image order of the next epoch: a function of (seed, epoch) only, so that every rank of a data-parallel job draws
+        the SAME permutation (the reference shuffles with the process-global `random`, S/dataset.py:289-291, which is only
+        right for its single process)"""
+        self.epoch += 1
+        random.Random(self.seed * 1000003 + self.epoch).shuffle(self.idxs)
         self._gen_chunks()
 
     def specify(self, targets):
@@ -75,13 +80,18 @@ class SyntheticLoader:
         img = self.base[lab].permute(2, 0, 1) + 20.0 * torch.randn(3, S, S, generator=g)
         return img.clamp(0, 255).to(torch.uint8), lab.to(torch.uint8)
 
-    def get_iterable_chunk(self, idx, random_tps=None):
+    def get_iterable_chunk(self, idx, random_tps=None, device=None, batch_size=None, shard=None):
+        """device=None: the reference's contract - an iterable of per-tile tuples for a DataLoader.  device given: the tiles
+        of the chunk are uploaded once and the iterable yields whole batches resident on the device (see DeviceTiles)."""
         patches = []
         for image in self.chunks[idx]:
             g = torch.Generator().manual_seed(self.seed * 100003 + image)
             for _ in range(self.tpi):
                 img, lab = self._tile(g)
                 patches.append((img, lab, torch.zeros(1), torch.zeros(1)))
+        if device is not None and torch.device(device).type == "cuda":
+            return DeviceTiles(torch.stack([p[0] for p in patches]).to(device), torch.stack([p[1] for p in patches]).to(device),
+                               batch_size or 1, shard)
         return _Chunk(patches)
 
     def get_class_weights(self, classes, ignore_background=False):
@@ -98,7 +108,7 @@ class Loader:
     non-overlapping `patch_size` tile of a chunk's images cropped eagerly (optionally shifted by +-20 px)."""
 
     def __init__(self, root, chunk_size, random_shift=False, patch_size=224, image_transforms=None, mask_transforms=None,
-                 load_context=False, load_color_mask=False):
+                 load_context=False, load_color_mask=False, seed=0):
         from PIL import Image  # noqa: F401
         assert patch_size in (224, 256, 512), "patch_size must be 224, 256 or 512"   # S/dataset.py:268
         self.root, self.chunk_size, self.random_shift, self.patch_size = root, chunk_size, random_shift, patch_size
@@ -112,6 +122,8 @@ class Loader:
         self.tpi = (H // patch_size) * (W // patch_size)
         self.H, self.W = H, W
         self.idxs = list(range(len(self.images)))
+        self.seed, self.epoch = seed, 0
+        self.device = None     # set (make_loader(device=...)) to count the class pixels with the device histogram
         self._gen_chunks()
         self.count = None
 
@@ -122,40 +134,104 @@ class Loader:
         return len(self.chunks)
 
     def shuffle(self):
-        random.shuffle(self.idxs)
+        """a function of (seed, epoch): identical on every rank of a data-parallel job (see SyntheticLoader.shuffle)"""
+        self.epoch += 1
+        random.Random(self.seed * 1000003 + self.epoch).shuffle(self.idxs)
         self._gen_chunks()
 
     def specify(self, targets):
         self.idxs = [self.idxs[i] for i in targets]
         self._gen_chunks()
 
-    def get_iterable_chunk(self, idx, random_tps=None):
+    def _decode(self, i):
         from PIL import Image
-        p, patches = self.patch_size, []
-        for i in self.chunks[idx]:
-            img = torch.from_numpy(np.array(Image.open(self.images[i]).convert("RGB"))).permute(2, 0, 1).contiguous()
-            mask = torch.from_numpy(np.array(Image.open(self.index_masks[i])))
-            if mask.dim() == 3:
-                mask = mask[..., 0]
+        img = torch.from_numpy(np.array(Image.open(self.images[i]).convert("RGB"))).permute(2, 0, 1).contiguous()
+        mask = torch.from_numpy(np.array(Image.open(self.index_masks[i])))
+        if mask.dim() == 3:
+            mask = mask[..., 0]
+        return img, mask.to(torch.uint8).contiguous()
+
+    def plan_items(self, idx):
+        """(position in the chunk, top, left) of every tile of chunk idx in the order they are served: the +-20 px random
+        shift (S/dataset.py:25-26,143) and the tile shuffle (S/dataset.py:198) are drawn from a generator seeded with
+        (seed, epoch, chunk) - the host path, the device path and every rank produce the same list."""
+        p = self.patch_size
+        rng = random.Random((self.seed * 1000003 + self.epoch) * 1000003 + idx)
+        items = []
+        for pos in range(len(self.chunks[idx])):
             for ty in range(self.H // p):
                 for tx in range(self.W // p):
                     y, x = ty * p, tx * p
                     if self.random_shift:
-                        y = min(max(y + random.randint(-20, 20), 0), self.H - p)
-                        x = min(max(x + random.randint(-20, 20), 0), self.W - p)
-                    patches.append((img[:, y:y + p, x:x + p].contiguous(), mask[y:y + p, x:x + p].contiguous().to(torch.uint8),
-                                    torch.zeros(1), torch.zeros(1)))
-        random.shuffle(patches)
+                        y, x = y + rng.randint(-20, 20), x + rng.randint(-20, 20)
+                    items.append((pos, y, x))
+        rng.shuffle(items)
+        return items
+
+    def get_iterable_chunk(self, idx, random_tps=None, device=None, batch_size=None, shard=None):
+        """device=None: the reference's contract (S/dataset.py:331-335) - an iterable of per-tile tuples for a DataLoader,
+        cropped on the host.  device given: the chunk's images are decoded once, kept resident on the device as u8, and
+        the iterable yields whole batches produced by one gather launch per source image (DeviceChunk)."""
+        decoded = [self._decode(i) for i in self.chunks[idx]]
+        items = self.plan_items(idx)
+        p = self.patch_size
+        if device is not None and torch.device(device).type == "cuda":
+            return DeviceChunk([im.to(device) for im, _ in decoded], [m.to(device) for _, m in decoded], p, batch_size or 1,
+                               items=items, shard=shard)
+        patches = [(crop_zero_filled(decoded[pos][0], y, x, p), crop_zero_filled(decoded[pos][1], y, x, p), torch.zeros(1), torch.zeros(1))
+                   for pos, y, x in items]
         return _Chunk(patches)
 
     def get_class_weights(self, classes, ignore_background=False):
-        from PIL import Image
         if self.count is None:
-            self.count = torch.zeros(classes, dtype=torch.float32)
-            for f in self.index_masks:
-                m = torch.from_numpy(np.array(Image.open(f))).reshape(-1).long()
-                self.count += torch.bincount(m, minlength=classes)[:classes].float()
+            if self.device is not None and torch.device(self.device).type == "cuda":
+                from . import ops
+                counts = torch.zeros(classes, dtype=torch.int64, device=self.device)
+                for i in range(len(self.index_masks)):
+                    ops.label_histogram(self._decode(i)[1].to(self.device), counts)
+                self.count = counts.cpu().float()
+            else:
+                self.count = torch.zeros(classes, dtype=torch.float32)
+                for i in range(len(self.index_masks)):
+                    m = self._decode(i)[1].reshape(-1).long()
+                    self.count += torch.bincount(m, minlength=classes)[:classes].float()
         return class_weights_from_counts(self.count, ignore_background)
+
+
+def crop_zero_filled(t: torch.Tensor, y: int, x: int, p: int):
+    """t[..., y:y+p, x:x+p] with the part of the window that lies outside the tensor filled with 0 - the semantics of
+    torchvision's v2.functional.crop that the reference's shifted tiles get (S/dataset.py:25-32,143): image pixels 0, index
+    mask 0 = the ignored class."""
+    H, W = t.shape[-2:]
+    out = torch.zeros(t.shape[:-2] + (p, p), dtype=t.dtype)
+    y0, y1, x0, x1 = max(y, 0), min(y + p, H), max(x, 0), min(x + p, W)
+    if y1 > y0 and x1 > x0:
+        out[..., y0 - y:y1 - y, x0 - x:x1 - x] = t[..., y0:y1, x0:x1]
+    return out
+
+
+class DeviceTiles:
+    """tiles already resident on the device as [N,3,p,p] / [N,p,p] u8: yields batches (or this rank's shard of them)"""
+
+    def __init__(self, images, masks, batch_size, shard=None):
+        self.images, self.masks, self.bs, self.shard = images, masks, batch_size, shard
+        self.chunk_crops = range(images.shape[0])
+
+    def __len__(self):
+        n = self.images.shape[0]
+        return n // self.bs if self.shard else (n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        n = self.images.shape[0]
+        for b0 in range(0, n, self.bs):
+            lo, hi = b0, min(b0 + self.bs, n)
+            if self.shard:
+                if hi - lo < self.bs:
+                    return          # drop the ragged last global batch (every rank must take the same number of steps)
+                r, w = self.shard
+                per = self.bs // w
+                lo, hi = b0 + r * per, b0 + (r + 1) * per
+            yield self.images[lo:hi], self.masks[lo:hi], torch.zeros(1), torch.zeros(1)
 
 
 class DeviceChunk:
@@ -164,11 +240,15 @@ class DeviceChunk:
     Iterating yields (image u8 [B,3,p,p], index_mask u8 [B,p,p], color_mask, context) already on the device, i.e. what
     the reference's DataLoader + `.to(device)` hand to the batch loop (S/train.py:114-115)."""
 
-    def __init__(self, images, masks, patch_size, batch_size, random_shift=False, shuffle=True, seed=0):
+    def __init__(self, images, masks, patch_size, batch_size, random_shift=False, shuffle=True, seed=0, items=None, shard=None):
         from . import ops
         self.ops = ops
         self.images, self.masks = images, masks
         self.p, self.bs = patch_size, batch_size
+        self.shard = shard     # (rank, world): serve this rank's slice [r*B/w, (r+1)*B/w) of every global batch of bs tiles
+        if items is not None:  # planned by Loader.plan_items: identical on every rank and on the host path
+            self.items = self.chunk_crops = list(items)
+            return
         g = torch.Generator().manual_seed(seed)
         items = []
         for i, im in enumerate(images):
@@ -187,13 +267,19 @@ class DeviceChunk:
         self.chunk_crops = items
 
     def __len__(self):
-        return (len(self.items) + self.bs - 1) // self.bs
+        return len(self.items) // self.bs if self.shard else (len(self.items) + self.bs - 1) // self.bs
 
     def __iter__(self):
         dev = self.images[0].device
         p = self.p
         for b0 in range(0, len(self.items), self.bs):
             batch = self.items[b0:b0 + self.bs]
+            if self.shard:
+                if len(batch) < self.bs:
+                    return      # ragged last global batch: dropped on every rank alike
+                r, w = self.shard
+                per = self.bs // w
+                batch = batch[r * per:(r + 1) * per]
             img = torch.empty((len(batch), 3, p, p), dtype=torch.uint8, device=dev)
             msk = torch.empty((len(batch), p, p), dtype=torch.uint8, device=dev)
             by_image = {}
@@ -222,10 +308,12 @@ def device_class_weights(masks, classes, ignore_background=False):
     return class_weights_from_counts(counts.cpu().float(), ignore_background)
 
 
-def make_loader(spec, chunk_size, patch_size, num_classes, random_shift=False, seed=0):
+def make_loader(spec, chunk_size, patch_size, num_classes, random_shift=False, seed=0, device=None):
     """`spec` is a dataset directory, or 'synthetic:<n_images>[:<tiles_per_image>]'."""
     if isinstance(spec, str) and spec.startswith("synthetic:"):
         parts = spec.split(":")
         return SyntheticLoader(int(parts[1]), chunk_size, patch_size, num_classes,
                                tiles_per_image=int(parts[2]) if len(parts) > 2 else 16, seed=seed)
-    return Loader(spec, chunk_size, random_shift=random_shift, patch_size=patch_size)
+    ld = Loader(spec, chunk_size, random_shift=random_shift, patch_size=patch_size, seed=seed)
+    ld.device = device
+    return ld

@@ -125,7 +125,10 @@ class DataParallel:
         optimizer.pre_step = self.reducer.finish
         if exact:
             assert criterion is not None, "exact=True needs the loss object (its mean spans all ranks' pixels)"
-            sync = SyncStats(group)
+            # the small statistics exchanges get their OWN communicator: on the bucket reducer's they would queue behind
+            # whatever 32 MiB all-reduce was issued before them (one internal stream per communicator) and stall the
+            # backward pass the buckets are meant to overlap
+            sync = SyncStats(dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None))
             net._engine.enable_sync_bn(sync)
             criterion.sync = sync
 

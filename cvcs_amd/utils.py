@@ -102,7 +102,7 @@ class _CEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         dl = ctx.crit._dl   # d(loss)/d(logits) was produced by the forward launch
-        if not ctx.crit.unit_grad:
+        if not ctx.crit.unit_grad and float(gout) != 1.0:
             dl.mul_(gout)   # chained through further autograd ops: scale by the incoming gradient
         return dl, None, None
 
@@ -110,11 +110,13 @@ class _CEFunction(torch.autograd.Function):
 class CrossEntropyLoss:
     """nn.CrossEntropyLoss(weight, ignore_index) (S/utils.py:230,238): one fused HIP launch produces the loss and
     d(loss)/d(logits).  target: uint8 or int64 [B,H,W].
-    unit_grad=True (default) assumes the loss is differentiated directly, `loss.backward()` with its implicit gradient
-    of 1 as S/train.py:125 does, and skips a 2-pass multiply over the logits-sized gradient; pass unit_grad=False when the
-    loss value is scaled / combined by further autograd ops before backward."""
+    unit_grad=True asserts that the loss is differentiated directly - `loss.backward()` with its implicit gradient of 1, as
+    S/train.py:125 does - and skips the check; by default the incoming gradient is compared with 1 on the device and the
+    logits-sized gradient is only rescaled (one extra pass) when the loss was scaled / combined by further autograd ops
+    (`(loss / accum).backward()`), so a drop-in use can never silently produce unscaled gradients.  load_loss opts in to
+    unit_grad for the training scripts of this repository."""
 
-    def __init__(self, weight=None, ignore_index=-100, unit_grad=True):
+    def __init__(self, weight=None, ignore_index=-100, unit_grad=False):
         self.weight = None if weight is None else weight.float()
         self.ignore_index = ignore_index
         self.unit_grad = unit_grad
@@ -135,13 +137,13 @@ def load_loss(config, device, dataset=None):
     ignore_background = config.get("ignore_background", False)
     ignore_index = 0 if ignore_background else -100
     if name == "CEL":
-        return CrossEntropyLoss(ignore_index=ignore_index)
+        return CrossEntropyLoss(ignore_index=ignore_index, unit_grad=True)   # S/train.py:125: loss.backward() directly
     elif name == "wCEL":
         print("Computing class weights, it might take several minutes...", flush=True)
         weights = dataset.get_class_weights(classes, ignore_background).to(device)
         for i, score in enumerate(weights):
             print(f"{labels.get(i, i):>22s} {score.item():.6f}")
-        return CrossEntropyLoss(weight=weights, ignore_index=ignore_index)
+        return CrossEntropyLoss(weight=weights, ignore_index=ignore_index, unit_grad=True)
     elif name == "MSE":
         raise NotImplementedError("MSE loss is not on the HIP path (the reference never trains with it)")
     else:
@@ -295,9 +297,7 @@ def eval_model(net, Loader_validation, device, batch_size=1, show_progress=False
     i = 0
     with torch.no_grad():
         for c in range(len(Loader_validation)):
-            dataset = Loader_validation.get_iterable_chunk(c)
-            dl = torch.utils.data.DataLoader(dataset, batch_size=batch_size)
-            for x, y, _, context in dl:
+            for x, y, _, context in chunk_batches(Loader_validation, c, batch_size, device):
                 i += 1
                 if shard is not None and (i - 1) % shard[1] != shard[0]:
                     continue
@@ -328,15 +328,32 @@ class NormalizedConfusion:
         return c / c.sum(dim=1, keepdim=True).clamp_min(1)
 
 
+def chunk_batches(loader, c, batch_size, device, random_tps=None, shard=None):
+    """batches of chunk c on `device`.  On the GPU the loader keeps the chunk's decoded images (or tiles) resident and
+    produces every batch with one gather launch (dataset.DeviceChunk / DeviceTiles - SURVEY section 8 f1); otherwise (and
+    for foreign loaders without the `device` keyword) the reference's route: per-tile iterable -> DataLoader -> `.to(device)`
+    (S/train.py:107-115).  shard=(rank, world): this rank's slice of every global batch of `batch_size` tiles."""
+    if torch.device(device).type == "cuda":
+        try:
+            return loader.get_iterable_chunk(c, random_tps, device=device, batch_size=batch_size, shard=shard)
+        except TypeError:
+            pass
+    ds = loader.get_iterable_chunk(c, random_tps) if random_tps is not None else loader.get_iterable_chunk(c)
+    dl = torch.utils.data.DataLoader(ds, batch_size=batch_size, drop_last=shard is not None)
+    if shard is None:
+        return dl
+    r, w = shard
+    per = batch_size // w
+    return ((b[0][r * per:(r + 1) * per], b[1][r * per:(r + 1) * per], b[2], b[3]) for b in dl)
+
+
 def validation_loss(net, Loader_validation, crit, device, bs, show_progress=False):
     """S/utils.py:106-126."""
     loss_values = []
     net.eval()
     with torch.no_grad():
         for c in range(len(Loader_validation)):
-            dataset = Loader_validation.get_iterable_chunk(c)
-            dl = torch.utils.data.DataLoader(dataset, batch_size=bs)
-            for image, index_mask, _, context in dl:
+            for image, index_mask, _, context in chunk_batches(Loader_validation, c, bs, device):
                 image, mask = image.to(device), mask_reshape(index_mask.to(device))
                 mask_pred = net(image, None)
                 loss = crit(mask_pred, mask)

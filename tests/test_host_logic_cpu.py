@@ -145,7 +145,10 @@ def test_host_only_c_abi_sizing_functions():
         d = _lib.ConvDesc()
         d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 2, 8, 8, 128, 8, 8, 256
         d.KH, d.KW, d.stride, d.pad, d.dil, d.dtype = 1, 1, 1, 0, 1, dtype
-        assert lib.cvcs_conv_stat_rows(C.byref(d)) == 2 * -(-2 * 8 * 8 // 128)     # generic kernel: two rows per 128-pixel tile
+        if dtype == _lib.BF16:   # 1x1 with 128 | Cout: the non-overlapping-taps kernel, four 64-pixel wave blocks per 256-pixel tile
+            assert lib.cvcs_conv_stat_rows(C.byref(d)) == 4 * -(-2 * 8 * 8 // 256)
+        else:                    # generic kernel: two rows per 128-pixel tile
+            assert lib.cvcs_conv_stat_rows(C.byref(d)) == 2 * -(-2 * 8 * 8 // 128)
     bad = _lib.ConvDesc()
     assert lib.cvcs_conv_stat_rows(C.byref(bad)) < 0
     # every layer of Unetv2 at B=32, S=512 (3x3 convs and the four 2x2/s2 ConvTranspose gradients): at least one slice, never

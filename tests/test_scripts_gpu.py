@@ -66,3 +66,46 @@ def test_train_script_two_ranks(tmp_path, exact):
     out = _run(cmd, env)
     assert out.count("Training Done!") == 2 and out.count("Saved checkpoint 1") == 1   # every rank trains, rank 0 saves
     assert "mIoU" in out
+
+
+def _gid_dir(root):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for sub in ("Image__8bit_NirRGB", "Annotation__index", "Annotation__color"):
+        os.makedirs(os.path.join(root, sub))
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (448, 672, 3), dtype=np.uint8)).save(os.path.join(root, "Image__8bit_NirRGB", f"im{i}.png"))
+        Image.fromarray(rng.integers(0, 5, (448, 672), dtype=np.uint8)).save(os.path.join(root, "Annotation__index", f"im{i}.png"))
+    return root
+
+
+def test_device_tile_producer_matches_host_crops_bit_for_bit(tmp_path):
+    """`Loader.get_iterable_chunk(device=...)` keeps the decoded images resident as u8 and produces every
+    batch with one gather launch per source image - the tiles must equal the host crops (the reference's eager crop with
+    v2.functional.crop's zero fill for shifted windows, S/dataset.py:25-32,136-172) bit for bit, for whole batches and for
+    the per-rank shards; the class-weight scan (S/dataset.py:346-384) by the device histogram equals the host bincount."""
+    import torch
+    from cvcs_amd import dataset, utils
+    root = _gid_dir(str(tmp_path / "gid"))
+    mk = lambda dev: dataset.make_loader(root, 2, 224, 5, random_shift=True, seed=3, device=dev)   # noqa: E731
+    host, devl = mk(None), mk("cuda:0")
+    for ld in (host, devl):
+        ld.shuffle()
+    for c in range(len(host)):
+        for shard in (None, (1, 2)):
+            hb = list(utils.chunk_batches(host, c, 4, "cpu", shard=shard))
+            db = list(utils.chunk_batches(devl, c, 4, "cuda:0", shard=shard))
+            assert len(hb) == len(db) and len(hb) > 0
+            for (hi, hm, _, _), (di, dm, _, _) in zip(hb, db):
+                assert di.is_cuda and di.dtype == torch.uint8 and torch.equal(di.cpu(), hi) and torch.equal(dm.cpu(), hm)
+    assert torch.equal(host.get_class_weights(5, True), devl.get_class_weights(5, True))
+
+
+def test_train_script_on_an_image_directory(tmp_path):
+    """train.py through the device-resident producer on a GID-15-shaped directory (224-pixel tiles, random shift, wCEL)"""
+    root = _gid_dir(str(tmp_path / "gid"))
+    os.makedirs(tmp_path / "ck")
+    out = _run([sys.executable, "train.py", _cfg(tmp_path, checkpoint_directory=str(tmp_path / "ck"), train=root, validation=root,
+                                                 patch_size=224, batch_size=3, chunk_size=2, validation_chunk_size=3, random_shift=True,
+                                                 loss="wCEL", epochs=1)])
+    assert "Training Done!" in out and "mIoU" in out

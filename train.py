@@ -21,14 +21,16 @@ world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK",
 if rank == 0:
     utils.display_configs(config)
 NC = config["num_classes"] + 1
+device = utils.load_device(config)
+# the loaders draw every random decision (image order, tile order, +-20 px shift) from (seed, epoch, chunk): all ranks agree
 Loader_train = dataset.make_loader(config["train"], config["chunk_size"], config["patch_size"], NC,
-                                   random_shift=config.get("random_shift", False), seed=0)
-Loader_validation = dataset.make_loader(config["validation"], config["validation_chunk_size"], config["patch_size"], NC, seed=1)
+                                   random_shift=config.get("random_shift", False), seed=config.get("seed", 0), device=device)
+Loader_validation = dataset.make_loader(config["validation"], config["validation_chunk_size"], config["patch_size"], NC, seed=1,
+                                        device=device)
 if config.get("debug"):
     Loader_train.specify([0, 1])
     Loader_validation.specify([0])
 
-device = utils.load_device(config)
 if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -43,9 +45,8 @@ print("parameters", utils.count_params(net), "| tiles/epoch", len(Loader_train.i
 crit = utils.load_loss(config, device, Loader_train)
 opt, scheduler = utils.load_optimizer(config, net)
 if world > 1:
-    from cvcs_amd.parallel import DataParallel, shard_batch
+    from cvcs_amd.parallel import DataParallel
     net.flat_parameters()
-    net(torch.zeros(1, 3, 32, 32, dtype=torch.uint8, device=device))
     # exact_data_parallel: SyncBN + whole-batch loss mean, i.e. the reference's single-process step on world x batch tiles
     DataParallel(net, opt, exact=bool(config.get("exact_data_parallel", False)), criterion=crit)
 
@@ -54,10 +55,12 @@ last_epoch = 0
 if "load_checkpoint" in config:
     ck = torch.load(config["load_checkpoint"], map_location="cpu", weights_only=False)
     net.load_state_dict(ck["model_state_dict"])
-    try:
-        opt.load_state_dict(ck["optimizer_state_dict"]); scheduler.load_state_dict(ck["scheduler_state_dict"])
-    except Exception:
-        print("Optimizer/scheduler state not compatible; starting them fresh.")
+    for obj, key in ((opt, "optimizer_state_dict"), (scheduler, "scheduler_state_dict")):
+        try:
+            obj.load_state_dict(ck[key])
+            print(f"Restored {key}.")
+        except Exception:
+            print(f"{key} not compatible; {type(obj).__name__} starts fresh.")
     last_epoch = ck["epoch"] + 1
     training_loss_values, validation_loss_values = ck["training_loss_values"], ck["validation_loss_values"]
 assert Path(config["checkpoint_directory"]).is_dir(), "Please provide a valid directory to save checkpoints in."
@@ -66,13 +69,12 @@ for epoch in range(last_epoch, config["epochs"]):
     print("Started epoch {}".format(epoch + 1), flush=True)
     Loader_train.shuffle()
     for c in range(len(Loader_train)):
-        ds = Loader_train.get_iterable_chunk(c, config.get("random_tps"))
-        dl = torch.utils.data.DataLoader(ds, batch_size=config["batch_size"] * world, drop_last=world > 1)
+        # GPU: the chunk's images stay resident on the device, every batch is one gather launch;
+        # N ranks: every rank takes its slice of the same global batch of batch_size * world tiles
+        batches = utils.chunk_batches(Loader_train, c, config["batch_size"] * world, device, config.get("random_tps"),
+                                      shard=(rank, world) if world > 1 else None)
         net.train()
-        for image, index_mask, color_mask, context in dl:
-            if world > 1:
-                lo, hi = shard_batch(image.shape[0], rank, world)
-                image, index_mask = image[lo:hi], index_mask[lo:hi]
+        for image, index_mask, color_mask, context in batches:
             image, mask = image.to(device), utils.mask_reshape(index_mask.to(device))
             mask_pred = net(image, None)
             loss = crit(mask_pred, mask)
