@@ -55,6 +55,7 @@ class WgradDesc(C.Structure):
         ("dtype", C.c_int32),
         ("aniso", C.c_int32), ("stride_w", C.c_int32), ("pad_w", C.c_int32),
         ("x_row_pitch", C.c_int64), ("x_img_pitch", C.c_int64),
+        ("dil", C.c_int32),
     ]
 
 
@@ -79,6 +80,15 @@ SIGNATURES = {
     "cvcs_pack_input_stem": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "cvcs_pack_stem_weight": (_i, [_vp, _i, _vp, _i, _vp]),
     "cvcs_unpack_stem_wgrad": (_i, [_vp, _i, _vp, _vp]),
+    "cvcs_resize_bilinear_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_resize_bilinear_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_resize_bilinear_nchw_fwd": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
+    "cvcs_resize_bilinear_nchw_bwd": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
+    "cvcs_image_sum": (_i, [_vp, _i64, _i, _i, _i, _f, _vp, _i64, _i, _vp]),
+    "cvcs_image_broadcast": (_i, [_vp, _i64, _i, _i, _i, _f, _vp, _i64, _i, _vp]),
+    "cvcs_linear_head_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "cvcs_linear_head_bwd_rows": (_i, [_i64]),
+    "cvcs_linear_head_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _vp]),
     "cvcs_bn_finalize_workspace_floats": (_i, [_i, _i]),
     "cvcs_bn_finalize": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_moments": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -123,7 +133,7 @@ _lib = None
 _recording = None          # the Recording that is capturing launches right now (None: plain eager calls)
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
-            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats"}
+            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows"}
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 
 
@@ -213,7 +223,7 @@ def _load():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 4:
+        if h.cvcs_abi_version() != 5:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")

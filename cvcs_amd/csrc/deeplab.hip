@@ -1,0 +1,485 @@
+// HBM-bound kernels of the DeepLabV3+ path (BASELINE.json configs[2]; the reference wraps torchvision's DeepLabV3 at
+// S/nets.py:234-311 behind the factory S/utils.py:174-195) on gfx950:
+//   * bilinear resize by an integer factor, align_corners=False - F.interpolate as torchvision's DeepLab heads call it
+//     (the wrapper returns d['out'], S/nets.py:248-250, which torchvision resizes to the input size) - for NHWC
+//     activations and for the NCHW f32 logits, forward and backward;
+//   * ASPP image pooling: per-image spatial mean and its broadcast (AdaptiveAvgPool2d(1) ... F.interpolate of a 1x1 map);
+//   * the 1x1 classifier on any channel count (the U-Net head kernels of head_loss.hip are built for 64 channels):
+//     NHWC activation -> NCHW f32 logits, fused argmax, backward (dx + partial dW/db rows).
+// Every backward is a GATHER (each input element sums the outputs it fed, fixed order): no atomics, bitwise reproducible.
+#include "common.h"
+
+namespace cvcs {
+
+static inline unsigned dl_grid(int64_t total, int cap = 256 * 32) {
+  int64_t g = cdiv(total, 256);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// source taps of output coordinate o at integer scale s (align_corners=False): src = (o + 0.5)/s - 0.5, clamped at 0
+__device__ __forceinline__ void bil_taps(int o, int s, int n, int& i0, int& i1, float& w0, float& w1) {
+  float src = ((float)o + 0.5f) / (float)s - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  w1 = src - (float)i0;
+  w0 = 1.f - w1;
+}
+
+// ------------------------------------------------------------------------------------------------ NHWC resize
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const char* in, int64_t in_ld, int B, int H, int W, int C, int s,
+                                                        char* out, int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V, Ho = H * s, Wo = W * s;
+  const int64_t total = (int64_t)B * Ho * Wo * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t op = id / CC;
+    const int ox = (int)(op % Wo);
+    const int64_t t = op / Wo;
+    const int oy = (int)(t % Ho);
+    const int64_t b = t / Ho;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bil_taps(oy, s, H, y0, y1, wy0, wy1);
+    bil_taps(ox, s, W, x0, x1, wx0, wx1);
+    float a[V], c[V], d[V], e[V], r[V];
+    const char* base = in + (b * H * W) * in_ld * ES + cc * 16;
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)y0 * W + x0) * in_ld * ES), a);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)y0 * W + x1) * in_ld * ES), c);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)y1 * W + x0) * in_ld * ES), d);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)y1 * W + x1) * in_ld * ES), e);
+#pragma unroll
+    for (int k = 0; k < V; ++k) r[k] = wy0 * (wx0 * a[k] + wx1 * c[k]) + wy1 * (wx0 * d[k] + wx1 * e[k]);
+    *reinterpret_cast<uint4*>(out + op * out_ld * ES + cc * 16) = Elem<T>::pack(r);
+  }
+}
+
+// weight with which output coordinate o (scale s, n inputs) reads input i
+__device__ __forceinline__ float bil_weight(int o, int s, int n, int i) {
+  int i0, i1;
+  float w0, w1;
+  bil_taps(o, s, n, i0, i1, w0, w1);
+  return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const char* g, int64_t g_ld, int B, int H, int W, int C, int s, char* gin,
+                                                        int64_t gin_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V, Ho = H * s, Wo = W * s;
+  const int64_t total = (int64_t)B * H * W * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t ip = id / CC;
+    const int ix = (int)(ip % W);
+    const int64_t t = ip / W;
+    const int iy = (int)(t % H);
+    const int64_t b = t / H;
+    // outputs whose source lies within one input pixel of (iy, ix): o in ((i - 1 + 0.5) s - 0.5, (i + 1 + 0.5) s - 0.5)
+    int oy_lo = (iy - 1) * s + s / 2 - 1, oy_hi = (iy + 1) * s + (s + 1) / 2;
+    int ox_lo = (ix - 1) * s + s / 2 - 1, ox_hi = (ix + 1) * s + (s + 1) / 2;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float wy = bil_weight(oy, s, H, iy);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float w = wy * bil_weight(ox, s, W, ix);
+        if (w == 0.f) continue;
+        float f[V];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(g + (((b * Ho + oy) * Wo + ox) * g_ld) * ES + cc * 16), f);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += w * f[k];
+      }
+    }
+    *reinterpret_cast<uint4*>(gin + ip * gin_ld * ES + cc * 16) = Elem<T>::pack(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ NCHW f32 resize (logits)
+__global__ __launch_bounds__(256) void resize_nchw_fwd_kernel(const float* __restrict__ in, int64_t planes, int H, int W, int s,
+                                                             float* __restrict__ out) {
+  const int Ho = H * s, Wo = W * s;
+  const int64_t total = planes * Ho * Wo;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(id % Wo);
+    const int64_t t = id / Wo;
+    const int oy = (int)(t % Ho);
+    const int64_t pl = t / Ho;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bil_taps(oy, s, H, y0, y1, wy0, wy1);
+    bil_taps(ox, s, W, x0, x1, wx0, wx1);
+    const float* p = in + pl * H * W;
+    out[id] = wy0 * (wx0 * p[y0 * W + x0] + wx1 * p[y0 * W + x1]) + wy1 * (wx0 * p[y1 * W + x0] + wx1 * p[y1 * W + x1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_nchw_bwd_kernel(const float* __restrict__ g, int64_t planes, int H, int W, int s,
+                                                             float* __restrict__ gin) {
+  const int Ho = H * s, Wo = W * s;
+  const int64_t total = planes * H * W;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(id % W);
+    const int64_t t = id / W;
+    const int iy = (int)(t % H);
+    const int64_t pl = t / H;
+    int oy_lo = (iy - 1) * s + s / 2 - 1, oy_hi = (iy + 1) * s + (s + 1) / 2;
+    int ox_lo = (ix - 1) * s + s / 2 - 1, ox_hi = (ix + 1) * s + (s + 1) / 2;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    const float* p = g + pl * Ho * Wo;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float wy = bil_weight(oy, s, H, iy);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += wy * bil_weight(ox, s, W, ix) * p[(int64_t)oy * Wo + ox];
+    }
+    gin[id] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ image pooling
+// out[b][c] = scale * sum over the HW pixels of image b (one workgroup per (image, 256-chunk group); fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void image_sum_kernel(const char* x, int64_t ld, int HW, int C, float scale, char* out,
+                                                       int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  __shared__ float red[256 * V];
+  const int CC = C / V;
+  const int ccw = CC < 256 ? CC : 256;
+  const int PL = 256 / ccw;
+  const int cl = threadIdx.x % ccw, pl = threadIdx.x / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  const int b = blockIdx.x;
+  float s[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) s[k] = 0.f;
+  for (int p = pl; p < HW; p += PL) {
+    float f[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p) * ld * ES + cc * 16), f);
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] += f[k];
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[threadIdx.x * V + k] = s[k];
+  __syncthreads();
+  if (pl == 0) {
+    float r[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float a = 0.f;
+      for (int q = 0; q < PL; ++q) a += red[(q * ccw + cl) * V + k];
+      r[k] = a * scale;
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)b * out_ld * ES + cc * 16) = Elem<T>::pack(r);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void image_broadcast_kernel(const char* v, int64_t v_ld, int B, int HW, int C, float scale,
+                                                             char* out, int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int64_t total = (int64_t)B * HW * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;
+    const int64_t b = pix / HW;
+    float f[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(v + b * v_ld * ES + cc * 16), f);
+#pragma unroll
+    for (int k = 0; k < V; ++k) f[k] *= scale;
+    *reinterpret_cast<uint4*>(out + pix * out_ld * ES + cc * 16) = Elem<T>::pack(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 1x1 classifier, any C
+constexpr int kLinMaxNC = 32;
+// forward / argmax: one pixel per thread, the NC x C weights in LDS, the pixel row streamed 16 bytes at a time
+template <typename T, bool ARGMAX>
+__global__ __launch_bounds__(256) void linear_head_kernel(const char* x, int64_t x_ld, int64_t P, int64_t HW, int C,
+                                                         const float* __restrict__ w, const float* __restrict__ bias, int NC,
+                                                         float* logits, uint8_t* labels) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  extern __shared__ float sw[];   // [NC][C] + [NC]
+  for (int i = threadIdx.x; i < NC * C; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < NC; i += 256) sw[NC * C + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * 256) {
+    float acc[kLinMaxNC];
+#pragma unroll
+    for (int c = 0; c < kLinMaxNC; ++c) acc[c] = c < NC ? sw[NC * C + c] : 0.f;
+    const char* row = x + pidx * x_ld * ES;
+    for (int k0 = 0; k0 < C; k0 += V) {
+      float f[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(row + k0 * ES), f);
+#pragma unroll
+      for (int c = 0; c < kLinMaxNC; ++c)
+        if (c < NC) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[c] += f[k] * sw[c * C + k0 + k];
+        }
+    }
+    if constexpr (ARGMAX) {
+      float best = acc[0];
+      int arg = 0;
+#pragma unroll
+      for (int c = 1; c < kLinMaxNC; ++c)
+        if (c < NC && acc[c] > best) { best = acc[c]; arg = c; }   // strict '>': the FIRST maximum
+      labels[pidx] = (uint8_t)arg;
+    } else {
+      const int64_t b = pidx / HW, hw = pidx - b * HW;
+#pragma unroll
+      for (int c = 0; c < kLinMaxNC; ++c)
+        if (c < NC) logits[(b * NC + c) * HW + hw] = acc[c];
+    }
+  }
+}
+
+// backward: dx[p][k] = sum_c dl[p][c] w[c][k]; partial dW[c][k] = sum_p dl[p][c] x[p][k], db[c] = sum_p dl[p][c] per
+// workgroup row (reduced by cvcs_colsum_finalize).  Workgroup: strips of 64 pixels staged in LDS (x as f32, dl);
+// thread t owns channel k = t (+256 j): its dW column of NC accumulators stays in registers over the whole strip loop.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_head_bwd_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P,
+                                                             int64_t HW, int C, const float* __restrict__ w, int NC, char* dx,
+                                                             int64_t dx_ld, float* part) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  constexpr int TP = 64;                       // pixels per strip
+  extern __shared__ float sm[];                // sx [TP][C] | sd [TP][NCP] | sw [NC][C]
+  const int NCP = NC + 1;
+  float* sx = sm;
+  float* sd = sx + TP * C;
+  float* sw = sd + TP * NCP;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NC * C; i += 256) sw[i] = w[i];
+  const int KPT = (C + 255) / 256;             // channels per thread (C <= 1024)
+  float acc[4][kLinMaxNC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < kLinMaxNC; ++c) acc[j][c] = 0.f;
+  float accb = 0.f;                            // db: thread c < NC sums its class
+  for (int64_t p0 = (int64_t)blockIdx.x * TP; p0 < P; p0 += (int64_t)gridDim.x * TP) {
+    __syncthreads();
+    for (int id = tid; id < TP * (C / V); id += 256) {
+      const int r = id / (C / V), cv = id - r * (C / V);
+      float f[V];
+      if (p0 + r < P) Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (p0 + r) * x_ld * ES + cv * 16), f);
+      else
+#pragma unroll
+        for (int q = 0; q < V; ++q) f[q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < V; ++q) sx[r * C + cv * V + q] = f[q];
+    }
+    for (int id = tid; id < TP * NC; id += 256) {
+      const int c = id / TP, r = id - c * TP;
+      float v = 0.f;
+      if (p0 + r < P) {
+        const int64_t pidx = p0 + r, b = pidx / HW, hw = pidx - b * HW;
+        v = dl[(b * NC + c) * HW + hw];
+      }
+      sd[r * NCP + c] = v;
+    }
+    __syncthreads();
+    if (tid < NC)
+      for (int r = 0; r < TP; ++r) accb += sd[r * NCP + tid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = tid + 256 * j;
+      if (j < KPT && k < C) {
+        for (int r = 0; r < TP; ++r) {
+          const float xv = sx[r * C + k];
+#pragma unroll
+          for (int c = 0; c < kLinMaxNC; ++c)
+            if (c < NC) acc[j][c] += sd[r * NCP + c] * xv;
+        }
+      }
+    }
+    // dx of the strip: thread -> (pixel r = id / (C/V), chunk): V channels
+    for (int id = tid; id < TP * (C / V); id += 256) {
+      const int r = id / (C / V), cv = id - r * (C / V);
+      if (p0 + r >= P) continue;
+      float o[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) o[q] = 0.f;
+      for (int c = 0; c < NC; ++c) {
+        const float d = sd[r * NCP + c];
+#pragma unroll
+        for (int q = 0; q < V; ++q) o[q] += d * sw[c * C + cv * V + q];
+      }
+      *reinterpret_cast<uint4*>(dx + (p0 + r) * dx_ld * ES + cv * 16) = Elem<T>::pack(o);
+    }
+  }
+  float* row = part + (int64_t)blockIdx.x * (NC * C + NC);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = tid + 256 * j;
+    if (j < KPT && k < C) {
+#pragma unroll
+      for (int c = 0; c < kLinMaxNC; ++c)
+        if (c < NC) row[c * C + k] = acc[j][c];
+    }
+  }
+  if (tid < NC) row[NC * C + tid] = accb;
+}
+
+static int dl_check_view(const char* fn, const void* ptr, int64_t ld, int C, int es) {
+  CVCS_CHECK_ARG(ptr != nullptr, "%s: null tensor", fn);
+  CVCS_CHECK_ARG(((uintptr_t)ptr % 16) == 0 && ld >= C && (ld * es) % 16 == 0, "%s: view must be 16-byte aligned with ld >= C", fn);
+  return CVCS_OK;
+}
+
+}  // namespace cvcs
+
+using namespace cvcs;
+#define DL_DT_OK(dt) ((dt) == CVCS_F32 || (dt) == CVCS_BF16)
+
+extern "C" int cvcs_resize_bilinear_fwd(const void* in, int64_t in_ld, int B, int H, int W, int C, int scale, void* out,
+                                        int64_t out_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_resize_bilinear_fwd";
+  CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0 && scale >= 1 && scale <= 32, "%s: bad shape", fn);
+  int rc;
+  if ((rc = dl_check_view(fn, in, in_ld, C, es)) || (rc = dl_check_view(fn, out, out_ld, C, es))) return rc;
+  const dim3 grid(dl_grid((int64_t)B * H * W * scale * scale * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((resize_fwd_kernel<float>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, scale, (char*)out, out_ld);
+  else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, scale, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_resize_bilinear_bwd(const void* gout, int64_t gout_ld, int B, int H, int W, int C, int scale, void* gin,
+                                        int64_t gin_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_resize_bilinear_bwd";
+  CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0 && scale >= 1 && scale <= 32, "%s: bad shape", fn);
+  int rc;
+  if ((rc = dl_check_view(fn, gout, gout_ld, C, es)) || (rc = dl_check_view(fn, gin, gin_ld, C, es))) return rc;
+  const dim3 grid(dl_grid((int64_t)B * H * W * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((resize_bwd_kernel<float>), grid, dim3(256), 0, st, (const char*)gout, gout_ld, B, H, W, C, scale, (char*)gin, gin_ld);
+  else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)gout, gout_ld, B, H, W, C, scale, (char*)gin, gin_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_resize_bilinear_nchw_fwd(const float* in, int64_t planes, int H, int W, int scale, float* out, void* stream) {
+  const char* fn = "cvcs_resize_bilinear_nchw_fwd";
+  CVCS_CHECK_ARG(in && out && planes > 0 && H > 0 && W > 0 && scale >= 1 && scale <= 32, "%s: bad arguments", fn);
+  hipLaunchKernelGGL(resize_nchw_fwd_kernel, dim3(dl_grid(planes * H * W * scale * scale)), dim3(256), 0, (hipStream_t)stream, in, planes, H, W, scale, out);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_resize_bilinear_nchw_bwd(const float* gout, int64_t planes, int H, int W, int scale, float* gin, void* stream) {
+  const char* fn = "cvcs_resize_bilinear_nchw_bwd";
+  CVCS_CHECK_ARG(gout && gin && planes > 0 && H > 0 && W > 0 && scale >= 1 && scale <= 32, "%s: bad arguments", fn);
+  hipLaunchKernelGGL(resize_nchw_bwd_kernel, dim3(dl_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, gout, planes, H, W, scale, gin);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_image_sum(const void* x, int64_t x_ld, int B, int HW, int C, float scale, void* out, int64_t out_ld, int dtype,
+                              void* stream) {
+  const char* fn = "cvcs_image_sum";
+  CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
+  const int CC = C / (16 / es), ccw = CC < 256 ? CC : 256;
+  CVCS_CHECK_ARG(256 % ccw == 0 && CC % ccw == 0, "%s: C/%d must divide 256 or be a multiple of 256", fn, 16 / es);
+  int rc;
+  if ((rc = dl_check_view(fn, x, x_ld, C, es)) || (rc = dl_check_view(fn, out, out_ld, C, es))) return rc;
+  const dim3 grid((unsigned)B, (unsigned)(CC / ccw));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((image_sum_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, HW, C, scale, (char*)out, out_ld);
+  else hipLaunchKernelGGL((image_sum_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)x, x_ld, HW, C, scale, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_image_broadcast(const void* v, int64_t v_ld, int B, int HW, int C, float scale, void* out, int64_t out_ld,
+                                    int dtype, void* stream) {
+  const char* fn = "cvcs_image_broadcast";
+  CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
+  int rc;
+  if ((rc = dl_check_view(fn, v, v_ld, C, es)) || (rc = dl_check_view(fn, out, out_ld, C, es))) return rc;
+  const dim3 grid(dl_grid((int64_t)B * HW * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((image_broadcast_kernel<float>), grid, dim3(256), 0, st, (const char*)v, v_ld, B, HW, C, scale, (char*)out, out_ld);
+  else hipLaunchKernelGGL((image_broadcast_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)v, v_ld, B, HW, C, scale, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+static int lin_args_ok(const char* fn, int C, int NC, int dtype) {
+  CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
+  CVCS_CHECK_ARG(C > 0 && C % 64 == 0 && C <= 1024, "%s: C=%d must be a multiple of 64, at most 1024", fn, C);
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kLinMaxNC, "%s: NC=%d out of [1,%d]", fn, NC, kLinMaxNC);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_linear_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias,
+                                    int NC, float* logits, uint8_t* labels, int dtype, void* stream) {
+  const char* fn = "cvcs_linear_head_fwd";
+  int rc;
+  if ((rc = lin_args_ok(fn, C, NC, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(x && w && (logits != nullptr) != (labels != nullptr) && B > 0 && H > 0 && W > 0, "%s: exactly one of logits / labels", fn);
+  if ((rc = dl_check_view(fn, x, x_ld, C, es))) return rc;
+  const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
+  const size_t lds = (size_t)(NC * C + NC) * 4;
+  const dim3 grid(dl_grid(P, 2048));
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_LIN(TT, AM)                                                                                                    \
+  do {                                                                                                                        \
+    static bool attr_done = false;                                                                                            \
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_head_kernel<TT, AM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+    hipLaunchKernelGGL((linear_head_kernel<TT, AM>), grid, dim3(256), lds, st, (const char*)x, x_ld, P, HW, C, w, bias, NC, logits, labels); \
+  } while (0)
+  if (dtype == CVCS_F32) { if (labels) LAUNCH_LIN(float, true); else LAUNCH_LIN(float, false); }
+  else { if (labels) LAUNCH_LIN(bf16_t, true); else LAUNCH_LIN(bf16_t, false); }
+#undef LAUNCH_LIN
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_linear_head_bwd_rows(int64_t P) {
+  int64_t r = cdiv(P, 64 * 8);   // ~8 strips per workgroup
+  return (int)(r < 1 ? 1 : (r > 512 ? 512 : r));
+}
+
+extern "C" int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w,
+                                    int NC, void* dx, int64_t dx_ld, float* part_dw, int dtype, void* stream) {
+  const char* fn = "cvcs_linear_head_bwd";
+  int rc;
+  if ((rc = lin_args_ok(fn, C, NC, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(x && dlogits && w && dx && part_dw && B > 0 && H > 0 && W > 0, "%s: null argument", fn);
+  if ((rc = dl_check_view(fn, x, x_ld, C, es)) || (rc = dl_check_view(fn, dx, dx_ld, C, es))) return rc;
+  const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
+  const size_t lds = (size_t)(64 * C + 64 * (NC + 1) + NC * C) * 4;
+  CVCS_CHECK_ARG(lds <= 160 * 1024, "%s: C=%d, NC=%d need %zu bytes of LDS", fn, C, NC, lds);
+  const dim3 grid((unsigned)cvcs_linear_head_bwd_rows(P));
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_LINB(TT)                                                                                                       \
+  do {                                                                                                                        \
+    static bool attr_done = false;                                                                                            \
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_head_bwd_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+    hipLaunchKernelGGL((linear_head_bwd_kernel<TT>), grid, dim3(256), lds, st, (const char*)x, x_ld, dlogits, P, HW, C, w, NC, (char*)dx, dx_ld, part_dw); \
+  } while (0)
+  if (dtype == CVCS_F32) LAUNCH_LINB(float); else LAUNCH_LINB(bf16_t);
+#undef LAUNCH_LINB
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}

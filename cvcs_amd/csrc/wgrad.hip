@@ -30,6 +30,10 @@ struct WgradArgs {
   int KW, stride, pad;
   int stride_w, pad_w;        // generic kernel: W axis (== stride / pad unless cvcs_wgrad_desc.aniso)
   int64_t x_row_pitch, x_img_pitch;   // generic kernel: pitches of `x` in elements
+  // dilated 3x3 weight gradients run tap by tap as SHIFTED 1x1 problems (x pixel = dy pixel + (sh_y, sh_x), zero outside the
+  // image): partial slabs are laid out [slice][9 taps][co][ci] (slice_stride != 0 overrides the kernel's own stride)
+  int sh_y, sh_x;
+  int64_t slice_stride;
   int TH, TW, HR, HC;         // K-tile and halo-tile extents
   int tiles_x, tiles_y;       // K-tiles per image
   int ktiles, per_slice;      // total K-tiles, K-tiles per slice
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   }
 
   // ---- partials: ws[slice][tap][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
-  const int64_t slice_stride = (int64_t)NT * p.Cout * p.Cin;
+  const int64_t slice_stride = p.slice_stride ? p.slice_stride : (int64_t)NT * p.Cout * p.Cin;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -289,11 +293,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
     if (blk < MB) { src0[i] = p.dy + ((int64_t)co0 + blk * 64) * 2 + c * 16; rowb[i] = p.dy_ld * 2; }
     else          { src0[i] = p.x + ((int64_t)ci0 + (blk - MB) * 64) * 2 + c * 16; rowb[i] = p.x_ld * 2; }
   }
+  const bool shifted = (p.sh_y | p.sh_x) != 0;
+  const int64_t sh_lin = (int64_t)p.sh_y * p.W + p.sh_x;
   auto issue_tile = [&](int kt, int st) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int64_t pix = (int64_t)kt * 32 + prow[i];
-      const char* src = pix < M ? src0[i] + pix * rowb[i] : reinterpret_cast<const char*>(&g_wzero16);
+      int64_t pix = (int64_t)kt * 32 + prow[i];
+      bool ok = pix < M;
+      if (shifted && (wave + 4 * i) >= 4 * MB) {      // an x piece of a shifted tap: the source pixel must stay inside its image
+        const int ox = (int)(pix % p.W), oy = (int)((pix / p.W) % p.H);
+        ok = ok && (unsigned)(oy + p.sh_y) < (unsigned)p.H && (unsigned)(ox + p.sh_x) < (unsigned)p.W;
+        pix += sh_lin;
+      }
+      const char* src = ok ? src0[i] + pix * rowb[i] : reinterpret_cast<const char*>(&g_wzero16);
       dma16(src, lds0 + st * STAGE + (wave + 4 * i) * 1024);
     }
   };
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
     if (++st == NS) st = 0;
   }
   // partials ws[slice][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
-  float* ws = p.ws + (int64_t)blockIdx.y * p.Cout * p.Cin;
+  float* ws = p.ws + (int64_t)blockIdx.y * (p.slice_stride ? p.slice_stride : (int64_t)p.Cout * p.Cin);
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -895,11 +907,82 @@ extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int K
   return n;
 }
 
+// Dilated 3x3 / stride 1 / pad = dil (ASPP rates 6 / 12 / 18 and the dilated last ResNet stage of DeepLabV3+): at those rates
+// a K-tile's nine taps touch nine disjoint windows, so there is no halo to share - each tap is a 1x1 weight gradient between
+// dy and the SHIFTED input, run on the 1x1 GEMM kernel (bf16) or the generic kernel with a signed padding (f32 parity path),
+// nine launches into one [slice][tap][co][ci] partial slab, one fixed-order reduce.
+static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
+  const int es = d->dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && !d->aniso && !d->x_row_pitch && !d->x_img_pitch,
+                 "cvcs_conv2d_wgrad: dilation is built for 3x3 / stride 1 / pad = dil");
+  CVCS_CHECK_ARG(d->H == d->Ho && d->W == d->Wo && d->Cin_real == d->Cin, "cvcs_conv2d_wgrad(dilated): same-size maps, no channel padding");
+  CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0 &&
+                 ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad(dilated): views");
+  WgradArgs a;
+  a.x = (const char*)d->x; a.dy = (const char*)d->dy;
+  a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KW = 1; a.stride = 1; a.stride_w = 1;
+  a.x_row_pitch = (int64_t)d->W * d->x_ld; a.x_img_pitch = (int64_t)d->H * a.x_row_pitch;
+  a.slice_stride = (int64_t)9 * d->Cout * d->Cin;
+  const bool gemm = d->dtype == CVCS_BF16 && gemm_shape(1, 1, 1, d->Cout, d->Cin);
+  int nslice;
+  if (gemm) {
+    const GemmPlan g = gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin);
+    a.ktiles = g.ktiles; a.per_slice = g.per_slice; a.ntile_n = g.ntile_n;
+    nslice = g.nslice;
+    const dim3 grid((unsigned)g.tiles_mn, (unsigned)g.nslice);
+    for (int t = 0; t < 9; ++t) {
+      a.sh_y = (t / 3 - 1) * d->dil; a.sh_x = (t % 3 - 1) * d->dil;
+      a.ws = d->workspace + (int64_t)t * d->Cout * d->Cin;
+      a.pad = 0; a.pad_w = 0;
+#define LAUNCH_GEMM_D(BM_, BN_)                                                                                                 \
+  do {                                                                                                                          \
+    const int lds = 3 * ((BM_) / 64 + (BN_) / 64) * 4096;                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_>), grid, dim3(256), lds, st, a);                                             \
+  } while (0)
+      if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM_D(128, 128);
+      else if (g.BM == 128) LAUNCH_GEMM_D(128, 64);
+      else LAUNCH_GEMM_D(64, 128);
+#undef LAUNCH_GEMM_D
+    }
+  } else {
+    WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 1, 0);
+    a.TH = pl.TH; a.TW = pl.TW; a.HR = pl.HR; a.HC = pl.HC;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ktiles = pl.ktiles; a.per_slice = pl.per_slice;
+    a.ntile_n = (int)cdiv(d->Cin, 64);
+    a.sh_y = a.sh_x = 0;
+    nslice = pl.nslice;
+    for (int t = 0; t < 9; ++t) {
+      a.pad = -(t / 3 - 1) * d->dil; a.pad_w = -(t % 3 - 1) * d->dil;   // signed padding = the tap's shift (loads are bounds-checked)
+      a.ws = d->workspace + (int64_t)t * d->Cout * d->Cin;
+      int rc = d->dtype == CVCS_F32 ? launch<float, 1>(a, pl, st) : launch<bf16_t, 1>(a, pl, st);
+      if (rc != CVCS_OK) return rc;
+    }
+  }
+  CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(dilated)");
+  const int64_t total = (int64_t)d->Cout * d->Cin;
+  int ks = 1;
+  while (ks < 16 && total * ks < 65536 && ks * 2 <= nslice) ks *= 4;
+  const unsigned blocks = (unsigned)(cdiv(total, 256 / ks) > 4096 ? 4096 : cdiv(total, 256 / ks));
+  if (ks >= 16) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 16>), dim3(blocks), dim3(256), 0, st, d->workspace, d->dw, nslice, d->Cout, d->Cin, d->Cin_real);
+  else if (ks >= 4) hipLaunchKernelGGL((wgrad_reduce_kernel<9, 4>), dim3(blocks), dim3(256), 0, st, d->workspace, d->dw, nslice, d->Cout, d->Cin, d->Cin_real);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<9, 1>), dim3(blocks), dim3(256), 0, st, d->workspace, d->dw, nslice, d->Cout, d->Cin, d->Cin_real);
+  CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(dilated reduce)");
+  return CVCS_OK;
+}
+
 // exact workspace size of one descriptor (covers the anisotropic / pitched case, which cvcs_wgrad_slices cannot express)
 extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 64 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   int n;
+  if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
+    const int a = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 1, 0).nslice;
+    const int g = gemm_shape(1, 1, 1, d->Cout, d->Cin) ? gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice : 0;
+    return (int64_t)(a > g ? a : g) * 9 * d->Cout * d->Cin;
+  }
   if (special) n = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, 0, d->aniso ? d->stride_w : d->stride).nslice;
   else n = cvcs_wgrad_slices(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride);
   return (int64_t)n * d->KH * d->KW * d->Cout * d->Cin;
@@ -916,6 +999,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   const int taps = d->KH * d->KW;
   CVCS_CHECK_ARG((d->KH == 3 && d->KW == 3) || (d->KH == 2 && d->KW == 2) || (d->KH == 1 && d->KW == 1) || (d->KH == 7 && d->KW == 1),
                  "cvcs_conv2d_wgrad: filter %dx%d not built (3x3, 2x2, 1x1, 7x1)", d->KH, d->KW);
+  if (d->dil > 1) return wgrad_dilated(d, (hipStream_t)stream);
   const bool aniso = d->aniso != 0, pitched = d->x_row_pitch != 0 || d->x_img_pitch != 0;
   const int stride_w = aniso ? d->stride_w : d->stride, pad_w = aniso ? d->pad_w : d->pad;
   CVCS_CHECK_ARG(d->stride >= 1 && d->stride <= 2 && d->pad >= 0 && stride_w >= 1 && stride_w <= 2 && pad_w >= 0, "cvcs_conv2d_wgrad: stride/pad");
@@ -937,6 +1021,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.stride_w = stride_w; a.pad_w = pad_w; a.x_row_pitch = row_pitch; a.x_img_pitch = img_pitch;
+  a.sh_y = a.sh_x = 0; a.slice_stride = 0;
   a.TH = pl.TH; a.TW = pl.TW; a.HR = pl.HR; a.HC = pl.HC;
   a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ktiles = pl.ktiles; a.per_slice = pl.per_slice;
   a.ntile_n = (int)cdiv(d->Cin, 64);

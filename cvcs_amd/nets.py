@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .engine import WIDTHS, UNetEngine
+from .deeplab_engine import LOW_LEVEL_CHANNELS, DeepLabEngine
 from .resnet_engine import ARCHS as RESNET_ARCHS, DECODER_CHANNELS, ResNetUNetEngine
 
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
@@ -304,3 +305,63 @@ class Resnet34Unet(ResnetUnet):
 
 class Resnet50Unet(ResnetUnet):
     arch = "resnet50"
+
+
+# ---------------------------------------------------------------------------------------------------- DeepLab family
+def deeplab_param_spec(arch: str, num_classes: int, plus: bool = True):
+    """(name, shape, kind): the ResNet encoder (torchvision names under `encoder.`), ASPP (`aspp.convs.N.*`, `aspp.project.*`
+    as in torchvision.models.segmentation.deeplabv3), then the V3+ decoder (`low_level`, `decoder.conv1/2`) or the V3 head
+    (`head`), and the 1x1 `classifier` (the reference's replaced `classifier[4]`, S/nets.py:243-244)."""
+    spec = [e for e in resnet_unet_param_spec(arch, num_classes) if e[0].startswith("encoder.")]
+    widths = RESNET_ARCHS[arch][2]
+
+    def conv(p, cin, cout, k, bias=False):
+        spec.append((p + ".weight", (cout, cin, k, k), "conv_w"))
+        if bias:
+            spec.append((p + ".bias", (cout,), "conv_b"))
+
+    def bn(p, c):
+        spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b"), (p + ".running_mean", (c,), "rm"),
+                     (p + ".running_var", (c,), "rv"), (p + ".num_batches_tracked", (), "nbt")])
+
+    cin = widths[3]
+    conv("aspp.convs.0.0", cin, 256, 1); bn("aspp.convs.0.1", 256)
+    for i in (1, 2, 3):
+        conv(f"aspp.convs.{i}.0", cin, 256, 3); bn(f"aspp.convs.{i}.1", 256)
+    conv("aspp.convs.4.1", cin, 256, 1); bn("aspp.convs.4.2", 256)
+    conv("aspp.project.0", 5 * 256, 256, 1); bn("aspp.project.1", 256)
+    if plus:
+        conv("low_level.0", widths[0], LOW_LEVEL_CHANNELS, 1); bn("low_level.1", LOW_LEVEL_CHANNELS)
+        conv("decoder.conv1.0", 256 + LOW_LEVEL_CHANNELS, 256, 3); bn("decoder.conv1.1", 256)
+        conv("decoder.conv2.0", 256, 256, 3); bn("decoder.conv2.1", 256)
+    else:
+        conv("head.0", 256, 256, 3); bn("head.1", 256)
+    conv("classifier", 256, num_classes, 1, bias=True)
+    return spec
+
+
+class DeepLabV3Plus(_HipUNet):
+    """DeepLabV3+ with a ResNet-50 encoder at output stride 16, ASPP rates 6/12/18 (BASELINE.json configs[2]) behind the
+    reference's nn.Module contract; see deeplab_engine.py.  The tile side must be a multiple of 32; train mode needs a batch
+    of at least 2 tiles (the image-pooling branch normalises a 1x1 map over the batch, as in torchvision)."""
+    arch, output_stride, plus = "resnet50", 16, True
+    variant = "DeepLab"
+
+    def _build_spec(self):
+        return deeplab_param_spec(self.arch, self.num_classes, self.plus)
+
+    def _build_engine(self, dev):
+        return DeepLabEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, self.output_stride, self.plus)
+
+
+class DeepLabv3Resnet101(DeepLabV3Plus):
+    """the network behind the reference's factory name `Resnet101` (S/nets.py:234-257: torchvision deeplabv3_resnet101 with
+    `classifier[4]` -> Conv2d(256, num_classes, 1), output stride 8, ASPP rates 12/24/36, forward returns d['out']), built on
+    the HIP kernels.  The reference loads COCO weights through a network fetch; here the weights are randomly initialised
+    unless a checkpoint is loaded (`wrapper` stays False: there is no inner torchvision module to unwrap)."""
+    arch, output_stride, plus = "resnet101", 8, False
+
+
+class DeepLabv3Resnet50(DeepLabV3Plus):
+    """S/nets.py:259-275 (same head on a ResNet-50; not reachable from the reference's load_network either)"""
+    arch, output_stride, plus = "resnet50", 8, False

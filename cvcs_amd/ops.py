@@ -205,8 +205,9 @@ def wgrad_workspace_floats(B, Ho, Wo, Cout, Cin, KH, KW, stride) -> int:
     return n * KH * KW * Cout * Cin
 
 
-def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None):
+def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1):
     d = WgradDesc()
+    d.dil = dil
     if virt is not None:   # the stem's weight gradient over virtual pixels (see _conv_desc)
         assert (KH, KW, stride, pad) == (7, 1, 2, 3) and x.C == 4 and x.off == 0
         Wv = (x.W - 8) // 2
@@ -221,18 +222,19 @@ def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None):
     return d
 
 
-def wgrad_workspace_floats_for(x: View, dy: View, KH, KW, stride, pad, virt=None) -> int:
+def wgrad_workspace_floats_for(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1) -> int:
     """exact split-K workspace (floats) of one weight-gradient launch"""
-    d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt)
+    d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt, dil)
     n = _lib.lib().cvcs_wgrad_workspace_floats(C.byref(d))
     if n < 0:
         raise _lib.CvcsError("cvcs_wgrad_workspace_floats: bad shape")
     return n
 
 
-def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, workspace: torch.Tensor, cin_real=None, virt=None):
+def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, workspace: torch.Tensor, cin_real=None, virt=None,
+                 dil=1):
     """dw[Cout][Cin_real][KH][KW] (f32, contiguous) = sum_p dy[p] (x) x[pix(p, tap)]."""
-    d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt)
+    d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt, dil)
     cin_real = d.Cin if cin_real is None else cin_real
     d.dw, d.Cin_real = dw.data_ptr(), cin_real
     d.workspace = workspace.data_ptr()
@@ -389,6 +391,66 @@ def pack_stem_weight(w: torch.Tensor, wf: torch.Tensor):
 def unpack_stem_wgrad(tmp: torch.Tensor, dw: torch.Tensor):
     assert tmp.dtype == torch.float32 and dw.dtype == torch.float32 and dw.is_contiguous() and tmp.numel() == dw.shape[0] * 32 * 7
     check(_lib.lib().cvcs_unpack_stem_wgrad(tmp.data_ptr(), dw.shape[0], dw.data_ptr(), _stream()), "cvcs_unpack_stem_wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ DeepLabV3+
+def resize_bilinear_fwd(x: View, out: View, scale: int):
+    assert (out.B, out.H, out.W, out.C) == (x.B, x.H * scale, x.W * scale, x.C)
+    check(_lib.lib().cvcs_resize_bilinear_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, scale, out.ptr, out.ld, x.code, _stream()),
+          "cvcs_resize_bilinear_fwd")
+
+
+def resize_bilinear_bwd(gout: View, gin: View, scale: int):
+    assert (gout.B, gout.H, gout.W, gout.C) == (gin.B, gin.H * scale, gin.W * scale, gin.C)
+    check(_lib.lib().cvcs_resize_bilinear_bwd(gout.ptr, gout.ld, gin.B, gin.H, gin.W, gin.C, scale, gin.ptr, gin.ld, gin.code,
+                                              _stream()), "cvcs_resize_bilinear_bwd")
+
+
+def resize_bilinear_nchw_fwd(x: torch.Tensor, out: torch.Tensor, scale: int):
+    """f32 [B,NC,H,W] -> [B,NC,H*scale,W*scale]"""
+    B, NC, H, W = x.shape
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    assert tuple(out.shape) == (B, NC, H * scale, W * scale)
+    check(_lib.lib().cvcs_resize_bilinear_nchw_fwd(x.data_ptr(), B * NC, H, W, scale, out.data_ptr(), _stream()),
+          "cvcs_resize_bilinear_nchw_fwd")
+
+
+def resize_bilinear_nchw_bwd(gout: torch.Tensor, gin: torch.Tensor, scale: int):
+    B, NC, H, W = gin.shape
+    assert gout.dtype == torch.float32 and gin.dtype == torch.float32 and gout.is_contiguous() and gin.is_contiguous()
+    assert tuple(gout.shape) == (B, NC, H * scale, W * scale)
+    check(_lib.lib().cvcs_resize_bilinear_nchw_bwd(gout.data_ptr(), B * NC, H, W, scale, gin.data_ptr(), _stream()),
+          "cvcs_resize_bilinear_nchw_bwd")
+
+
+def image_sum(x: View, out: View, scale: float):
+    """out [B,1,1,C] = scale * per-image sum over the pixels of x"""
+    assert (out.B, out.H, out.W, out.C) == (x.B, 1, 1, x.C)
+    check(_lib.lib().cvcs_image_sum(x.ptr, x.ld, x.B, x.H * x.W, x.C, scale, out.ptr, out.ld, x.code, _stream()), "cvcs_image_sum")
+
+
+def image_broadcast(v: View, out: View, scale: float):
+    assert (v.B, v.H, v.W, v.C) == (out.B, 1, 1, out.C)
+    check(_lib.lib().cvcs_image_broadcast(v.ptr, v.ld, out.B, out.H * out.W, out.C, scale, out.ptr, out.ld, out.code, _stream()),
+          "cvcs_image_broadcast")
+
+
+def linear_head_fwd(x: View, w, bias, logits=None, labels=None):
+    """1x1 classifier on any channel count: NCHW f32 logits, or (labels given) the fused argmax"""
+    NC = w.shape[0]
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == NC * x.C
+    check(_lib.lib().cvcs_linear_head_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), _ptr(bias), NC, _ptr(logits), _ptr(labels),
+                                          x.code, _stream()), "cvcs_linear_head_fwd")
+
+
+def linear_head_bwd_rows(P: int) -> int:
+    return _lib.lib().cvcs_linear_head_bwd_rows(P)
+
+
+def linear_head_bwd(x: View, dlogits, w, dx: View, part_dw):
+    NC = w.shape[0]
+    check(_lib.lib().cvcs_linear_head_bwd(x.ptr, x.ld, dlogits.data_ptr(), x.B, x.H, x.W, x.C, w.data_ptr(), NC, dx.ptr, dx.ld,
+                                          part_dw.data_ptr(), x.code, _stream()), "cvcs_linear_head_bwd")
 
 
 # ------------------------------------------------------------------------------------------------ bilinear

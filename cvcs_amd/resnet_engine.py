@@ -35,7 +35,25 @@ ARCHS = {
     "resnet18": ("basic", (2, 2, 2, 2), (64, 128, 256, 512)),
     "resnet34": ("basic", (3, 4, 6, 3), (64, 128, 256, 512)),
     "resnet50": ("bottleneck", (3, 4, 6, 3), (256, 512, 1024, 2048)),
+    "resnet101": ("bottleneck", (3, 4, 23, 3), (256, 512, 1024, 2048)),
 }
+
+
+def stage_plan(arch, output_stride=32):
+    """[(stage, block, stride, dilation)]: torchvision's `replace_stride_with_dilation` rule (the DeepLab encoders) - once the
+    output stride is reached a stage's stride-2 block keeps stride 1 (and the dilation so far), its later blocks double it"""
+    _, depths, _ = ARCHS[arch]
+    plan, cur, dil = [], 4, 1
+    for s, n in enumerate(depths, start=1):
+        first_stride, first_dil = 1, dil
+        if s > 1:
+            if cur >= output_stride:
+                dil *= 2
+            else:
+                first_stride, cur = 2, cur * 2
+        for b in range(n):
+            plan.append((s, b, first_stride if b == 0 else 1, first_dil if b == 0 else dil))
+    return plan
 DECODER_CHANNELS = (256, 128, 64, 64, 64)
 
 
@@ -50,8 +68,9 @@ class Act:
 class Unit:
     """one conv (+ BatchNorm): input view, conv output y, geometry"""
 
-    def __init__(self, x, y, conv, bn, k, stride, pad, virt=False):
+    def __init__(self, x, y, conv, bn, k, stride, pad, virt=False, dil=1):
         self.x, self.y, self.conv, self.bn, self.k, self.stride, self.pad, self.virt = x, y, conv, bn, k, stride, pad, virt
+        self.dil = dil
 
 
 class ResNetUNetEngine:
@@ -61,6 +80,7 @@ class ResNetUNetEngine:
         self.kind, self.depths, self.widths = ARCHS[arch]
         self.dec = tuple(decoder_channels)
         assert self.dec[-1] == 64, "the 1x1 head kernels take 64 input channels"
+        self.head_name = "segmentation_head.0"
         self.code = ops.dtype_code(dtype)
         self.P = self.G = self.Bf = None
         self.shape = None
@@ -85,7 +105,7 @@ class ResNetUNetEngine:
         self.packed = {}
         entries = []
         for name, w in params.items():
-            if w.dim() != 4 or name in ("encoder.conv1.weight", "segmentation_head.0.weight"):
+            if w.dim() != 4 or name in ("encoder.conv1.weight", self.head_name + ".weight"):
                 continue
             cout, cin, kh, kw = w.shape
             pk = dict(wf=torch.empty(kh * kw, cout, cin, dtype=dt, device=dev), wd=torch.empty(kh * kw, cin, cout, dtype=dt, device=dev))
@@ -123,7 +143,7 @@ class ResNetUNetEngine:
         return self._buf(f"scratch.{tag}", (int(n),), dtype)
 
     # ------------------------------------------------------------------------------------------------ forward pieces
-    def _unit(self, x: View, conv, bn, k, stride, pad, train, act_out: View | None, relu=True, virt=False) -> Unit:
+    def _unit(self, x: View, conv, bn, k, stride, pad, train, act_out: View | None, relu=True, virt=False, dil=1) -> Unit:
         """conv (+ batch statistics) -> BatchNorm finalize [-> apply (+ReLU) into act_out].  act_out None: the caller applies
         the BatchNorm itself (block tail).  Eval mode: the BatchNorm is folded into the conv epilogue; y then holds bn(conv)."""
         B = x.B
@@ -135,7 +155,7 @@ class ResNetUNetEngine:
             wf = self.stem_wf
             kh, kw = 7, 1
         else:
-            Ho, Wo = ops.conv_out_hw(x.H, x.W, k, k, stride, pad)
+            Ho, Wo = ops.conv_out_hw(x.H, x.W, k, k, stride, pad, dil)
             wf = self.packed[conv]["wf"]
             kh = kw = k
         st = self.bn[bn]
@@ -144,20 +164,20 @@ class ResNetUNetEngine:
             ops.bn_finalize(None, 0, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
                             self.Bf[bn + ".running_var"], False, st.scale, st.shift, None, None)
             out = act_out if act_out is not None else ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
-            ops.conv2d(x, wf, None, out, kh, kw, stride, pad, relu=relu and act_out is not None, pre_affine=(st.scale, st.shift),
+            ops.conv2d(x, wf, None, out, kh, kw, stride, pad, dil, relu=relu and act_out is not None, pre_affine=(st.scale, st.shift),
                        virt=virt or None)
-            return Unit(x, out, conv, bn, k, stride, pad, virt)
+            return Unit(x, out, conv, bn, k, stride, pad, virt, dil)
         y = ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
-        rows = ops.conv_stat_rows(x, cout, kh, kw, stride, pad, virt=virt or None)
+        rows = ops.conv_stat_rows(x, cout, kh, kw, stride, pad, dil, virt=virt or None)
         stats = (self._scratch("stat_sum", rows * cout), self._scratch("stat_m2", rows * cout), self._scratch("stat_cnt", rows))
-        ops.conv2d(x, wf, None, y, kh, kw, stride, pad, stats=stats, virt=virt or None)
+        ops.conv2d(x, wf, None, y, kh, kw, stride, pad, dil, stats=stats, virt=virt or None)
         need = ops.bn_finalize_workspace_floats(rows, cout)
         ops.bn_finalize(stats, rows, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
                         self.Bf[bn + ".running_var"], True, st.scale, st.shift, st.mean, st.invstd,
                         workspace=self._scratch("bn_ws", max(need, 4)))
         if act_out is not None:
             ops.bn_act(y, st.scale, st.shift, relu, act_out)
-        u = Unit(x, y, conv, bn, k, stride, pad, virt)
+        u = Unit(x, y, conv, bn, k, stride, pad, virt, dil)
         self.units[conv] = (u, act_out)     # persistent views of this shape's plan (layer-wise parity tests read them)
         if act_out is not None and relu:
             self.relu_order.append(act_out)
@@ -175,15 +195,15 @@ class ResNetUNetEngine:
         else:   # the BatchNorms are already inside the conv epilogues
             ops.bn_add_act(u3.y, self.one[:C_], self.zero[:C_], ud.y if ud is not None else h.v, None, None, out)
 
-    def _block(self, h: Act, p, stride, out: View, train, tape) -> Act:
+    def _block(self, h: Act, p, stride, out: View, train, tape, dil=1) -> Act:
         B = h.v.B
         has_ds = (p + ".downsample.0.weight") in self.P
         if self.kind == "basic":
             w = self.P[p + ".conv1.weight"].shape[0]
             Ho, Wo = h.v.H // stride, h.v.W // stride
             a1 = Act(ops.view(self._act(p + ".a1", B, Ho, Wo, w)))
-            u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 3, stride, 1, train, a1.v)
-            ut = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, 1, 1, train, None)
+            u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 3, stride, dil, train, a1.v, dil=dil)
+            ut = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, 1, dil, train, None, dil=dil)
             chain = [(u1, h, a1)]
             last_in = a1
         else:
@@ -192,7 +212,7 @@ class ResNetUNetEngine:
             a1 = Act(ops.view(self._act(p + ".a1", B, h.v.H, h.v.W, mid)))
             a2 = Act(ops.view(self._act(p + ".a2", B, Ho, Wo, mid)))
             u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 1, 1, 0, train, a1.v)
-            u2 = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, stride, 1, train, a2.v)
+            u2 = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, stride, dil, train, a2.v, dil=dil)
             ut = self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
             chain = [(u1, h, a1), (u2, a1, a2)]
             last_in = a2
@@ -236,7 +256,7 @@ class ResNetUNetEngine:
         workgroup narrow tiles, i.e. up to 128 channels - on the wide kernel the longer epilogue is exposed)"""
         y = consumer.y
         return (self.fuse_bn_bwd and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
-                y.H >= 8 and y.W >= 8 and y.C <= 128)
+                producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128)
 
     def _unit_bwd(self, u: Unit, g: View, mode, fused=None) -> View:
         """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
@@ -267,8 +287,8 @@ class ResNetUNetEngine:
             ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch("wg_ws", need), cin_real=32, virt=True)
             ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
         else:
-            need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad)
-            ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch("wg_ws", need))
+            need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
+            ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch("wg_ws", need), dil=u.dil)
         return dy
 
     def _dgrad(self, u: Unit, dy: View, name, fuse_into: Unit | None = None):
@@ -297,7 +317,7 @@ class ResNetUNetEngine:
             return gx, u.stride == 2
         gx = ops.view(self._act(name, B, x.H, x.W, cin))
         if u.stride == 1:
-            ops.conv2d(dy, wd, None, gx, 3, 3, 1, 1)
+            ops.conv2d(dy, wd, None, gx, 3, 3, 1, u.dil, u.dil)   # (dilated: the generic gather kernel, see wgrad_dilated)
         else:
             # 3x3 / stride 2 / pad 1: dx = conv3x3/s1/p1(zero-dilated dy, flipped weights) - on the halo kernel
             dil = ops.view(self._scratch("dilated", B * x.H * x.W * dy.C, self.dtype).view(B, x.H, x.W, dy.C))
@@ -328,37 +348,9 @@ class ResNetUNetEngine:
             cin = dec[i]
         upc = [widths[3]] + list(dec[:4])                    # channels of the up-sampled part of cat[i]
         skip_view = lambda i: View(cat[i], upc[i], skipc[i])  # noqa: E731
-        in4 = ops.view(self._buf("in4", (B, S, S + 8, 4)))
-        f1 = Act(skip_view(3))
-        u0 = self._unit(in4, "encoder.conv1", "encoder.bn1", 7, 2, 3, train, f1.v, virt=True)
-        p0 = Act(ops.view(self._act("pool0", B, S // 4, S // 4, 64)))
-        idx = self._buf("pool0.idx", (B * (S // 4) * (S // 4) * 64,), torch.uint8)
-        ops.maxpool3x3s2_fwd(f1.v, p0.v, idx)
-        if train:
-            def stem_bwd():
-                dx = ops.view(self._act("pool0.dx", B, S // 2, S // 2, 64))
-                g = [v for v, _ in p0.grads]
-                ops.maxpool3x3s2_bwd(g[0], g[1] if len(g) > 1 else None, idx, dx)
-                f1.grads.append((dx, False))
-                dz = ops.view(self._act("stem.dz", B, S // 2, S // 2, 64))
-                ops.relu_bwd_sum(f1.v, f1.grads, dz)
-                self._unit_bwd(u0, dz, 0)
-                self._ready("encoder.conv1.weight")
-            tape.append(stem_bwd)
-        h = p0
-        feats = {}
-        for s, n in enumerate(self.depths, start=1):
-            for b in range(n):
-                p = f"encoder.layer{s}.{b}"
-                stride = 2 if (b == 0 and s > 1) else 1
-                hs = h.v.H // stride
-                w = widths[s - 1]
-                if b == n - 1 and s < 4:
-                    out = skip_view(3 - s)          # stage 1 -> cat[2], stage 2 -> cat[1], stage 3 -> cat[0]
-                else:
-                    out = ops.view(self._act(p + ".out", B, hs, hs, w))
-                h = self._block(h, p, stride, out, train, tape)
-            feats[s] = h
+        f1, p0 = self._stem(B, S, train, tape, skip_view(3))
+        feats = self._stages(p0, train, tape, lambda s: skip_view(3 - s) if s < 4 else None)   # stage s -> cat[3 - s]
+        h = feats[4]
         # decoder
         for i in range(5):
             s = S >> (4 - i)
@@ -393,6 +385,41 @@ class ResNetUNetEngine:
             self._tape = tape
         self._last = h
         return h
+
+    def _stages(self, h: Act, train, tape, stage_out, output_stride=32):
+        """the four residual stages after the stem's max-pool; stage_out(s) -> view the last block of stage s writes its
+        output to (a channel range of a decoder's concat buffer) or None; returns {stage: Act}"""
+        feats, B = {}, h.v.B
+        for s, b, stride, dil in stage_plan(self.arch, output_stride):
+            p = f"encoder.layer{s}.{b}"
+            hs, w = h.v.H // stride, self.widths[s - 1]
+            out = stage_out(s) if b == self.depths[s - 1] - 1 else None
+            if out is None:
+                out = ops.view(self._act(p + ".out", B, hs, hs, w))
+            h = self._block(h, p, stride, out, train, tape, dil)
+            feats[s] = h
+        return feats
+
+    def _stem(self, B, S, train, tape, f1_view: View | None = None):
+        """packed input -> 7x7/s2 conv -> BN -> ReLU (f1, optionally into a concat buffer) -> 3x3/s2 max-pool (p0)"""
+        in4 = ops.view(self._buf("in4", (B, S, S + 8, 4)))
+        f1 = Act(f1_view if f1_view is not None else ops.view(self._act("stem.f1", B, S // 2, S // 2, 64)))
+        u0 = self._unit(in4, "encoder.conv1", "encoder.bn1", 7, 2, 3, train, f1.v, virt=True)
+        p0 = Act(ops.view(self._act("pool0", B, S // 4, S // 4, 64)))
+        idx = self._buf("pool0.idx", (B * (S // 4) * (S // 4) * 64,), torch.uint8)
+        ops.maxpool3x3s2_fwd(f1.v, p0.v, idx)
+        if train:
+            def stem_bwd():
+                dx = ops.view(self._act("pool0.dx", B, S // 2, S // 2, 64))
+                g = [v for v, _ in p0.grads]
+                ops.maxpool3x3s2_bwd(g[0], g[1] if len(g) > 1 else None, idx, dx)
+                f1.grads.append((dx, False))
+                dz = ops.view(self._act("stem.dz", B, S // 2, S // 2, 64))
+                ops.relu_bwd_sum(f1.v, f1.grads, dz)
+                self._unit_bwd(u0, dz, 0)
+                self._ready("encoder.conv1.weight")
+            tape.append(stem_bwd)
+        return f1, p0
 
     def _plan(self, B, S):
         if self.shape != (B, S):

@@ -57,7 +57,14 @@ def load_network(config, device):
         except Exception:
             print("Some error occured when loading ensemble!")
             raise
-    elif netname in ("Resnet101", "MobileNet", "SegformerMod"):
+    elif netname == "DeepLabV3Plus":
+        # BASELINE.json configs[2]: DeepLabV3+ (ResNet-50, ASPP 6/12/18) - a new factory name behind the same seam
+        return nets.DeepLabV3Plus(classes, precision).to(device)
+    elif netname == "Resnet101":
+        # S/utils.py:180-181 -> nets.DeepLabv3Resnet101: DeepLabV3 on a dilated ResNet-101, on the HIP kernels (random-init:
+        # the reference's COCO weights come from a network fetch)
+        return nets.DeepLabv3Resnet101(classes, precision).to(device)
+    elif netname in ("MobileNet", "SegformerMod"):
         raise NotImplementedError(f"network '{netname}' wraps third-party pretrained models in the reference "
                                   "(S/nets.py:234-356) and is outside the MI355X hot path of this build")
     else:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 4
+#define CVCS_ABI_VERSION 5
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -118,6 +118,9 @@ typedef struct {
    * 7x1 are built for this case (the stem's weight gradient over virtual channels).                              */
   int32_t aniso, stride_w, pad_w;
   int64_t x_row_pitch, x_img_pitch;
+  /* ABI 5: dilation (0 / 1 = none).  dil > 1 is built for 3x3 / stride 1 / pad = dil (DeepLabV3+: ASPP rates, dilated last
+   * stage): nine shifted 1x1 weight gradients into one partial slab (workspace: cvcs_wgrad_workspace_floats).       */
+  int32_t dil;
 } cvcs_wgrad_desc;
 int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
 /* exact workspace size (floats) of one descriptor; covers the anisotropic / pitched case cvcs_wgrad_slices cannot express */
@@ -316,6 +319,34 @@ int cvcs_pack_input_stem(const void* src, int src_is_u8, int B, int H, int W, vo
  * way back for its gradient: tmp f32 [Cout][32][7] (what cvcs_conv2d_wgrad writes for the 7x1 virtual filter) -> OIHW */
 int cvcs_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void* stream);
 int cvcs_unpack_stem_wgrad(const float* tmp, int Cout, float* dw, void* stream);
+
+/* ---- DeepLabV3+ (BASELINE.json configs[2]; the reference wraps torchvision's DeepLabV3 at S/nets.py:234-311 and returns
+ * d['out'] :248-250, which torchvision resizes bilinearly to the input size) ------------------------------------------
+ * Bilinear resize by an integer factor, align_corners=False (F.interpolate): NHWC activations [B,H,W,C] -> [B,H*s,W*s,C]
+ * and the NCHW f32 logits (`planes` = B*NC maps of H x W); the backward calls take the gradient of the LARGE map and
+ * write the gradient of the small one (H, W are the small map's), as gathers (no atomics).                          */
+int cvcs_resize_bilinear_fwd(const void* in, int64_t in_ld, int B, int H, int W, int C, int scale, void* out, int64_t out_ld,
+                             int dtype, void* stream);
+int cvcs_resize_bilinear_bwd(const void* gout, int64_t gout_ld, int B, int H, int W, int C, int scale, void* gin,
+                             int64_t gin_ld, int dtype, void* stream);
+int cvcs_resize_bilinear_nchw_fwd(const float* in, int64_t planes, int H, int W, int scale, float* out, void* stream);
+int cvcs_resize_bilinear_nchw_bwd(const float* gout, int64_t planes, int H, int W, int scale, float* gin, void* stream);
+/* ASPP image pooling: out[b][c] = scale * sum over the HW pixels of image b (nn.AdaptiveAvgPool2d(1): scale = 1/HW; the
+ * backward of the broadcast below: scale = 1), and the broadcast of a [B][C] vector over HW pixels times `scale`
+ * (F.interpolate of a 1x1 map: scale = 1; the backward of the mean: scale = 1/HW).                                   */
+int cvcs_image_sum(const void* x, int64_t x_ld, int B, int HW, int C, float scale, void* out, int64_t out_ld, int dtype,
+                   void* stream);
+int cvcs_image_broadcast(const void* v, int64_t v_ld, int B, int HW, int C, float scale, void* out, int64_t out_ld, int dtype,
+                         void* stream);
+/* 1x1 classifier on any channel count C (multiple of 64, <= 1024; the replaced `classifier[4]` of S/nets.py:243-244):
+ * NHWC `dtype` -> NCHW f32 logits [B,NC,H,W] (labels NULL) or u8 argmax labels [B,H,W] (logits NULL; ties -> lowest
+ * class); backward: dx NHWC and partial rows [cvcs_linear_head_bwd_rows(P)][NC*C + NC] of dW | db for
+ * cvcs_colsum_finalize.                                                                                             */
+int cvcs_linear_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                         float* logits, uint8_t* labels, int dtype, void* stream);
+int cvcs_linear_head_bwd_rows(int64_t P);
+int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
+                         void* dx, int64_t dx_ld, float* part_dw, int dtype, void* stream);
 
 /* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
  * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).

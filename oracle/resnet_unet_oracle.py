@@ -43,6 +43,7 @@ ARCHS = {
     "resnet18": ("basic", (2, 2, 2, 2), (64, 128, 256, 512)),
     "resnet34": ("basic", (3, 4, 6, 3), (64, 128, 256, 512)),
     "resnet50": ("bottleneck", (3, 4, 6, 3), (256, 512, 1024, 2048)),
+    "resnet101": ("bottleneck", (3, 4, 23, 3), (256, 512, 1024, 2048)),
 }
 DECODER_CHANNELS = (256, 128, 64, 64, 64)
 
@@ -159,23 +160,24 @@ def _bn(x, p, prefix, train):
                         eps=BN_EPS)
 
 
-def _conv(x, p, name, stride=1, pad=0, q=False):
+def _conv(x, p, name, stride=1, pad=0, q=False, dil=1):
     # x is already bf16-representable in emulation mode (every stored activation is rounded where it is produced)
-    return _q(F.conv2d(x, _qw(p[name + ".weight"], q), p.get(name + ".bias"), stride=stride, padding=pad), q)
+    return _q(F.conv2d(x, _qw(p[name + ".weight"], q), p.get(name + ".bias"), stride=stride, padding=pad, dilation=dil), q)
 
 
-def _cbr(x, p, conv, bn, stride, pad, q, train, relu=True):
-    y = _bn(_conv(x, p, conv, stride, pad, q), p, bn, train)
+def _cbr(x, p, conv, bn, stride, pad, q, train, relu=True, dil=1):
+    y = _bn(_conv(x, p, conv, stride, pad, q, dil), p, bn, train)
     return _q(F.relu(y), q) if relu else y
 
 
-def _block(x, p, prefix, kind, stride, q, train):
+def _block(x, p, prefix, kind, stride, q, train, dil=1):
+    """dil: dilation (= padding) of the block's 3x3 convolution(s) - the dilated stages of the DeepLab encoders"""
     if kind == "basic":
-        y = _cbr(x, p, prefix + ".conv1", prefix + ".bn1", stride, 1, q, train)
-        z = _cbr(y, p, prefix + ".conv2", prefix + ".bn2", 1, 1, q, train, relu=False)
+        y = _cbr(x, p, prefix + ".conv1", prefix + ".bn1", stride, dil, q, train, dil=dil)
+        z = _cbr(y, p, prefix + ".conv2", prefix + ".bn2", 1, dil, q, train, relu=False, dil=dil)
     else:
         y = _cbr(x, p, prefix + ".conv1", prefix + ".bn1", 1, 0, q, train)
-        y = _cbr(y, p, prefix + ".conv2", prefix + ".bn2", stride, 1, q, train)
+        y = _cbr(y, p, prefix + ".conv2", prefix + ".bn2", stride, dil, q, train, dil=dil)
         z = _cbr(y, p, prefix + ".conv3", prefix + ".bn3", 1, 0, q, train, relu=False)
     if (prefix + ".downsample.0.weight") in p:
         idt = _cbr(x, p, prefix + ".downsample.0", prefix + ".downsample.1", stride, 0, q, train, relu=False)
@@ -184,18 +186,35 @@ def _block(x, p, prefix, kind, stride, q, train):
     return _q(F.relu(z + idt), q)
 
 
-def encoder_features(p, x, arch, train=False, emulate_bf16=False):
-    """[f1 (64, S/2), f2 (S/4), f3 (S/8), f4 (S/16), f5 (S/32)]"""
+def stage_plan(arch, output_stride=32):
+    """[(stage, block, stride, dilation)]: torchvision's `replace_stride_with_dilation` rule - once the output stride is
+    reached, a stage's stride-2 block keeps stride 1 (and the dilation so far), the stage's later blocks double the dilation"""
+    _, depths, _ = ARCHS[arch]
+    plan, cur, dil = [], 4, 1
+    for s, n in enumerate(depths, start=1):
+        first_stride, first_dil = 1, dil
+        if s > 1:
+            if cur >= output_stride:
+                dil *= 2
+            else:
+                first_stride, cur = 2, cur * 2
+        for b in range(n):
+            plan.append((s, b, first_stride if b == 0 else 1, first_dil if b == 0 else dil))
+    return plan
+
+
+def encoder_features(p, x, arch, train=False, emulate_bf16=False, output_stride=32):
+    """[f1 (64, S/2), f2 (S/4), f3 (S/8), f4 (S/16), f5 (S/32)]  (output_stride 16 / 8: the last one / two stages dilated)"""
     kind, depths, _ = ARCHS[arch]
     q = emulate_bf16
     x = _q(x, q)
     f1 = _cbr(x, p, "encoder.conv1", "encoder.bn1", 2, 3, q, train)
     h = F.max_pool2d(f1, 3, 2, 1)
     feats = [f1]
-    for s, n in enumerate(depths, start=1):
-        for b in range(n):
-            h = _block(h, p, f"encoder.layer{s}.{b}", kind, 2 if (b == 0 and s > 1) else 1, q, train)
-        feats.append(h)
+    for s, b, stride, dil in stage_plan(arch, output_stride):
+        h = _block(h, p, f"encoder.layer{s}.{b}", kind, stride, q, train, dil)
+        if b == depths[s - 1] - 1:
+            feats.append(h)
     return feats
 
 
