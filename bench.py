@@ -55,8 +55,13 @@ def cpu_baseline(net, nc, tile, tiles, steps):
     from oracle import unet_oracle as O
     torch.set_num_threads(min(host_cores(), 32))
     img, lab = O.synthetic_tiles(tiles, tile, nc, seed=1234)
-    if net == "Unetv2":
-        tr, what = O.OracleTrainer("Unetv2", nc, opt="SGD2", ignore_index=0, seed=0), "oracle.unet_oracle (torch-CPU fp32 Unetv2"
+    if net in ("Unetv2", "Unet"):
+        tr, what = O.OracleTrainer(net, nc, opt="SGD2", ignore_index=0, seed=0), f"oracle.unet_oracle (torch-CPU fp32 {net}"
+    elif net in ("DeepLabV3Plus", "Resnet101"):
+        from oracle import deeplab_oracle as D
+        plus = net == "DeepLabV3Plus"
+        tr = D.OracleTrainer("resnet50" if plus else "resnet101", nc, opt="SGD2", ignore_index=0, seed=0, output_stride=16 if plus else 8, plus=plus)
+        what = f"oracle.deeplab_oracle (torch-CPU fp32 {net}"
     else:
         arch = {"Resnet50Unet": "resnet50", "Resnet18Unet": "resnet18", "Resnet34Unet": "resnet34"}[net]
         tr, what = R.OracleTrainer(arch, nc, opt="SGD2", ignore_index=0, seed=0), f"oracle.resnet_unet_oracle (torch-CPU fp32 {net}"
@@ -89,7 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
-    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "Unetv2", "Unet"])
+    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -173,6 +178,8 @@ def main():
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
         model = {"Resnet50Unet": "ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder 256/128/64/64/64, 1x1 head)",
                  "Resnet18Unet": "ResNet18-UNet", "Resnet34Unet": "ResNet34-UNet",
+                 "DeepLabV3Plus": "DeepLabV3+ (ResNet-50 v1.5 at output stride 16, ASPP rates 6/12/18, 64-channel low-level branch)",
+                 "Resnet101": "DeepLabV3-ResNet101 (the reference's factory name Resnet101, S/nets.py:234-257; output stride 8, ASPP 12/24/36)",
                  "Unetv2": "Unetv2 (the reference's own U-Net, source/scripts/nets.py:117-199)", "Unet": "Unet (reference)"}[a.net]
         out = {
             "metric": "512x512 tiles/sec (train fwd+bwd)" if a.tile == 512 else f"{a.tile}x{a.tile} tiles/sec (train fwd+bwd)",

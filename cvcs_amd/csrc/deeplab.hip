@@ -248,9 +248,8 @@ __global__ __launch_bounds__(256) void linear_head_kernel(const char* x, int64_t
 template <typename T>
 __global__ __launch_bounds__(256) void linear_head_bwd_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P,
                                                              int64_t HW, int C, const float* __restrict__ w, int NC, char* dx,
-                                                             int64_t dx_ld, float* part) {
+                                                             int64_t dx_ld, float* part, int TP /* pixels per strip */) {
   constexpr int ES = sizeof(T), V = 16 / ES;
-  constexpr int TP = 64;                       // pixels per strip
   extern __shared__ float sm[];                // sx [TP][C] | sd [TP][NCP] | sw [NC][C]
   const int NCP = NC + 1;
   float* sx = sm;
@@ -454,8 +453,10 @@ extern "C" int cvcs_linear_head_fwd(const void* x, int64_t x_ld, int B, int H, i
   return CVCS_OK;
 }
 
+static int lin_strip(int C) { return C <= 256 ? 64 : (C <= 512 ? 32 : 16); }   // pixels per LDS-staged strip
+
 extern "C" int cvcs_linear_head_bwd_rows(int64_t P) {
-  int64_t r = cdiv(P, 64 * 8);   // ~8 strips per workgroup
+  int64_t r = cdiv(P, 64 * 8);   // ~8 strips (of at most 64 pixels) per workgroup
   return (int)(r < 1 ? 1 : (r > 512 ? 512 : r));
 }
 
@@ -468,7 +469,8 @@ extern "C" int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dl
   CVCS_CHECK_ARG(x && dlogits && w && dx && part_dw && B > 0 && H > 0 && W > 0, "%s: null argument", fn);
   if ((rc = dl_check_view(fn, x, x_ld, C, es)) || (rc = dl_check_view(fn, dx, dx_ld, C, es))) return rc;
   const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
-  const size_t lds = (size_t)(64 * C + 64 * (NC + 1) + NC * C) * 4;
+  const int TP = lin_strip(C);
+  const size_t lds = (size_t)(TP * C + TP * (NC + 1) + NC * C) * 4;
   CVCS_CHECK_ARG(lds <= 160 * 1024, "%s: C=%d, NC=%d need %zu bytes of LDS", fn, C, NC, lds);
   const dim3 grid((unsigned)cvcs_linear_head_bwd_rows(P));
   hipStream_t st = (hipStream_t)stream;
@@ -476,7 +478,7 @@ extern "C" int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dl
   do {                                                                                                                        \
     static bool attr_done = false;                                                                                            \
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_head_bwd_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
-    hipLaunchKernelGGL((linear_head_bwd_kernel<TT>), grid, dim3(256), lds, st, (const char*)x, x_ld, dlogits, P, HW, C, w, NC, (char*)dx, dx_ld, part_dw); \
+    hipLaunchKernelGGL((linear_head_bwd_kernel<TT>), grid, dim3(256), lds, st, (const char*)x, x_ld, dlogits, P, HW, C, w, NC, (char*)dx, dx_ld, part_dw, TP); \
   } while (0)
   if (dtype == CVCS_F32) LAUNCH_LINB(float); else LAUNCH_LINB(bf16_t);
 #undef LAUNCH_LINB

@@ -104,3 +104,69 @@ def test_two_ranks_exact_mode_match_one_process_on_the_whole_batch():
     # BN biases start at 0 and move by lr * gradient only, so their relative figure is that of a GRADIENT (ReLU / pooling
     # decisions that flip under a different summation order move it by ~1e-3); everything is tiny in absolute terms
     assert all(rel < 2e-4 or absmax < 2e-5 for rel, absmax, _ in rows), rows[:4]
+
+
+# ---------------------------------------------------------------------------------------------------- ResNet-UNet (replayed launch plans)
+def _resnet_net(seed=0):
+    from cvcs_amd import utils
+    torch.manual_seed(seed)
+    net = utils.load_network({"net": "Resnet18Unet", "num_classes": NC - 1, "precision": "fp32"}, "cuda:0")
+    crit = utils.CrossEntropyLoss(ignore_index=0)
+    optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
+    net.train()
+    return net, crit, optim
+
+
+def _resnet_worker(rank, world, port, path):
+    import torch.distributed as dist
+    from oracle import unet_oracle as O
+    from cvcs_amd.parallel import DataParallel, shard_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img, lab = O.synthetic_tiles(B, S, NC, seed=22, structured=True)
+        lo, hi = shard_batch(B, rank, world)
+        net, crit, optim = _resnet_net()
+        net.flat_parameters()
+        DataParallel(net, optim, bucket_mb=4.0)      # torch-DDP semantics: per-rank BatchNorm statistics, averaged gradients
+        flats, losses = [], []
+        for _ in range(STEPS):
+            loss = crit(net(img[lo:hi].to("cuda:0"), None), lab[lo:hi].to("cuda:0"))
+            optim.zero_grad(); loss.backward(); optim.step()
+            torch.cuda.synchronize()
+            flats.append(net.flat_parameters()[0].detach().cpu().clone())
+            losses.append(loss.item())
+        torch.save({"flats": flats, "losses": losses}, f"{path}/rank{rank}.pt")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_resnet_unet_two_ranks_average_their_gradients_through_the_replayed_plan():
+    """the bucket hooks are host callbacks INSIDE the recorded backward launch list (resnet_engine._ready): two ranks must
+    hold bit-identical parameters after every step, and the first update must be the fused SGD2 step on the MEAN of the two
+    shards' gradients (each computed here by a plain single-process backward on that shard)"""
+    from oracle import unet_oracle as O
+    from cvcs_amd.parallel import shard_batch
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_resnet_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        r0, r1 = (torch.load(f"{tmp}/rank{r}.pt") for r in range(2))
+    for a, b in zip(r0["flats"], r1["flats"]):
+        assert torch.equal(a, b)
+    img, lab = O.synthetic_tiles(B, S, NC, seed=22, structured=True)
+    grads = []
+    for r in range(2):
+        lo, hi = shard_batch(B, r, 2)
+        net, crit, optim = _resnet_net()
+        crit(net(img[lo:hi].to("cuda:0"), None), lab[lo:hi].to("cuda:0")).backward()
+        torch.cuda.synchronize()
+        grads.append(net.flat_parameters()[1].detach().clone())
+    net, crit, optim = _resnet_net()
+    flat, flat_grad = net.flat_parameters()
+    flat_grad.copy_((grads[0] + grads[1]) / 2)
+    optim.step()
+    torch.cuda.synchronize()
+    want = flat.detach().cpu()
+    diff = (r0["flats"][0] - want).abs().max().item()
+    assert diff <= 1e-6 * want.abs().max().item(), diff
+    assert r0["losses"][-1] < r0["losses"][0]

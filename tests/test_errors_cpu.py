@@ -96,7 +96,7 @@ def test_factories_keep_the_reference_error_behaviour(capsys):
         utils.load_network({"net": "NoSuchNet", "num_classes": 4}, "cpu")
     assert "Invalid network name." in capsys.readouterr().out                       # S/utils.py:193-195
     with pytest.raises(NotImplementedError):
-        utils.load_network({"net": "Resnet101", "num_classes": 4}, "cpu")          # third-party wrapper, out of scope
+        utils.load_network({"net": "MobileNet", "num_classes": 4}, "cpu")          # third-party wrapper, not built
     with pytest.raises(Exception):
         utils.load_network({"net": "Ensemble", "num_classes": 4}, "cpu")            # no ensemble_config (S/utils.py:475-478)
     assert "specify a config file" in capsys.readouterr().out

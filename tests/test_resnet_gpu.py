@@ -320,10 +320,12 @@ def test_fp32_train_steps_match_oracle(arch, B, S, NC):
     img, lab = O.synthetic_tiles(B, S, NC, seed=5, structured=True)
     net.train()
     for step in range(3):
-        # the float64 yardstick is evaluated at the HIP network's OWN current parameters (after step 1 they differ from the
-        # oracle trainer's by one update with gradients that differ by the counted ReLU decisions)
+        # every step is checked at the HIP network's OWN current parameters (the two trajectories part ways after the first
+        # update: gradients that differ by a handful of ReLU decisions, then train-mode BatchNorm over few values amplifies)
         p_before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
-        want_loss, want_logits, want_grads = tr.step(img, lab)
+        with torch.no_grad():
+            want_logits = R.forward({k: v.clone() for k, v in p_before.items()}, img.float(), arch, train=True)
+            want_loss = O.cross_entropy(want_logits, lab.long(), None, 0).item()
         logits = net(img.to(DEV), None)
         loss = crit(logits, lab.to(DEV))
         optim.zero_grad()
@@ -339,20 +341,23 @@ def test_fp32_train_steps_match_oracle(arch, B, S, NC):
         nflip, nrelu = sum(n for n, _ in flips), sum(m.numel() for m in masks)
         assert all(mx <= 1e-5 for _, mx in flips), [f for f in flips if f[0]]
         e_hip = sorted((rel_l2(grads[k].double(), g64[k]), k) for k in g64)
-        e_cpu = sorted((rel_l2(want_grads[k].double(), g64[k]), k) for k in g64)
         print(f"step {step}: {nflip} of {nrelu} ReLU decisions differ from the float64 oracle's own (largest |x|/max|x| "
-              f"{max(mx for _, mx in flips):.1e}); gradient rel-L2 vs float64 at the HIP decisions: HIP f32 worst {e_hip[-1]}, median "
-              f"{e_hip[len(e_hip) // 2][0]:.2e}  [torch-CPU f32 with ITS OWN decisions: worst {e_cpu[-1][0]:.2e}]")
+              f"{max(mx for _, mx in flips):.1e}); gradient rel-L2 vs float64 at the HIP decisions: worst {e_hip[-1]}, median "
+              f"{e_hip[len(e_hip) // 2][0]:.2e}")
         assert e_hip[-1][0] <= 2e-4, e_hip[-1]
-    sd = net.state_dict()
-    worstp = max((rel_l2(sd[k].cpu(), tr.p[k].detach()), k) for k in tr.p)
-    assert worstp[0] <= 1e-4, worstp
+        if step == 0:
+            # the first update against the oracle trainer (identical parameters going in): SGD2 step + BatchNorm running stats
+            tr.step(img, lab)
+            sd = net.state_dict()
+            worstp = max((rel_l2(sd[k].cpu(), tr.p[k].detach()), k) for k in tr.p)
+            assert worstp[0] <= 1e-4, worstp
     # eval mode (running statistics, BatchNorm folded into the conv epilogues) + fused head/argmax
     net.eval()
+    final = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
     with torch.no_grad():
         ev = net(img.to(DEV), None).cpu()
-        want = R.forward({k: v.detach() for k, v in tr.p.items()}, img.float(), arch, train=False)
-        want64 = R.forward({k: v.detach().double() for k, v in tr.p.items()}, img.double(), arch, train=False)
+        want = R.forward({k: v.clone() for k, v in final.items()}, img.float(), arch, train=False)
+        want64 = R.forward({k: v.double() for k, v in final.items()}, img.double(), arch, train=False)
         labels = net.predict_labels(img.to(DEV)).cpu()
     close(ev, want, 1e-3, "eval logits")
     assert torch.equal(labels.long(), ev.argmax(1))
