@@ -193,6 +193,18 @@ class UNetEngine:
         so, uo = (0, w) if SKIP_FIRST[d] else (w, 0)
         return View(self.cat[L], so, w), View(self.cat[L], uo, w), View(self.g_cat[L], so, w), View(self.g_cat[L], uo, w)
 
+    @property
+    def relu_order(self):
+        """views of every ReLU output of the last train-mode forward, in execution order (parity tests read the path's own
+        ReLU decisions from them): encoder a = relu(bn(conv)) twice per level, decoder r = relu(conv) twice per stage"""
+        out = []
+        for L in range(1, 6):
+            out.append(ops.view(self.aa[L]))
+            out.append(self._skip_up(5 - L)[0] if L < 5 else ops.view(self.x5))
+        for d in range(1, 5):
+            out += [ops.view(self.ra[d]), ops.view(self.rb[d])]
+        return out
+
     def enable_sync_bn(self, sync):
         """sync: object with .world and .all_reduce(tensor) (sum over ranks, in place, ordered on the current stream)"""
         self.sync_bn = sync

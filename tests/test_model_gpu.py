@@ -101,41 +101,111 @@ def test_fp32_path_replays_reference_golden(golden_dir, tag, variant, opt, ignor
         assert (lab_hip[decided] == g["labels_eval"][decided]).all()
 
 
-@pytest.mark.parametrize("variant", ["Unetv2", "Unet"])
-def test_fp32_gradients_vs_f64_oracle(variant):
-    """every parameter gradient of one train step against the oracle evaluated in float64 (5e-4 of max|grad|)."""
-    NC, B, S = 5, 2, 64
-    img, lab = O.synthetic_tiles(B, S, NC, seed=11)
-    p = {k: v.double() for k, v in O.init_params(variant, NC, seed=3).items()}
+def _f64_gradients_at(variant, p32, img, lab, relu_masks, weight=None, ignore=0, pool_indices=None):
+    """gradients of the oracle in float64 at the given f32 parameters, every ReLU evaluated with the GIVEN decision (x * mask)
+    instead of its own and every 2x2 max-pool routed through the GIVEN window element; returns (gradients, [(decisions that
+    differ from the oracle's own, largest |x| (ReLU) / largest gap to the true maximum (pool) among them, relative to
+    max|x|)])"""
+    import torch.nn.functional as F
+    p = {k: v.detach().double().clone() for k, v in p32.items()}
     names = [k for k in p if not O.is_buffer(k)]
     for k in names:
         p[k].requires_grad_(True)
-    logits = O.unet_forward(p, img.double(), variant, train=True)
-    ref_loss = O.cross_entropy(logits, lab.long(), None, 0)
-    ref = dict(zip(names, torch.autograd.grad(ref_loss, [p[k] for k in names])))
+    flips, it, orig = [], iter(relu_masks), F.relu
+    orig_pool, pit = F.max_pool2d, iter(pool_indices or [])
+
+    def forced_pool(x, kernel_size=2, stride=2, **kw):
+        idx = next(pit)                                    # flat h*w index of the chosen element per output, as torch returns it
+        own, own_idx = orig_pool(x, 2, 2, return_indices=True)
+        out = x.flatten(2).gather(2, idx.flatten(2)).view_as(own)
+        bad = idx != own_idx
+        n = int(bad.sum())
+        flips.append((n, ((own - out).detach()[bad].max() / x.detach().abs().max()).item() if n else 0.0))
+        return out
+    if pool_indices is not None:
+        F.max_pool2d = forced_pool
+
+    def forced(x, *a, **k):
+        m = next(it)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        bad = m != (x > 0)
+        n = int(bad.sum())
+        flips.append((n, (x.detach().abs()[bad].max() / x.detach().abs().max()).item() if n else 0.0))
+        return x * m
+    F.relu = forced
+    try:
+        loss = O.cross_entropy(O.unet_forward(p, img.double(), variant, train=True), lab.long(),
+                               None if weight is None else weight.double(), ignore)
+    finally:
+        F.relu, F.max_pool2d = orig, orig_pool
+    return dict(zip(names, torch.autograd.grad(loss, [p[k] for k in names]))), flips
+
+
+def _assert_argmax_near_ties(got, want64, rel):
+    """every argmax mismatch against the float64 oracle must be a near-tie THERE (top-2 margin below rel * max|logit|)"""
+    a, b = got.argmax(1), want64.argmax(1)
+    bad = a != b
+    n = int(bad.sum())
+    if n:
+        top2 = want64.topk(2, dim=1).values
+        assert (top2[:, 0] - top2[:, 1])[bad].max().item() <= rel * want64.abs().max().item()
+    return n, a.numel()
+
+
+@pytest.mark.parametrize("variant,B,S,NC", [("Unetv2", 4, 128, 5), ("Unet", 2, 128, 16), ("Unetv2", 2, 64, 5)])
+def test_fp32_train_steps_float64_yardstick(variant, B, S, NC):
+    """The reference's U-Nets, three SGD2 steps in its order (S/train.py:121-126), every step checked at the HIP network's
+    own current parameters: train-mode logits within 1e-3 of max|logit| and loss within 1e-5 of the f32 oracle (the oracle
+    is pinned by the reference's own outputs, tests/test_oracle_golden.py); EVERY gradient tensor within 2e-4 relative L2 of
+    the oracle in float64 evaluated with the HIP path's own ReLU and max-pool decisions (read back from its stored
+    activations) - the decisions that differ from the float64 oracle's own are counted and each must sit on a pre-activation
+    (ReLU) / a gap between the two window candidates (pool) below 1e-5 of its tensor's max, i.e. be a float64 near-tie that ANY
+    two f32 implementations may decide differently, not an error.
+    (This replaces the 1e-1-of-max bound the round-1 test needed on a 2 x 64 x 64 fixture.)"""
     net = _build(variant, NC, "fp32")
+    w = torch.tensor([0.0] + [0.5 + 0.1 * i for i in range(NC - 1)]) if variant == "Unet" else None
+    crit = utils.CrossEntropyLoss(weight=None if w is None else w.to(DEV), ignore_index=0)
+    optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
+    tr = O.OracleTrainer(variant, NC, opt="SGD2", ignore_index=0, seed=3, weight=w)
+    img, lab = O.synthetic_tiles(B, S, NC, seed=11, structured=True)
     net.train()
-    pred = net(img.to(DEV).float(), None)
-    loss = utils.CrossEntropyLoss(ignore_index=0)(pred, lab.to(DEV))
-    loss.backward()
-    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
-    assert (pred.detach().cpu().double() - logits.detach()).abs().max() < 1e-4 * logits.abs().max()
-    worst = (0.0, "")
-    for k, q in net.named_parameters():
-        sc = ref[k].abs().max().item()
-        if sc < 1e-12:   # conv bias in front of a train-mode BN: exactly zero in exact arithmetic
-            assert q.grad.abs().max().item() < 1e-5
-            continue
-        err = (q.grad.cpu().double() - ref[k]).abs().max().item() / sc
-        # Typical error is 1-2e-5 (scripts/grad_noise_probe.py).  A ReLU / max-pool decision that sits on a rounding
-        # boundary flips one pixel's mask; with only 8192 pixels in this fixture (128 at the deepest level) one flip moves
-        # a weight gradient by ~1/sqrt(pixels) = 1e-2 .. 9e-2 and every layer upstream of it by a fraction of that
-        # (torch-CPU fp32 shows the same events); gradients that are sums with heavy cancellation (biases in front of
-        # ReLU + BN) amplify it.  The last layers cannot be downstream of a flip and are held to the tight bound.
-        tight = k.startswith(("decode_forward4.1", "decode_forward4.0.layer.5"))
-        worst = max(worst, (err, k)) if not tight else worst
-        assert err < (5e-4 if tight else 1e-1), f"{k}: rel err {err:.2e}"
-    print("largest loose-set error:", worst)
+    for step in range(3):
+        p_before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+        with torch.no_grad():
+            want = O.unet_forward({k: v.clone() for k, v in p_before.items()}, img.float(), variant, train=True)
+            want_loss = O.cross_entropy(want, lab.long(), w, 0).item()
+        logits = net(img.to(DEV), None)
+        loss = crit(logits, lab.to(DEV))
+        optim.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        acts = [v.torch().float().cpu().permute(0, 3, 1, 2).contiguous() for v in net._engine.relu_order]
+        masks = [a > 0 for a in acts]
+        # the path's own max-pool decisions: it recomputes relu(scale * y + shift) - the values it stored - and takes the FIRST
+        # maximum of each 2x2 window, which is what torch returns for the stored values (levels 1-4: acts[1], [3], [5], [7])
+        pools = [torch.nn.functional.max_pool2d(acts[2 * L + 1], 2, 2, return_indices=True)[1] for L in range(4)]
+        got = logits.detach().cpu().clone()
+        grads = {k: q.grad.detach().cpu().clone() for k, q in net.named_parameters()}
+        optim.step()
+        assert (got - want).abs().max().item() <= 1e-3 * want.abs().max().item()
+        assert abs(loss.item() - want_loss) <= 1e-5 * max(1.0, abs(want_loss)), (step, loss.item(), want_loss)
+        g64, flips = _f64_gradients_at(variant, p_before, img, lab, masks, w, pool_indices=pools)
+        assert all(mx <= 1e-5 for _, mx in flips), [f for f in flips if f[0]]
+        worst = (0.0, "")
+        for k, gq in g64.items():
+            if gq.norm().item() < 1e-9 * max(1.0, grads[k].numel() ** 0.5):   # conv bias in front of a train-mode BN: exactly zero
+                assert grads[k].abs().max().item() < 1e-5, k
+                continue
+            worst = max(worst, (((grads[k].double() - gq).norm() / gq.norm()).item(), k))
+        print(f"{variant} step {step}: {sum(n for n, _ in flips)} of {sum(m.numel() for m in masks)} ReLU / max-pool decisions differ "
+              f"from the float64 oracle's own; worst gradient rel-L2 at the HIP decisions {worst}")
+        assert worst[0] <= 2e-4, worst
+        if step == 0:   # the first update against the oracle trainer (identical parameters going in)
+            tr.step(img, lab)
+            sd = net.state_dict()
+            for k, v in tr.p.items():
+                d = (sd[k].cpu() - v.detach()).norm().item()
+                assert d <= 1e-4 * v.detach().norm().item() + 1e-7, (k, d)
 
 
 @pytest.mark.parametrize("variant", ["Unetv2", "Unet"])
@@ -153,11 +223,13 @@ def test_fp32_forward_argmax_vs_oracle_256(variant):
     scale = ref.abs().max().item()
     err = (out.cpu() - ref).abs().max().item() / scale
     assert err < 1e-3, f"logits rel err {err:.2e}"
-    top2 = torch.topk(ref, 2, dim=1).values
-    decided = (top2[:, 0] - top2[:, 1]) > 4 * err * scale
-    hip_lab, ref_lab = torch.argmax(out.cpu(), 1), torch.argmax(ref, 1)
-    assert torch.equal(hip_lab[decided], ref_lab[decided])
-    assert (hip_lab == ref_lab).float().mean() > 0.9995
+    # argmax labels: the mismatches against the FLOAT64 oracle are counted, and each must be a float64 near-tie (top-2
+    # margin inside the logit tolerance) - a pixel that float32 itself cannot decide
+    with torch.no_grad():
+        ref64 = O.unet_forward({k: v.double() for k, v in p.items()}, img.double(), variant, train=False)
+    n, tot = _assert_argmax_near_ties(out.cpu().double(), ref64, 1e-3)
+    print(f"{variant} 4x256x256 eval: {n} of {tot} argmax labels differ from the float64 oracle (all float64 near-ties; logit err {err:.1e})")
+    assert n <= 1e-4 * tot
 
 
 def test_bf16_path_tracks_oracle_training():
@@ -252,7 +324,7 @@ def test_heldout_miou_after_training_matches_cpu_reference(precision):
     spec.loader.exec_module(mod)
     m_o, m_h = mod.run(precision, steps=40, S=64, verbose=False)
     assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
-    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.5, (m_o["mIoU"], m_h["mIoU"])
+    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.1   # the north star's bound, (m_o["mIoU"], m_h["mIoU"])
 
 
 @pytest.mark.parametrize("variant,B,S", [("Unetv2", 4, 128), ("Unet", 2, 128), ("Unetv2", 2, 256)])
