@@ -88,6 +88,13 @@ SIGNATURES = {
     "cvcs_image_broadcast": (_i, [_vp, _i64, _i, _i, _i, _f, _vp, _i64, _i, _vp]),
     "cvcs_linear_head_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "cvcs_linear_head_bwd_rows": (_i, [_i64]),
+    "cvcs_gn_rows": (_i, [_i]),
+    "cvcs_gn_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
+    "cvcs_gn_finalize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_gn_act_fwd": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _i, _vp]),
+    "cvcs_gn_act_bwd_reduce": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "cvcs_gn_bwd_finalize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_gn_act_bwd_apply": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "cvcs_linear_head_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _vp]),
     "cvcs_bn_finalize_workspace_floats": (_i, [_i, _i]),
     "cvcs_bn_finalize": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -133,7 +140,7 @@ _lib = None
 _recording = None          # the Recording that is capturing launches right now (None: plain eager calls)
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
-            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows"}
+            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows"}
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 
 
@@ -223,7 +230,7 @@ def _load():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 5:
+        if h.cvcs_abi_version() != 6:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")

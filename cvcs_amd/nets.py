@@ -236,7 +236,7 @@ class Urnetv2(_HipUNet):
 
 
 # ---------------------------------------------------------------------------------------------------- ResNet-encoder U-Nets
-def resnet_unet_param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS):
+def resnet_unet_param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS, decoder_norm="bn_relu"):
     """(name, shape, kind) in forward order.  Encoder names are torchvision's ResNet names under `encoder.` (ImageNet /
     torchvision checkpoints map one to one); decoder / head names follow the common `decoder.blocks.N.convK.{0,1}` /
     `segmentation_head.0` scheme.  No conv of the encoder or decoder has a bias (each is followed by a BatchNorm)."""
@@ -271,10 +271,16 @@ def resnet_unet_param_spec(arch: str, num_classes: int, decoder_channels=DECODER
                 conv(p + ".downsample.0", cin, w, 1); bn(p + ".downsample.1", w)
             cin = w
     skips = [widths[2], widths[1], widths[0], 64, 0]
+    def dnorm(p, c):   # decoder_norm="gn_silu": GroupNorm(32) affine only - no running statistics
+        if decoder_norm == "gn_silu":
+            spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b")])
+        else:
+            bn(p, c)
+
     for i, (dc, sk) in enumerate(zip(decoder_channels, skips)):
         p = f"decoder.blocks.{i}"
-        conv(p + ".conv1.0", cin + sk, dc, 3); bn(p + ".conv1.1", dc)
-        conv(p + ".conv2.0", dc, dc, 3); bn(p + ".conv2.1", dc)
+        conv(p + ".conv1.0", cin + sk, dc, 3); dnorm(p + ".conv1.1", dc)
+        conv(p + ".conv2.0", dc, dc, 3); dnorm(p + ".conv2.1", dc)
         cin = dc
     conv("segmentation_head.0", cin, num_classes, 1, bias=True)
     return spec
@@ -288,11 +294,18 @@ class ResnetUnet(_HipUNet):
     arch = "resnet50"
     variant = "ResnetUnet"
 
+    def __init__(self, num_classes: int, precision: str = "bf16", decoder_norm: str = "bn_relu"):
+        """decoder_norm: "bn_relu" (default: conv -> BatchNorm -> ReLU) | "gn_silu" (conv -> GroupNorm(32) -> SiLU, normalisation and
+        activation fused in one pass; config key `decoder_norm`)"""
+        assert decoder_norm in ("bn_relu", "gn_silu")
+        self.decoder_norm = decoder_norm
+        super().__init__(num_classes, precision)
+
     def _build_spec(self):
-        return resnet_unet_param_spec(self.arch, self.num_classes)
+        return resnet_unet_param_spec(self.arch, self.num_classes, decoder_norm=self.decoder_norm)
 
     def _build_engine(self, dev):
-        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev)
+        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, decoder_norm=self.decoder_norm)
 
 
 class Resnet18Unet(ResnetUnet):

@@ -393,6 +393,42 @@ def unpack_stem_wgrad(tmp: torch.Tensor, dw: torch.Tensor):
     check(_lib.lib().cvcs_unpack_stem_wgrad(tmp.data_ptr(), dw.shape[0], dw.data_ptr(), _stream()), "cvcs_unpack_stem_wgrad")
 
 
+# ------------------------------------------------------------------------------------------------ GroupNorm + SiLU
+def gn_rows(HW: int) -> int:
+    return _lib.lib().cvcs_gn_rows(HW)
+
+
+def gn_stats(y: View, part):
+    check(_lib.lib().cvcs_gn_stats(y.ptr, y.ld, y.B, y.H * y.W, y.C, part.data_ptr(), y.code, _stream()), "cvcs_gn_stats")
+
+
+def gn_finalize(part, B, HW, C_, G, gamma, beta, scale, shift, mean, invstd, eps=1e-5):
+    check(_lib.lib().cvcs_gn_finalize(part.data_ptr(), B, HW, C_, G, gamma.data_ptr(), beta.data_ptr(), eps, scale.data_ptr(),
+                                      shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _stream()), "cvcs_gn_finalize")
+
+
+def gn_act_fwd(y: View, scale, shift, silu: bool, out: View):
+    check(_lib.lib().cvcs_gn_act_fwd(y.ptr, y.ld, y.B, y.H * y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(silu), out.ptr, out.ld,
+                                     y.code, _stream()), "cvcs_gn_act_fwd")
+
+
+def gn_act_bwd_reduce(y: View, g: View, scale, shift, silu: bool, part):
+    check(_lib.lib().cvcs_gn_act_bwd_reduce(y.ptr, y.ld, g.ptr, g.ld, y.B, y.H * y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(silu),
+                                            part.data_ptr(), y.code, _stream()), "cvcs_gn_act_bwd_reduce")
+
+
+def gn_bwd_finalize(part, B, HW, C_, G, gamma, mean, invstd, tmp, dgamma, dbeta, ca, cb, cc):
+    check(_lib.lib().cvcs_gn_bwd_finalize(part.data_ptr(), B, HW, C_, G, gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                          tmp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ca.data_ptr(), cb.data_ptr(),
+                                          cc.data_ptr(), _stream()), "cvcs_gn_bwd_finalize")
+
+
+def gn_act_bwd_apply(y: View, g: View, scale, shift, silu: bool, ca, cb, cc, dy: View):
+    check(_lib.lib().cvcs_gn_act_bwd_apply(y.ptr, y.ld, g.ptr, g.ld, y.B, y.H * y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(silu),
+                                           ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dy.ptr, dy.ld, y.code, _stream()),
+          "cvcs_gn_act_bwd_apply")
+
+
 # ------------------------------------------------------------------------------------------------ DeepLabV3+
 def resize_bilinear_fwd(x: View, out: View, scale: int):
     assert (out.B, out.H, out.W, out.C) == (x.B, x.H * scale, x.W * scale, x.C)

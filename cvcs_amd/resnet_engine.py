@@ -55,6 +55,7 @@ def stage_plan(arch, output_stride=32):
             plan.append((s, b, first_stride if b == 0 else 1, first_dil if b == 0 else dil))
     return plan
 DECODER_CHANNELS = (256, 128, 64, 64, 64)
+GN_GROUPS = 32
 
 
 class Act:
@@ -74,8 +75,10 @@ class Unit:
 
 
 class ResNetUNetEngine:
-    def __init__(self, arch: str, num_classes: int, dtype: torch.dtype, device, decoder_channels=DECODER_CHANNELS):
-        assert arch in ARCHS
+    def __init__(self, arch: str, num_classes: int, dtype: torch.dtype, device, decoder_channels=DECODER_CHANNELS,
+                 decoder_norm="bn_relu"):
+        assert arch in ARCHS and decoder_norm in ("bn_relu", "gn_silu")
+        self.decoder_norm = decoder_norm
         self.arch, self.NC, self.dtype, self.dev = arch, num_classes, dtype, torch.device(device)
         self.kind, self.depths, self.widths = ARCHS[arch]
         self.dec = tuple(decoder_channels)
@@ -119,6 +122,7 @@ class ResNetUNetEngine:
         self.one = torch.ones(cmax, dtype=torch.float32, device=dev)
         self.zero = torch.zeros(cmax, dtype=torch.float32, device=dev)
         self._rec, self._bufs, self.shape = {}, {}, None
+        self.gn = {}                     # GroupNorm state per layer (allocated per batch size at plan time)
 
     def enable_sync_bn(self, sync):
         raise NotImplementedError("exact (SyncBN) data-parallel mode is built for the reference's U-Nets only so far; "
@@ -160,6 +164,8 @@ class ResNetUNetEngine:
             kh = kw = k
         st = self.bn[bn]
         M = B * Ho * Wo
+        if (bn + ".running_mean") not in self.Bf:
+            return self._unit_gn(x, conv, bn, wf, k, stride, pad, dil, Ho, Wo, cout, act_out)
         if not train:
             ops.bn_finalize(None, 0, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
                             self.Bf[bn + ".running_var"], False, st.scale, st.shift, None, None)
@@ -181,6 +187,26 @@ class ResNetUNetEngine:
         self.units[conv] = (u, act_out)     # persistent views of this shape's plan (layer-wise parity tests read them)
         if act_out is not None and relu:
             self.relu_order.append(act_out)
+        return u
+
+    def _unit_gn(self, x, conv, gn, wf, k, stride, pad, dil, Ho, Wo, cout, act_out: View):
+        """conv -> GroupNorm(32) -> SiLU (train and eval alike: a GroupNorm has no running statistics): one streaming pass for
+        the per-(image, channel) sums, a tiny finalize, ONE pass that normalises, scales and applies the SiLU"""
+        B, HW = x.B, Ho * Wo
+        y = ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
+        ops.conv2d(x, wf, None, y, k, k, stride, pad, dil)
+        st = self.gn.setdefault(gn, {n: torch.empty(B * cout, dtype=torch.float32, device=self.dev) for n in ("scale", "shift", "ca", "cb", "cc")})
+        if "mean" not in st:
+            st["mean"], st["invstd"] = (torch.empty(B * GN_GROUPS, dtype=torch.float32, device=self.dev) for _ in range(2))
+            st["tmp"] = torch.empty(B * 2 * cout, dtype=torch.float32, device=self.dev)
+        part = self._scratch("gn_part", B * ops.gn_rows(HW) * 2 * cout)
+        ops.gn_stats(y, part)
+        ops.gn_finalize(part, B, HW, cout, GN_GROUPS, self.P[gn + ".weight"], self.P[gn + ".bias"], st["scale"], st["shift"], st["mean"],
+                        st["invstd"])
+        ops.gn_act_fwd(y, st["scale"], st["shift"], True, act_out)
+        u = Unit(x, y, conv, gn, k, stride, pad, False, dil)
+        u.gn = True
+        self.units[conv] = (u, act_out)
         return u
 
     def _tail(self, u3: Unit, ud: Unit | None, h: Act, out: View, train):
@@ -255,16 +281,27 @@ class ResNetUNetEngine:
         reduce pass of consumer's BatchNorm backward?  (cvcs_conv_desc.bwd_y: bf16 3x3 / stride 1 launches on the three-
         workgroup narrow tiles, i.e. up to 128 channels - on the wide kernel the longer epilogue is exposed)"""
         y = consumer.y
-        return (self.fuse_bn_bwd and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
+        return (self.fuse_bn_bwd and not getattr(consumer, "gn", False) and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
                 producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128)
 
     def _unit_bwd(self, u: Unit, g: View, mode, fused=None) -> View:
         """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
         output) in a scratch buffer that lives until the next _unit_bwd.  fused = (part_dz, part_dzx, rows): the reduce pass
         was taken by the launch that produced g (one partial row per 16x16 tile)"""
-        st = self.bn[u.bn]
         y = u.y
         M, C_ = y.B * y.H * y.W, y.C
+        if getattr(u, "gn", False):
+            st, HW = self.gn[u.bn], y.H * y.W
+            part = self._scratch("gn_part", y.B * ops.gn_rows(HW) * 2 * C_)
+            ops.gn_act_bwd_reduce(y, g, st["scale"], st["shift"], True, part)
+            ops.gn_bwd_finalize(part, y.B, HW, C_, GN_GROUPS, self.P[u.bn + ".weight"], st["mean"], st["invstd"], st["tmp"],
+                                self.G[u.bn + ".weight"], self.G[u.bn + ".bias"], st["ca"], st["cb"], st["cc"])
+            dy = ops.view(self._scratch(u.conv + ".dy" if self.keep_all else "dy", M * C_, self.dtype).view(y.B, y.H, y.W, C_))
+            ops.gn_act_bwd_apply(y, g, st["scale"], st["shift"], True, st["ca"], st["cb"], st["cc"], dy)
+            need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
+            ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch("wg_ws", need), dil=u.dil)
+            return dy
+        st = self.bn[u.bn]
         rows = ops.bn_bwd_rows(M)
         p0, p1, p2 = (self._scratch(f"bnb{i}", rows * C_) for i in range(3))
         if fused is not None:
@@ -425,7 +462,7 @@ class ResNetUNetEngine:
         if self.shape != (B, S):
             assert S % 32 == 0, "tile side must be a multiple of 32 (the encoder reduces the resolution 32 times)"
             self.shape = (B, S)
-            self._rec, self._bufs = {}, {}
+            self._rec, self._bufs, self.gn = {}, {}, {}
             self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
 
     def _run(self, key, fn):

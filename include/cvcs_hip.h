@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 5
+#define CVCS_ABI_VERSION 6
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -347,6 +347,29 @@ int cvcs_linear_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C
 int cvcs_linear_head_bwd_rows(int64_t P);
 int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dlogits, int B, int H, int W, int C, const float* w, int NC,
                          void* dx, int64_t dx_ld, float* part_dw, int dtype, void* stream);
+
+/* ---- fused GroupNorm + SiLU (north star "fused BN/GN+SiLU"; the `decoder_norm: gn_silu` option of the ResNet-UNets; the
+ * reference itself only has BatchNorm + ReLU, S/blocks.py:8-49) ----------------------------------------------------------
+ * nn.GroupNorm(G, C) statistics are per (image, group).  Forward: cvcs_gn_stats (per-(image, channel) partial sums of y and
+ * y^2: part[B][cvcs_gn_rows(HW)][2][C]) -> cvcs_gn_finalize (merges the channels of a group in f64; per-(image, channel)
+ * scale / shift [B][C], mean / invstd [B][G]) -> cvcs_gn_act_fwd: out = act(scale*y + shift), act = SiLU (silu = 1) or identity
+ * - normalisation, affine and activation in ONE pass.  Backward: cvcs_gn_act_bwd_reduce (partial sums of dz and dz*y,
+ * dz = g * act'(z) recomputed) -> cvcs_gn_bwd_finalize (dgamma, dbeta; tmp [B][2][C]; coefficients ca, cb, cc [B][C]) ->
+ * cvcs_gn_act_bwd_apply: dy = ca*dz + cb + cc*y.                                                                        */
+int cvcs_gn_rows(int HW);
+int cvcs_gn_stats(const void* y, int64_t y_ld, int B, int HW, int C, float* part, int dtype, void* stream);
+int cvcs_gn_finalize(const float* part, int B, int HW, int C, int G, const float* gamma, const float* beta, float eps,
+                     float* scale, float* shift, float* mean, float* invstd, void* stream);
+int cvcs_gn_act_fwd(const void* y, int64_t y_ld, int B, int HW, int C, const float* scale, const float* shift, int silu,
+                    void* out, int64_t out_ld, int dtype, void* stream);
+int cvcs_gn_act_bwd_reduce(const void* y, int64_t y_ld, const void* g, int64_t g_ld, int B, int HW, int C, const float* scale,
+                           const float* shift, int silu, float* part, int dtype, void* stream);
+int cvcs_gn_bwd_finalize(const float* part, int B, int HW, int C, int G, const float* gamma, const float* mean,
+                         const float* invstd, float* tmp, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
+                         void* stream);
+int cvcs_gn_act_bwd_apply(const void* y, int64_t y_ld, const void* g, int64_t g_ld, int B, int HW, int C, const float* scale,
+                          const float* shift, int silu, const float* ca, const float* cb, const float* cc, void* dy,
+                          int64_t dy_ld, int dtype, void* stream);
 
 /* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
  * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).

@@ -49,9 +49,13 @@ DECODER_CHANNELS = (256, 128, 64, 64, 64)
 
 
 # --------------------------------------------------------------------------- parameter table
-def param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS):
+GN_GROUPS = 32
+
+
+def param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS, decoder_norm="bn_relu"):
     """ordered (name, shape); encoder names are torchvision's ResNet names under `encoder.`, so ImageNet / torchvision
-    checkpoints map one to one."""
+    checkpoints map one to one.  decoder_norm="gn_silu": the decoder's conv -> BatchNorm -> ReLU pairs become
+    conv -> GroupNorm(32) -> SiLU (north star "fused BN/GN+SiLU"); a GroupNorm has no running statistics."""
     kind, depths, widths = ARCHS[arch]
     spec = []
 
@@ -62,6 +66,12 @@ def param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS):
 
     def bn(p, c):
         spec.extend([(p + ".weight", (c,)), (p + ".bias", (c,)), (p + ".running_mean", (c,)), (p + ".running_var", (c,))])
+
+    def dnorm(p, c):
+        if decoder_norm == "gn_silu":
+            spec.extend([(p + ".weight", (c,)), (p + ".bias", (c,))])
+        else:
+            bn(p, c)
 
     conv("encoder.conv1", 3, 64, 7)
     bn("encoder.bn1", 64)
@@ -84,8 +94,8 @@ def param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS):
     skips = [widths[2], widths[1], widths[0], 64, 0]
     for i, (dc, sk) in enumerate(zip(decoder_channels, skips)):
         p = f"decoder.blocks.{i}"
-        conv(p + ".conv1.0", cin + sk, dc, 3); bn(p + ".conv1.1", dc)
-        conv(p + ".conv2.0", dc, dc, 3); bn(p + ".conv2.1", dc)
+        conv(p + ".conv1.0", cin + sk, dc, 3); dnorm(p + ".conv1.1", dc)
+        conv(p + ".conv2.0", dc, dc, 3); dnorm(p + ".conv2.1", dc)
         cin = dc
     conv("segmentation_head.0", cin, num_classes, 1, bias=True)
     return spec
@@ -95,14 +105,14 @@ def is_buffer(name):
     return name.endswith("running_mean") or name.endswith("running_var")
 
 
-def init_params(arch, num_classes, seed=0, decoder_channels=DECODER_CHANNELS):
+def init_params(arch, num_classes, seed=0, decoder_channels=DECODER_CHANNELS, decoder_norm="bn_relu"):
     """deterministic synthetic weights, independent of torch's default init: conv ~ N(0, 2/fan_in); BN gamma in [0.5,1.5]
     (the last BN of every residual block in [0.2,0.6] so that 16 stacked blocks keep O(1) activations), beta small."""
     g = torch.Generator().manual_seed(seed)
     kind = ARCHS[arch][0]
     last_bn = ".bn3.weight" if kind == "bottleneck" else ".bn2.weight"
     out = OrderedDict()
-    for name, shape in param_spec(arch, num_classes, decoder_channels):
+    for name, shape in param_spec(arch, num_classes, decoder_channels, decoder_norm):
         if name.endswith("running_mean"):
             t = torch.zeros(shape)
         elif name.endswith("running_var"):
@@ -218,6 +228,12 @@ def encoder_features(p, x, arch, train=False, emulate_bf16=False, output_stride=
     return feats
 
 
+def _cgs(x, p, conv, gn, q):
+    """conv3x3 -> GroupNorm(32 groups, eps 1e-5) -> SiLU (the decoder_norm="gn_silu" option)"""
+    y = _conv(x, p, conv, 1, 1, q)
+    return _q(F.silu(F.group_norm(y, GN_GROUPS, p[gn + ".weight"], p[gn + ".bias"], eps=BN_EPS)), q)
+
+
 def forward(p, x, arch="resnet50", train=False, emulate_bf16=False, return_acts=False):
     """x f32 [B,3,S,S] raw 0..255 (S % 32 == 0) -> logits f32 [B,NC,S,S]"""
     q = emulate_bf16
@@ -231,8 +247,12 @@ def forward(p, x, arch="resnet50", train=False, emulate_bf16=False, return_acts=
         if skips[i] is not None:
             h = torch.cat([h, skips[i]], dim=1)
         pre = f"decoder.blocks.{i}"
-        h = _cbr(h, p, pre + ".conv1.0", pre + ".conv1.1", 1, 1, q, train)
-        h = _cbr(h, p, pre + ".conv2.0", pre + ".conv2.1", 1, 1, q, train)
+        if (pre + ".conv1.1.running_mean") in p:
+            h = _cbr(h, p, pre + ".conv1.0", pre + ".conv1.1", 1, 1, q, train)
+            h = _cbr(h, p, pre + ".conv2.0", pre + ".conv2.1", 1, 1, q, train)
+        else:   # GroupNorm + SiLU decoder
+            h = _cgs(h, p, pre + ".conv1.0", pre + ".conv1.1", q)
+            h = _cgs(h, p, pre + ".conv2.0", pre + ".conv2.1", q)
         acts[f"decoder{i}"] = h
         i += 1
     # the head reads the stored activation and keeps f32 weights / f32 logits in both precisions
@@ -278,9 +298,9 @@ class OracleTrainer:
     """forward -> loss -> zero_grad -> backward -> opt.step (S/train.py:121-126) on the ResNet-UNet definition above"""
 
     def __init__(self, arch, num_classes, opt="SGD2", epochs=20, ignore_index=-100, weight=None, seed=0, params=None,
-                 emulate_bf16=False):
+                 emulate_bf16=False, decoder_norm="bn_relu"):
         self.arch = arch
-        self.p = params if params is not None else init_params(arch, num_classes, seed)
+        self.p = params if params is not None else init_params(arch, num_classes, seed, decoder_norm=decoder_norm)
         self.trainable = [k for k in self.p if not is_buffer(k)]
         for k in self.trainable:
             self.p[k].requires_grad_(True)

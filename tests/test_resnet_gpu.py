@@ -255,11 +255,45 @@ def test_batchnorm_backward_without_relu(dtype):
     close(from_nhwc(dy), yr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "dy")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C_,H,W", [(64, 16, 16), (256, 5, 7), (128, 32, 32)])
+def test_groupnorm_silu_forward_and_backward(dtype, C_, H, W):
+    """fused GroupNorm(32) + SiLU (north star "fused BN/GN+SiLU") against F.group_norm + F.silu and their autograd"""
+    g = torch.Generator().manual_seed(C_ + H)
+    B, G = 3, 32
+    y = rq(torch.randn(B, C_, H, W, generator=g) * 1.5 + 0.3, dtype).requires_grad_(True)
+    gamma = (torch.rand(C_, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C_, generator=g) * 0.3).requires_grad_(True)
+    ref = F.silu(F.group_norm(y, G, gamma, beta, eps=1e-5))
+    go = rq(torch.randn(ref.shape, generator=g), dtype)
+    ref.backward(go)
+    yd, gd = to_nhwc(y.detach(), dtype), to_nhwc(go, dtype)
+    HW = H * W
+    part = torch.empty(B * ops.gn_rows(HW) * 2 * C_, device=DEV)
+    scale, shift, ca, cb, cc = (torch.empty(B * C_, device=DEV) for _ in range(5))
+    mean, invstd = (torch.empty(B * G, device=DEV) for _ in range(2))
+    tmp = torch.empty(B * 2 * C_, device=DEV)
+    dgamma, dbeta = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV)
+    out, dy = torch.empty_like(yd), torch.empty_like(yd)
+    ops.gn_stats(ops.view(yd), part)
+    ops.gn_finalize(part, B, HW, C_, G, gamma.detach().to(DEV), beta.detach().to(DEV), scale, shift, mean, invstd)
+    ops.gn_act_fwd(ops.view(yd), scale, shift, True, ops.view(out))
+    ops.gn_act_bwd_reduce(ops.view(yd), ops.view(gd), scale, shift, True, part)
+    ops.gn_bwd_finalize(part, B, HW, C_, G, gamma.detach().to(DEV), mean, invstd, tmp, dgamma, dbeta, ca, cb, cc)
+    ops.gn_act_bwd_apply(ops.view(yd), ops.view(gd), scale, shift, True, ca, cb, cc, ops.view(dy))
+    torch.cuda.synchronize()
+    t = 2e-5 if dtype == torch.float32 else 1e-2
+    close(from_nhwc(out), ref.detach(), t, "GN+SiLU forward")
+    close(from_nhwc(dy), y.grad, 5e-5 if dtype == torch.float32 else 1e-2, "GN+SiLU backward dy")
+    close(dgamma.cpu(), gamma.grad, 1e-4, "dgamma")
+    close(dbeta.cpu(), beta.grad, 1e-4, "dbeta")
+
+
 # ---------------------------------------------------------------------------------------------------- whole network
-def _build(arch, NC, precision, seed=3):
+def _build(arch, NC, precision, seed=3, decoder_norm="bn_relu"):
     cls = {"resnet18": nets.Resnet18Unet, "resnet50": nets.Resnet50Unet}[arch]
-    net = cls(NC, precision)
-    missing, unexpected = net.load_state_dict(R.init_params(arch, NC, seed=seed), strict=False)
+    net = cls(NC, precision, decoder_norm)
+    missing, unexpected = net.load_state_dict(R.init_params(arch, NC, seed=seed, decoder_norm=decoder_norm), strict=False)
     assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
     return net.to(DEV)
 
@@ -362,6 +396,53 @@ def test_fp32_train_steps_match_oracle(arch, B, S, NC):
     close(ev, want, 1e-3, "eval logits")
     assert torch.equal(labels.long(), ev.argmax(1))
     _assert_argmax(ev, want64, 1e-3)
+
+
+def test_gn_silu_decoder_variant_matches_oracle():
+    """ResNet18-UNet with the `decoder_norm: gn_silu` option (conv -> GroupNorm(32) -> SiLU in the decoder) through the factory:
+    f32 logits 1e-3 / loss 1e-4, gradients 2e-4 of the float64 oracle at the path's own (encoder) ReLU decisions, two steps; the
+    bf16 path trains"""
+    arch, NC, B, S = "resnet18", 5, 2, 64
+    net = utils.load_network({"net": "Resnet18Unet", "num_classes": NC - 1, "precision": "fp32", "decoder_norm": "gn_silu"}, DEV)
+    net.load_state_dict(R.init_params(arch, NC, seed=3, decoder_norm="gn_silu"), strict=False)
+    assert not any("decoder" in k and "running" in k for k in net.state_dict())
+    crit = utils.CrossEntropyLoss(ignore_index=0)
+    optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
+    img, lab = O.synthetic_tiles(B, S, NC, seed=5, structured=True)
+    net.train()
+    for step in range(2):
+        p_before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+        with torch.no_grad():
+            want_logits = R.forward({k: v.clone() for k, v in p_before.items()}, img.float(), arch, train=True)
+            want_loss = O.cross_entropy(want_logits, lab.long(), None, 0).item()
+        logits = net(img.to(DEV), None)
+        loss = crit(logits, lab.to(DEV))
+        optim.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        masks = [from_nhwc(v.torch()) > 0 for v in net._engine.relu_order]
+        grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+        close(logits.detach().cpu(), want_logits, 1e-3, f"step {step} logits")
+        assert abs(loss.item() - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+        optim.step()
+        _, g64, flips = _f64_gradients(arch, p_before, img, lab, masks)
+        assert all(mx <= 1e-5 for _, mx in flips)
+        worst = max((rel_l2(grads[k].double(), g64[k]), k) for k in g64)
+        print(f"gn_silu step {step}: worst gradient rel-L2 vs float64 {worst}")
+        assert worst[0] <= 2e-4, worst
+    net.eval()
+    with torch.no_grad():
+        final = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+        close(net(img.to(DEV), None).cpu(), R.forward(final, img.float(), arch, train=False), 1e-3, "eval logits")
+    nb = _build(arch, NC, "bf16", decoder_norm="gn_silu")
+    ob, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, nb)
+    nb.train()
+    ls = []
+    for _ in range(8):
+        l_ = crit(nb(img.to(DEV), None), lab.to(DEV))
+        ob.zero_grad(); l_.backward(); ob.step()
+        ls.append(l_.item())
+    assert ls[-1] < ls[0], ls
 
 
 def _assert_argmax(got, want64, rel):
