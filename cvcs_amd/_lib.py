@@ -89,6 +89,19 @@ SIGNATURES = {
     "cvcs_linear_head_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "cvcs_linear_head_bwd_rows": (_i, [_i64]),
     "cvcs_gn_rows": (_i, [_i]),
+    "cvcs_layernorm_rows": (_i, [_i64]),
+    "cvcs_layernorm_fwd": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _f, _vp, _i64, _vp, _vp, _i, _vp]),
+    "cvcs_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_gelu": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp]),
+    "cvcs_pack_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cvcs_patch_merge": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp]),
+    "cvcs_window_gather": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_window_reverse": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_window_attention_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _i, _vp]),
+    "cvcs_window_attention_bwd_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "cvcs_window_attention_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
+    "cvcs_adaptive_avg_pool": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp]),
+    "cvcs_resize_bilinear_any": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
     "cvcs_gn_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
     "cvcs_gn_finalize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_gn_act_fwd": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _i, _vp]),
@@ -140,7 +153,8 @@ _lib = None
 _recording = None          # the Recording that is capturing launches right now (None: plain eager calls)
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
-            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows"}
+            "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
+            "cvcs_window_attention_bwd_workspace_floats"}
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 
 
@@ -230,7 +244,7 @@ def _load():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 6:
+        if h.cvcs_abi_version() != 7:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")

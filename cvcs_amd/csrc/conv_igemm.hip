@@ -134,9 +134,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int nsteps = taps * nslice;
   const int64_t wt_tap_stride = (int64_t)p.Cout * p.Cin;  // elements
   const char* bsrc[BPW];
+  bool bvalid[BPW];     // output channels beyond Cout (a last column tile that is not full: Swin's 96 / 288 widths) read zero weights
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
     const int row = (wave + 4 * j) * 16 + rr;
+    bvalid[j] = n0 + row < p.Cout;
     bsrc[j] = p.wt + ((int64_t)(n0 + row) * p.Cin) * ES + swz(row, pc) * 16;
   }
   auto dma_step = [&](int tap, int cs, int stage) {
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
     const int64_t soff = ((int64_t)tap * wt_tap_stride + (int64_t)cs * KG) * ES;
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) dma16(bsrc[j] + soff, sb + (wave + 4 * j) * 1024);
+    for (int j = 0; j < BPW; ++j) dma16(bvalid[j] ? bsrc[j] + soff : reinterpret_cast<const char*>(&g_gzero16), sb + (wave + 4 * j) * 1024);
   };
 
   f32x4 acc[MREP][NREP];
@@ -209,9 +211,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
-    const float bv = p.bias ? p.bias[n] : 0.f;
-    const float s1 = p.pre_scale ? p.pre_scale[n] : 1.f, t1 = p.pre_scale ? p.pre_shift[n] : 0.f;
-    const float s2 = p.post_scale ? p.post_scale[n] : 1.f, t2 = p.post_scale ? p.post_shift[n] : 0.f;
+    const bool nok = n < p.Cout;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+    const float s1 = (p.pre_scale && nok) ? p.pre_scale[n] : 1.f, t1 = (p.pre_scale && nok) ? p.pre_shift[n] : 0.f;
+    const float s2 = (p.post_scale && nok) ? p.post_scale[n] : 1.f, t2 = (p.post_scale && nok) ? p.post_shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
@@ -254,8 +257,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       if (fg == 0) {
         const int n = n0 + wn * WN + j * 16 + fr;
         const int64_t row = (int64_t)blockIdx.x * 2 + wm;
-        p.stat_sum[row * p.Cout + n] = s;
-        p.stat_m2[row * p.Cout + n] = q;
+        if (n < p.Cout) {
+          p.stat_sum[row * p.Cout + n] = s;
+          p.stat_m2[row * p.Cout + n] = q;
+        }
       }
     }
     if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[(int64_t)blockIdx.x * 2 + wm] = (float)nvalid;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int id = tid; id < kBM * CPR; id += 256) {
     int row = id / CPR, c = id - row * CPR;
     int m = m0 + row;
-    if (m >= p.M) continue;
+    if (m >= p.M || (!p.pixel_shuffle && n0 + c * (16 / ES) >= p.Cout)) continue;
     uint4 v = *reinterpret_cast<const uint4*>(smem + row * OROW + c * 16);
     int64_t pix = m;
     if (p.pixel_shuffle) {
@@ -1333,7 +1338,7 @@ static int launch(const ConvArgs& a, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(a.M, kBM), (unsigned)(a.Cout / BN));
+  dim3 grid((unsigned)cdiv(a.M, kBM), (unsigned)cdiv(a.Cout, BN));
   hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), grid, dim3(256), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d");
   return CVCS_OK;
@@ -1349,7 +1354,7 @@ extern "C" int cvcs_probe_read(void* host, size_t bytes) { return (int)hipMemcpy
 
 // 3x3 / stride 1 / pad 1 / dil 1 convolutions whose image is at least half a tile wide take the halo kernel
 static bool use_halo(const cvcs_conv_desc* d) {
-  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
+  return d->Cout % 64 == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
          d->W >= 8;
 }
 // bf16 1x1/s1 and 2x2/s2 convolutions without padding (1x1 forward / data gradient of the residual blocks, the
@@ -1386,7 +1391,11 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->in && d->wt && d->out, "cvcs_conv2d: null tensor");
   CVCS_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "cvcs_conv2d: bad shape");
   CVCS_CHECK_ARG(d->Cin > 0 && d->Cin % kg == 0, "cvcs_conv2d: Cin=%d must be a multiple of %d", d->Cin, kg);
-  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 64 == 0, "cvcs_conv2d: Cout=%d must be a multiple of 64", d->Cout);
+  // (a multiple of 32 that is no multiple of 64 - the 96 / 288 widths of Swin-T's first stage - runs on the generic kernel,
+  //  whose last column tile masks the channels beyond Cout)
+  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 32 == 0, "cvcs_conv2d: Cout=%d must be a multiple of 32", d->Cout);
+  const bool ragged_n = d->Cout % 64 != 0;
+  CVCS_CHECK_ARG(!ragged_n || !d->pixel_shuffle, "cvcs_conv2d: pixel_shuffle needs Cout %% 64 == 0");
   CVCS_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "cvcs_conv2d: bad filter geometry");
   // output extent must match the filter geometry (every gathered pixel is range-checked in the kernel, but the
   // host refuses inconsistent shapes so that no tile silently reads the wrong window)
@@ -1449,7 +1458,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   a.stride_w = stride_w; a.pad_w = pad_w; a.in_row_pitch = row_pitch; a.in_img_pitch = img_pitch;
   hipStream_t st = (hipStream_t)stream;
-  const bool plain = !aniso && !pitched;   // the specialised kernels assume the isotropic, densely packed case
+  const bool plain = !aniso && !pitched && !ragged_n;   // the specialised kernels assume the isotropic, densely packed case
   if (plain && use_halo(d)) {
     static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 64;   // tuning knob
     // a launch that carries the fused BatchNorm-backward reduce needs neighbours on its CU to hide the longer epilogue: up to

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const int hrows = p.HR * p.HC;
   const int xpieces = (hrows + RPP - 1) / RPP;
   const int cin_rem = p.Cin - ci0;
+  const int cout_rem = p.Cout - co0;            // < 64 in the last row tile of a Cout that is no multiple of 64 (Swin's 96 / 288)
   const int rr = lane / CPR, pc = lane % CPR;   // row / physical 16-byte chunk of this lane inside a DMA piece
   const int my_pieces = DYP / 4 + (xpieces - wave + 3) / 4;   // DMA instructions this wave issues per K-tile
 
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       const int c = swz_chunk(k, pc);
       const int oy = ty0 + k / p.TW, ox = tx0 + k % p.TW;
       const char* src = reinterpret_cast<const char*>(&g_wzero16);
-      if (oy < p.Ho && ox < p.Wo) src = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0) * ES + c * 16;
+      if (oy < p.Ho && ox < p.Wo && c * (16 / ES) < cout_rem)
+        src = p.dy + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0) * ES + c * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sdy + pi * 1024), 16, 0, 0);
     }
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + wm * 32 + i * 16 + fg * 4 + r;
-          p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j][r];
+          if (co < p.Cout) p.ws[slice * slice_stride + ((int64_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j][r];
         }
       }
 }
@@ -813,7 +815,7 @@ static WgradPlan make_plan(int B, int Ho, int Wo, int Cout, int Cin, int KH, int
   pl.tiles_x = (int)cdiv(Wo, pl.TW);
   pl.tiles_y = (int)cdiv(Ho, pl.TH);
   pl.ktiles = B * pl.tiles_x * pl.tiles_y;
-  pl.tiles_mn = (fast == 2 ? Cout / 128 : Cout / 64) * (int)cdiv(Cin, 64);
+  pl.tiles_mn = (fast == 2 ? Cout / 128 : (int)cdiv(Cout, 64)) * (int)cdiv(Cin, 64);
   // ~2 resident workgroups per CU (one for the 8-wave kernel); fewer slices = less partial-slab traffic
   int want = (int)cdiv(fast == 2 ? 256 : 512, pl.tiles_mn);
   if (want > pl.ktiles) want = pl.ktiles;
@@ -857,6 +859,7 @@ static bool s2_shape(const cvcs_wgrad_desc* d) {
          (int64_t)d->H * d->W * d->x_ld * 2 < (1ll << 31) && (int64_t)d->Ho * d->Wo * d->dy_ld * 2 < (1ll << 31);
 }
 static int fast_path(const cvcs_wgrad_desc* d) {
+  if (d->Cout % 64 != 0) return 0;   // a last row tile that is not full: the generic kernel masks it
   static const int force64 = getenv("CVCS_WGRAD_64") ? atoi(getenv("CVCS_WGRAD_64")) : 0;   // tuning knob
   if (s2_shape(d)) return 2;
   if (!fast_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->H, d->W, d->Ho, d->Wo, d->x_ld, d->dy_ld)) return 0;
@@ -886,7 +889,7 @@ static GemmPlan gemm_plan(int B, int Ho, int Wo, int Cout, int Cin) {
 
 // worst case over both kernels (the slice count of the generic and of the fast plan can differ)
 extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
-  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 64 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 32 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
   int n = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 0).nslice;
   if (gemm_shape(KH, KW, stride, Cout, Cin)) {
     const int g = gemm_plan(B, Ho, Wo, Cout, Cin).nslice;
@@ -975,7 +978,7 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
 
 // exact workspace size of one descriptor (covers the anisotropic / pitched case, which cvcs_wgrad_slices cannot express)
 extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
-  if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 64 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
+  if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 32 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   int n;
   if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
@@ -993,7 +996,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->dtype == CVCS_F32 || d->dtype == CVCS_BF16, "cvcs_conv2d_wgrad: bad dtype");
   const int es = d->dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(d->x && d->dy && d->dw && d->workspace, "cvcs_conv2d_wgrad: null tensor");
-  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 64 == 0, "cvcs_conv2d_wgrad: Cout=%d must be a multiple of 64", d->Cout);
+  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 32 == 0, "cvcs_conv2d_wgrad: Cout=%d must be a multiple of 32", d->Cout);
   CVCS_CHECK_ARG(d->Cin > 0 && d->Cin % (16 / es) == 0, "cvcs_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, 16 / es);
   CVCS_CHECK_ARG(d->Cin_real > 0 && d->Cin_real <= d->Cin, "cvcs_conv2d_wgrad: Cin_real");
   const int taps = d->KH * d->KW;

@@ -393,6 +393,83 @@ def unpack_stem_wgrad(tmp: torch.Tensor, dw: torch.Tensor):
     check(_lib.lib().cvcs_unpack_stem_wgrad(tmp.data_ptr(), dw.shape[0], dw.data_ptr(), _stream()), "cvcs_unpack_stem_wgrad")
 
 
+# ------------------------------------------------------------------------------------------------ Swin-T + UPerNet
+def layernorm_rows(M: int) -> int:
+    return _lib.lib().cvcs_layernorm_rows(M)
+
+
+def layernorm_fwd(x: View, gamma, beta, out: View, mean, invstd, eps=1e-5):
+    M = x.B * x.H * x.W
+    check(_lib.lib().cvcs_layernorm_fwd(x.ptr, x.ld, M, x.C, gamma.data_ptr(), beta.data_ptr(), eps, out.ptr, out.ld, mean.data_ptr(),
+                                        invstd.data_ptr(), x.code, _stream()), "cvcs_layernorm_fwd")
+
+
+def layernorm_bwd(x: View, g: View, gamma, mean, invstd, dx: View, part):
+    M = x.B * x.H * x.W
+    check(_lib.lib().cvcs_layernorm_bwd(x.ptr, x.ld, g.ptr, g.ld, M, x.C, gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dx.ptr,
+                                        dx.ld, part.data_ptr(), x.code, _stream()), "cvcs_layernorm_bwd")
+
+
+def gelu(x: View, out: View, g: View | None = None):
+    """g None: out = gelu(x) (erf form); else out = g * gelu'(x)"""
+    M = x.B * x.H * x.W
+    check(_lib.lib().cvcs_gelu(x.ptr, x.ld, 0 if g is None else g.ptr, 0 if g is None else g.ld, M, x.C, out.ptr, out.ld, x.code, _stream()),
+          "cvcs_gelu")
+
+
+def pack_patches(src: torch.Tensor, dst: torch.Tensor):
+    B, C_, H, W = src.shape
+    assert C_ == 3 and src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, H // 4, W // 4, 64)
+    check(_lib.lib().cvcs_pack_patches(src.data_ptr(), int(src.dtype == torch.uint8), B, H, W, dst.data_ptr(), dtype_code(dst.dtype),
+                                       _stream()), "cvcs_pack_patches")
+
+
+def patch_merge(fine: View, merged: View, reverse=False):
+    """forward: fine [B,H,W,C] -> merged [B,H/2,W/2,4C]; reverse: merged (gradient) -> fine (gradient)"""
+    src, dst = (merged, fine) if reverse else (fine, merged)
+    check(_lib.lib().cvcs_patch_merge(src.ptr, src.ld, fine.B, fine.H, fine.W, fine.C, dst.ptr, dst.ld, int(reverse), fine.code, _stream()),
+          "cvcs_patch_merge")
+
+
+def window_gather(tokens: View, win: View, shift: int):
+    check(_lib.lib().cvcs_window_gather(tokens.ptr, tokens.ld, tokens.B, tokens.H, tokens.W, tokens.C, shift, win.ptr, win.ld, tokens.code,
+                                        _stream()), "cvcs_window_gather")
+
+
+def window_reverse(win: View, res: View | None, out: View, shift: int):
+    check(_lib.lib().cvcs_window_reverse(win.ptr, win.ld, 0 if res is None else res.ptr, 0 if res is None else res.ld, out.B, out.H, out.W,
+                                         out.C, shift, out.ptr, out.ld, out.code, _stream()), "cvcs_window_reverse")
+
+
+def window_attention_fwd(qkv: View, B, H, W, heads, shift, table, out: View):
+    check(_lib.lib().cvcs_window_attention_fwd(qkv.ptr, qkv.ld, B, H, W, out.C, heads, shift, table.data_ptr(), out.ptr, out.ld, qkv.code,
+                                               _stream()), "cvcs_window_attention_fwd")
+
+
+def window_attention_bwd_workspace(B, H, W, heads) -> int:
+    return _lib.lib().cvcs_window_attention_bwd_workspace_floats(B, H, W, heads)
+
+
+def window_attention_bwd(qkv: View, dout: View, B, H, W, heads, shift, table, dqkv: View, dtable, workspace):
+    check(_lib.lib().cvcs_window_attention_bwd(qkv.ptr, qkv.ld, dout.ptr, dout.ld, B, H, W, dout.C, heads, shift, table.data_ptr(), dqkv.ptr,
+                                               dqkv.ld, dtable.data_ptr(), workspace.data_ptr(), qkv.code, _stream()),
+          "cvcs_window_attention_bwd")
+
+
+def adaptive_avg_pool(x: View, out: View, backward=False):
+    """forward: x [B,H,W,C] -> out [B,S,S,C]; backward: x = gradient [B,S,S,C] -> out = gradient [B,H,W,C]"""
+    big, small = (out, x) if backward else (x, out)
+    check(_lib.lib().cvcs_adaptive_avg_pool(x.ptr, x.ld, big.B, big.H, big.W, big.C, small.H, out.ptr, out.ld, int(backward), x.code,
+                                            _stream()), "cvcs_adaptive_avg_pool")
+
+
+def resize_any(a: View, out: View, backward=False, accumulate=False):
+    """forward: a [B,Hi,Wi,C] -> out [B,Ho,Wo,C] (accumulate: out +=); backward: a = gradient of the LARGE map -> out = gradient of the small"""
+    small, big = (out, a) if backward else (a, out)
+    check(_lib.lib().cvcs_resize_bilinear_any(a.ptr, a.ld, a.B, small.H, small.W, big.H, big.W, a.C, out.ptr, out.ld, int(backward),
+                                              int(accumulate), a.code, _stream()), "cvcs_resize_bilinear_any")
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU
 def gn_rows(HW: int) -> int:
     return _lib.lib().cvcs_gn_rows(HW)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 6
+#define CVCS_ABI_VERSION 7
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -44,7 +44,8 @@ int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, 
  * replaces: nn.Conv2d k3 p1 (S/blocks.py:3-4 via :13,:40,:43), nn.ConvTranspose2d k2 s2 (S/nets.py:150,156,162,168;
  * pixel_shuffle=1), and the input-gradient half of convolution_backward for both (S/train.py:125).
  *   out[p, n] = act( bias[n] + sum_{kh,kw,c} in[pix(p,kh,kw), c] * wt[kh*KW+kw][n][c] )
- * M = B*Ho*Wo output pixels; wt is [KH*KW][Cout][Cin] in `dtype`; Cin % (64/sizeof(dtype)) == 0, Cout % 64 == 0.
+ * M = B*Ho*Wo output pixels; wt is [KH*KW][Cout][Cin] in `dtype`; Cin % (64/sizeof(dtype)) == 0, Cout % 32 == 0 (a Cout that
+ * is no multiple of 64 - the 96 / 288 widths of Swin-T's first stage - runs on the generic kernel with a masked last tile).
  * stat_sum/stat_m2 (optional, f32 [rows][Cout]) and stat_cnt (f32 [rows]), rows = cvcs_conv_stat_rows(desc): per
  * wave-sized block of output pixels and channel, the pixel count, the sum and the second moment centred on the
  * block's own mean of the values written - the BatchNorm batch statistics, fused into the epilogue.
@@ -370,6 +371,46 @@ int cvcs_gn_bwd_finalize(const float* part, int B, int HW, int C, int G, const f
 int cvcs_gn_act_bwd_apply(const void* y, int64_t y_ld, const void* g, int64_t g_ld, int B, int HW, int C, const float* scale,
                           const float* shift, int silu, const float* ca, const float* cb, const float* cc, void* dy,
                           int64_t dy_ld, int dtype, void* stream);
+
+/* ---- Swin-T + UPerNet (BASELINE.json configs[3]; north star "patch-embed + windowed attention for the ViT/Swin encoder
+ * variant"; the reference documents TSwin / BSwin at configs/train/README.txt:44-45 without a definition) ------------------
+ * Tokens are NHWC pixels, every nn.Linear is a 1x1 cvcs_conv2d (+ cvcs_conv2d_wgrad, bias gradient by cvcs_colsum_*).
+ * LayerNorm over the C channels of each of M tokens (eps as given); mean / invstd f32 [M] are saved for the backward, which
+ * writes dx and partial rows part[cvcs_layernorm_rows(M)][2][C] of (dgamma | dbeta) for cvcs_colsum_finalize(2C columns).  */
+int cvcs_layernorm_rows(int64_t M);
+int cvcs_layernorm_fwd(const void* x, int64_t x_ld, int64_t M, int C, const float* gamma, const float* beta, float eps, void* out,
+                       int64_t out_ld, float* mean, float* invstd, int dtype, void* stream);
+int cvcs_layernorm_bwd(const void* x, int64_t x_ld, const void* g, int64_t g_ld, int64_t M, int C, const float* gamma, const float* mean,
+                       const float* invstd, void* dx, int64_t dx_ld, float* part, int dtype, void* stream);
+/* GELU (erf form): g == NULL: out = gelu(x); else out = g * gelu'(x)                                                        */
+int cvcs_gelu(const void* x, int64_t x_ld, const void* g, int64_t g_ld, int64_t M, int C, void* out, int64_t out_ld, int dtype, void* stream);
+/* patch embedding input: u8 | f32 NCHW [B,3,H,W] -> [B,H/4,W/4,64] `dtype`, channel c*16 + kh*4 + kw (the flattening of the
+ * [96,3,4,4] projection weight; channels 48..63 zero): the 4x4 / stride 4 convolution becomes a 1x1 convolution               */
+int cvcs_pack_patches(const void* src, int src_is_u8, int B, int H, int W, void* dst, int dtype, void* stream);
+/* SwinPatchMerging gather: [B,H,W,C] -> [B,H/2,W/2,4C], block col*2+row = pixel (2y+row, 2x+col); reverse = its transpose  */
+int cvcs_patch_merge(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld, int reverse, int dtype, void* stream);
+/* window partition: the [B,H,W,C] token map zero-padded to multiples of 7 and rolled by -shift -> windows [B*nW*49][C]; and
+ * the inverse fused with the residual add: out = (res ? res : 0) + un-partitioned windows (padding dropped).  Each is the
+ * other's backward.                                                                                                        */
+int cvcs_window_gather(const void* map, int64_t map_ld, int B, int H, int W, int C, int shift, void* win, int64_t win_ld, int dtype, void* stream);
+int cvcs_window_reverse(const void* win, int64_t win_ld, const void* res, int64_t res_ld, int B, int H, int W, int C, int shift, void* out,
+                        int64_t out_ld, int dtype, void* stream);
+/* window-7 multi-head attention (head dim 32) over the window tokens: qkv [T][3C] = (q | k | v), table f32 [169][heads]
+ * (relative-position bias), shift > 0 adds Swin's -100 region mask; out [T][C].  Backward: dqkv [T][3C] and dtable
+ * [169][heads] (workspace: cvcs_window_attention_bwd_workspace_floats; fixed-order reduction).                             */
+int cvcs_window_attention_fwd(const void* qkv, int64_t qkv_ld, int B, int H, int W, int C, int heads, int shift, const float* table,
+                              void* out, int64_t out_ld, int dtype, void* stream);
+int64_t cvcs_window_attention_bwd_workspace_floats(int B, int H, int W, int heads);
+int cvcs_window_attention_bwd(const void* qkv, int64_t qkv_ld, const void* dout, int64_t dout_ld, int B, int H, int W, int C, int heads,
+                              int shift, const float* table, void* dqkv, int64_t dqkv_ld, float* dtable, float* workspace, int dtype,
+                              void* stream);
+/* UPerNet: nn.AdaptiveAvgPool2d(S) forward ([B,H,W,C] -> [B,S,S,C]) / backward (in = gradient [B,S,S,C] -> [B,H,W,C]);
+ * F.interpolate(size=(Ho,Wo), 'bilinear', align_corners=False) between arbitrary sizes: forward [B,Hi,Wi,C] -> [B,Ho,Wo,C]
+ * (accumulate = 1: out += - the FPN top-down add) / backward (a = gradient [B,Ho,Wo,C] -> gradient [B,Hi,Wi,C], a gather). */
+int cvcs_adaptive_avg_pool(const void* in, int64_t in_ld, int B, int H, int W, int C, int S, void* out, int64_t out_ld, int backward,
+                           int dtype, void* stream);
+int cvcs_resize_bilinear_any(const void* a, int64_t a_ld, int B, int Hi, int Wi, int Ho, int Wo, int C, void* out, int64_t out_ld,
+                             int backward, int accumulate, int dtype, void* stream);
 
 /* ---- fused optimisers over a flat f32 parameter buffer -------------------------------------------------------
  * replaces: torch.optim.SGD(momentum, weight_decay).step() / torch.optim.Adam.step() (S/utils.py:214,217; S/train.py:126).

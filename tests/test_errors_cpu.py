@@ -39,7 +39,7 @@ def _desc(a, **kw):
 @pytest.mark.parametrize("kw,msg", [
     (dict(dtype=7), b"bad dtype"),
     (dict(Cin=24, in_ld=24), b"Cin=24 must be a multiple of 32"),
-    (dict(Cout=48), b"Cout=48 must be a multiple of 64"),
+    (dict(Cout=48), b"Cout=48 must be a multiple of 32"),
     (dict(Ho=7), b"geometry gives 8,8"),
     (dict(B=0), b"bad shape"),
     (dict(in_ld=16), b"in_ld"),
@@ -71,8 +71,8 @@ def test_wgrad_rejects_unbuilt_filters_and_bad_shapes(lib):
     d.KH = d.KW = 3
     d.pad = 0
     assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"geometry gives 6,6" in lib.cvcs_last_error()
-    d.pad, d.Cout = 1, 32
-    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"Cout=32" in lib.cvcs_last_error()
+    d.pad, d.Cout = 1, 48
+    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"Cout=48" in lib.cvcs_last_error()
     assert lib.cvcs_wgrad_slices(0, 8, 8, 64, 64, 3, 3, 1) == -1
 
 

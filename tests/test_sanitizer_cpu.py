@@ -18,7 +18,7 @@ from cvcs_amd import _lib
 h = C.CDLL(%(lib)r)
 for name, (res, args) in _lib.SIGNATURES.items():
     fn = getattr(h, name); fn.restype = res; fn.argtypes = args
-assert h.cvcs_abi_version() == 6
+assert h.cvcs_abi_version() == 7
 assert h.cvcs_sizeof_conv_desc() == C.sizeof(_lib.ConvDesc) and h.cvcs_sizeof_wgrad_desc() == C.sizeof(_lib.WgradDesc)
 n = 0
 # planners / sizing queries over a sweep of shapes (pure host code)
@@ -55,7 +55,7 @@ for name, (res, args) in _lib.SIGNATURES.items():
     assert len(h.cvcs_last_error()) > 0
     bad += 1
 # descriptors with inconsistent geometry / misaligned views / bad channel counts
-for mut in (dict(Cin=33), dict(Cout=96), dict(Ho=7), dict(in_ld=3), dict(dtype=9), dict(stride=0), dict(Cin_valid=5)):
+for mut in (dict(Cin=33), dict(Cout=80), dict(Ho=7), dict(in_ld=3), dict(dtype=9), dict(stride=0), dict(Cin_valid=5)):
     c = _lib.ConvDesc()
     c.in_, c.wt, c.out = 4096, 4096, 4096
     c.B, c.H, c.W, c.Cin, c.Cout, c.KH, c.KW, c.stride, c.pad, c.dil, c.dtype, c.Ho, c.Wo, c.in_ld, c.out_ld = 1, 8, 8, 64, 64, 3, 3, 1, 1, 1, 1, 8, 8, 64, 64
