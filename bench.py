@@ -33,6 +33,7 @@ FAMILY_KERNEL = {
     "conv_taps": "conv_taps_kernel (non-overlapping taps: 1x1 forward / data gradient, ConvTranspose forward / data gradient)",
     "conv_igemm": "conv_igemm_kernel (generic gather: strided convs, the 7x1 virtual-pixel stem, 1x1 with < 128 output channels)",
     "wgrad": "wgrad_* kernels (all weight gradients, split-K reduce included)",
+    "window_attention": "attn_fwd_kernel / attn_bwd_kernel (7x7-window attention, one wavefront per (window, head), VALU; scores recomputed in backward)",
     "wgrad_1x1": "wgrad_gemm_kernel (1x1 weight gradients as one transposed GEMM)",
 }
 
@@ -57,6 +58,9 @@ def cpu_baseline(net, nc, tile, tiles, steps):
     img, lab = O.synthetic_tiles(tiles, tile, nc, seed=1234)
     if net in ("Unetv2", "Unet"):
         tr, what = O.OracleTrainer(net, nc, opt="SGD2", ignore_index=0, seed=0), f"oracle.unet_oracle (torch-CPU fp32 {net}"
+    elif net == "SwinTUperNet":
+        from oracle import swin_upernet_oracle as W
+        tr, what = W.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0), "oracle.swin_upernet_oracle (torch-CPU fp32 Swin-T + UPerNet"
     elif net in ("DeepLabV3Plus", "Resnet101"):
         from oracle import deeplab_oracle as D
         plus = net == "DeepLabV3Plus"
@@ -94,7 +98,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
-    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "Unetv2", "Unet"])
+    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -180,6 +184,7 @@ def main():
                  "Resnet18Unet": "ResNet18-UNet", "Resnet34Unet": "ResNet34-UNet",
                  "DeepLabV3Plus": "DeepLabV3+ (ResNet-50 v1.5 at output stride 16, ASPP rates 6/12/18, 64-channel low-level branch)",
                  "Resnet101": "DeepLabV3-ResNet101 (the reference's factory name Resnet101, S/nets.py:234-257; output stride 8, ASPP 12/24/36)",
+                 "SwinTUperNet": "Swin-T + UPerNet (BASELINE configs[3]: embed 96, depths 2/2/6/2, window 7; UPerNet hidden 512, pool scales 1/2/3/6)",
                  "Unetv2": "Unetv2 (the reference's own U-Net, source/scripts/nets.py:117-199)", "Unet": "Unet (reference)"}[a.net]
         out = {
             "metric": "512x512 tiles/sec (train fwd+bwd)" if a.tile == 512 else f"{a.tile}x{a.tile} tiles/sec (train fwd+bwd)",

@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
 // partial per-channel sums of a view: part[blockIdx.x][c] = sum over this workgroup's pixels (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const char* x, int64_t ld, int64_t M, int C, float* part) {
+  // any C that is a multiple of the 16-byte chunk (the 3 * 2^k widths of Swin are no powers of two): a workgroup covers
+  // ccw = min(C/V, 256) chunks x PL = floor(256 / ccw) pixel lanes; the threads beyond ccw * PL idle
   constexpr int ES = sizeof(T), V = 16 / ES;
   __shared__ float red[256 * V];
   const int CC = C / V;
@@ -335,19 +337,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* x, int64_t ld, 
   const int tid = threadIdx.x;
   const int cl = tid % ccw, pl = tid / ccw;
   const int cc = blockIdx.y * ccw + cl;
+  const bool active = pl < PL && cc < CC;
   float s[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) s[k] = 0.f;
-  for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < M; it += (int64_t)gridDim.x * PL) {
-    float f[V];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (it * ld) * ES + cc * 16), f);
+  if (active)
+    for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < M; it += (int64_t)gridDim.x * PL) {
+      float f[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (it * ld) * ES + cc * 16), f);
 #pragma unroll
-    for (int k = 0; k < V; ++k) s[k] += f[k];
-  }
+      for (int k = 0; k < V; ++k) s[k] += f[k];
+    }
 #pragma unroll
   for (int k = 0; k < V; ++k) red[tid * V + k] = s[k];
   __syncthreads();
-  if (pl == 0) {
+  if (pl == 0 && cc < CC) {
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       float a = 0.f;
@@ -796,11 +800,10 @@ extern "C" int cvcs_colsum_partial(const void* x, int64_t x_ld, int64_t M, int C
   const int V = 16 / es;
   CVCS_CHECK_ARG(M > 0 && C > 0 && C % V == 0 && part, "cvcs_colsum_partial: bad shape");
   const int CC = C / V;
-  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % 256 == 0, "cvcs_colsum_partial: C/%d must be a power of two", V);
   int rc;
   if ((rc = check_view("cvcs_colsum_partial", x, x_ld, C, es))) return rc;
   const int ccw = CC < 256 ? CC : 256;
-  dim3 grid((unsigned)cvcs_bn_bwd_rows(M), (unsigned)(CC / ccw));
+  dim3 grid((unsigned)cvcs_bn_bwd_rows(M), (unsigned)cdiv(CC, ccw));
   if (dtype == CVCS_F32)
     hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, part);
   else

@@ -19,6 +19,7 @@ import torch.nn as nn
 from .engine import WIDTHS, UNetEngine
 from .deeplab_engine import LOW_LEVEL_CHANNELS, DeepLabEngine
 from .resnet_engine import ARCHS as RESNET_ARCHS, DECODER_CHANNELS, ResNetUNetEngine
+from .swin_engine import DEPTHS as SWIN_DEPTHS, DIMS as SWIN_DIMS, HEADS as SWIN_HEADS, HIDDEN as UPER_HIDDEN, POOL_SCALES, SwinUPerNetEngine
 
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
@@ -119,6 +120,10 @@ class _HipUNet(nn.Module):
                 w = holder._parameters["weight"]
                 bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
                 holder.register_parameter(leaf, nn.Parameter((torch.rand(shape, generator=g) * 2 - 1) * bound))
+            elif kind == "lin_w":      # nn.Linear / relative-position table: truncated-normal(0.02)-like small uniform
+                holder.register_parameter(leaf, nn.Parameter((torch.rand(shape, generator=g) * 2 - 1) * 0.035))
+            elif kind == "lin_b":
+                holder.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
             elif kind == "bn_w":
                 holder.register_parameter(leaf, nn.Parameter(torch.ones(shape)))
             elif kind == "bn_b":
@@ -137,10 +142,14 @@ class _HipUNet(nn.Module):
         return UNetEngine(self.variant, self.num_classes, PRECISIONS[self.precision], dev)
 
     # ------------------------------------------------------------------------------------------------ flat storage
+    def _flat_order(self, params):
+        """order of the parameters inside the flat buffers (an internal layout: state_dict / named_parameters are unaffected)"""
+        return params
+
     def _ensure_flat(self):
         """(re)build the flat f32 parameter / gradient buffers on the parameters' current device and re-point every
         nn.Parameter at its slice (needed after `.to(device)` / `load_state_dict`, both of which keep the objects)."""
-        params = OrderedDict(self.named_parameters())
+        params = self._flat_order(OrderedDict(self.named_parameters()))
         first = next(iter(params.values()))
         dev = first.device
         if dev.type != "cuda":
@@ -378,3 +387,90 @@ class DeepLabv3Resnet101(DeepLabV3Plus):
 class DeepLabv3Resnet50(DeepLabV3Plus):
     """S/nets.py:259-275 (same head on a ResNet-50; not reachable from the reference's load_network either)"""
     arch, output_stride, plus = "resnet50", 8, False
+
+
+# ---------------------------------------------------------------------------------------------------- Swin-T + UPerNet
+def swin_upernet_param_spec(num_classes: int):
+    """(name, shape, kind): the parameter names of transformers' UperNetForSemanticSegmentation over a SwinBackbone (embed 96, depths
+    2/2/6/2, heads 3/6/12/24, window 7; UPerNet hidden 512, pool scales 1/2/3/6), so its checkpoints load by name.  Within an
+    attention block the q / k / v weights, then their biases, are registered ADJACENTLY: in the flat parameter buffer they form one
+    [3C, C] matrix and one [3C] bias, which the engine runs as a single GEMM."""
+    spec = []
+
+    def lin(p, cin, cout, bias=True):
+        spec.append((p + ".weight", (cout, cin), "lin_w"))
+        if bias:
+            spec.append((p + ".bias", (cout,), "lin_b"))
+
+    def ln(p, c):
+        spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b")])
+
+    def cbr(p, cin, cout, k):
+        spec.append((p + ".conv.weight", (cout, cin, k, k), "conv_w"))
+        spec.extend([(p + ".batch_norm.weight", (cout,), "bn_w"), (p + ".batch_norm.bias", (cout,), "bn_b"),
+                     (p + ".batch_norm.running_mean", (cout,), "rm"), (p + ".batch_norm.running_var", (cout,), "rv"),
+                     (p + ".batch_norm.num_batches_tracked", (), "nbt")])
+
+    pe = "backbone.swin.embeddings.patch_embeddings.projection"
+    spec.append((pe + ".weight", (SWIN_DIMS[0], 3, 4, 4), "conv_w"))
+    spec.append((pe + ".bias", (SWIN_DIMS[0],), "conv_b"))
+    ln("backbone.swin.embeddings.norm", SWIN_DIMS[0])
+    for s, (depth, dim, heads) in enumerate(zip(SWIN_DEPTHS, SWIN_DIMS, SWIN_HEADS)):
+        for b in range(depth):
+            p = f"backbone.swin.encoder.layers.{s}.blocks.{b}"
+            for n in ("q_proj", "k_proj", "v_proj"):
+                spec.append((f"{p}.attention.{n}.weight", (dim, dim), "lin_w"))
+            for n in ("q_proj", "k_proj", "v_proj"):
+                spec.append((f"{p}.attention.{n}.bias", (dim,), "lin_b"))
+            lin(f"{p}.attention.o_proj", dim, dim)
+            spec.append((f"{p}.attention.relative_position_bias.relative_position_bias_table", (169, heads), "lin_w"))
+            ln(p + ".layernorm_before", dim)
+            ln(p + ".layernorm_after", dim)
+            lin(p + ".mlp.fc1", dim, 4 * dim)
+            lin(p + ".mlp.fc2", 4 * dim, dim)
+        if s < 3:
+            lin(f"backbone.swin.encoder.layers.{s}.downsample.reduction", 4 * dim, 2 * dim, bias=False)
+            ln(f"backbone.swin.encoder.layers.{s}.downsample.norm", 4 * dim)
+    for s, dim in enumerate(SWIN_DIMS, start=1):
+        ln(f"backbone.hidden_states_norms.stage{s}", dim)
+    for i in range(len(POOL_SCALES)):
+        cbr(f"decode_head.psp_modules.{i}.1", SWIN_DIMS[3], UPER_HIDDEN, 1)
+    cbr("decode_head.bottleneck", SWIN_DIMS[3] + len(POOL_SCALES) * UPER_HIDDEN, UPER_HIDDEN, 3)
+    for i in range(3):
+        cbr(f"decode_head.lateral_convs.{i}", SWIN_DIMS[i], UPER_HIDDEN, 1)
+    for i in range(3):
+        cbr(f"decode_head.fpn_convs.{i}", UPER_HIDDEN, UPER_HIDDEN, 3)
+    cbr("decode_head.fpn_bottleneck", 4 * UPER_HIDDEN, UPER_HIDDEN, 3)
+    spec.append(("decode_head.classifier.weight", (num_classes, UPER_HIDDEN, 1, 1), "conv_w"))
+    spec.append(("decode_head.classifier.bias", (num_classes,), "conv_b"))
+    return spec
+
+
+class SwinTUperNet(_HipUNet):
+    """Swin-T encoder + UPerNet decoder (BASELINE.json configs[3]; the reference documents `TSwin` at configs/train/README.txt:44
+    without a definition) behind the reference's nn.Module contract; see swin_engine.py.  Stochastic depth / dropout are off.  The
+    tile side must be a multiple of 32; train mode needs a batch of at least 2 tiles (the 1x1 pyramid-pooling branch normalises a
+    1x1 map over the batch).  Raw 0..255 inputs like every network of the reference (S/train.py:121)."""
+    variant = "SwinTUperNet"
+
+    def _build_spec(self):
+        return swin_upernet_param_spec(self.num_classes)
+
+    def _build_engine(self, dev):
+        return SwinUPerNetEngine(self.num_classes, PRECISIONS[self.precision], dev)
+
+    def _flat_order(self, params):
+        # q | k | v weights, then their biases, adjacent: the engine runs the three projections as one [3C, C] GEMM
+        out = OrderedDict()
+        for name, p in params.items():
+            if name.endswith(".attention.q_proj.weight"):
+                att = name[:-len("q_proj.weight")]
+                for leaf in ("weight", "bias"):
+                    for n in ("q_proj", "k_proj", "v_proj"):
+                        out[f"{att}{n}.{leaf}"] = params[f"{att}{n}.{leaf}"]
+            elif ".attention.q_proj." in name or ".attention.k_proj." in name or ".attention.v_proj." in name:
+                continue
+            else:
+                out[name] = p
+        assert len(out) == len(params)
+        return out

@@ -441,7 +441,16 @@ def window_reverse(win: View, res: View | None, out: View, shift: int):
                                          out.C, shift, out.ptr, out.ld, out.code, _stream()), "cvcs_window_reverse")
 
 
+def _attn_tag(B, H, W, C_, passes):
+    """timer family of the window-attention launches (replayed plans only): QK^T + AV over the padded 49-token windows = 4 * 49 * C FLOPs
+    per token and pass (forward 1 pass; backward recomputes the scores and forms dP, dV, dQ, dK: 5 GEMM-shaped products = 2.5 passes)"""
+    if _lib._recording is not None:
+        T = B * (-(-H // 7) * 7) * (-(-W // 7) * 7)
+        _lib.pending_tag = ("window_attention" + (f":{SCOPE}" if SCOPE else ""), 4.0 * 49 * C_ * T * passes)
+
+
 def window_attention_fwd(qkv: View, B, H, W, heads, shift, table, out: View):
+    _attn_tag(B, H, W, out.C, 1.0)
     check(_lib.lib().cvcs_window_attention_fwd(qkv.ptr, qkv.ld, B, H, W, out.C, heads, shift, table.data_ptr(), out.ptr, out.ld, qkv.code,
                                                _stream()), "cvcs_window_attention_fwd")
 
@@ -451,6 +460,7 @@ def window_attention_bwd_workspace(B, H, W, heads) -> int:
 
 
 def window_attention_bwd(qkv: View, dout: View, B, H, W, heads, shift, table, dqkv: View, dtable, workspace):
+    _attn_tag(B, H, W, dout.C, 2.5)
     check(_lib.lib().cvcs_window_attention_bwd(qkv.ptr, qkv.ld, dout.ptr, dout.ld, B, H, W, dout.C, heads, shift, table.data_ptr(), dqkv.ptr,
                                                dqkv.ld, dtable.data_ptr(), workspace.data_ptr(), qkv.code, _stream()),
           "cvcs_window_attention_bwd")

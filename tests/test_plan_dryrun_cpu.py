@@ -1,0 +1,63 @@
+"""Host logic of the launch plans, without a GPU: every network's forward (train + eval) and backward plan is recorded with CPU
+tensors standing in for the device buffers.  Each C-ABI call then runs its full argument validation (shapes, leading dimensions,
+alignment, workspace sizes, channel-count rules) and fails only at the launch itself ("no device"), which this test tolerates;
+any CVCS_EINVAL, Python-side shape assertion or mis-sized buffer fails the test.  Nothing is computed here - numerical parity is
+the job of the `-m gpu` tests."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from cvcs_amd import _lib, nets, ops
+
+
+@pytest.fixture()
+def no_device(monkeypatch):
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the launches would run")
+    failed = [0]
+
+    def check(rc, what=""):
+        if rc == 0:
+            return
+        msg = _lib._load().cvcs_last_error().decode(errors="replace")
+        if rc == -2 and "launch failed" in msg:      # CVCS_EHIP from CVCS_CHECK_LAUNCH: the arguments were accepted
+            failed[0] += 1
+            return
+        raise _lib.CvcsError(f"{what} failed ({rc}): {msg}")
+    monkeypatch.setattr(ops, "_stream", lambda: 0)
+    monkeypatch.setattr(ops, "check", check)
+    monkeypatch.setattr(_lib, "check", check)
+    return failed
+
+
+def _bind_on_cpu(net, dtype):
+    params = net._flat_order(OrderedDict(net.named_parameters()))
+    total = sum(nets._align4(p.numel()) for p in params.values())
+    flat, fg, off = torch.zeros(total), torch.zeros(total), 0
+    P, G = OrderedDict(), OrderedDict()
+    for k, p in params.items():
+        n = p.numel()
+        P[k], G[k] = flat[off:off + n].view(p.shape), fg[off:off + n].view(p.shape)
+        off += nets._align4(n)
+    eng = net._build_engine("cpu")
+    eng.bind(P, G, {k: v for k, v in net.named_buffers() if v.dtype == torch.float32})
+    return eng
+
+
+CASES = [("SwinTUperNet", {}, 4, 64), ("SwinTUperNet", {}, 2, 224), ("Resnet18Unet", {}, 2, 64), ("Resnet50Unet", {}, 2, 96),
+         ("Resnet50Unet", {"decoder_norm": "gn_silu"}, 2, 64), ("DeepLabV3Plus", {}, 2, 64), ("DeepLabv3Resnet101", {}, 2, 64)]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("cls,kw,B,S", CASES)
+def test_every_launch_of_the_plan_passes_the_c_abi_argument_checks(no_device, cls, kw, B, S, precision):
+    net = getattr(nets, cls)(5, precision, **kw)
+    eng = _bind_on_cpu(net, nets.PRECISIONS[precision])
+    x = torch.zeros(B, 3, S, S)
+    out = eng.forward(x, True)
+    assert tuple(out.shape) == (B, 5, S, S)
+    eng.backward(torch.zeros_like(out))
+    eng.forward(x, False)
+    fwd, bwd = len(eng._rec["fwd_train"].items), len(eng._rec["bwd"].items)
+    assert fwd > 20 and bwd > fwd and no_device[0] >= fwd + bwd
