@@ -9,8 +9,8 @@
 //     softmax, PV - one wave per (window, head), scores in registers, K / V in LDS; the backward recomputes the probabilities,
 //     and the gradient of the bias table comes out as per-chunk partial sums reduced in a fixed order (no atomics),
 //   adaptive average pooling (UPerNet's pyramid pooling) fwd / bwd, bilinear resize between arbitrary sizes fwd / bwd (gather).
-// A first, correct-by-construction version: the attention runs on the VALU (49 x 49 x 32 per window-head is 0.5 % of the
-// model's multiplies); its MFMA version (49 padded to 64) is listed in DESIGN.md section 7.
+// The f32 attention (parity path) runs on the VALU, one wave per (window, head); the bf16 attention on the matrix cores with the 49
+// tokens padded to 64 (attn_fwd_mfma_kernel / attn_bwd_mfma_kernel below).
 #include "common.h"
 
 namespace cvcs {
@@ -424,6 +424,356 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ window attention on the matrix cores (bf16)
+// One wave per (window, head); the 49 tokens are padded to 64 (keys j >= 49 get a bias of -1e30, queries i >= 49 are discarded).
+// Everything is computed TRANSPOSED so that no accumulator ever has to change lanes (cdna_hip_programming.md, "an accumulator tile
+// as the next MFMA's operand"):
+//   S^T[j][i] = sum_d K[j][d] Q[i][d]      A = K rows, B = Q rows: both fragments are 16-byte loads of a token row (no LDS);
+//                                          the accumulators START at bias[i][j] / scale (an LDS image in accumulator layout)
+//   softmax over j for a fixed i           i is the lane's column: 16 values in registers, two cross-lane steps
+//   O^T[d][i] = sum_j V[j][d] P[i][j]      B = P^T straight from the S^T accumulators (lane group g holds j = 4g..4g+3 and
+//                                          16+4g..16+4g+3 of each 32-key step); A = V^T by ds_read_b64_tr_b16 from a row-major V
+//                                          tile, whose 4-row blocks are exactly that k permutation
+//   the O^T accumulators hold 4 consecutive d of one token: 8-byte stores.
+// LDS V tile: [64 rows][64 B], the two 32-byte halves of a row swapped on rows with bit 2 set (lane groups g, g+1 of a 32-lane
+// half then read different banks); rows 49..63 are zeroed once.
+constexpr int kAttnWaves = 8;      // forward: waves per workgroup
+constexpr int kAttnBwdWaves = 4;   // backward
+
+__device__ __forceinline__ unsigned attn_tile_off(int row, int half) { return (unsigned)(row * 64 + ((half ^ ((row >> 2) & 1)) << 5)); }
+
+typedef __attribute__((ext_vector_type(4))) short at_s16x4;
+typedef __attribute__((ext_vector_type(8))) short at_s16x8;
+// A-operand fragment of X^T (X row-major [64][32] bf16 in LDS): lane (row d = 16*dt + l%16, group g), k = X rows 32*ks + {4g..4g+3, 16+4g..}
+__device__ __forceinline__ bf16x8 attn_tr_frag(const char* tile, int dt, int ks, int l) {
+  const int g = l >> 4, q = (l >> 2) & 3, pp = l & 3;
+  const int r0 = 32 * ks + 4 * g + q;
+  const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(tile + attn_tile_off(r0, dt) + 8 * pp));
+  const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(tile + attn_tile_off(r0 + 16, dt) + 8 * pp));
+  return __builtin_bit_cast(bf16x8, (at_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ f32x4 attn_mfma(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 attn_mfma(const bf16x8& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// two accumulator tiles (k rows 4g..4g+3 and 16+4g..) -> one 8-element bf16 operand fragment
+__device__ __forceinline__ uint4 attn_pack(const f32x4& a, const f32x4& b) {
+  return make_uint4(pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3]));
+}
+__device__ __forceinline__ float attn_red_max(float v) {   // over the four lane groups (lanes l, l^16, l^32, l^48)
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float attn_red_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+// bias image in accumulator layout: img[(a*4 + b)*64 + lane][r]; transposed = false: the tile (a, b) = (key tile, query tile) of S^T;
+// true: (query tile, key tile) of S.  Keys >= 49: -1e30; queries >= 49: 0.
+__device__ __forceinline__ void attn_bias_image(float* img, const float* __restrict__ table, int heads, int h, float inv_scale, bool transposed,
+                                                int tid, int nthreads) {
+  for (int e = tid; e < 16 * 64 * 4; e += nthreads) {
+    const int r = e & 3, ln = (e >> 2) & 63, t = e >> 8, a = t >> 2, b = t & 3;
+    const int row = 16 * a + 4 * (ln >> 4) + r, col = 16 * b + (ln & 15);
+    const int i = transposed ? row : col, j = transposed ? col : row;
+    float v;
+    if (j >= 49) v = -1e30f;
+    else if (i >= 49) v = 0.f;
+    else v = table[((i / 7 - j / 7 + 6) * 13 + (i % 7 - j % 7 + 6)) * heads + h] * inv_scale;
+    img[e] = v;
+  }
+}
+// region ids (shifted windows) of the tokens this lane meets: lane-indexed tokens 16x + c (x = 0..3) and row-indexed tokens
+// 16x + 4g + r (x = 0..3, r = 0..3); tokens >= 49 get region 15 (never equal matters not: their scores are masked or discarded)
+struct AttnRegions { int lane_tok[4]; int row_tok[4][4]; };
+__device__ __forceinline__ int attn_tok_region(const AttnArgs& p, int wy, int wx, int t) {
+  return t >= 49 ? 15 : attn_region(wy * 7 + t / 7, wx * 7 + t % 7, p.Hp, p.Wp, p.shift);
+}
+
+__global__ __launch_bounds__(kAttnWaves * 64) void attn_fwd_mfma_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) float sbias[16 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) char sv_all[kAttnWaves][64 * 64];
+  const int h = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+  attn_bias_image(sbias, p.table, p.heads, h, 1.f / p.scale, false, tid, kAttnWaves * 64);
+  char* sv = sv_all[wv];
+  if (l < 60) *reinterpret_cast<uint4*>(sv + 49 * 64 + l * 16) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  const int64_t ldb = p.qkv_ld * 2;
+  for (int w = blockIdx.x * kAttnWaves + wv; w < p.nwin; w += gridDim.x * kAttnWaves) {
+    const char* base = p.qkv + (int64_t)w * 49 * ldb + h * 64;
+    uint4 qf[4], kf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = min(16 * t + c, 48);
+      qf[t] = *reinterpret_cast<const uint4*>(base + row * ldb + g * 16);
+      kf[t] = *reinterpret_cast<const uint4*>(base + p.C * 2 + row * ldb + g * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = l + 64 * k;
+      if (e < 196) {
+        const int row = e >> 2, ch = e & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(base + 2 * p.C * 2 + row * ldb + ch * 16);
+        *reinterpret_cast<uint4*>(sv + attn_tile_off(row, ch >> 1) + ((ch & 1) << 4)) = v;
+      }
+    }
+    f32x4 acc[4][4];     // [key tile mt][query tile nt]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = attn_mfma(kf[mt], qf[nt], *reinterpret_cast<const f32x4*>(&sbias[((mt * 4 + nt) * 64 + l) * 4]));
+    const int wi = w % (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi % p.nwx;
+    const bool masked = p.shift != 0 && (wy == p.nwy - 1 || wx == p.nwx - 1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] *= p.scale;
+    if (masked) {
+      int rl[4], rr[4][4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        rl[x] = attn_tok_region(p, wy, wx, 16 * x + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[x][r] = attn_tok_region(p, wy, wx, 16 * x + 4 * g + r);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] += rr[mt][r] != rl[nt] ? -100.f : 0.f;
+    }
+    uint4 pf[4][2];      // P^T fragments [query tile][key step]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[mt][nt][r]);
+      mx = attn_red_max(mx);
+      float se = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[mt][nt][r] = __expf(acc[mt][nt][r] - mx); se += acc[mt][nt][r]; }
+      const float inv = 1.f / attn_red_sum(se);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] *= inv;
+      pf[nt][0] = attn_pack(acc[0][nt], acc[1][nt]);
+      pf[nt][1] = attn_pack(acc[2][nt], acc[3][nt]);
+    }
+    // (the V tile was written by this wave's own ds_write above: LDS operations of one wave complete in order)
+    bf16x8 vf[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) vf[dt][ks] = attn_tr_frag(sv, dt, ks, l);
+    char* obase = p.out + (int64_t)w * 49 * p.out_ld * 2 + h * 64;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int i = 16 * nt + c;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = attn_mfma(vf[dt][0], pf[nt][0], o);
+        o = attn_mfma(vf[dt][1], pf[nt][1], o);
+        if (i < 49) *reinterpret_cast<uint2*>(obase + (int64_t)i * p.out_ld * 2 + (16 * dt + 4 * g) * 2) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+      }
+    }
+  }
+}
+
+// Backward.  Per (window, head), with P recomputed:
+//   T pass (per 16-query column block): S^T, dP^T[j][i] = sum_d V[j][d] dO[i][d]  ->  softmax statistics and delta_i = sum_j P dP
+//     (kept in LDS for the second pass), dS^T = P^T (dP^T - delta)  ->  dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]  (A = K^T by transposed read)
+//   N pass (per 16-key column block): S[i][j], dP[i][j] in the other orientation (the same row fragments with A and B swapped), P and dS
+//     from the stored statistics  ->  dV^T[d][j] = sum_i dO[i][d] P[i][j],  dK^T[d][j] = sum_i Q[i][d] dS[i][j]  (A = dO^T, Q^T by
+//     transposed reads); dS is also accumulated over the wave's windows for the gradient of the bias table.
+// LDS per wave: Q, K, dO tiles ([64][64 B], as the forward's V tile) + 3 x 64 statistics; per workgroup the two bias images.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char at_smem[];
+  float* sbiasT = reinterpret_cast<float*>(at_smem);
+  float* sbiasN = sbiasT + 16 * 64 * 4;
+  const int h = blockIdx.y, tid = threadIdx.x, wv = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+  char* wbase = at_smem + 2 * 16384 + wv * (3 * 4096 + 768);
+  char* sq = wbase;
+  char* sk = wbase + 4096;
+  char* sdo = wbase + 8192;
+  float* stat = reinterpret_cast<float*>(wbase + 12288);     // max[64] | 1/sum[64] | delta[64]
+  attn_bias_image(sbiasT, p.table, p.heads, h, 1.f / p.scale, false, tid, NW * 64);
+  attn_bias_image(sbiasN, p.table, p.heads, h, 1.f / p.scale, true, tid, NW * 64);
+  if (l < 60) {
+    *reinterpret_cast<uint4*>(sq + 49 * 64 + l * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(sk + 49 * 64 + l * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(sdo + 49 * 64 + l * 16) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  f32x4 dsum[4][4];    // [query tile it][key tile jt], summed over this wave's windows
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dsum[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t ldb = p.qkv_ld * 2, ldd = p.dout_ld * 2, ldo = p.out_ld * 2;
+  for (int w = blockIdx.x * NW + wv; w < p.nwin; w += gridDim.x * NW) {
+    const char* base = p.qkv + (int64_t)w * 49 * ldb + h * 64;
+    const char* dbase = p.dout + (int64_t)w * 49 * ldd + h * 64;
+    char* obase = p.out + (int64_t)w * 49 * ldo + h * 64;
+    uint4 qf[4], kf[4], vf[4], dof[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = min(16 * t + c, 48);
+      qf[t] = *reinterpret_cast<const uint4*>(base + row * ldb + g * 16);
+      kf[t] = *reinterpret_cast<const uint4*>(base + p.C * 2 + row * ldb + g * 16);
+      vf[t] = *reinterpret_cast<const uint4*>(base + 2 * p.C * 2 + row * ldb + g * 16);
+      dof[t] = *reinterpret_cast<const uint4*>(dbase + row * ldd + g * 16);
+      if (16 * t + c < 49) {   // the same fragments fill the tiles the transposed reads take (chunk g of row 16t + c)
+        const unsigned off = attn_tile_off(16 * t + c, g >> 1) + ((g & 1) << 4);
+        *reinterpret_cast<uint4*>(sq + off) = qf[t];
+        *reinterpret_cast<uint4*>(sk + off) = kf[t];
+        *reinterpret_cast<uint4*>(sdo + off) = dof[t];
+      }
+    }
+    const int wi = w % (p.nwy * p.nwx), wy = wi / p.nwx, wx = wi % p.nwx;
+    const bool masked = p.shift != 0 && (wy == p.nwy - 1 || wx == p.nwx - 1);
+    unsigned rl = 0, rr[4] = {0, 0, 0, 0};     // 4-bit region ids: rl nibble x = token 16x + c; rr[x] nibble r = token 16x + 4g + r
+    if (masked) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        rl |= (unsigned)attn_tok_region(p, wy, wx, 16 * x + c) << (4 * x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[x] |= (unsigned)attn_tok_region(p, wy, wx, 16 * x + 4 * g + r) << (4 * r);
+      }
+    }
+    // ---- T pass: queries on the lanes
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        s[mt] = attn_mfma(kf[mt], qf[nt], *reinterpret_cast<const f32x4*>(&sbiasT[((mt * 4 + nt) * 64 + l) * 4])) * p.scale;
+        dp[mt] = attn_mfma(vf[mt], dof[nt], (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+      if (masked) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[mt][r] += ((rr[mt] >> (4 * r)) & 15u) != ((rl >> (4 * nt)) & 15u) ? -100.f : 0.f;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[mt][r]);
+      mx = attn_red_max(mx);
+      float se = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[mt][r] = __expf(s[mt][r] - mx); se += s[mt][r]; }
+      const float inv = 1.f / attn_red_sum(se);
+      float delta = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[mt][r] *= inv; delta += s[mt][r] * dp[mt][r]; }
+      delta = attn_red_sum(delta);
+      if (g == 0) { stat[16 * nt + c] = mx; stat[64 + 16 * nt + c] = inv; stat[128 + 16 * nt + c] = delta; }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[mt][r] *= dp[mt][r] - delta;      // dS^T
+      const uint4 ds0 = attn_pack(s[0], s[1]), ds1 = attn_pack(s[2], s[3]);
+      const int i = 16 * nt + c;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = attn_mfma(attn_tr_frag(sk, dt, 0, l), ds0, o);
+        o = attn_mfma(attn_tr_frag(sk, dt, 1, l), ds1, o);
+        o *= p.scale;
+        if (i < 49) *reinterpret_cast<uint2*>(obase + (int64_t)i * ldo + (16 * dt + 4 * g) * 2) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the column blocks apart: interleaved, their live tiles exceed the 256 registers of 2 waves / SIMD
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's statistics are in LDS (same-wave ordering; compiler fence)
+    // ---- N pass: keys on the lanes
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        s[it] = attn_mfma(qf[it], kf[jt], *reinterpret_cast<const f32x4*>(&sbiasN[((it * 4 + jt) * 64 + l) * 4])) * p.scale;
+        dp[it] = attn_mfma(dof[it], vf[jt], (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+      if (masked) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[it][r] += ((rr[it] >> (4 * r)) & 15u) != ((rl >> (4 * jt)) & 15u) ? -100.f : 0.f;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const f32x4 rmx = *reinterpret_cast<const f32x4*>(&stat[16 * it + 4 * g]);
+        const f32x4 rinv = *reinterpret_cast<const f32x4*>(&stat[64 + 16 * it + 4 * g]);
+        const f32x4 rdel = *reinterpret_cast<const f32x4*>(&stat[128 + 16 * it + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = 16 * it + 4 * g + r < 49;
+          const float pv = valid ? __expf(s[it][r] - rmx[r]) * rinv[r] : 0.f;
+          const float dsv = pv * (dp[it][r] - rdel[r]);
+          s[it][r] = pv;
+          dp[it][r] = valid ? dsv : 0.f;
+          dsum[it][jt][r] += dp[it][r];
+        }
+      }
+      const uint4 p0 = attn_pack(s[0], s[1]), p1 = attn_pack(s[2], s[3]);
+      const uint4 d0 = attn_pack(dp[0], dp[1]), d1 = attn_pack(dp[2], dp[3]);
+      const int j = 16 * jt + c;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
+        ov = attn_mfma(attn_tr_frag(sdo, dt, 0, l), p0, ov);
+        ov = attn_mfma(attn_tr_frag(sdo, dt, 1, l), p1, ov);
+        ok = attn_mfma(attn_tr_frag(sq, dt, 0, l), d0, ok);
+        ok = attn_mfma(attn_tr_frag(sq, dt, 1, l), d1, ok);
+        ok *= p.scale;
+        if (j < 49) {
+          char* row = obase + (int64_t)j * ldo + (16 * dt + 4 * g) * 2;
+          *reinterpret_cast<uint2*>(row + p.C * 2) = make_uint2(pack2_bf16(ok[0], ok[1]), pack2_bf16(ok[2], ok[3]));
+          *reinterpret_cast<uint2*>(row + 2 * p.C * 2) = make_uint2(pack2_bf16(ov[0], ov[1]), pack2_bf16(ov[2], ov[3]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tiles and statistics are rewritten by the next window
+  }
+  // per-wave partial of the bias-table gradient: part[chunk = workgroup * waves + wave][head][i * 49 + j]
+  float* o = p.dtable_part + ((int64_t)(blockIdx.x * NW + wv) * p.heads + h) * 49 * 49;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * it + 4 * g + r, j = 16 * jt + c;
+        if (i < 49 && j < 49) o[i * 49 + j] = dsum[it][jt][r];
+      }
+}
+
+// sum[h][t*49 + j] = sum over chunks of part[chunk][h][t*49 + j], chunk 0 first (coalesced over the entries; double accumulation)
+__global__ __launch_bounds__(256) void attn_dtable_sum_kernel(const float* __restrict__ part, int chunks, int heads, float* __restrict__ sum) {
+  const int id = blockIdx.x * 256 + threadIdx.x, n = heads * 49 * 49;
+  if (id >= n) return;
+  double a = 0.0;
+#pragma unroll 8
+  for (int c = 0; c < chunks; ++c) a += (double)part[(int64_t)c * n + id];
+  sum[id] = (float)a;
+}
+
 // dtable[r][h] = sum over chunks and the (t, j) pairs whose relative index is r, in a fixed order
 __global__ void attn_dtable_kernel(const float* __restrict__ part, int chunks, int heads, float* dtable) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -744,6 +1094,14 @@ static int attn_setup(const char* fn, AttnArgs& a, const void* qkv, int64_t qkv_
   return CVCS_OK;
 }
 
+// workgroups along x of the MFMA kernels: every wave of a workgroup walks windows of one head; about `per_cu` workgroups per CU in all
+static int attn_mfma_groups(int nwin, int heads, int per_cu, int waves) {
+  int g = (256 * per_cu) / heads;
+  if (g < 1) g = 1;
+  const int need = (int)cdiv(nwin, waves);
+  return need < g ? need : g;
+}
+
 extern "C" int cvcs_window_attention_fwd(const void* qkv, int64_t qkv_ld, int B, int H, int W, int C, int heads, int shift, const float* table,
                                          void* out, int64_t out_ld, int dtype, void* stream) {
   const char* fn = "cvcs_window_attention_fwd";
@@ -752,10 +1110,14 @@ extern "C" int cvcs_window_attention_fwd(const void* qkv, int64_t qkv_ld, int B,
   if ((rc = attn_setup(fn, a, qkv, qkv_ld, B, H, W, C, heads, shift, table, dtype))) return rc;
   if ((rc = sw_view(fn, out, out_ld, C, dtype == CVCS_F32 ? 4 : 2))) return rc;
   a.out = (char*)out; a.out_ld = out_ld;
-  const dim3 grid((unsigned)(a.nwin > 16384 ? 16384 : a.nwin), (unsigned)heads);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVCS_F32) hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(64), 0, st, a);
+  if (dtype == CVCS_F32) {
+    const dim3 grid((unsigned)(a.nwin > 16384 ? 16384 : a.nwin), (unsigned)heads);
+    hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, dim3(64), 0, st, a);
+  } else {
+    const dim3 grid((unsigned)attn_mfma_groups(a.nwin, heads, 4, kAttnWaves), (unsigned)heads);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(kAttnWaves * 64), 0, st, a);
+  }
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
@@ -770,7 +1132,8 @@ extern "C" int64_t cvcs_window_attention_bwd_workspace_floats(int B, int H, int 
   if (B <= 0 || H <= 0 || W <= 0 || heads <= 0) return CVCS_EINVAL;
   const int nwin = B * ((H + 6) / 7) * ((W + 6) / 7);
   int per;
-  return (int64_t)attn_chunking(nwin, per) * heads * 49 * 49;
+  const int valu = attn_chunking(nwin, per), mfma = attn_mfma_groups(nwin, heads, 1, kAttnBwdWaves) * kAttnBwdWaves;   // (one size for both dtypes)
+  return (int64_t)((valu > mfma ? valu : mfma) + 1) * heads * 49 * 49;   // (+1: the slab of the summed partials)
 }
 
 extern "C" int cvcs_window_attention_bwd(const void* qkv, int64_t qkv_ld, const void* dout, int64_t dout_ld, int B, int H, int W, int C, int heads,
@@ -784,12 +1147,24 @@ extern "C" int cvcs_window_attention_bwd(const void* qkv, int64_t qkv_ld, const 
   if ((rc = sw_view(fn, dout, dout_ld, C, es)) || (rc = sw_view(fn, dqkv, dqkv_ld, 3 * C, es))) return rc;
   CVCS_CHECK_ARG(dtable && workspace, "%s: null argument", fn);
   a.dout = (const char*)dout; a.dout_ld = dout_ld; a.out = (char*)dqkv; a.out_ld = dqkv_ld; a.dtable_part = workspace;
-  const int chunks = attn_chunking(a.nwin, a.wins_per_chunk);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)chunks, (unsigned)heads);
-  if (dtype == CVCS_F32) hipLaunchKernelGGL((attn_bwd_kernel<float>), grid, dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, dim3(64), 0, st, a);
-  hipLaunchKernelGGL(attn_dtable_kernel, dim3((unsigned)cdiv(169 * heads, 64)), dim3(64), 0, st, workspace, chunks, heads, dtable);
+  int chunks;
+  if (dtype == CVCS_F32) {
+    chunks = attn_chunking(a.nwin, a.wins_per_chunk);
+    hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3((unsigned)chunks, (unsigned)heads), dim3(64), 0, st, a);
+  } else {
+    // one workgroup of 4 waves per CU (84 KB of LDS, one wave per SIMD with up to 512 registers): with 8 waves the 256-register
+    // limit of two waves per SIMD spills 79 registers of the bias-gradient accumulators and the launch measured 8 % slower
+    const int groups = attn_mfma_groups(a.nwin, heads, 1, kAttnBwdWaves);
+    chunks = groups * kAttnBwdWaves;
+    constexpr int lds = 2 * 16384 + kAttnBwdWaves * (3 * 4096 + 768);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<kAttnBwdWaves>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel<kAttnBwdWaves>, dim3((unsigned)groups, (unsigned)heads), dim3(kAttnBwdWaves * 64), lds, st, a);
+  }
+  // partials -> one [heads][49*49] slab behind them -> the 169 x heads table entries
+  float* slab = workspace + (int64_t)chunks * heads * 49 * 49;
+  hipLaunchKernelGGL(attn_dtable_sum_kernel, dim3((unsigned)cdiv(heads * 49 * 49, 256)), dim3(256), 0, st, workspace, chunks, heads, slab);
+  hipLaunchKernelGGL(attn_dtable_kernel, dim3((unsigned)cdiv(169 * heads, 64)), dim3(64), 0, st, slab, 1, heads, dtable);
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }

@@ -150,7 +150,7 @@ def _attention_reference(qkv, B, H, Wd, heads, shift, table):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H,Wd,heads,shift", [(14, 14, 3, 0), (16, 16, 3, 3), (9, 12, 6, 3), (7, 7, 12, 0)])
+@pytest.mark.parametrize("H,Wd,heads,shift", [(14, 14, 3, 0), (16, 16, 3, 3), (9, 12, 6, 3), (7, 7, 12, 0), (140, 133, 3, 3)])
 def test_window_attention_forward_and_backward(dtype, H, Wd, heads, shift):
     g = torch.Generator().manual_seed(H * heads + shift)
     B, C_ = 2, heads * 32
