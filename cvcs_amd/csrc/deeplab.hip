@@ -328,6 +328,137 @@ __global__ __launch_bounds__(256) void linear_head_bwd_kernel(const char* x, int
   if (tid < NC) row[NC * C + tid] = accb;
 }
 
+// The same backward on the matrix cores (bf16 activations, HW % 32 == 0, C % 64 == 0): strips of 32 pixels of ONE image.
+//   dx^T[k][p] = sum_c w[c][k] dl[p][c]    A = w^T rows from an LDS image [C][32 classes] (bf16, zero rows for c >= NC), B = dl of the
+//                                          strip (the gradient of the logits enters every other data gradient of the bf16 path in bf16 too);
+//                                          the accumulators hold 4 consecutive channels of one pixel: 8-byte stores
+//   dW[c][k] = sum_p dl[p][c] x[p][k]      A = dl^T[c][p] (f32 strip image in LDS, split into bf16 high + low parts: two MFMAs keep the
+//                                          f32 gradient of the logits), B = x^T by ds_read_b64_tr_b16 from the row-major strip
+//                                          [32 px][C] (+32 B per row: the eight rows a 32-lane half reads fall on distinct banks);
+//                                          accumulators stay in registers over the workgroup's strips -> part[row][c][k]
+//   db[c]     = sum_p dl[p][c]             wave 0, from the same fragments (f32)
+// 4 waves: dx tiles split (pixel tile, channel half); dW channel tiles split in quarters.
+typedef __attribute__((ext_vector_type(4))) short lin_s16x4;
+typedef __attribute__((ext_vector_type(8))) short lin_s16x8;
+template <int MT>   // class tiles of 16: NC <= 16 -> 1, NC <= 32 -> 2
+__global__ __launch_bounds__(256, 2) void linear_head_bwd_mfma_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P,
+                                                                     int64_t HW, int C, const float* __restrict__ w, int NC, char* dx,
+                                                                     int64_t dx_ld, float* part) {
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  const int RS = C * 2 + 32;                   // x strip row stride (bytes)
+  char* sx = lsm;                              // [32][RS]
+  char* swT = sx + 32 * RS;                    // [C][64 B]: 32 classes of channel k, 16-byte chunk q stored at q ^ ((k >> 2) & 3)
+  float* sdl = reinterpret_cast<float*>(swT + C * 64);   // [32 classes][32 px] f32
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+  for (int id = tid; id < C * 4; id += 256) {
+    const int k = id >> 2, q = id & 3;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 8 * q + e < NC ? w[(int64_t)(8 * q + e) * C + k] : 0.f;
+    *reinterpret_cast<uint4*>(swT + k * 64 + ((q ^ ((k >> 2) & 3)) << 4)) = Elem<bf16_t>::pack(f);
+  }
+  for (int id = tid; id < 32 * 32; id += 256) sdl[id] = 0.f;
+  const int NTW = C / 64;                      // dW channel tiles per wave (C / 16 tiles over 4 waves)
+  f32x4 acc[MT][8];                            // up to C = 512 per pass; wider heads take a second pass over the tiles
+  float accb[MT] = {};
+  const int npass = (NTW + 7) / 8;
+  float* prow = part + (int64_t)blockIdx.x * ((int64_t)NC * C + NC);
+  const int64_t nstrips = P / 32;
+  for (int pass = 0; pass < npass; ++pass) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 8; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int64_t s = blockIdx.x; s < nstrips; s += gridDim.x) {
+      const int64_t p0 = s * 32, b = p0 / HW, hw0 = p0 - b * HW;
+      __syncthreads();
+      for (int id = tid; id < 32 * (C / 8); id += 256) {
+        const int r = id / (C / 8), cv = id - r * (C / 8);
+        *reinterpret_cast<uint4*>(sx + r * RS + cv * 16) = *reinterpret_cast<const uint4*>(x + (p0 + r) * x_ld * 2 + cv * 16);
+      }
+      for (int id = tid; id < NC * 32; id += 256) {
+        const int cc = id >> 5, pp = id & 31;
+        sdl[id] = dl[(b * NC + cc) * HW + hw0 + pp];
+      }
+      __syncthreads();
+      if (pass == 0) {
+        // ---- dx: wave -> pixel tile (wv & 1), channel tiles of half (wv >> 1)
+        const int pt = wv & 1;
+        float d8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d8[q] = sdl[(8 * g + q) * 32 + 16 * pt + c16];
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, Elem<bf16_t>::pack(d8));
+        const int kt0 = (wv >> 1) * (C / 32), kt1 = kt0 + C / 32;
+        char* drow = dx + (p0 + 16 * pt + c16) * dx_ld * 2;
+        for (int kt = kt0; kt < kt1; ++kt) {
+          const int k = 16 * kt + c16;
+          const uint4 a = *reinterpret_cast<const uint4*>(swT + k * 64 + ((g ^ ((k >> 2) & 3)) << 4));
+          const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), bfrag, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          *reinterpret_cast<uint2*>(drow + (16 * kt + 4 * g) * 2) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+        }
+      }
+      // ---- dW: A = dl^T[class 16m + c16][pixels 4g..4g+3, 16+4g..] as high + low bf16 parts
+      bf16x8 ahi[MT], alo[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sdl[(16 * m + c16) * 32 + 4 * g]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&sdl[(16 * m + c16) * 32 + 16 + 4 * g]);
+        float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, lo[8];
+        const uint4 hi = Elem<bf16_t>::pack(f);
+        float fh[8];
+        Elem<bf16_t>::unpack(hi, fh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lo[e] = f[e] - fh[e];
+        ahi[m] = __builtin_bit_cast(bf16x8, hi);
+        alo[m] = __builtin_bit_cast(bf16x8, Elem<bf16_t>::pack(lo));
+        if (pass == 0 && wv == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) accb[m] += f[e];
+        }
+      }
+      const int q4 = (l >> 2) & 3, pp4 = l & 3;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int nt = wv * NTW + pass * 8 + n;
+        if (pass * 8 + n < NTW) {
+          const char* a0 = sx + (4 * g + q4) * RS + (16 * nt + 4 * pp4) * 2;
+          const lin_s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lin_s16x4*)a0);
+          const lin_s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lin_s16x4*)(a0 + 16 * RS));
+          const bf16x8 bx = __builtin_bit_cast(bf16x8, (lin_s16x8)__builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[m], bx, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[m], bx, acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // partial row: acc tile (m, n): lane holds classes 16m + 4g + r of channel 16nt + c16
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int nt = wv * NTW + pass * 8 + n;
+      if (pass * 8 + n < NTW) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cc = 16 * m + 4 * g + r;
+            if (cc < NC) prow[(int64_t)cc * C + 16 * nt + c16] = acc[m][n][r];
+          }
+      }
+    }
+  }
+  if (wv == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v = accb[m];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (g == 0 && 16 * m + c16 < NC) prow[(int64_t)NC * C + 16 * m + c16] = v;
+    }
+  }
+}
+
 static int dl_check_view(const char* fn, const void* ptr, int64_t ld, int C, int es) {
   CVCS_CHECK_ARG(ptr != nullptr, "%s: null tensor", fn);
   CVCS_CHECK_ARG(((uintptr_t)ptr % 16) == 0 && ld >= C && (ld * es) % 16 == 0, "%s: view must be 16-byte aligned with ld >= C", fn);
@@ -469,11 +600,24 @@ extern "C" int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dl
   CVCS_CHECK_ARG(x && dlogits && w && dx && part_dw && B > 0 && H > 0 && W > 0, "%s: null argument", fn);
   if ((rc = dl_check_view(fn, x, x_ld, C, es)) || (rc = dl_check_view(fn, dx, dx_ld, C, es))) return rc;
   const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_BF16 && HW % 32 == 0 && C % 64 == 0) {   // matrix-core path (see linear_head_bwd_mfma_kernel)
+    const size_t lds_m = (size_t)32 * (C * 2 + 32) + (size_t)C * 64 + 32 * 32 * 4;
+    const dim3 grid_m((unsigned)cvcs_linear_head_bwd_rows(P));
+    if (NC <= 16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_head_bwd_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((linear_head_bwd_mfma_kernel<1>), grid_m, dim3(256), lds_m, st, (const char*)x, x_ld, dlogits, P, HW, C, w, NC, (char*)dx, dx_ld, part_dw);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_head_bwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((linear_head_bwd_mfma_kernel<2>), grid_m, dim3(256), lds_m, st, (const char*)x, x_ld, dlogits, P, HW, C, w, NC, (char*)dx, dx_ld, part_dw);
+    }
+    CVCS_CHECK_LAUNCH(fn);
+    return CVCS_OK;
+  }
   const int TP = lin_strip(C);
   const size_t lds = (size_t)(TP * C + TP * (NC + 1) + NC * C) * 4;
   CVCS_CHECK_ARG(lds <= 160 * 1024, "%s: C=%d, NC=%d need %zu bytes of LDS", fn, C, NC, lds);
   const dim3 grid((unsigned)cvcs_linear_head_bwd_rows(P));
-  hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_LINB(TT)                                                                                                       \
   do {                                                                                                                        \
     static bool attr_done = false;                                                                                            \

@@ -93,11 +93,13 @@ def test_image_pooling_mean_and_broadcast(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C_,NC", [(256, 21), (64, 5), (512, 16)])
-def test_linear_head_any_channel_count(dtype, C_, NC):
+@pytest.mark.parametrize("C_,NC,H,W", [(256, 21, 9, 13), (64, 5, 9, 13), (512, 16, 9, 13),
+                                       # H * W a multiple of 32 and C of 64: the bf16 backward runs on the matrix cores
+                                       (512, 16, 8, 16), (256, 21, 16, 16), (64, 5, 4, 8), (1024, 3, 8, 8), (192, 32, 8, 12)])
+def test_linear_head_any_channel_count(dtype, C_, NC, H, W):
     """the 1x1 classifier (S/nets.py:243-244) on C channels: logits, fused argmax, backward (dx, dW, db)"""
     g = torch.Generator().manual_seed(C_ + NC)
-    B, H, W = 2, 9, 13
+    B = 3
     x = rq(torch.randn(B, C_, H, W, generator=g), dtype).requires_grad_(True)
     w = (torch.randn(NC, C_, 1, 1, generator=g) / C_ ** 0.5).requires_grad_(True)
     b = torch.randn(NC, generator=g).requires_grad_(True)
