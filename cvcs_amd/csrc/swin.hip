@@ -21,72 +21,83 @@ static inline unsigned sw_grid(int64_t total, int cap = 256 * 32) {
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// one wave per token; lane l holds the 16-byte chunks l, l+64, ... (C <= 1536: 3 chunks per lane in bf16, 6 in f32)
+// G lanes per token (G = 64: one wave per token, lane l holds the 16-byte chunks l, l+64, ... - C <= 1536: 3 chunks per lane in bf16, 6 in
+// f32; G = 16 / 32: the narrow stages - C = 96 is 12 chunks in bf16 - put 4 / 2 tokens on a wave, one chunk per lane)
 template <typename T> struct LnChunks { static constexpr int n = sizeof(T) == 4 ? 6 : 3; };
-template <typename T>
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T, int G>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const char* x, int64_t x_ld, int64_t M, int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, char* out, int64_t out_ld,
                                                            float* mean_out, float* invstd_out) {
-  constexpr int ES = sizeof(T), V = 16 / ES, kLnMaxChunks = LnChunks<T>::n;
+  constexpr int ES = sizeof(T), V = 16 / ES, NCH = G == 64 ? LnChunks<T>::n : 1, TPW = 64 / G;
   const int CC = C / V;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t tok = (int64_t)blockIdx.x * 4 + wave; tok < M; tok += (int64_t)gridDim.x * 4) {
-    float v[kLnMaxChunks][V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / G, sl = lane % G;
+  for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TPW; t0 < M; t0 += (int64_t)gridDim.x * 4 * TPW) {
+    const int64_t tok = t0 + sub;
+    const bool live = tok < M;
+    float v[NCH][V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnMaxChunks; ++i) {
-      const int cc = lane + 64 * i;
-      if (cc < CC) {
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = sl + G * i;
+      if (live && cc < CC) {
         Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + tok * x_ld * ES + cc * 16), v[i]);
 #pragma unroll
         for (int k = 0; k < V; ++k) s += v[i][k];
       }
     }
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = group_sum<G>(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnMaxChunks; ++i)
-      if (lane + 64 * i < CC) {
+    for (int i = 0; i < NCH; ++i)
+      if (live && sl + G * i < CC) {
 #pragma unroll
         for (int k = 0; k < V; ++k) { const float d = v[i][k] - mean; q += d * d; }
       }
-    const float invstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+    const float invstd = 1.f / sqrtf(group_sum<G>(q) / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < kLnMaxChunks; ++i) {
-      const int cc = lane + 64 * i;
-      if (cc < CC) {
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = sl + G * i;
+      if (live && cc < CC) {
 #pragma unroll
         for (int k = 0; k < V; ++k) v[i][k] = (v[i][k] - mean) * invstd * gamma[cc * V + k] + beta[cc * V + k];
         *reinterpret_cast<uint4*>(out + tok * out_ld * ES + cc * 16) = Elem<T>::pack(v[i]);
       }
     }
-    if (lane == 0) { mean_out[tok] = mean; invstd_out[tok] = invstd; }
+    if (live && sl == 0) { mean_out[tok] = mean; invstd_out[tok] = invstd; }
   }
 }
 
 // backward: dx = invstd * (gamma*g - mean_c(gamma*g) - xhat * mean_c(gamma*g*xhat)); partial rows part[block][0|1][C] of
 // dgamma = sum_tokens g*xhat and dbeta = sum_tokens g (reduced by cvcs_colsum_finalize over 2C columns)
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const char* x, int64_t x_ld, const char* g, int64_t g_ld, int64_t M, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, char* dx, int64_t dx_ld, float* part) {
-  constexpr int ES = sizeof(T), V = 16 / ES, kLnMaxChunks = LnChunks<T>::n;
-  extern __shared__ float sred[];      // [4 waves][2][C]
+  constexpr int ES = sizeof(T), V = 16 / ES, NCH = G == 64 ? LnChunks<T>::n : 1, TPW = 64 / G;
+  extern __shared__ float sred[];      // [4 waves * TPW token slots][2][C]
   const int CC = C / V;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[kLnMaxChunks][V], db[kLnMaxChunks][V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / G, sl = lane % G;
+  float dg[NCH][V], db[NCH][V];
 #pragma unroll
-  for (int i = 0; i < kLnMaxChunks; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int k = 0; k < V; ++k) { dg[i][k] = 0.f; db[i][k] = 0.f; }
-  for (int64_t tok = (int64_t)blockIdx.x * 4 + wave; tok < M; tok += (int64_t)gridDim.x * 4) {
-    const float mu = mean[tok], is = invstd[tok];
-    float xh[kLnMaxChunks][V], gg[kLnMaxChunks][V];
+  for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TPW; t0 < M; t0 += (int64_t)gridDim.x * 4 * TPW) {
+    const int64_t tok = t0 + sub;
+    const bool live = tok < M;
+    const float mu = live ? mean[tok] : 0.f, is = live ? invstd[tok] : 0.f;
+    float xh[NCH][V], gg[NCH][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnMaxChunks; ++i) {
-      const int cc = lane + 64 * i;
-      if (cc < CC) {
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = sl + G * i;
+      if (live && cc < CC) {
         float gv[V];
         Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + tok * x_ld * ES + cc * 16), xh[i]);
         Elem<T>::unpack(*reinterpret_cast<const uint4*>(g + tok * g_ld * ES + cc * 16), gv);
@@ -101,12 +112,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const char* x, int64
         }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    s1 = group_sum<G>(s1) / (float)C;
+    s2 = group_sum<G>(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < kLnMaxChunks; ++i) {
-      const int cc = lane + 64 * i;
-      if (cc < CC) {
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = sl + G * i;
+      if (live && cc < CC) {
         float o[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) o[k] = is * (gg[i][k] - s1 - xh[i][k] * s2);
@@ -114,21 +125,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const char* x, int64
       }
     }
   }
+  const int slot = wave * TPW + sub;
 #pragma unroll
-  for (int i = 0; i < kLnMaxChunks; ++i) {
-    const int cc = lane + 64 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int cc = sl + G * i;
     if (cc < CC)
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        sred[(wave * 2 + 0) * C + cc * V + k] = dg[i][k];
-        sred[(wave * 2 + 1) * C + cc * V + k] = db[i][k];
+        sred[(slot * 2 + 0) * C + cc * V + k] = dg[i][k];
+        sred[(slot * 2 + 1) * C + cc * V + k] = db[i][k];
       }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int which = i / C, c = i - which * C;
-    part[(int64_t)blockIdx.x * 2 * C + i] = sred[(0 * 2 + which) * C + c] + sred[(1 * 2 + which) * C + c] + sred[(2 * 2 + which) * C + c] +
-                                            sred[(3 * 2 + which) * C + c];
+    float a = 0.f;
+#pragma unroll
+    for (int sidx = 0; sidx < 4 * TPW; ++sidx) a += sred[(sidx * 2 + which) * C + c];
+    part[(int64_t)blockIdx.x * 2 * C + i] = a;
   }
 }
 
@@ -966,10 +980,13 @@ extern "C" int cvcs_layernorm_fwd(const void* x, int64_t x_ld, int64_t M, int C,
   CVCS_CHECK_ARG(gamma && beta && mean && invstd, "%s: null argument", fn);
   int rc;
   if ((rc = sw_view(fn, x, x_ld, C, es)) || (rc = sw_view(fn, out, out_ld, C, es))) return rc;
-  const dim3 grid((unsigned)(cdiv(M, 4) > 16384 ? 16384 : cdiv(M, 4)));
+  const dim3 grid((unsigned)(cdiv(M, 16) > 16384 ? 16384 : cdiv(M, 16)));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVCS_F32) hipLaunchKernelGGL((layernorm_fwd_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, M, C, gamma, beta, eps, (char*)out, out_ld, mean, invstd);
-  else hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)x, x_ld, M, C, gamma, beta, eps, (char*)out, out_ld, mean, invstd);
+  const int CC = C / (16 / es), G = CC <= 16 ? 16 : (CC <= 32 ? 32 : 64);     // lanes per token
+#define LN_F(TT, GG) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, GG>), grid, dim3(256), 0, st, (const char*)x, x_ld, M, C, gamma, beta, eps, (char*)out, out_ld, mean, invstd)
+  if (dtype == CVCS_F32) { if (G == 16) LN_F(float, 16); else if (G == 32) LN_F(float, 32); else LN_F(float, 64); }
+  else { if (G == 16) LN_F(bf16_t, 16); else if (G == 32) LN_F(bf16_t, 32); else LN_F(bf16_t, 64); }
+#undef LN_F
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
@@ -984,10 +1001,13 @@ extern "C" int cvcs_layernorm_bwd(const void* x, int64_t x_ld, const void* g, in
   int rc;
   if ((rc = sw_view(fn, x, x_ld, C, es)) || (rc = sw_view(fn, g, g_ld, C, es)) || (rc = sw_view(fn, dx, dx_ld, C, es))) return rc;
   const dim3 grid((unsigned)cvcs_layernorm_rows(M));
-  const size_t lds = (size_t)4 * 2 * C * 4;
+  const int CC = C / V, G = CC <= 16 ? 16 : (CC <= 32 ? 32 : 64);
+  const size_t lds = (size_t)4 * (64 / G) * 2 * C * 4;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVCS_F32) hipLaunchKernelGGL((layernorm_bwd_kernel<float>), grid, dim3(256), lds, st, (const char*)x, x_ld, (const char*)g, g_ld, M, C, gamma, mean, invstd, (char*)dx, dx_ld, part);
-  else hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), grid, dim3(256), lds, st, (const char*)x, x_ld, (const char*)g, g_ld, M, C, gamma, mean, invstd, (char*)dx, dx_ld, part);
+#define LN_B(TT, GG) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, GG>), grid, dim3(256), lds, st, (const char*)x, x_ld, (const char*)g, g_ld, M, C, gamma, mean, invstd, (char*)dx, dx_ld, part)
+  if (dtype == CVCS_F32) { if (G == 16) LN_B(float, 16); else if (G == 32) LN_B(float, 32); else LN_B(float, 64); }
+  else { if (G == 16) LN_B(bf16_t, 16); else if (G == 32) LN_B(bf16_t, 32); else LN_B(bf16_t, 64); }
+#undef LN_B
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }

@@ -460,9 +460,19 @@ class SwinTUperNet(_HipUNet):
         return SwinUPerNetEngine(self.num_classes, PRECISIONS[self.precision], dev)
 
     def _flat_order(self, params):
-        # q | k | v weights, then their biases, adjacent: the engine runs the three projections as one [3C, C] GEMM
+        # (1) q | k | v weights, then their biases, adjacent: the engine runs the three projections as one [3C, C] GEMM;
+        # (2) the output LayerNorm of stage s right behind that stage's blocks (registered after the whole encoder, its gradient is
+        #     finished between the downsample's and the blocks' - the data-parallel reducer takes "every gradient at a flat offset >= x
+        #     is final" signals, so the flat order must be the reverse of the order the backward finishes gradients in)
+        stage_norm = {s: [n for n in params if n.startswith(f"backbone.hidden_states_norms.stage{s + 1}.")] for s in range(3)}
         out = OrderedDict()
         for name, p in params.items():
+            for s in range(3):
+                if name == f"backbone.swin.encoder.layers.{s}.downsample.reduction.weight":
+                    for n in stage_norm[s]:
+                        out[n] = params[n]
+            if any(name in v for v in stage_norm.values()):
+                continue
             if name.endswith(".attention.q_proj.weight"):
                 att = name[:-len("q_proj.weight")]
                 for leaf in ("weight", "bias"):

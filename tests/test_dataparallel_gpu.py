@@ -107,17 +107,17 @@ def test_two_ranks_exact_mode_match_one_process_on_the_whole_batch():
 
 
 # ---------------------------------------------------------------------------------------------------- ResNet-UNet (replayed launch plans)
-def _resnet_net(seed=0):
+def _resnet_net(seed=0, name="Resnet18Unet"):
     from cvcs_amd import utils
     torch.manual_seed(seed)
-    net = utils.load_network({"net": "Resnet18Unet", "num_classes": NC - 1, "precision": "fp32"}, "cuda:0")
+    net = utils.load_network({"net": name, "num_classes": NC - 1, "precision": "fp32"}, "cuda:0")
     crit = utils.CrossEntropyLoss(ignore_index=0)
     optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
     net.train()
     return net, crit, optim
 
 
-def _resnet_worker(rank, world, port, path):
+def _resnet_worker(rank, world, port, path, name="Resnet18Unet"):
     import torch.distributed as dist
     from oracle import unet_oracle as O
     from cvcs_amd.parallel import DataParallel, shard_batch
@@ -127,7 +127,7 @@ def _resnet_worker(rank, world, port, path):
     try:
         img, lab = O.synthetic_tiles(B, S, NC, seed=22, structured=True)
         lo, hi = shard_batch(B, rank, world)
-        net, crit, optim = _resnet_net()
+        net, crit, optim = _resnet_net(name=name)
         net.flat_parameters()
         DataParallel(net, optim, bucket_mb=4.0)      # torch-DDP semantics: per-rank BatchNorm statistics, averaged gradients
         flats, losses = [], []
@@ -142,14 +142,16 @@ def _resnet_worker(rank, world, port, path):
         dist.destroy_process_group()
 
 
-def test_resnet_unet_two_ranks_average_their_gradients_through_the_replayed_plan():
-    """the bucket hooks are host callbacks INSIDE the recorded backward launch list (resnet_engine._ready): two ranks must
+@pytest.mark.parametrize("name", ["Resnet18Unet", "TSwin"])
+def test_resnet_unet_two_ranks_average_their_gradients_through_the_replayed_plan(name):
+    """(also Swin-T + UPerNet, whose flat parameter order is arranged for exactly this: nets.SwinTUperNet._flat_order)
+    the bucket hooks are host callbacks INSIDE the recorded backward launch list (resnet_engine._ready): two ranks must
     hold bit-identical parameters after every step, and the first update must be the fused SGD2 step on the MEAN of the two
     shards' gradients (each computed here by a plain single-process backward on that shard)"""
     from oracle import unet_oracle as O
     from cvcs_amd.parallel import shard_batch
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_resnet_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        mp.spawn(_resnet_worker, args=(2, _free_port(), tmp, name), nprocs=2, join=True)
         r0, r1 = (torch.load(f"{tmp}/rank{r}.pt") for r in range(2))
     for a, b in zip(r0["flats"], r1["flats"]):
         assert torch.equal(a, b)
@@ -157,11 +159,11 @@ def test_resnet_unet_two_ranks_average_their_gradients_through_the_replayed_plan
     grads = []
     for r in range(2):
         lo, hi = shard_batch(B, r, 2)
-        net, crit, optim = _resnet_net()
+        net, crit, optim = _resnet_net(name=name)
         crit(net(img[lo:hi].to("cuda:0"), None), lab[lo:hi].to("cuda:0")).backward()
         torch.cuda.synchronize()
         grads.append(net.flat_parameters()[1].detach().clone())
-    net, crit, optim = _resnet_net()
+    net, crit, optim = _resnet_net(name=name)
     flat, flat_grad = net.flat_parameters()
     flat_grad.copy_((grads[0] + grads[1]) / 2)
     optim.step()

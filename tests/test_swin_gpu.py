@@ -39,7 +39,7 @@ def tok(t, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C_,M", [(96, 70), (384, 33), (1536, 9), (768, 130)])
+@pytest.mark.parametrize("C_,M", [(96, 70), (192, 45), (384, 33), (1536, 9), (768, 130)])
 def test_layernorm_forward_and_backward(dtype, C_, M):
     g = torch.Generator().manual_seed(C_)
     x = rq(torch.randn(M, C_, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
