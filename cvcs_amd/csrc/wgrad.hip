@@ -286,14 +286,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
   const char* src0[PPW];
   int64_t rowb[PPW];      // bytes per pixel row of the source
   int prow[PPW];          // pixel row inside the K-tile
+  bool colok[PPW];        // channel counts that are no multiple of the tile (96 * 2^k): chunks beyond the last channel read zeros
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int pi = wave + 4 * i;
     const int blk = pi >> 2, row = (pi & 3) * 8 + rr;
     const int c = pc ^ (((row >> 1) & 3) << 1);   // logical 16-byte chunk stored at physical chunk pc
     prow[i] = row;
-    if (blk < MB) { src0[i] = p.dy + ((int64_t)co0 + blk * 64) * 2 + c * 16; rowb[i] = p.dy_ld * 2; }
-    else          { src0[i] = p.x + ((int64_t)ci0 + (blk - MB) * 64) * 2 + c * 16; rowb[i] = p.x_ld * 2; }
+    if (blk < MB) { src0[i] = p.dy + ((int64_t)co0 + blk * 64) * 2 + c * 16; rowb[i] = p.dy_ld * 2; colok[i] = co0 + blk * 64 + c * 8 < p.Cout; }
+    else          { src0[i] = p.x + ((int64_t)ci0 + (blk - MB) * 64) * 2 + c * 16; rowb[i] = p.x_ld * 2; colok[i] = ci0 + (blk - MB) * 64 + c * 8 < p.Cin; }
   }
   const bool shifted = (p.sh_y | p.sh_x) != 0;
   const int64_t sh_lin = (int64_t)p.sh_y * p.W + p.sh_x;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       int64_t pix = (int64_t)kt * 32 + prow[i];
-      bool ok = pix < M;
+      bool ok = pix < M && colok[i];
       if (shifted && (wave + 4 * i) >= 4 * MB) {      // an x piece of a shifted tap: the source pixel must stay inside its image
         const int ox = (int)(pix % p.W), oy = (int)((pix / p.W) % p.H);
         ok = ok && (unsigned)(oy + p.sh_y) < (unsigned)p.H && (unsigned)(ox + p.sh_x) < (unsigned)p.W;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wm * (BM / 2) + i * 16 + fg * 4 + r;
-        ws[(int64_t)co * p.Cin + ci] = acc[i][j][r];
+        if (co < p.Cout && ci < p.Cin) ws[(int64_t)co * p.Cin + ci] = acc[i][j][r];
       }
     }
 }
@@ -870,15 +871,20 @@ static int fast_path(const cvcs_wgrad_desc* d) {
 struct GemmPlan { int BM, BN, ktiles, per_slice, nslice, tiles_mn, ntile_n; };
 static bool gemm_shape(int KH, int KW, int stride, int Cout, int Cin) {
   static const int on = getenv("CVCS_WGRAD_GEMM") ? atoi(getenv("CVCS_WGRAD_GEMM")) : 1;   // tuning knob
-  return on && KH == 1 && KW == 1 && stride == 1 && Cout % 64 == 0 && Cin % 64 == 0 && (Cout % 128 == 0 || Cin % 128 == 0);
+  // channel counts: multiples of 8 (a 16-byte chunk); the last tile of a count that is no multiple of the tile is masked
+  // (chunks beyond the last channel read zeros, their outputs are not stored) - the 96 * 2^k widths of Swin
+  return on && KH == 1 && KW == 1 && stride == 1 && Cout % 8 == 0 && Cin % 8 == 0 && (Cout > 64 || Cin > 64);
 }
 static GemmPlan gemm_plan(int B, int Ho, int Wo, int Cout, int Cin) {
   GemmPlan g;
-  g.BM = Cout % 128 == 0 ? 128 : 64;
-  g.BN = Cin % 128 == 0 ? 128 : 64;
+  g.BM = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 128);
+  g.BN = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 128);
+  if (g.BM == 64 && g.BN == 64) {           // (no 64 x 64 instance)
+    if (Cout >= Cin) g.BM = 128; else g.BN = 128;
+  }
   g.ktiles = (int)cdiv((int64_t)B * Ho * Wo, 32);
-  g.ntile_n = Cin / g.BN;
-  g.tiles_mn = (Cout / g.BM) * g.ntile_n;
+  g.ntile_n = (int)cdiv(Cin, g.BN);
+  g.tiles_mn = (int)cdiv(Cout, g.BM) * g.ntile_n;
   int want = (int)cdiv(512, g.tiles_mn);     // two resident workgroups per CU
   if (want > g.ktiles) want = g.ktiles;
   if (want < 1) want = 1;
