@@ -159,8 +159,22 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    probe = {}
     if not a.no_kernel_timers:
+        # Every tagged launch bracketed by two HIP events costs the step ~2.5 % (600 launches): two untimed, fully instrumented steps give
+        # the kernel-family table and name the dominant conv family; the TIMED region then brackets that family only (+ the 3x3 halo
+        # convs for `roofline_encoder`) - `roofline` is measured live over exactly the timed steps, `kernel_families` over the probe steps
         ops.TIMERS = ops.KernelTimers()
+        for _ in range(2):
+            step()
+        probe = ops.TIMERS.summary()
+        pf = {}
+        for kind, t in probe.items():
+            if kind.startswith("conv"):
+                pf[kind.split(":")[0]] = pf.get(kind.split(":")[0], 0.0) + t["total_ms"]
+        dom_family = max(pf, key=pf.get)
+        ops.TIMERS = ops.KernelTimers(only={dom_family, "conv3x3_halo"})
+        fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
@@ -200,29 +214,35 @@ def main():
             "median_ms_per_step": round(statistics.median(per_step), 3),
         }
         if timers:
-            # kernel families (HIP-event brackets on the launch stream inside the timed region); scopes: enc / dec
-            fams = {}
-            for kind, t in timers.items():
-                fam = kind.split(":")[0]
-                f = fams.setdefault(fam, dict(ms=0.0, flops=0.0, launches=0))
-                f["ms"] += t["total_ms"]; f["flops"] += t["flops"]; f["launches"] += t["launches"]
+            # kernel families (HIP-event brackets on the launch stream); scopes: enc / dec.  `live`: inside the timed region
+            def families(tt):
+                out_ = {}
+                for kind, t in tt.items():
+                    fam = kind.split(":")[0]
+                    f = out_.setdefault(fam, dict(ms=0.0, flops=0.0, launches=0))
+                    f["ms"] += t["total_ms"]; f["flops"] += t["flops"]; f["launches"] += t["launches"]
+                return out_
+            live, fams = families(timers), families(probe)
+            psteps = 2
 
-            def line(f, kernel):
+            def line(f, kernel, nsteps):
                 tf = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
                 return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tf / peak, 4), "launches_per_step": f["launches"] // a.steps,
+                        "frac": round(tf / peak, 4), "launches_per_step": f["launches"] // nsteps,
                         "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
-                        "algorithmic_gflop_per_step": round(f["flops"] / a.steps / 1e9, 1),
-                        "ms_per_step": round(f["ms"] / a.steps, 3)}
+                        "algorithmic_gflop_per_step": round(f["flops"] / nsteps / 1e9, 1),
+                        "ms_per_step": round(f["ms"] / nsteps, 3)}
             dom = max((k for k in fams if k.startswith("conv")), key=lambda k: fams[k]["ms"])
-            out["roofline"] = line(fams[dom], FAMILY_KERNEL.get(dom, dom))
+            out["roofline"] = line(live[dom], FAMILY_KERNEL.get(dom, dom), a.steps)
+            out["roofline"]["measured"] = f"HIP events on the launch stream around every launch of this family in the {a.steps} timed steps"
             out["roofline"]["traffic"] = None
-            out["kernel_families"] = {k: line(f, FAMILY_KERNEL.get(k, k)) for k, f in fams.items() if k != dom}
+            out["kernel_families"] = {k: line(f, FAMILY_KERNEL.get(k, k), psteps) for k, f in fams.items() if k != dom}
+            out["kernel_families_measured"] = f"{psteps} fully instrumented steps before the timed region (bracketing all ~600 launches costs the step 2.5 %)"
             # the 3x3 ENCODER convolutions (the set the north star's >= 50 % target is written for), forward + data gradient
             enc = [t for kind, t in timers.items() if kind.startswith("conv3x3_halo") and kind.endswith(":enc")]
             if enc:
                 e = dict(ms=sum(t["total_ms"] for t in enc), flops=sum(t["flops"] for t in enc), launches=sum(t["launches"] for t in enc))
-                out["roofline_encoder"] = line(e, "conv3x3_halo_kernel, encoder 3x3 convolutions only (forward + data gradient)")
+                out["roofline_encoder"] = line(e, "conv3x3_halo_kernel, encoder 3x3 convolutions only (forward + data gradient)", a.steps)
             pmc = os.path.join(ROOT, "profiles", PMC_FILES.get(a.net, ""))
             if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and os.path.isfile(pmc):
                 kern = {"conv3x3_halo": "conv3x3_halo_kernel", "conv_taps": "conv_taps_kernel", "conv_igemm": "conv_igemm_kernel"}.get(dom)
@@ -230,10 +250,10 @@ def main():
                 if pm:
                     out["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
                     out["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{PMC_FILES[a.net]})"
-            tot = sum(f["ms"] for f in fams.values())
-            out["mfma_kernels_share_of_step"] = round(tot / (1e3 * dt), 3)
-            out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in fams.values()) / a.steps / 1e9, 1)
-            out["step_tflops"] = round(sum(f["flops"] for f in fams.values()) / dt / 1e12, 1)
+            tot = sum(f["ms"] for f in fams.values()) / psteps
+            out["mfma_kernels_share_of_step"] = round(tot / (1e3 * dt / a.steps), 3)
+            out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in fams.values()) / psteps / 1e9, 1)
+            out["step_tflops"] = round(sum(f["flops"] for f in fams.values()) / psteps * a.steps / dt / 1e12, 1)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.net, NC, a.tile, 2, 2)
         print(json.dumps(out), flush=True)

@@ -158,15 +158,24 @@ _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvc
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 
 
+lane = 0                   # 0: the launch belongs to the main chain of the plan; 1: it may run beside it (ops.side_lane())
+
+
 class Recording:
     """A launch plan: the sequence of C-ABI launches (function, arguments without the stream) that one pass of a network
     issues for one input shape, captured while it runs eagerly ONCE and replayed every later step with no Python between
     the launches but this loop.  Every pointer in it is a persistent engine buffer; descriptors are kept alive by the
     argument tuples.  ("HIP streams and graphs instead of a tracing compiler": this is the host-side launch list; the same
-    replay runs under a HIP-graph capture unchanged.)  Host callbacks (data-parallel bucket hooks) are recorded in place."""
+    replay runs under a HIP-graph capture unchanged.)  Host callbacks (data-parallel bucket hooks) are recorded in place.
+
+    Two lanes: launches recorded inside `side_lane()` (weight gradients: nothing of the backward chain waits for them) are
+    replayed on a second HIP stream when `replay` is given one - ordered after everything recorded before them (an event
+    of the main stream), with explicit `wait_side(i)` markers where the main chain is about to overwrite a buffer side
+    launch i reads, and a full join in front of every host callback and at the end."""
 
     def __init__(self):
-        self.items = []     # (fn, args, tag) | (None, callable, None)
+        self.items = []     # (fn, args, tag, lane) | (None, callable, None, 0) | ("wait", index | None, None, 0)
+        self._ev = None     # per-item events of the two-lane replay (created once)
 
     def __enter__(self):
         global _recording
@@ -182,15 +191,68 @@ class Recording:
 
     def host(self, fn):
         """run fn() now and at this point of every replay"""
-        self.items.append((None, fn, None))
+        self.items.append((None, fn, None, 0))
         fn()
 
-    def replay(self, stream: int, timers=None):
-        for fn, args, tag in self.items:
-            if fn is None:
-                args()
+    def last_index(self) -> int:
+        return len(self.items) - 1
+
+    def wait_side(self, index=None):
+        """the main chain must not pass this point before side launch `index` (None: every side launch so far) is done"""
+        self.items.append(("wait", index, None, 0))
+
+    def replay(self, stream: int, timers=None, side=None):
+        """stream: raw handle of the main stream.  side: a torch.cuda.Stream for the side lane (None: one stream, in order)"""
+        if side is None:
+            for fn, args, tag, _ in self.items:
+                if fn is None:
+                    args()
+                    continue
+                if fn == "wait":
+                    continue
+                if timers is not None and tag is not None:
+                    ev = timers.bracket(*tag)
+                    ev[0].record()
+                    rc = fn(*args, stream)
+                    ev[1].record()
+                else:
+                    rc = fn(*args, stream)
+                if rc != 0:
+                    check(rc, fn.__name__)
+            return
+        import torch
+        main = torch.cuda.current_stream()
+        assert main.cuda_stream == stream
+        if self._ev is None:
+            self._ev = {i: (torch.cuda.Event(), torch.cuda.Event()) for i, it in enumerate(self.items) if it[3] == 1}
+            self._join = torch.cuda.Event()
+        side_h = side.cuda_stream
+        pending = False     # side work issued since the last full join
+        for i, (fn, args, tag, ln) in enumerate(self.items):
+            if fn is None or fn == "wait":
+                if fn == "wait" and args is not None:
+                    main.wait_event(self._ev[args][1])
+                elif pending:
+                    self._join.record(side)
+                    main.wait_event(self._join)
+                    pending = False
+                if fn is None:
+                    args()
                 continue
-            if timers is not None and tag is not None:
+            if ln == 1:
+                fork, done = self._ev[i]
+                fork.record(main)
+                side.wait_event(fork)
+                if timers is not None and tag is not None:
+                    ev = timers.bracket(*tag)
+                    ev[0].record(side)
+                    rc = fn(*args, side_h)
+                    ev[1].record(side)
+                else:
+                    rc = fn(*args, side_h)
+                done.record(side)
+                pending = True
+            elif timers is not None and tag is not None:
                 ev = timers.bracket(*tag)
                 ev[0].record()
                 rc = fn(*args, stream)
@@ -199,6 +261,22 @@ class Recording:
                 rc = fn(*args, stream)
             if rc != 0:
                 check(rc, fn.__name__)
+        if pending:
+            self._join.record(side)
+            main.wait_event(self._join)
+
+
+class side_lane:
+    """launches issued inside this context may run beside the main chain of a recorded plan (Recording)"""
+
+    def __enter__(self):
+        global lane
+        self._prev, lane = lane, 1
+
+    def __exit__(self, *exc):
+        global lane
+        lane = self._prev
+        return False
 
 
 class _Proxy:
@@ -213,7 +291,7 @@ class _Proxy:
         def call(*args):
             global pending_tag
             tag, pending_tag = pending_tag, None
-            _recording.items.append((fn, args[:-1], tag))
+            _recording.items.append((fn, args[:-1], tag, lane))
             return fn(*args)
         return call
 

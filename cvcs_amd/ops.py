@@ -34,10 +34,18 @@ class KernelTimers:
     stream handed to the C-ABI).  bench.py switches this on for the timed region to measure the dominant kernels'
     average launch duration; off (None) by default, so the product path records nothing."""
 
-    def __init__(self):
+    class _Off:
+        def record(self, *a):
+            pass
+    _OFF = (_Off(), _Off())
+
+    def __init__(self, only=None):
         self.records = {}   # kind -> list of (start_event, end_event, algorithmic_flops)
+        self.only = only    # None: every tagged launch; else a set of kernel families ("family[:scope]" kinds; the others are not bracketed)
 
     def bracket(self, kind, flops):
+        if self.only is not None and kind.split(":")[0] not in self.only:
+            return self._OFF
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.setdefault(kind, []).append((s, e, flops))
         return s, e

@@ -23,6 +23,7 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -96,6 +97,13 @@ class ResNetUNetEngine:
         self._saved_train = False
         self._last_act = {}
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
+        # Weight gradients are off the critical chain of backward (dy -> data gradient -> BatchNorm backward of the layer below): they
+        # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
+        # beside the HBM-bound BatchNorm / residual passes (CVCS_OVERLAP_WGRAD=0: one stream, in program order)
+        self.overlap_wgrad = os.environ.get("CVCS_OVERLAP_WGRAD", "0") == "1"
+        self._side_stream = None
+        self._dy_reader = {}             # dy scratch buffer -> index of the side launch that read it last (this recording)
+        self._dy_toggle = 0
         self.keep_all = False            # tests: every backward intermediate in its own buffer (no scratch reuse) + a registry
         self.bwd_units = {}
 
@@ -315,17 +323,28 @@ class ResNetUNetEngine:
             ops.bn_bwd_reduce(y, g, None, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
             ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
                                 st.ca, st.cb)
-        dy = ops.view(self._scratch(u.conv + ".dy" if self.keep_all else "dy", M * C_, self.dtype).view(y.B, y.H, y.W, C_))
+        # two dy buffers in turn: the weight gradient of unit k (side lane) may still read its dy while unit k + 1 writes the other one
+        self._dy_toggle ^= 1
+        dyname = u.conv + ".dy" if self.keep_all else ("dy" if not self.overlap_wgrad else f"dy{self._dy_toggle}")
+        dy = ops.view(self._scratch(dyname, M * C_, self.dtype).view(y.B, y.H, y.W, C_))
         if self.keep_all:
             self.bwd_units[u.conv] = dict(unit=u, g=g, mode=mode, dy=dy)
+        rec = _lib._recording
+        if self.overlap_wgrad and rec is not None and dyname in self._dy_reader:
+            rec.wait_side(self._dy_reader[dyname])
         ops.bn_bwd_apply(y, g, None, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, dy, p2)
-        if u.virt:
-            need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
-            ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch("wg_ws", need), cin_real=32, virt=True)
-            ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
-        else:
-            need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
-            ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch("wg_ws", need), dil=u.dil)
+        side = self.overlap_wgrad and rec is not None
+        ws_name = "wg_ws_side" if side else "wg_ws"      # (the side lane's launches share one workspace: their stream serialises them)
+        with (_lib.side_lane() if side else contextlib.nullcontext()):
+            if u.virt:
+                need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
+                ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch(ws_name, need), cin_real=32, virt=True)
+                ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
+            else:
+                need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
+                ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)
+        if side:
+            self._dy_reader[dyname] = rec.last_index()
         return dy
 
     def _dgrad(self, u: Unit, dy: View, name, fuse_into: Unit | None = None):
@@ -469,9 +488,14 @@ class ResNetUNetEngine:
         """first time: run fn() eagerly while recording its launches; afterwards replay the recording"""
         rec = self._rec.get(key)
         if rec is None:
+            self._dy_reader = {}
             with _lib.Recording() as rec:
                 fn()
             self._rec[key] = rec
+        elif self.overlap_wgrad and key == "bwd":
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.dev)
+            rec.replay(torch.cuda.current_stream().cuda_stream, ops.TIMERS, side=self._side_stream)
         else:
             rec.replay(torch.cuda.current_stream().cuda_stream, ops.TIMERS)
 

@@ -19,6 +19,8 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _lib, ops
@@ -105,7 +107,10 @@ class SwinUPerNetEngine(ResNetUNetEngine):
         ops.SCOPE = "enc" if key.startswith("backbone") else "dec"
         need = ops.wgrad_workspace_floats_for(x, g, 1, 1, 1, 0)
         gw = self.GW4[key]
-        ops.conv2d_wgrad(x, g, gw, 1, 1, 1, 0, self._scratch("wg_ws", need), cin_real=48 if key == PE else None)
+        # (x and g are per-layer buffers that nothing overwrites during this backward: no hazard on the side lane)
+        side = self.overlap_wgrad and _lib._recording is not None
+        with (_lib.side_lane() if side else contextlib.nullcontext()):
+            ops.conv2d_wgrad(x, g, gw, 1, 1, 1, 0, self._scratch("wg_ws_side" if side else "wg_ws", need), cin_real=48 if key == PE else None)
         if bias:
             gb = self.GW4.get(key + ".bias")
             if gb is None:
