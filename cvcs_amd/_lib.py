@@ -77,6 +77,7 @@ SIGNATURES = {
     "cvcs_maxpool3x3s2_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
     "cvcs_maxpool3x3s2_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_dilate2x": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_regrid": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_pack_input_stem": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "cvcs_pack_stem_weight": (_i, [_vp, _i, _vp, _i, _vp]),
     "cvcs_unpack_stem_wgrad": (_i, [_vp, _i, _vp, _vp]),
@@ -322,7 +323,7 @@ def _load():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 7:
+        if h.cvcs_abi_version() != 8:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")

@@ -207,6 +207,34 @@ __global__ __launch_bounds__(256) void dilate2x_kernel(const char* in, int64_t i
   }
 }
 
+// ------------------------------------------------------------------------------------------------ sub-grid layouts (dilated stages)
+// Layout L_d of a [B, H, W, C] map (d | H, d | W): image n = b*d*d + sy*d + sx holds the pixels (y*d + sy, x*d + sx), y < H/d, x < W/d.
+// A 3x3 convolution with dilation d and padding d on the map IS a plain 3x3 / pad 1 convolution on the B*d*d sub-images of L_d (a tap at
+// +-d lands on the neighbouring pixel of the same sub-image, and beyond its border exactly where the dilated tap meets the zero padding):
+// the dilated stages of the DeepLab encoders then run on the halo kernels (forward, data and weight gradient) like every other 3x3.
+// This gather moves a map from L_a to L_b (a, b >= 1); its backward is the same gather from L_b to L_a.
+template <typename T>
+__global__ __launch_bounds__(256) void regrid_kernel(const char* in, int64_t in_ld, int B, int H, int W, int C, int a, int b_, char* out,
+                                                    int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const int Hb = H / b_, Wb = W / b_, Ha = H / a, Wa = W / a;
+  const int64_t total = (int64_t)B * H * W * CC;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;                      // linear pixel of the destination (layout L_b)
+    const int xb = (int)(pix % Wb);
+    int64_t t = pix / Wb;
+    const int yb = (int)(t % Hb);
+    t /= Hb;
+    const int sb = (int)(t % (b_ * b_));
+    const int64_t img = t / (b_ * b_);
+    const int Y = yb * b_ + sb / b_, X = xb * b_ + sb % b_;
+    const int64_t src = ((img * (a * a) + (Y % a) * a + (X % a)) * Ha + Y / a) * Wa + X / a;
+    *reinterpret_cast<uint4*>(out + pix * out_ld * ES + cc * 16) = *reinterpret_cast<const uint4*>(in + src * in_ld * ES + cc * 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ stem boundary
 template <typename T, typename S>
 __global__ __launch_bounds__(256) void pack_input_stem_kernel(const S* __restrict__ src, int B, int H, int W, T* dst) {
@@ -365,6 +393,23 @@ extern "C" int cvcs_dilate2x(const void* in, int64_t in_ld, int B, int H, int W,
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CVCS_F32) hipLaunchKernelGGL((dilate2x_kernel<float>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
   else hipLaunchKernelGGL((dilate2x_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_regrid(const void* in, int64_t in_ld, int B, int H, int W, int C, int a, int b, void* out, int64_t out_ld, int dtype,
+                           void* stream) {
+  const char* fn = "cvcs_regrid";
+  CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0 && a >= 1 && b >= 1 && H % a == 0 && W % a == 0 && H % b == 0 && W % b == 0,
+                 "%s: bad shape (both grid factors must divide H and W)", fn);
+  int rc;
+  if ((rc = res_check_view(fn, in, in_ld, C, es)) || (rc = res_check_view(fn, out, out_ld, C, es))) return rc;
+  const dim3 grid(res_grid((int64_t)B * H * W * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((regrid_kernel<float>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, a, b, (char*)out, out_ld);
+  else hipLaunchKernelGGL((regrid_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)in, in_ld, B, H, W, C, a, b, (char*)out, out_ld);
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }

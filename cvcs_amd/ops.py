@@ -381,6 +381,13 @@ def dilate2x(x: View, out: View):
     check(_lib.lib().cvcs_dilate2x(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, x.code, _stream()), "cvcs_dilate2x")
 
 
+def regrid(x: View, out: View, H, W, a, b):
+    """x: the [B, H, W, C] map in sub-grid layout L_a ([B*a*a, H/a, W/a, C]) -> out in L_b (cvcs_regrid)"""
+    B = x.B // (a * a)
+    assert (x.B, x.H, x.W) == (B * a * a, H // a, W // a) and (out.B, out.H, out.W, out.C) == (B * b * b, H // b, W // b, x.C)
+    check(_lib.lib().cvcs_regrid(x.ptr, x.ld, B, H, W, x.C, a, b, out.ptr, out.ld, x.code, _stream()), "cvcs_regrid")
+
+
 def pack_input_stem(src: torch.Tensor, dst: torch.Tensor):
     """src NCHW u8|f32 [B,3,H,W] -> dst [B,H,W+8,4] (real column x at x+3; margins and channel 3 zero)"""
     assert src.is_contiguous() and dst.is_contiguous() and src.dtype in (torch.uint8, torch.float32)

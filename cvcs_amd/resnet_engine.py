@@ -67,6 +67,18 @@ class Act:
         self.grads = []
 
 
+class GridView:
+    """an activation stored in sub-grid layout L_d, presented in the ordinary pixel order (tests read relu_order through .torch())"""
+
+    def __init__(self, v: View, d: int):
+        self.v, self.d = v, d
+
+    def torch(self):
+        t, d = self.v.torch(), self.d
+        Bd, Hd, Wd, C_ = t.shape
+        return t.reshape(Bd // (d * d), d, d, Hd, Wd, C_).permute(0, 3, 1, 4, 2, 5).reshape(Bd // (d * d), Hd * d, Wd * d, C_)
+
+
 class Unit:
     """one conv (+ BatchNorm): input view, conv output y, geometry"""
 
@@ -101,6 +113,8 @@ class ResNetUNetEngine:
         # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
         # beside the HBM-bound BatchNorm / residual passes (CVCS_OVERLAP_WGRAD=0: one stream, in program order)
         self.overlap_wgrad = os.environ.get("CVCS_OVERLAP_WGRAD", "0") == "1"
+        self.grid_dilated = os.environ.get("CVCS_GRID_DILATED", "1") == "1"   # dilated stages in sub-grid layout (see _stages)
+        self._grid = 1
         self._side_stream = None
         self._dy_reader = {}             # dy scratch buffer -> index of the side launch that read it last (this recording)
         self._dy_toggle = 0
@@ -194,7 +208,7 @@ class ResNetUNetEngine:
         u = Unit(x, y, conv, bn, k, stride, pad, virt, dil)
         self.units[conv] = (u, act_out)     # persistent views of this shape's plan (layer-wise parity tests read them)
         if act_out is not None and relu:
-            self.relu_order.append(act_out)
+            self.relu_order.append(act_out if self._grid == 1 else GridView(act_out, self._grid))
         return u
 
     def _unit_gn(self, x, conv, gn, wf, k, stride, pad, dil, Ho, Wo, cout, act_out: View):
@@ -252,7 +266,7 @@ class ResNetUNetEngine:
             last_in = a2
         ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
         self._tail(ut, ud, h, out, train)
-        self.relu_order.append(out)
+        self.relu_order.append(out if self._grid == 1 else GridView(out, self._grid))
         o = Act(out)
         if train:
             def bwd():
@@ -446,15 +460,53 @@ class ResNetUNetEngine:
         """the four residual stages after the stem's max-pool; stage_out(s) -> view the last block of stage s writes its
         output to (a channel range of a decoder's concat buffer) or None; returns {stage: Act}"""
         feats, B = {}, h.v.B
-        for s, b, stride, dil in stage_plan(self.arch, output_stride):
+        grid = 1      # sub-grid layout L_grid of h (cvcs_regrid): a block of dilation d runs as a PLAIN 3x3 block on the B*d*d sub-sampled
+        #               images of L_d - halo kernels for forward, data and weight gradient instead of the generic gather kernel and nine
+        #               shifted 1x1 weight-gradient problems; 1x1 convs, BatchNorm, ReLU and the residual add do not care about pixel order
+        plan = stage_plan(self.arch, output_stride)
+        for i, (s, b, stride, dil) in enumerate(plan):
             p = f"encoder.layer{s}.{b}"
-            hs, w = h.v.H // stride, self.widths[s - 1]
-            out = stage_out(s) if b == self.depths[s - 1] - 1 else None
-            if out is None:
-                out = ops.view(self._act(p + ".out", B, hs, hs, w))
-            h = self._block(h, p, stride, out, train, tape, dil)
-            feats[s] = h
+            hfull = h.v.H * grid
+            hs, w = hfull // stride, self.widths[s - 1]
+            last = b == self.depths[s - 1] - 1
+            out = stage_out(s) if last else None
+            want = dil if (self.grid_dilated and dil > 1 and stride == 1 and out is None and hs % dil == 0) else 1
+            if want != grid:
+                h = self._regrid(h, B, hfull, grid, want, train, tape, p + ".regrid")
+                grid = want
+            if grid > 1:
+                out = ops.view(self._act(p + ".out", B * grid * grid, hs // grid, hs // grid, w))
+                self._grid = grid
+                h = self._block(h, p, 1, out, train, tape, 1)
+                self._grid = 1
+                if i + 1 == len(plan):      # the consumers of the last stage read the ordinary layout
+                    h = self._regrid(h, B, hs, grid, 1, train, tape, p + ".ungrid")
+                    grid = 1
+            else:
+                if out is None:
+                    out = ops.view(self._act(p + ".out", B, hs, hs, w))
+                h = self._block(h, p, stride, out, train, tape, dil)
+            if grid == 1:
+                feats[s] = h
         return feats
+
+    def _regrid(self, h: Act, B, H, a, b, train, tape, name) -> Act:
+        """h in sub-grid layout L_a of a [B, H, H, C] map -> a new activation in L_b; the gradient is the same gather from L_b to L_a"""
+        C_ = h.v.C
+        out = Act(ops.view(self._act(name, B * b * b, H // b, H // b, C_)))
+        ops.regrid(h.v, out.v, H, H, a, b)
+        if train:
+            def bwd():
+                assert 1 <= len(out.grads) <= 3 and not any(half for _, half in out.grads)
+                g = out.grads[0][0]
+                if len(out.grads) > 1:
+                    g = ops.view(self._act(name + ".gsum", B * b * b, H // b, H // b, C_))
+                    ops.relu_bwd_sum(None, out.grads, g)
+                gx = ops.view(self._act(name + ".gx", B * a * a, H // a, H // a, C_))
+                ops.regrid(g, gx, H, H, b, a)
+                h.grads.append((gx, False))
+            tape.append(bwd)
+        return out
 
     def _stem(self, B, S, train, tape, f1_view: View | None = None):
         """packed input -> 7x7/s2 conv -> BN -> ReLU (f1, optionally into a concat buffer) -> 3x3/s2 max-pool (p0)"""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 7
+#define CVCS_ABI_VERSION 8
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -313,6 +313,12 @@ int cvcs_maxpool3x3s2_bwd(const void* g0, int64_t g0_ld, const void* g1, int64_t
  * flipped weights - it then runs on the halo kernel like every other data gradient.                                 */
 int cvcs_dilate2x(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld, int dtype,
                   void* stream);
+/* sub-grid layout change of a [B, H, W, C] map (the dilated stages of torchvision's DeepLab encoders, S/nets.py:234-257: a 3x3
+ * convolution with dilation d and padding d equals a plain 3x3 / pad 1 convolution on the d*d sub-sampled images).  Layout L_d:
+ * image n = b*d*d + sy*d + sx of [B*d*d, H/d, W/d, C] holds the pixels (y*d + sy, x*d + sx).  in is in L_a, out in L_b (a, b >= 1
+ * divide H and W, which are the sizes of the ORIGINAL map); the gradient of the operation is the same call with a and b swapped.     */
+int cvcs_regrid(const void* in, int64_t in_ld, int B, int H, int W, int C, int a, int b, void* out, int64_t out_ld, int dtype,
+                void* stream);
 /* stem boundary: u8 | f32 NCHW [B,3,H,W] -> [B, H, W + 8, 4] `dtype` (real column x at index x + 3, margins and the
  * 4th channel zero) - the layout the virtual-pixel stem convolution reads (cvcs_conv_desc.aniso).                    */
 int cvcs_pack_input_stem(const void* src, int src_is_u8, int B, int H, int W, void* dst, int dtype, void* stream);

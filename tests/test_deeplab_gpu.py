@@ -156,6 +156,33 @@ def test_dilated_conv_forward_data_and_weight_gradient(dtype, dil, cin, cout, S)
     close(dw.cpu(), wq.grad, 1e-4, "weight gradient")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,a,b", [(8, 12, 1, 2), (8, 12, 2, 1), (16, 16, 2, 4), (16, 16, 4, 1), (12, 12, 1, 3)])
+def test_sub_grid_layout_change_and_dilated_conv_as_plain_conv(dtype, H, W, a, b):
+    """cvcs_regrid L_a -> L_b against the definition; and the point of it: a 3x3 convolution with dilation d on the map equals the
+    plain 3x3 / pad 1 convolution on the d*d sub-sampled images of L_d (forward of the dilated ResNet stages)"""
+    g = torch.Generator().manual_seed(H + a + b)
+    B, C_ = 2, 32
+    x = rq(torch.randn(B, C_, H, W, generator=g), dtype)
+
+    def to_grid(t, d):     # [B, C, H, W] -> L_d as NHWC [B*d*d, H/d, W/d, C]
+        Bn, Cn, Hn, Wn = t.shape
+        return t.reshape(Bn, Cn, Hn // d, d, Wn // d, d).permute(0, 3, 5, 2, 4, 1).reshape(Bn * d * d, Hn // d, Wn // d, Cn).contiguous()
+    src = to_grid(x, a).to(dtype).to(DEV).contiguous()
+    out = torch.empty(B * b * b, H // b, W // b, C_, dtype=dtype, device=DEV)
+    ops.regrid(ops.view(src), ops.view(out), H, W, a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), to_grid(x, b))
+    if a == 1 and b > 1:
+        w = rq(torch.randn(C_, C_, 3, 3, generator=g) / (C_ * 9) ** 0.5, dtype)
+        ref = F.conv2d(x, w, None, 1, b, b)
+        wf, _ = ops.pack_conv_weight(w.to(DEV), C_, dtype)
+        y = torch.empty_like(out)
+        ops.conv2d(ops.view(out), wf, None, ops.view(y), 3, 3, 1, 1, 1)
+        torch.cuda.synchronize()
+        close(y.float().cpu(), to_grid(ref, b), 1e-4 if dtype == torch.float32 else 2e-2, "dilated conv as a plain conv on the sub-grid layout")
+
+
 # ---------------------------------------------------------------------------------------------------- whole networks
 def _build(cls, arch, NC, precision, plus, seed=3):
     net = cls(NC, precision)
@@ -241,7 +268,9 @@ def test_fp32_train_steps_match_oracle(cls, arch, os_, plus, B, S, NC):
             tr.step(img, lab)
             sd = net.state_dict()
             worstp = max((rel_l2(sd[k].cpu(), tr.p[k].detach()), k) for k in tr.p)
-            assert worstp[0] <= 1e-4, worstp
+            # (BatchNorm biases start at 0: their relative figure after one update IS the relative error between two f32 gradients,
+            #  each with its own handful of ReLU decisions - the same 2e-4 as the gradient bound above; weights are 100x tighter)
+            assert worstp[0] <= 2e-4, worstp
     net.eval()
     final = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
     with torch.no_grad():
