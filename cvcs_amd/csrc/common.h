@@ -80,6 +80,16 @@ template <> struct Elem<bf16_t> {
   }
 };
 
+// XCD-aware workgroup order (cdna_hip_programming.md T1): the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, each
+// with its own L2; the blocks with the same (id % 8) share an XCD.  Logical ids are handed out so that each XCD's blocks get a contiguous
+// range: tiles that share an operand panel (consecutive logical ids) then run on ONE XCD, back to back, and the panel is an L2 hit
+// instead of a separate fetch per XCD.  Bijective for any workgroup count.  A speed choice only: correctness never depends on placement.
+__device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nwg) {
+  if (nwg < 16) return bid;
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

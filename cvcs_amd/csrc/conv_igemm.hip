@@ -51,6 +51,7 @@ struct ConvArgs {
   // generic kernel: W-axis stride / padding (== stride / pad unless cvcs_conv_desc.aniso) and the pitches of `in` (elements)
   int stride_w, pad_w;
   int64_t in_row_pitch, in_img_pitch;
+  int xcd_order;          // taps kernel: XCD-aware workgroup order (CVCS_XCD_ORDER=0 switches it off: a tuning knob)
 };
 
 template <typename T> struct Mma;
@@ -1125,7 +1126,12 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const int rr = lane >> 2, pc = lane & 3;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // 1-D grid in XCD-aware order, column tiles fastest: the Cout / 128 workgroups that read the same 256 pixel rows run on one XCD
+  // back to back (with a (row, column) grid they were a whole grid row apart: every column tile re-fetched the input through the fabric)
+  const unsigned lid = p.xcd_order ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int ncol = p.Cout / BN;
+  const int bx = (int)(lid / ncol), by = (int)(lid % ncol);
+  const int m0 = bx * BM, n0 = by * BN;
   const int nslice = p.Cin / KG;
   const int nsteps = TAPS * nslice;
   const int64_t wt_tap_bytes = (int64_t)p.Cout * p.Cin * ES;
@@ -1220,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
     int nvalid = p.M - rbase;
     nvalid = nvalid < 0 ? 0 : (nvalid > 64 ? 64 : nvalid);
     const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
-    const int64_t srow = (int64_t)blockIdx.x * 4 + wm;
+    const int64_t srow = (int64_t)bx * 4 + wm;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1243,7 +1249,7 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
           p.stat_m2[srow * p.Cout + n] = q;
         }
       }
-    if (blockIdx.y == 0 && wn == 0 && lane == 0) p.stat_cnt[srow] = (float)nvalid;
+    if (by == 0 && wn == 0 && lane == 0) p.stat_cnt[srow] = (float)nvalid;
   }
   auto stage = [&](auto relu_) {
     constexpr bool RELU = decltype(relu_)::value;
@@ -1301,7 +1307,7 @@ static int launch_taps(const ConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_taps_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(a.M, 256), (unsigned)(a.Cout / 128));
+  dim3 grid((unsigned)(cdiv(a.M, 256) * (a.Cout / 128)));
   hipLaunchKernelGGL((conv_taps_kernel<TAPS>), grid, dim3(512), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d(taps)");
   return CVCS_OK;
@@ -1428,6 +1434,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     if ((d->Cout / 4) % 128 != 0) bn = 64;  // a column tile must not straddle two (dy,dx) groups
   }
   ConvArgs a;
+  static const int xcd_on = getenv("CVCS_XCD_ORDER") ? atoi(getenv("CVCS_XCD_ORDER")) : 1;   // tuning knob
+  a.xcd_order = xcd_on;
   a.in = (const char*)d->in; a.wt = (const char*)d->wt; a.bias = d->bias; a.out = (char*)d->out;
   a.stat_sum = d->stat_sum; a.stat_m2 = d->stat_m2; a.stat_cnt = d->stat_cnt;
   CVCS_CHECK_ARG((d->pre_scale == nullptr) == (d->pre_shift == nullptr) && (d->post_scale == nullptr) == (d->post_shift == nullptr),

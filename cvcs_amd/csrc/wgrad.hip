@@ -38,6 +38,7 @@ struct WgradArgs {
   int tiles_x, tiles_y;       // K-tiles per image
   int ktiles, per_slice;      // total K-tiles, K-tiles per slice
   int ntile_n;                // Cin tiles
+  int tiles_mn, xcd_order;    // GEMM kernel: (co, ci) tiles per K-slice; XCD-aware workgroup order (CVCS_XCD_ORDER=0: off)
 };
 
 __device__ uint4 g_wzero16;  // zero word: LDS-DMA source of padding pixels / absent channels
@@ -274,10 +275,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tn = blockIdx.x % p.ntile_n, tm = blockIdx.x / p.ntile_n;
+  // 1-D grid in XCD-aware order, the (co, ci) tiles of one K-slice consecutive: they all read that slice's pixels of dy and x, so the
+  // slice crosses the fabric once per XCD-resident group instead of once per tile
+  const unsigned lid = p.xcd_order ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int tile = (int)(lid % p.tiles_mn), kslice = (int)(lid / p.tiles_mn);
+  const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
   const int co0 = tm * BM, ci0 = tn * BN;
   const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
-  const int kt_begin = blockIdx.y * p.per_slice;
+  const int kt_begin = kslice * p.per_slice;
   int kt_end = kt_begin + p.per_slice;
   if (kt_end > p.ktiles) kt_end = p.ktiles;
 
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
     if (++st == NS) st = 0;
   }
   // partials ws[slice][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
-  float* ws = p.ws + (int64_t)blockIdx.y * (p.slice_stride ? p.slice_stride : (int64_t)p.Cout * p.Cin);
+  float* ws = p.ws + (int64_t)kslice * (p.slice_stride ? p.slice_stride : (int64_t)p.Cout * p.Cin);
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -867,6 +872,11 @@ static int fast_path(const cvcs_wgrad_desc* d) {
   return (d->Cout % 128 == 0 && !force64) ? 2 : 1;
 }
 
+static int wgrad_xcd_order() {
+  static const int on = getenv("CVCS_XCD_ORDER") ? atoi(getenv("CVCS_XCD_ORDER")) : 1;   // tuning knob
+  return on;
+}
+
 // 1x1 / stride 1 GEMM path: tile shape and split-K plan
 struct GemmPlan { int BM, BN, ktiles, per_slice, nslice, tiles_mn, ntile_n; };
 static bool gemm_shape(int KH, int KW, int stride, int Cout, int Cin) {
@@ -928,6 +938,7 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
   CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0 &&
                  ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad(dilated): views");
   WgradArgs a;
+  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order();
   a.x = (const char*)d->x; a.dy = (const char*)d->dy;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -940,7 +951,8 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
     const GemmPlan g = gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin);
     a.ktiles = g.ktiles; a.per_slice = g.per_slice; a.ntile_n = g.ntile_n;
     nslice = g.nslice;
-    const dim3 grid((unsigned)g.tiles_mn, (unsigned)g.nslice);
+    const dim3 grid((unsigned)(g.tiles_mn * g.nslice));
+    a.tiles_mn = g.tiles_mn;
     for (int t = 0; t < 9; ++t) {
       a.sh_y = (t / 3 - 1) * d->dil; a.sh_x = (t % 3 - 1) * d->dil;
       a.ws = d->workspace + (int64_t)t * d->Cout * d->Cin;
@@ -1025,6 +1037,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, fastp, stride_w);
   CVCS_CHECK_ARG(pl.HR * pl.HC <= (fastp ? 128 : kXRows), "cvcs_conv2d_wgrad: halo tile too large");
   WgradArgs a;
+  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order();
   a.x = (const char*)d->x; a.dy = (const char*)d->dy; a.ws = d->workspace;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -1042,7 +1055,8 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     const GemmPlan g = gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin);
     a.ktiles = g.ktiles; a.per_slice = g.per_slice; a.ntile_n = g.ntile_n;
     nslice_used = g.nslice;
-    const dim3 grid((unsigned)g.tiles_mn, (unsigned)g.nslice);
+    a.tiles_mn = g.tiles_mn;
+    const dim3 grid((unsigned)(g.tiles_mn * g.nslice));
 #define LAUNCH_GEMM(BM_, BN_)                                                                                                   \
   do {                                                                                                                          \
     const int lds = 3 * ((BM_) / 64 + (BN_) / 64) * 4096;                                                                       \
