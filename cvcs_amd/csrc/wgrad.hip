@@ -261,15 +261,20 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* smem_base, unsigned off0, 
 // fragment is a transposed LDS read (ds_read_b64_tr_b16) exactly as in the kernel above; the tile is kept as 64-channel
 // column blocks of [32 pixels][128 B] so that its bank swizzle is that kernel's.  Same LDS-DMA ring (3 stages, two K-tiles
 // ahead, counted vmcnt), same split-K partial slabs + fixed-order reduce.
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
+// WMV waves along the co axis x 2 along ci (4 or 8 waves).  The kernel is bound by the L2 -> LDS path, not by the matrix cores: a BM x BN
+// tile moves (BM + BN) * 64 bytes per 32-pixel K-tile for BM * BN * 64 FLOP, i.e. BM*BN/(BM+BN) FLOP per byte - 64 for 128 x 128, 85 for
+// 256 x 128 (8 waves, still two workgroups per CU), 128 for 256 x 256 (8 waves, 96 KB of LDS, one workgroup per CU).
+template <int BM, int BN, int WMV = 2>
+__global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgrad_gemm_kernel(WgradArgs p) {
+  constexpr int NWV = WMV * 2;                    // waves
   constexpr int MB = BM / 64, NB = BN / 64;       // 64-channel blocks of the dy / x tile
   constexpr int BLK = 32 * 128;                   // bytes of one block: 32 pixels x 64 channels
   constexpr int STAGE = (MB + NB) * BLK;
   constexpr int NS = 3, D = 2;
   constexpr int PIECES = (MB + NB) * 4;           // 1 KiB DMA pieces per K-tile (8 pixel rows of one block each)
-  constexpr int PPW = PIECES / 4;                 // per wave
-  constexpr int MR = BM / 32, NR = BN / 32;       // 16-channel fragments per wave (wave tile BM/2 x BN/2)
+  constexpr int PPW = PIECES / NWV;               // per wave
+  static_assert(PIECES % NWV == 0 && PPW <= 4, "DMA pieces must divide over the waves");
+  constexpr int MR = BM / WMV / 16, NR = BN / 32; // 16-channel fragments per wave (wave tile BM/WMV x BN/2)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
   bool colok[PPW];        // channel counts that are no multiple of the tile (96 * 2^k): chunks beyond the last channel read zeros
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int pi = wave + 4 * i;
+    const int pi = wave + NWV * i;
     const int blk = pi >> 2, row = (pi & 3) * 8 + rr;
     const int c = pc ^ (((row >> 1) & 3) << 1);   // logical 16-byte chunk stored at physical chunk pc
     prow[i] = row;
@@ -308,13 +313,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
     for (int i = 0; i < PPW; ++i) {
       int64_t pix = (int64_t)kt * 32 + prow[i];
       bool ok = pix < M && colok[i];
-      if (shifted && (wave + 4 * i) >= 4 * MB) {      // an x piece of a shifted tap: the source pixel must stay inside its image
+      if (shifted && (wave + NWV * i) >= 4 * MB) {      // an x piece of a shifted tap: the source pixel must stay inside its image
         const int ox = (int)(pix % p.W), oy = (int)((pix / p.W) % p.H);
         ok = ok && (unsigned)(oy + p.sh_y) < (unsigned)p.H && (unsigned)(ox + p.sh_x) < (unsigned)p.W;
         pix += sh_lin;
       }
       const char* src = ok ? src0[i] + pix * rowb[i] : reinterpret_cast<const char*>(&g_wzero16);
-      dma16(src, lds0 + st * STAGE + (wave + 4 * i) * 1024);
+      dma16(src, lds0 + st * STAGE + (wave + NWV * i) * 1024);
     }
   };
 
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
     bf16x8 af[MR], bfr[NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-      const int ch = wm * (BM / 2) + i * 16;
+      const int ch = wm * (BM / WMV) + i * 16;
       const char* blk = sb + (ch >> 6) * BLK;
       af[i] = tr_pair(blk, off0[(ch >> 4) & 3], off1[(ch >> 4) & 3]);
     }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs p) {
       const int ci = ci0 + wn * (BN / 2) + j * 16 + fr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wm * (BM / 2) + i * 16 + fg * 4 + r;
+        const int co = co0 + wm * (BM / WMV) + i * 16 + fg * 4 + r;
         if (co < p.Cout && ci < p.Cin) ws[(int64_t)co * p.Cin + ci] = acc[i][j][r];
       }
     }
@@ -892,6 +897,13 @@ static GemmPlan gemm_plan(int B, int Ho, int Wo, int Cout, int Cin) {
   if (g.BM == 64 && g.BN == 64) {           // (no 64 x 64 instance)
     if (Cout >= Cin) g.BM = 128; else g.BN = 128;
   }
+  // 8-wave 256 x 128 tiles for LARGE problems only (>= 16 tiles of 128 x 128 and >= 64 K pixels): measured +2 % on the DeepLabV3-ResNet101
+  // step (1024 x 256 and 2048 x 512 gradients over 131 072 pixels), -1 % on ResNet50-UNet (the same matrices over 32 768 pixels: fewer,
+  // longer workgroups); 256 x 256 (one workgroup per CU) measured no better anywhere.  CVCS_WGRAD_GEMM_BIG: 0 = never, 2 = also 256 x 256
+  static const int big = getenv("CVCS_WGRAD_GEMM_BIG") ? atoi(getenv("CVCS_WGRAD_GEMM_BIG")) : 1;
+  const int64_t pixels = (int64_t)B * Ho * Wo;
+  if (big >= 1 && g.BM == 128 && g.BN == 128 && Cout % 256 == 0 && (Cout / 128) * (Cin / 128) >= 16 && pixels >= 65536) g.BM = 256;
+  if (big >= 2 && g.BM == 256 && Cin % 256 == 0) g.BN = 256;
   g.ktiles = (int)cdiv((int64_t)B * Ho * Wo, 32);
   g.ntile_n = (int)cdiv(Cin, g.BN);
   g.tiles_mn = (int)cdiv(Cout, g.BM) * g.ntile_n;
@@ -957,15 +969,17 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
       a.sh_y = (t / 3 - 1) * d->dil; a.sh_x = (t % 3 - 1) * d->dil;
       a.ws = d->workspace + (int64_t)t * d->Cout * d->Cin;
       a.pad = 0; a.pad_w = 0;
-#define LAUNCH_GEMM_D(BM_, BN_)                                                                                                 \
+#define LAUNCH_GEMM_D(BM_, BN_, WMV_)                                                                                           \
   do {                                                                                                                          \
     const int lds = 3 * ((BM_) / 64 + (BN_) / 64) * 4096;                                                                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_>), grid, dim3(256), lds, st, a);                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_, WMV_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_, WMV_>), grid, dim3((WMV_) * 128), lds, st, a);                              \
   } while (0)
-      if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM_D(128, 128);
-      else if (g.BM == 128) LAUNCH_GEMM_D(128, 64);
-      else LAUNCH_GEMM_D(64, 128);
+      if (g.BM == 256 && g.BN == 256) LAUNCH_GEMM_D(256, 256, 4);
+      else if (g.BM == 256) LAUNCH_GEMM_D(256, 128, 4);
+      else if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM_D(128, 128, 2);
+      else if (g.BM == 128) LAUNCH_GEMM_D(128, 64, 2);
+      else LAUNCH_GEMM_D(64, 128, 2);
 #undef LAUNCH_GEMM_D
     }
   } else {
@@ -1057,19 +1071,21 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     nslice_used = g.nslice;
     a.tiles_mn = g.tiles_mn;
     const dim3 grid((unsigned)(g.tiles_mn * g.nslice));
-#define LAUNCH_GEMM(BM_, BN_)                                                                                                   \
+#define LAUNCH_GEMM(BM_, BN_, WMV_)                                                                                             \
   do {                                                                                                                          \
     const int lds = 3 * ((BM_) / 64 + (BN_) / 64) * 4096;                                                                       \
     static bool attr_done = false;                                                                                              \
     if (!attr_done) {                                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_, WMV_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
       attr_done = true;                                                                                                         \
     }                                                                                                                           \
-    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_>), grid, dim3(256), lds, st, a);                                             \
+    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_, WMV_>), grid, dim3((WMV_) * 128), lds, st, a);                              \
   } while (0)
-    if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM(128, 128);
-    else if (g.BM == 128) LAUNCH_GEMM(128, 64);
-    else LAUNCH_GEMM(64, 128);
+    if (g.BM == 256 && g.BN == 256) LAUNCH_GEMM(256, 256, 4);
+    else if (g.BM == 256) LAUNCH_GEMM(256, 128, 4);
+    else if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM(128, 128, 2);
+    else if (g.BM == 128) LAUNCH_GEMM(128, 64, 2);
+    else LAUNCH_GEMM(64, 128, 2);
 #undef LAUNCH_GEMM
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(gemm)");
     rc = CVCS_OK;
