@@ -137,8 +137,8 @@ def test_strided_and_pointwise_convs(dtype, k, stride, pad, cin, cout, S):
 @pytest.mark.parametrize("cin,cout,S,off", [(256, 128, 24, 64), (64, 256, 20, 0), (128, 128, 17, 32), (256, 64, 12, 0),
                                             # channel counts that are no multiple of the GEMM tiles (Swin's 96 * 2^k widths): masked last tiles
                                             (96, 96, 21, 32), (96, 288, 14, 0), (384, 96, 9, 0), (192, 576, 11, 64), (96, 512, 10, 0),
-                                            # the 8-wave 256 x 128 and 256 x 256 weight-gradient tiles
-                                            (128, 256, 13, 0), (256, 256, 10, 32), (512, 512, 9, 0), (256, 768, 7, 0)])
+                                            # channel counts of the 8-wave 256 x 128 weight-gradient tile (taken from 65 536 pixels on: the last case)
+                                            (128, 256, 13, 0), (256, 256, 10, 32), (512, 512, 9, 0), (256, 768, 7, 0), (512, 512, 148, 0)])
 def test_pointwise_conv_statistics_and_gemm_weight_gradient(cin, cout, S, off):
     """bf16 1x1 convolutions of the bottlenecks: forward on the non-overlapping-taps kernel WITH the BatchNorm statistics
     epilogue (cout % 128 == 0; else the generic kernel), weight gradient as one transposed GEMM (wgrad_gemm_kernel; pixel
