@@ -114,6 +114,27 @@ def init_params(num_classes, seed=0):
     return out
 
 
+# --------------------------------------------------------------------------- bf16 emulation
+# forward(..., emulate_bf16=True) rounds to bfloat16 where the HIP bf16 path stores or feeds bf16: the weights of every linear / conv
+# layer but the classifier, every stored activation (linear / LayerNorm / GELU / attention / residual-add / BatchNorm+ReLU / pooling /
+# resize outputs) and the attention probabilities that enter P.V; sums, softmax, LayerNorm and BatchNorm arithmetic stay f32.
+_EMULATE = False
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _q(x):
+    return _RoundSTE.apply(x) if _EMULATE else x
+
+
 # --------------------------------------------------------------------------- Swin pieces
 def relative_position_index():
     c = torch.stack(torch.meshgrid(torch.arange(WINDOW), torch.arange(WINDOW), indexing="ij")).flatten(1)   # 2, 49
@@ -151,7 +172,7 @@ def shift_mask(Hp, Wp, shift, dtype):
 def swin_block(x, H, W, p, pre, heads, shift):
     """x [B, H*W, C]"""
     B, L, C = x.shape
-    h = F.layer_norm(x, (C,), p[pre + ".layernorm_before.weight"], p[pre + ".layernorm_before.bias"], LN_EPS).view(B, H, W, C)
+    h = _q(F.layer_norm(x, (C,), p[pre + ".layernorm_before.weight"], p[pre + ".layernorm_before.bias"], LN_EPS)).view(B, H, W, C)
     pr, pb = (WINDOW - W % WINDOW) % WINDOW, (WINDOW - H % WINDOW) % WINDOW
     h = F.pad(h, (0, 0, 0, pr, 0, pb))                       # zero tokens AFTER the LayerNorm
     Hp, Wp = H + pb, W + pr
@@ -159,7 +180,7 @@ def swin_block(x, H, W, p, pre, heads, shift):
         h = torch.roll(h, shifts=(-shift, -shift), dims=(1, 2))
     win = window_partition(h)                                # [B*nW, 49, C]
     d = C // heads
-    q, k, v = (F.linear(win, p[f"{pre}.attention.{n}.weight"], p[f"{pre}.attention.{n}.bias"]).view(-1, 49, heads, d).transpose(1, 2)
+    q, k, v = (_q(F.linear(win, _q(p[f"{pre}.attention.{n}.weight"]), p[f"{pre}.attention.{n}.bias"])).view(-1, 49, heads, d).transpose(1, 2)
                for n in ("q_proj", "k_proj", "v_proj"))
     bias = p[pre + ".attention.relative_position_bias.relative_position_bias_table"][relative_position_index().view(-1)]
     bias = bias.view(49, 49, heads).permute(2, 0, 1).unsqueeze(0)            # [1, heads, 49, 49]
@@ -167,40 +188,40 @@ def swin_block(x, H, W, p, pre, heads, shift):
     if shift:
         m = shift_mask(Hp, Wp, shift, att.dtype)                             # [nW, 49, 49]
         att = (att.view(B, -1, heads, 49, 49) + m[None, :, None]).view(-1, heads, 49, 49)
-    att = torch.softmax(att, dim=-1)
-    o = (att @ v).transpose(1, 2).reshape(-1, 49, C)
-    o = F.linear(o, p[pre + ".attention.o_proj.weight"], p[pre + ".attention.o_proj.bias"])
+    att = _q(torch.softmax(att, dim=-1))
+    o = _q((att @ v).transpose(1, 2).reshape(-1, 49, C))
+    o = _q(F.linear(o, _q(p[pre + ".attention.o_proj.weight"]), p[pre + ".attention.o_proj.bias"]))
     o = window_reverse(o, Hp, Wp)
     if shift:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
     o = o[:, :H, :W, :].reshape(B, L, C)
-    x = x + o
-    h = F.layer_norm(x, (C,), p[pre + ".layernorm_after.weight"], p[pre + ".layernorm_after.bias"], LN_EPS)
-    h = F.gelu(F.linear(h, p[pre + ".mlp.fc1.weight"], p[pre + ".mlp.fc1.bias"]))
-    return x + F.linear(h, p[pre + ".mlp.fc2.weight"], p[pre + ".mlp.fc2.bias"])
+    x = _q(x + o)
+    h = _q(F.layer_norm(x, (C,), p[pre + ".layernorm_after.weight"], p[pre + ".layernorm_after.bias"], LN_EPS))
+    h = _q(F.gelu(_q(F.linear(h, _q(p[pre + ".mlp.fc1.weight"]), p[pre + ".mlp.fc1.bias"]))))
+    return _q(x + _q(F.linear(h, _q(p[pre + ".mlp.fc2.weight"]), p[pre + ".mlp.fc2.bias"])))
 
 
 def patch_merge(x, H, W, p, pre):
     B, L, C = x.shape
     x = x.view(B, H, W, C)
     x = torch.cat([x[:, r::2, c::2, :] for c in range(2) for r in range(2)], dim=-1).view(B, -1, 4 * C)
-    x = F.layer_norm(x, (4 * C,), p[pre + ".norm.weight"], p[pre + ".norm.bias"], LN_EPS)
-    return F.linear(x, p[pre + ".reduction.weight"])
+    x = _q(F.layer_norm(x, (4 * C,), p[pre + ".norm.weight"], p[pre + ".norm.bias"], LN_EPS))
+    return _q(F.linear(x, _q(p[pre + ".reduction.weight"])))
 
 
 def backbone(p, x):
     """-> [stage1 .. stage4] feature maps NCHW after the per-stage output LayerNorm (what UPerNet consumes)"""
-    y = F.conv2d(x, p["backbone.swin.embeddings.patch_embeddings.projection.weight"],
-                 p["backbone.swin.embeddings.patch_embeddings.projection.bias"], stride=4)
+    y = _q(F.conv2d(x, _q(p["backbone.swin.embeddings.patch_embeddings.projection.weight"]),
+                    p["backbone.swin.embeddings.patch_embeddings.projection.bias"], stride=4))
     B, C, H, W = y.shape
     t = y.flatten(2).transpose(1, 2)
-    t = F.layer_norm(t, (C,), p["backbone.swin.embeddings.norm.weight"], p["backbone.swin.embeddings.norm.bias"], LN_EPS)
+    t = _q(F.layer_norm(t, (C,), p["backbone.swin.embeddings.norm.weight"], p["backbone.swin.embeddings.norm.bias"], LN_EPS))
     feats = []
     for s, (depth, heads) in enumerate(zip(DEPTHS, HEADS)):
         for b in range(depth):
             t = swin_block(t, H, W, p, f"backbone.swin.encoder.layers.{s}.blocks.{b}", heads, 0 if b % 2 == 0 else WINDOW // 2)
         C = t.shape[-1]
-        n = F.layer_norm(t, (C,), p[f"backbone.hidden_states_norms.stage{s + 1}.weight"], p[f"backbone.hidden_states_norms.stage{s + 1}.bias"], LN_EPS)
+        n = _q(F.layer_norm(t, (C,), p[f"backbone.hidden_states_norms.stage{s + 1}.weight"], p[f"backbone.hidden_states_norms.stage{s + 1}.bias"], LN_EPS))
         feats.append(n.view(B, H, W, C).permute(0, 3, 1, 2).contiguous())
         if s < 3:
             t = patch_merge(t, H, W, p, f"backbone.swin.encoder.layers.{s}.downsample")
@@ -210,34 +231,39 @@ def backbone(p, x):
 
 # --------------------------------------------------------------------------- UPerNet head
 def _cbr(x, p, pre, pad, train):
-    y = F.conv2d(x, p[pre + ".conv.weight"], None, padding=pad)
+    y = _q(F.conv2d(x, _q(p[pre + ".conv.weight"]), None, padding=pad))
     y = F.batch_norm(y, p[pre + ".batch_norm.running_mean"], p[pre + ".batch_norm.running_var"], p[pre + ".batch_norm.weight"],
                      p[pre + ".batch_norm.bias"], training=train, momentum=U.BN_MOMENTUM, eps=U.BN_EPS)
-    return F.relu(y)
+    return _q(F.relu(y))
 
 
 def upernet_head(p, feats, train):
     x = feats[-1]
     outs = [x]
     for i, s in enumerate(POOL_SCALES):
-        o = _cbr(F.adaptive_avg_pool2d(x, s), p, f"decode_head.psp_modules.{i}.1", 0, train)
-        outs.append(F.interpolate(o, size=x.shape[2:], mode="bilinear", align_corners=False))
+        o = _cbr(_q(F.adaptive_avg_pool2d(x, s)), p, f"decode_head.psp_modules.{i}.1", 0, train)
+        outs.append(_q(F.interpolate(o, size=x.shape[2:], mode="bilinear", align_corners=False)))
     laterals = [_cbr(feats[i], p, f"decode_head.lateral_convs.{i}", 0, train) for i in range(3)]
     laterals.append(_cbr(torch.cat(outs, 1), p, "decode_head.bottleneck", 1, train))
     for i in range(3, 0, -1):
-        laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], mode="bilinear", align_corners=False)
+        laterals[i - 1] = _q(laterals[i - 1] + _q(F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], mode="bilinear", align_corners=False)))
     fpn = [_cbr(laterals[i], p, f"decode_head.fpn_convs.{i}", 1, train) for i in range(3)] + [laterals[3]]
     for i in range(3, 0, -1):
-        fpn[i] = F.interpolate(fpn[i], size=fpn[0].shape[2:], mode="bilinear", align_corners=False)
+        fpn[i] = _q(F.interpolate(fpn[i], size=fpn[0].shape[2:], mode="bilinear", align_corners=False))
     y = _cbr(torch.cat(fpn, 1), p, "decode_head.fpn_bottleneck", 1, train)
     return F.conv2d(y, p["decode_head.classifier.weight"], p["decode_head.classifier.bias"])
 
 
-def forward(p, x, train=False, return_feats=False):
+def forward(p, x, train=False, return_feats=False, emulate_bf16=False):
     """x f32 [B,3,S,S] raw 0..255 -> logits f32 [B,NC,S,S]"""
-    feats = backbone(p, x)
-    z = upernet_head(p, feats, train)
-    logits = F.interpolate(z, size=x.shape[2:], mode="bilinear", align_corners=False)
+    global _EMULATE
+    prev, _EMULATE = _EMULATE, bool(emulate_bf16)
+    try:
+        feats = backbone(p, x)
+        z = upernet_head(p, feats, train)
+        logits = F.interpolate(z, size=x.shape[2:], mode="bilinear", align_corners=False)
+    finally:
+        _EMULATE = prev
     return (logits, feats) if return_feats else logits
 
 

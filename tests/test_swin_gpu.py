@@ -411,6 +411,28 @@ def test_bf16_against_the_f32_path():
     assert rel_l2(out["bf16"][1]["decode_head.classifier.weight"], g32["decode_head.classifier.weight"]) <= 5e-2
 
 
+def test_bf16_end_to_end_inside_the_rounding_noise_floor():
+    """train-mode logits of the bf16 path, 4 x 128 x 128, every branch on: the yardstick is the network's own rounding-noise floor - the
+    distance between the f32 oracle and its bf16-EMULATION mode (rounding where the HIP path stores bf16, f32 arithmetic), measured on the
+    CPU.  The HIP path must stay within 1.5x of it (max and RMS) and must be no further from the emulation than the emulation is from f32."""
+    NC, B, S = 16, 4, 128
+    img, _ = O.synthetic_tiles(B, S, NC, seed=9, structured=True)
+    net = _build(NC, "bf16")
+    net.train()
+    with torch.no_grad():
+        got = net(img.to(DEV), None).cpu()
+        p = W.init_params(NC, seed=3)
+        want32 = W.forward(p, img.float(), train=True)
+        emu = W.forward(p, img.float(), train=True, emulate_bf16=True)
+    scale = want32.abs().max().item()
+    floor, floor_rms = (emu - want32).abs().max().item() / scale, (emu - want32).pow(2).mean().sqrt().item() / scale
+    e32, rms32 = (got - want32).abs().max().item() / scale, (got - want32).pow(2).mean().sqrt().item() / scale
+    rms_emu = (got - emu).pow(2).mean().sqrt().item() / scale
+    print(f"bf16 logits / max|logit|: max {e32:.3e}, rms {rms32:.3e} from the f32 oracle (emulation: max {floor:.3e}, rms {floor_rms:.3e}); "
+          f"rms {rms_emu:.3e} from the emulation")
+    assert e32 <= 1.5 * floor and rms32 <= 1.5 * floor_rms and rms_emu <= 1.5 * floor_rms
+
+
 def test_swin_trains_reproducibly():
     img, lab = O.synthetic_tiles(4, 128, 5, seed=2, structured=True)
     runs = []
