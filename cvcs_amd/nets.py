@@ -376,17 +376,65 @@ class DeepLabV3Plus(_HipUNet):
         return DeepLabEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, self.output_stride, self.plus)
 
 
-class DeepLabv3Resnet101(DeepLabV3Plus):
+class _TorchvisionDeepLabKeys:
+    """`state_dict()` / `load_state_dict()` in the key names of the reference's wrapper modules (S/nets.py:234-275: `self.model =
+    torchvision deeplabv3_resnet*`, so a reference checkpoint reads `model.backbone.layer3.0.conv1.weight`,
+    `model.classifier.0.convs.1.0.weight`, `model.classifier.4.bias` ...): checkpoints written by the reference load here and the
+    ones written here load in the reference.  torchvision's auxiliary FCN head (`model.aux_classifier.*`, present when the reference
+    starts from the COCO weights; its forward never uses it, S/nets.py:248-250) is accepted and dropped on load."""
+    _KEYS = (("encoder.", "model.backbone."), ("aspp.convs.", "model.classifier.0.convs."), ("aspp.project.", "model.classifier.0.project."),
+             ("head.0.", "model.classifier.1."), ("head.1.", "model.classifier.2."), ("classifier.", "model.classifier.4."))
+
+    @classmethod
+    def _to_reference(cls, k):
+        for mine, ref in cls._KEYS:
+            if k.startswith(mine):
+                return ref + k[len(mine):]
+        return k
+
+    @classmethod
+    def _from_reference(cls, k):
+        if k.startswith("module."):          # DataParallel prefix (S/nets.py:252-257)
+            k = k[len("module."):]
+        for mine, ref in cls._KEYS:
+            if k.startswith(ref):
+                return mine + k[len(ref):]
+        return k
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        out = type(sd)((self._to_reference(k), v) for k, v in sd.items())
+        if hasattr(sd, "_metadata"):
+            out._metadata = sd._metadata
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        sd = OrderedDict((self._from_reference(k), v) for k, v in state_dict.items() if ".aux_classifier." not in k)
+        return super().load_state_dict(sd, strict=strict, **kwargs)
+
+    def custom_load(self, checkpoint):       # S/nets.py:252-257, called by the reference's load_checkpoint when net.wrapper
+        self.load_state_dict(checkpoint["model_state_dict"])
+
+
+class DeepLabv3Resnet101(_TorchvisionDeepLabKeys, DeepLabV3Plus):
     """the network behind the reference's factory name `Resnet101` (S/nets.py:234-257: torchvision deeplabv3_resnet101 with
     `classifier[4]` -> Conv2d(256, num_classes, 1), output stride 8, ASPP rates 12/24/36, forward returns d['out']), built on
-    the HIP kernels.  The reference loads COCO weights through a network fetch; here the weights are randomly initialised
-    unless a checkpoint is loaded (`wrapper` stays False: there is no inner torchvision module to unwrap)."""
+    the HIP kernels, with the reference module's `wrapper` / `custom_load` contract and state_dict key names.  The reference loads
+    COCO weights through a network fetch; here the weights are randomly initialised unless a checkpoint is loaded."""
     arch, output_stride, plus = "resnet101", 8, False
 
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.wrapper = True
 
-class DeepLabv3Resnet50(DeepLabV3Plus):
+
+class DeepLabv3Resnet50(_TorchvisionDeepLabKeys, DeepLabV3Plus):
     """S/nets.py:259-275 (same head on a ResNet-50; not reachable from the reference's load_network either)"""
     arch, output_stride, plus = "resnet50", 8, False
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.wrapper = True
 
 
 # ---------------------------------------------------------------------------------------------------- Swin-T + UPerNet

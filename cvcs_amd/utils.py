@@ -196,8 +196,11 @@ def load_checkpoint(config, net, load_confusion=False):
     DataParallel `module.` prefix, S/nets.py:252-257) or by save_model above."""
     if "load_checkpoint" in config.keys():
         checkpoint = torch.load(config["load_checkpoint"], map_location="cpu", weights_only=False)
-        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint["model_state_dict"].items()}
-        net.load_state_dict(sd)
+        if getattr(net, "wrapper", False):      # S/utils.py:286-287: the wrapper modules translate their own key names
+            net.custom_load(checkpoint)
+        else:
+            sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint["model_state_dict"].items()}
+            net.load_state_dict(sd)
         TL, VL = checkpoint.get("training_loss_values", []), checkpoint.get("validation_loss_values", [])
         mIoU, wIoU = checkpoint.get("macro_precision", []), checkpoint.get("weighted_precision", [])
         print("Loaded checkpoint {}".format(config["load_checkpoint"]), flush=True)

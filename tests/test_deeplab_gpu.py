@@ -191,6 +191,34 @@ def _build(cls, arch, NC, precision, plus, seed=3):
     return net.to(DEV)
 
 
+def _oracle_named(net):
+    """the network's state under the oracle's (= the engine's internal) key names: the reference wrappers DeepLabv3Resnet50/101 export
+    torchvision's names (`model.backbone.*`, `model.classifier.*`)"""
+    back = getattr(net, "_from_reference", lambda k: k)
+    return {back(k): v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+
+
+def test_reference_checkpoint_key_names_of_the_deeplabv3_wrappers(tmp_path):
+    """S/nets.py:234-257 + S/utils.py:282-299: a checkpoint as the reference writes it for `Resnet101` (torchvision key names under
+    `model.`, a DataParallel `module.` prefix, the unused auxiliary head) loads through `wrapper` / `custom_load`; what this package
+    saves carries the same names"""
+    net = utils.load_network({"net": "Resnet101", "num_classes": 15, "precision": "bf16"}, DEV)
+    assert net.wrapper
+    sd = net.state_dict()
+    for k in ("model.backbone.conv1.weight", "model.backbone.layer3.22.conv2.weight", "model.classifier.0.convs.3.0.weight",
+              "model.classifier.0.convs.4.1.weight", "model.classifier.0.project.1.running_var", "model.classifier.1.weight",
+              "model.classifier.2.bias", "model.classifier.4.weight", "model.classifier.4.bias"):
+        assert k in sd, k
+    assert tuple(sd["model.classifier.4.weight"].shape) == (16, 256, 1, 1)
+    ck = {"model_state_dict": {"module." + k: (v.float() * 0 + 0.25 if v.dtype == torch.float32 else v).cpu() for k, v in sd.items()}}
+    ck["model_state_dict"]["module.model.aux_classifier.4.weight"] = torch.zeros(21, 256, 1, 1)
+    path = str(tmp_path / "checkpoint1")
+    torch.save(ck, path)
+    other = utils.load_network({"net": "Resnet101", "num_classes": 15, "precision": "bf16"}, DEV)
+    utils.load_checkpoint({"load_checkpoint": path}, other)
+    assert all((v == 0.25).all() for k, v in other.state_dict().items() if v.dtype == torch.float32)
+
+
 def _f64_gradients(arch, p32, img, lab, os_, plus, relu_masks):
     p = {k: v.detach().double().clone() for k, v in p32.items()}
     names = [k for k in p if not D.is_buffer(k)]
@@ -241,7 +269,7 @@ def test_fp32_train_steps_match_oracle(cls, arch, os_, plus, B, S, NC):
     img, lab = O.synthetic_tiles(B, S, NC, seed=5, structured=True)
     net.train()
     for step in range(3):
-        p_before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+        p_before = _oracle_named(net)
         with torch.no_grad():   # every step is checked at the HIP network's own current parameters
             want_logits = D.forward({k: v.clone() for k, v in p_before.items()}, img.float(), arch, train=True, output_stride=os_, plus=plus)
             want_loss = O.cross_entropy(want_logits, lab.long(), None, 0).item()
@@ -266,13 +294,13 @@ def test_fp32_train_steps_match_oracle(cls, arch, os_, plus, B, S, NC):
         assert e[-1][0] <= 2e-4, e[-1]
         if step == 0:   # the first update against the oracle trainer (identical parameters going in)
             tr.step(img, lab)
-            sd = net.state_dict()
-            worstp = max((rel_l2(sd[k].cpu(), tr.p[k].detach()), k) for k in tr.p)
+            sd = _oracle_named(net)
+            worstp = max((rel_l2(sd[k], tr.p[k].detach()), k) for k in tr.p)
             # (BatchNorm biases start at 0: their relative figure after one update IS the relative error between two f32 gradients,
             #  each with its own handful of ReLU decisions - the same 2e-4 as the gradient bound above; weights are 100x tighter)
             assert worstp[0] <= 2e-4, worstp
     net.eval()
-    final = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+    final = _oracle_named(net)
     with torch.no_grad():
         ev = net(img.to(DEV), None).cpu()
         want = D.forward(final, img.float(), arch, train=False, output_stride=os_, plus=plus)
