@@ -38,9 +38,10 @@ def load_device(config):
 
 
 def load_network(config, device):
-    """S/utils.py:174-195.  `Unet` / `Unetv2` are the HIP models; the torchvision / HuggingFace wrappers of the
-    reference (`Resnet101`, `MobileNet`, `SegformerMod`) are not on the hot path and not built; `Ensemble` votes over
-    HIP member networks."""
+    """S/utils.py:174-195, every network on the HIP kernels: the reference's `Unet` / `Unetv2` and `Resnet101` (DeepLabV3 on a dilated
+    ResNet-101, torchvision key names), `Ensemble` (votes over HIP member networks), BASELINE.json's `Resnet18Unet` / `Resnet34Unet` /
+    `Resnet50Unet`, `DeepLabV3Plus` and `TSwin` (Swin-T + UPerNet).  `MobileNet` and `SegformerMod` (depthwise convolutions, global
+    attention, 8x8 transposed convolutions) are not built and raise."""
     netname = config["net"]
     classes = config["num_classes"] + 1
     precision = config.get("precision", "bf16")
