@@ -11,7 +11,8 @@ lib.cvcs_conv2d.argtypes = [C.POINTER(_lib.ConvDesc), C.c_void_p]
 lib.cvcs_probe_read.argtypes = [C.c_void_p, C.c_size_t]
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
-for (B, S, Cin, Cout, stats) in ((32, 512, 64, 64, 0), (32, 512, 64, 64, 1), (32, 512, 128, 64, 1), (32, 256, 128, 128, 0), (32, 64, 512, 512, 0)):
+SHAPES = ((32, 128, 64, 64, 1), (32, 64, 128, 128, 1), (32, 32, 256, 256, 1), (32, 16, 512, 512, 1)) if os.environ.get("PROBE_SHAPES") == "resnet" else ((32, 512, 64, 64, 0), (32, 512, 64, 64, 1), (32, 512, 128, 64, 1), (32, 256, 128, 128, 0), (32, 64, 512, 512, 0))
+for (B, S, Cin, Cout, stats) in SHAPES:
     x = torch.randn(B, S, S, Cin, device=dev).clamp_(min=0).to(torch.bfloat16)
     w = (torch.randn(9, Cout, Cin, device=dev) / (9 * Cin) ** 0.5).to(torch.bfloat16)
     out = torch.empty(B, S, S, Cout, dtype=torch.bfloat16, device=dev)
