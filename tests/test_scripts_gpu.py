@@ -30,9 +30,12 @@ def _run(cmd, env=None):
     return r.stdout
 
 
-def test_train_eval_inference_scripts(tmp_path):
+@pytest.mark.parametrize("netname", ["Unetv2", "Resnet18Unet", "Resnet101", "TSwin"])
+def test_train_eval_inference_scripts(tmp_path, netname):
+    """the three reference entry points end to end for the reference's own U-Net, BASELINE cfg 1's ResNet18-UNet, the reference's
+    `Resnet101` (DeepLabV3, checkpoint in torchvision key names) and `TSwin` (Swin-T + UPerNet)"""
     from PIL import Image
-    out = _run([sys.executable, "train.py", _cfg(tmp_path, epochs=2)])
+    out = _run([sys.executable, "train.py", _cfg(tmp_path, epochs=2, net=netname)])
     assert "Training Done!" in out and "Saved checkpoint 2" in out and "mIoU" in out
     losses = [float(v) for v in re.findall(r"Reached (?:training|validation) loss: ([0-9.eE+-]+)", out)]
     assert len(losses) == 2 and all(np.isfinite(losses))
@@ -40,7 +43,7 @@ def test_train_eval_inference_scripts(tmp_path):
     assert os.path.exists(ck)
     # evaluation.py on the checkpoint
     ecfg = os.path.join(tmp_path, "eval.yaml")
-    yaml.safe_dump({"net": "Unetv2", "num_classes": 4, "device": "gpu", "precision": "bf16", "load_checkpoint": ck,
+    yaml.safe_dump({"net": netname, "num_classes": 4, "device": "gpu", "precision": "bf16", "load_checkpoint": ck,
                     "dataset": "synthetic:1:8", "patch_size": 64, "ignore_background": True}, open(ecfg, "w"))
     out = _run([sys.executable, "evaluation.py", ecfg])
     assert "mIoU" in out
@@ -48,7 +51,7 @@ def test_train_eval_inference_scripts(tmp_path):
     rng = np.random.default_rng(0)
     Image.fromarray(rng.integers(0, 256, (200, 264, 3), dtype=np.uint8)).save(os.path.join(tmp_path, "img.png"))
     icfg = os.path.join(tmp_path, "inf.yaml")
-    yaml.safe_dump({"net": "Unetv2", "num_classes": 4, "device": "gpu", "load_checkpoint": ck, "image": os.path.join(str(tmp_path), "img.png"),
+    yaml.safe_dump({"net": netname, "num_classes": 4, "device": "gpu", "load_checkpoint": ck, "image": os.path.join(str(tmp_path), "img.png"),
                     "patch_size": 64, "border_correction": 96, "out_image": os.path.join(str(tmp_path), "out.png")}, open(icfg, "w"))
     _run([sys.executable, "inference.py", icfg])
     assert Image.open(os.path.join(tmp_path, "out.png")).size == (256, 192)     # (W // p) * p, (H // p) * p
