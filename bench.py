@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_TFLOPS = 157.3
-PMC_FILES = {"Resnet50Unet": "r02_pmc_traffic_resnet50unet_b32_s512_bf16.json", "SwinTUperNet": "r02_pmc_traffic_swintupernet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json"}
+PMC_FILES = {"Resnet50Unet": "r02_pmc_traffic_resnet50unet_b32_s512_bf16.json", "DeepLabV3Plus": "r02_pmc_traffic_deeplabv3plus_b32_s512_bf16.json", "SwinTUperNet": "r02_pmc_traffic_swintupernet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json"}
 FAMILY_KERNEL = {
     "conv3x3_halo": "conv3x3_halo_kernel (3x3 / stride 1 forward and data-gradient launches; strided 3x3 data gradients run it on the zero-dilated gradient, counted at their algorithmic FLOPs)",
     "conv3x3_halo_bn_bwd": "conv3x3_halo_kernel + fused BatchNorm-backward reduce pass (conv FLOPs only)",
