@@ -62,8 +62,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gradient_allreducer_gloo_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradient_allreducer_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
