@@ -128,6 +128,8 @@ class DeepLabEngine(ResNetUNetEngine):
             self.dlogits_lo = torch.empty_like(self.logits_lo)
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
+        if train and x.shape[0] < 2:   # (torchvision's ASPPPooling BatchNorm raises the same on a 1x1 map of one image)
+            raise ValueError("Expected more than 1 value per channel when training: DeepLab needs a batch of at least 2 tiles")
         if self.shape != (x.shape[0], x.shape[2]):
             self._last_act = {}
         h = self._forward_backbone(x, train)

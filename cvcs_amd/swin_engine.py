@@ -370,6 +370,8 @@ class SwinUPerNetEngine(ResNetUNetEngine):
     def _forward_backbone(self, x, train):
         B, C_, S, S2 = x.shape
         assert C_ == 3 and S == S2
+        if train and B < 2:   # (torch raises the same for the BatchNorm of the 1x1 pyramid-pooling branch)
+            raise ValueError("Expected more than 1 value per channel when training: Swin-T + UPerNet needs a batch of at least 2 tiles")
         self._plan(B, S)
         ops.pack_patches(x.contiguous(), self._buf("pe_in", (B, S // 4, S // 4, 64)))
         key = "fwd_train" if train else "fwd_eval"

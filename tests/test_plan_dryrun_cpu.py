@@ -61,3 +61,13 @@ def test_every_launch_of_the_plan_passes_the_c_abi_argument_checks(no_device, cl
     eng.forward(x, False)
     fwd, bwd = len(eng._rec["fwd_train"].items), len(eng._rec["bwd"].items)
     assert fwd > 20 and bwd > fwd and no_device[0] >= fwd + bwd
+
+
+@pytest.mark.parametrize("cls", ["SwinTUperNet", "DeepLabV3Plus"])
+def test_one_tile_batches_are_refused_in_train_mode_like_torch(no_device, cls):
+    """a BatchNorm over a 1x1 map of ONE image has no variance: torch raises ValueError, so do these engines (eval mode is fine)"""
+    net = getattr(nets, cls)(5, "fp32")
+    eng = _bind_on_cpu(net, torch.float32)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        eng.forward(torch.zeros(1, 3, 64, 64), True)
+    assert tuple(eng.forward(torch.zeros(1, 3, 64, 64), False).shape) == (1, 5, 64, 64)
