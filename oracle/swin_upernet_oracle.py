@@ -294,7 +294,8 @@ def forward_gflop_per_tile(num_classes, S):
 class OracleTrainer:
     """forward -> loss -> zero_grad -> backward -> opt.step (S/train.py:121-126) on the definition above"""
 
-    def __init__(self, num_classes, opt="SGD2", epochs=20, ignore_index=-100, weight=None, seed=0, params=None):
+    def __init__(self, num_classes, opt="SGD2", epochs=20, ignore_index=-100, weight=None, seed=0, params=None, emulate_bf16=False):
+        self.emulate_bf16 = emulate_bf16
         self.p = params if params is not None else init_params(num_classes, seed)
         self.trainable = [k for k in self.p if not is_buffer(k)]
         for k in self.trainable:
@@ -309,7 +310,7 @@ class OracleTrainer:
         return U.polynomial_lr(self.cfg["lr"], self.epoch, self.cfg["total_iters"], self.cfg["power"])
 
     def step(self, x_u8, target_u8):
-        logits = forward(self.p, x_u8.to(torch.float32), train=True)
+        logits = forward(self.p, x_u8.to(torch.float32), train=True, emulate_bf16=self.emulate_bf16)
         loss = U.cross_entropy(logits, target_u8.long(), self.weight, self.ignore_index)
         grads = torch.autograd.grad(loss, [self.p[k] for k in self.trainable])
         self.nstep += 1

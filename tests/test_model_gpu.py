@@ -318,13 +318,29 @@ def test_data_parallel_single_rank_matches_plain_training():
 def test_heldout_miou_after_training_matches_cpu_reference(precision):
     """north star: mIoU on a held-out synthetic set vs the CPU reference (S/utils.py:311-364 definition) after the
     same 40-step SGD2 schedule on structured tiles.  Measured differences: 0.06 points (bf16), see README."""
+    mod = _miou_parity()
+    m_o, m_h = mod.run(precision, steps=40, S=64, verbose=False)
+    assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
+    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.1   # the north star's bound, (m_o["mIoU"], m_h["mIoU"])
+
+
+def _miou_parity():
     import importlib.util
     spec = importlib.util.spec_from_file_location("miou_parity", os.path.join(os.path.dirname(__file__), "..", "scripts", "miou_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    m_o, m_h = mod.run(precision, steps=40, S=64, verbose=False)
-    assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
-    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.1   # the north star's bound, (m_o["mIoU"], m_h["mIoU"])
+    return mod
+
+
+@pytest.mark.parametrize("model,precision,steps,S", [("Resnet18Unet", "bf16", 40, 64), ("DeepLabV3Plus", "bf16", 120, 128), ("TSwin", "fp32", 120, 128)])
+def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, precision, steps, S):
+    """the same for BASELINE's model families (measured on the MI355X: ResNet18-UNet bf16 0.012, ResNet50-UNet bf16 0.005, DeepLabV3+ bf16
+    0.005, Swin-T + UPerNet f32 0.030 points).  Swin in bf16 lands 0.15-0.24 points from the f32 oracle after this schedule (its mIoU
+    plateaus at 95 % and the trajectory is chaotic: the oracle trained in its own forward-only bf16 emulation lands 0.08 away) - reported by
+    `scripts/miou_parity.py bf16 120 128 TSwin emu`, not asserted here."""
+    m_o, m_h = _miou_parity().run(precision, steps=steps, S=S, verbose=False, model=model)
+    assert m_o["mIoU"] > 0.9, "the schedule must actually learn the task"
+    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.1, (m_o["mIoU"], m_h["mIoU"])
 
 
 @pytest.mark.parametrize("variant,B,S", [("Unetv2", 4, 128), ("Unet", 2, 128), ("Unetv2", 2, 256)])
