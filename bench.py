@@ -58,9 +58,10 @@ def cpu_baseline(net, nc, tile, tiles, steps):
     img, lab = O.synthetic_tiles(tiles, tile, nc, seed=1234)
     if net in ("Unetv2", "Unet"):
         tr, what = O.OracleTrainer(net, nc, opt="SGD2", ignore_index=0, seed=0), f"oracle.unet_oracle (torch-CPU fp32 {net}"
-    elif net == "SwinTUperNet":
+    elif net in ("SwinTUperNet", "SwinBUperNet"):
         from oracle import swin_upernet_oracle as W
-        tr, what = W.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0), "oracle.swin_upernet_oracle (torch-CPU fp32 Swin-T + UPerNet"
+        v = "tiny" if net == "SwinTUperNet" else "base"
+        tr, what = W.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0, variant=v), f"oracle.swin_upernet_oracle (torch-CPU fp32 Swin-{v[0].upper()} + UPerNet"
     elif net in ("DeepLabV3Plus", "Resnet101"):
         from oracle import deeplab_oracle as D
         plus = net == "DeepLabV3Plus"
@@ -98,7 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
-    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "Unetv2", "Unet"])
+    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "SwinBUperNet", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -199,6 +200,7 @@ def main():
                  "DeepLabV3Plus": "DeepLabV3+ (ResNet-50 v1.5 at output stride 16, ASPP rates 6/12/18, 64-channel low-level branch)",
                  "Resnet101": "DeepLabV3-ResNet101 (the reference's factory name Resnet101, S/nets.py:234-257; output stride 8, ASPP 12/24/36)",
                  "SwinTUperNet": "Swin-T + UPerNet (BASELINE configs[3]: embed 96, depths 2/2/6/2, window 7; UPerNet hidden 512, pool scales 1/2/3/6)",
+                 "SwinBUperNet": "Swin-B + UPerNet (the reference's documented `BSwin` name: embed 128, depths 2/2/18/2, window 7; UPerNet hidden 512)",
                  "Unetv2": "Unetv2 (the reference's own U-Net, source/scripts/nets.py:117-199)", "Unet": "Unet (reference)"}[a.net]
         out = {
             "metric": "512x512 tiles/sec (train fwd+bwd)" if a.tile == 512 else f"{a.tile}x{a.tile} tiles/sec (train fwd+bwd)",

@@ -21,9 +21,9 @@ static inline unsigned sw_grid(int64_t total, int cap = 256 * 32) {
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// G lanes per token (G = 64: one wave per token, lane l holds the 16-byte chunks l, l+64, ... - C <= 1536: 3 chunks per lane in bf16, 6 in
-// f32; G = 16 / 32: the narrow stages - C = 96 is 12 chunks in bf16 - put 4 / 2 tokens on a wave, one chunk per lane)
-template <typename T> struct LnChunks { static constexpr int n = sizeof(T) == 4 ? 6 : 3; };
+// G lanes per token (G = 64: one wave per token, lane l holds the 16-byte chunks l, l+64, ... - C <= 2048: 4 chunks per lane in bf16, 8 in
+// f32 (Swin-B merges 4 x 512 channels); G = 16 / 32: the narrow stages - C = 96 is 12 chunks in bf16 - put 4 / 2 tokens on a wave, one chunk per lane)
+template <typename T> struct LnChunks { static constexpr int n = sizeof(T) == 4 ? 8 : 4; };
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -976,7 +976,7 @@ extern "C" int cvcs_layernorm_fwd(const void* x, int64_t x_ld, int64_t M, int C,
   const char* fn = "cvcs_layernorm_fwd";
   CVCS_CHECK_ARG(SW_DT(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
-  CVCS_CHECK_ARG(M > 0 && C > 0 && C % V == 0 && C <= 1536, "%s: C=%d must be a multiple of %d, at most 1536", fn, C, V);
+  CVCS_CHECK_ARG(M > 0 && C > 0 && C % V == 0 && C <= 2048, "%s: C=%d must be a multiple of %d, at most 2048", fn, C, V);
   CVCS_CHECK_ARG(gamma && beta && mean && invstd, "%s: null argument", fn);
   int rc;
   if ((rc = sw_view(fn, x, x_ld, C, es)) || (rc = sw_view(fn, out, out_ld, C, es))) return rc;
@@ -996,7 +996,7 @@ extern "C" int cvcs_layernorm_bwd(const void* x, int64_t x_ld, const void* g, in
   const char* fn = "cvcs_layernorm_bwd";
   CVCS_CHECK_ARG(SW_DT(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
-  CVCS_CHECK_ARG(M > 0 && C > 0 && C % V == 0 && C <= 1536, "%s: bad C", fn);
+  CVCS_CHECK_ARG(M > 0 && C > 0 && C % V == 0 && C <= 2048, "%s: bad C", fn);
   CVCS_CHECK_ARG(gamma && mean && invstd && part, "%s: null argument", fn);
   int rc;
   if ((rc = sw_view(fn, x, x_ld, C, es)) || (rc = sw_view(fn, g, g_ld, C, es)) || (rc = sw_view(fn, dx, dx_ld, C, es))) return rc;

@@ -19,7 +19,7 @@ import torch.nn as nn
 from .engine import WIDTHS, UNetEngine
 from .deeplab_engine import LOW_LEVEL_CHANNELS, DeepLabEngine
 from .resnet_engine import ARCHS as RESNET_ARCHS, DECODER_CHANNELS, ResNetUNetEngine
-from .swin_engine import DEPTHS as SWIN_DEPTHS, DIMS as SWIN_DIMS, HEADS as SWIN_HEADS, HIDDEN as UPER_HIDDEN, POOL_SCALES, SwinUPerNetEngine
+from .swin_engine import HIDDEN as UPER_HIDDEN, POOL_SCALES, VARIANTS as SWIN_VARIANTS, SwinUPerNetEngine
 
 PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
@@ -438,11 +438,13 @@ class DeepLabv3Resnet50(_TorchvisionDeepLabKeys, DeepLabV3Plus):
 
 
 # ---------------------------------------------------------------------------------------------------- Swin-T + UPerNet
-def swin_upernet_param_spec(num_classes: int):
+def swin_upernet_param_spec(num_classes: int, variant: str = "tiny"):
     """(name, shape, kind): the parameter names of transformers' UperNetForSemanticSegmentation over a SwinBackbone (embed 96, depths
     2/2/6/2, heads 3/6/12/24, window 7; UPerNet hidden 512, pool scales 1/2/3/6), so its checkpoints load by name.  Within an
     attention block the q / k / v weights, then their biases, are registered ADJACENTLY: in the flat parameter buffer they form one
     [3C, C] matrix and one [3C] bias, which the engine runs as a single GEMM."""
+    embed, SWIN_DEPTHS, SWIN_HEADS = SWIN_VARIANTS[variant]      # noqa: N806
+    SWIN_DIMS = tuple(embed * 2 ** i for i in range(4))          # noqa: N806
     spec = []
 
     def lin(p, cin, cout, bias=True):
@@ -500,12 +502,13 @@ class SwinTUperNet(_HipUNet):
     tile side must be a multiple of 32; train mode needs a batch of at least 2 tiles (the 1x1 pyramid-pooling branch normalises a
     1x1 map over the batch).  Raw 0..255 inputs like every network of the reference (S/train.py:121)."""
     variant = "SwinTUperNet"
+    swin = "tiny"
 
     def _build_spec(self):
-        return swin_upernet_param_spec(self.num_classes)
+        return swin_upernet_param_spec(self.num_classes, self.swin)
 
     def _build_engine(self, dev):
-        return SwinUPerNetEngine(self.num_classes, PRECISIONS[self.precision], dev)
+        return SwinUPerNetEngine(self.num_classes, PRECISIONS[self.precision], dev, self.swin)
 
     def _flat_order(self, params):
         # (1) q | k | v weights, then their biases, adjacent: the engine runs the three projections as one [3C, C] GEMM;
@@ -532,3 +535,10 @@ class SwinTUperNet(_HipUNet):
                 out[name] = p
         assert len(out) == len(params)
         return out
+
+
+class SwinBUperNet(SwinTUperNet):
+    """Swin-B encoder (embed 128, depths 2/2/18/2, heads 4/8/16/32) + the same UPerNet decoder: the `BSwin` name of the reference's
+    documentation (configs/train/README.txt:45)"""
+    variant = "SwinBUperNet"
+    swin = "base"

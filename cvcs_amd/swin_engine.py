@@ -29,13 +29,17 @@ from .resnet_engine import Act, ResNetUNetEngine
 
 EMBED, DEPTHS, HEADS, WINDOW, HIDDEN, POOL_SCALES = 96, (2, 2, 6, 2), (3, 6, 12, 24), 7, 512, (1, 2, 3, 6)
 DIMS = tuple(EMBED * 2 ** i for i in range(4))
+# (embed dim, depths, heads): Swin-T (the module constants above) and Swin-B (`BSwin`, configs/train/README.txt:45); head dim 32 in both
+VARIANTS = {"tiny": (EMBED, DEPTHS, HEADS), "base": (128, (2, 2, 18, 2), (4, 8, 16, 32))}
 PE = "backbone.swin.embeddings.patch_embeddings.projection"
 
 
 class SwinUPerNetEngine(ResNetUNetEngine):
-    def __init__(self, num_classes: int, dtype: torch.dtype, device):
+    def __init__(self, num_classes: int, dtype: torch.dtype, device, variant="tiny"):
         super().__init__("resnet18", num_classes, dtype, device)   # (arch only sizes helper vectors; no ResNet stage is built)
         self.head_name = "decode_head.classifier"
+        self.embed, self.swin_depths, self.swin_heads = VARIANTS[variant]
+        self.dims = tuple(self.embed * 2 ** i for i in range(4))
 
     # ------------------------------------------------------------------------------------------------ binding
     def bind(self, params, grads, buffers):
@@ -72,7 +76,7 @@ class SwinUPerNetEngine(ResNetUNetEngine):
             elif key.endswith((".k_proj", ".v_proj")):
                 continue
             elif key == PE:
-                add(key, w.view(EMBED, 48, 1, 1), grads[name].view(EMBED, 48, 1, 1), want_dgrad=False, cin_pad=64)
+                add(key, w.view(self.embed, 48, 1, 1), grads[name].view(self.embed, 48, 1, 1), want_dgrad=False, cin_pad=64)
             elif w.dim() == 2:
                 add(key, w.view(w.shape[0], w.shape[1], 1, 1), grads[name].view(w.shape[0], w.shape[1], 1, 1))
             elif w.dim() == 4:
@@ -219,27 +223,27 @@ class SwinUPerNetEngine(ResNetUNetEngine):
         h4, h1 = S // 32, S // 4
         # ---- patch embedding (the packed patches come from the eager cvcs_pack_patches launch in _forward_backbone)
         pe_in = ops.view(self._buf("pe_in", (B, H, H, 64)))
-        e = self._tokens("pe.out", B, H, H, EMBED)
+        e = self._tokens("pe.out", B, H, H, self.embed)
         self._lin(pe_in, PE, e)
-        x = Act(self._tokens("pe.norm", B, H, H, EMBED))
+        x = Act(self._tokens("pe.norm", B, H, H, self.embed))
         st0 = self._ln(e, "backbone.swin.embeddings.norm", x.v)
         if train:
             def pe_bwd(x=x, H=H):
                 g = self._sum_grads(x, "pe.g")
-                g_e = self._tokens("pe.g_e", B, H, H, EMBED)
+                g_e = self._tokens("pe.g_e", B, H, H, self.embed)
                 self._ln_bwd(e, g, "backbone.swin.embeddings.norm", st0, g_e)
                 self._lin_bwd(pe_in, g_e, PE, None, want_dx=False)
                 self._ready(PE + ".weight")
             tape.append(pe_bwd)
         # ---- UPerNet input buffers the encoder writes into
-        psp_cat = self._act("psp_cat", B, h4, h4, DIMS[3] + len(POOL_SCALES) * HIDDEN)
+        psp_cat = self._act("psp_cat", B, h4, h4, self.dims[3] + len(POOL_SCALES) * HIDDEN)
         feats = []
-        for s, (depth, heads) in enumerate(zip(DEPTHS, HEADS)):
-            C_ = DIMS[s]
+        for s, (depth, heads) in enumerate(zip(self.swin_depths, self.swin_heads)):
+            C_ = self.dims[s]
             for b in range(depth):
                 p = f"backbone.swin.encoder.layers.{s}.blocks.{b}"
                 x = self._block(x, p, heads, 0 if b % 2 == 0 else WINDOW // 2, self._tokens(p + ".out", B, H, H, C_), train, tape)
-            fv = View(psp_cat, 0, DIMS[3]) if s == 3 else self._tokens(f"feat{s}", B, H, H, C_)
+            fv = View(psp_cat, 0, self.dims[3]) if s == 3 else self._tokens(f"feat{s}", B, H, H, C_)
             f = Act(fv)
             nname = f"backbone.hidden_states_norms.stage{s + 1}"
             stn = self._ln(x.v, nname, f.v)
@@ -276,11 +280,11 @@ class SwinUPerNetEngine(ResNetUNetEngine):
         f4 = feats[3]
         psp_units = []
         for i, sc in enumerate(POOL_SCALES):
-            pooled = self._tokens(f"psp{i}.pooled", B, sc, sc, DIMS[3])
+            pooled = self._tokens(f"psp{i}.pooled", B, sc, sc, self.dims[3])
             ops.adaptive_avg_pool(f4.v, pooled)
             pa = Act(self._tokens(f"psp{i}.act", B, sc, sc, HIDDEN))
             u = self._unit(pooled, f"{D}.psp_modules.{i}.1.conv", f"{D}.psp_modules.{i}.1.batch_norm", 1, 1, 0, train, pa.v)
-            ops.resize_any(pa.v, View(psp_cat, DIMS[3] + i * HIDDEN, HIDDEN))
+            ops.resize_any(pa.v, View(psp_cat, self.dims[3] + i * HIDDEN, HIDDEN))
             psp_units.append((u, pooled, pa, sc))
         lat = [None] * 4
         lat_units = [None] * 4
@@ -338,16 +342,16 @@ class SwinUPerNetEngine(ResNetUNetEngine):
                     feats[i].grads.append(self._dgrad(lat_units[i], dyl, f"lat{i}.g_feat"))
                 dyb = self._unit_bwd(lat_units[3], g_ls[3], 0)
                 gpc, _ = self._dgrad(lat_units[3], dyb, "psp_cat.g")
-                parts = [(View(gpc.t, 0, DIMS[3]), False)]
+                parts = [(View(gpc.t, 0, self.dims[3]), False)]
                 for i, (u, pooled, pa, sc) in enumerate(psp_units):
                     g_pa = self._tokens(f"psp{i}.g_act", B, sc, sc, HIDDEN)
-                    ops.resize_any(View(gpc.t, DIMS[3] + i * HIDDEN, HIDDEN), g_pa, backward=True)
+                    ops.resize_any(View(gpc.t, self.dims[3] + i * HIDDEN, HIDDEN), g_pa, backward=True)
                     dyp = self._unit_bwd(u, g_pa, 0)
                     g_pool, _ = self._dgrad(u, dyp, f"psp{i}.g_pooled")
-                    g_f4 = self._tokens(f"psp{i}.g_f4", B, h4, h4, DIMS[3])
+                    g_f4 = self._tokens(f"psp{i}.g_f4", B, h4, h4, self.dims[3])
                     ops.adaptive_avg_pool(g_pool, g_f4, backward=True)
                     parts.append((g_f4, False))
-                s3 = self._tokens("f4.g_sum3", B, h4, h4, DIMS[3])
+                s3 = self._tokens("f4.g_sum3", B, h4, h4, self.dims[3])
                 ops.relu_bwd_sum(None, parts[:3], s3)
                 f4.grads.append((s3, False))
                 f4.grads.extend(parts[3:])

@@ -61,6 +61,8 @@ def load_network(config, device):
     elif netname in ("TSwin", "SwinTUperNet"):
         # the reference documents `TSwin` (configs/train/README.txt:44) without a definition: Swin-T + UPerNet of BASELINE configs[3]
         return nets.SwinTUperNet(classes, precision).to(device)
+    elif netname in ("BSwin", "SwinBUperNet"):
+        return nets.SwinBUperNet(classes, precision).to(device)   # configs/train/README.txt:45
     elif netname == "DeepLabV3Plus":
         # BASELINE.json configs[2]: DeepLabV3+ (ResNet-50, ASPP 6/12/18) - a new factory name behind the same seam
         return nets.DeepLabV3Plus(classes, precision).to(device)

@@ -31,13 +31,17 @@ from . import unet_oracle as U
 
 EMBED, DEPTHS, HEADS, WINDOW, MLP_RATIO, LN_EPS = 96, (2, 2, 6, 2), (3, 6, 12, 24), 7, 4, 1e-5
 HIDDEN, POOL_SCALES = 512, (1, 2, 3, 6)
+# (embed dim, depths, heads): Swin-T (`TSwin`) and Swin-B (`BSwin`, configs/train/README.txt:44-45); head dim 32 in both
+VARIANTS = {"tiny": (96, (2, 2, 6, 2), (3, 6, 12, 24)), "base": (128, (2, 2, 18, 2), (4, 8, 16, 32))}
 
 
-def stage_dims():
-    return [EMBED * 2 ** i for i in range(4)]
+def stage_dims(variant="tiny"):
+    return [VARIANTS[variant][0] * 2 ** i for i in range(4)]
 
 
-def param_spec(num_classes: int):
+def param_spec(num_classes: int, variant="tiny"):
+    EMBED, DEPTHS, HEADS = VARIANTS[variant]      # noqa: N806  (shadow the Swin-T module constants)
+    stage_dims = lambda: [EMBED * 2 ** i for i in range(4)]   # noqa: E731
     spec = []
 
     def lin(p, cin, cout, bias=True):
@@ -88,12 +92,12 @@ def is_buffer(name):
     return name.endswith("running_mean") or name.endswith("running_var")
 
 
-def init_params(num_classes, seed=0):
+def init_params(num_classes, seed=0, variant="tiny"):
     """deterministic synthetic weights: linear / conv ~ N(0, 1/fan_in)-ish scales that keep activations O(1), LayerNorm / BatchNorm
     gamma in [0.5, 1.5], small biases, relative-position tables ~ N(0, 0.5)"""
     g = torch.Generator().manual_seed(seed)
     out = OrderedDict()
-    for name, shape in param_spec(num_classes):
+    for name, shape in param_spec(num_classes, variant):
         if name.endswith("running_mean"):
             t = torch.zeros(shape)
         elif name.endswith("running_var"):
@@ -217,7 +221,9 @@ def backbone(p, x):
     t = y.flatten(2).transpose(1, 2)
     t = _q(F.layer_norm(t, (C,), p["backbone.swin.embeddings.norm.weight"], p["backbone.swin.embeddings.norm.bias"], LN_EPS))
     feats = []
-    for s, (depth, heads) in enumerate(zip(DEPTHS, HEADS)):
+    depths = [1 + max(int(k.split(".")[6]) for k in p if k.startswith(f"backbone.swin.encoder.layers.{s}.blocks.")) for s in range(4)]
+    heads_ = [p[f"backbone.swin.encoder.layers.{s}.blocks.0.attention.relative_position_bias.relative_position_bias_table"].shape[1] for s in range(4)]
+    for s, (depth, heads) in enumerate(zip(depths, heads_)):     # (Swin-T or Swin-B: read off the parameters)
         for b in range(depth):
             t = swin_block(t, H, W, p, f"backbone.swin.encoder.layers.{s}.blocks.{b}", heads, 0 if b % 2 == 0 else WINDOW // 2)
         C = t.shape[-1]
@@ -267,11 +273,12 @@ def forward(p, x, train=False, return_feats=False, emulate_bf16=False):
     return (logits, feats) if return_feats else logits
 
 
-def forward_gflop_per_tile(num_classes, S):
+def forward_gflop_per_tile(num_classes, S, variant="tiny"):
     """algorithmic forward GFLOP per tile: linear layers, attention (QK^T and AV over the padded windows), convolutions"""
+    EMBED, DEPTHS, HEADS = VARIANTS[variant]      # noqa: N806
     fl = 2.0 * 3 * 16 * EMBED * (S // 4) ** 2
     H = S // 4
-    for s, (depth, dim, heads) in enumerate(zip(DEPTHS, stage_dims(), HEADS)):
+    for s, (depth, dim, heads) in enumerate(zip(DEPTHS, stage_dims(variant), HEADS)):
         L = H * H
         Hp = -(-H // WINDOW) * WINDOW
         Lp = Hp * Hp
@@ -280,7 +287,7 @@ def forward_gflop_per_tile(num_classes, S):
         if s < 3:
             fl += 2.0 * (L // 4) * 4 * dim * 2 * dim
             H //= 2
-    d = stage_dims()
+    d = stage_dims(variant)
     h4, h1 = S // 32, S // 4
     fl += sum(2.0 * d[3] * HIDDEN * s * s for s in POOL_SCALES)
     fl += 2.0 * (d[3] + 4 * HIDDEN) * HIDDEN * 9 * h4 * h4
@@ -294,9 +301,10 @@ def forward_gflop_per_tile(num_classes, S):
 class OracleTrainer:
     """forward -> loss -> zero_grad -> backward -> opt.step (S/train.py:121-126) on the definition above"""
 
-    def __init__(self, num_classes, opt="SGD2", epochs=20, ignore_index=-100, weight=None, seed=0, params=None, emulate_bf16=False):
+    def __init__(self, num_classes, opt="SGD2", epochs=20, ignore_index=-100, weight=None, seed=0, params=None, emulate_bf16=False,
+                 variant="tiny"):
         self.emulate_bf16 = emulate_bf16
-        self.p = params if params is not None else init_params(num_classes, seed)
+        self.p = params if params is not None else init_params(num_classes, seed, variant)
         self.trainable = [k for k in self.p if not is_buffer(k)]
         for k in self.trainable:
             self.p[k].requires_grad_(True)

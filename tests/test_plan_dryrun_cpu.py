@@ -45,7 +45,7 @@ def _bind_on_cpu(net, dtype):
     return eng
 
 
-CASES = [("SwinTUperNet", {}, 4, 64), ("SwinTUperNet", {}, 2, 224), ("Resnet18Unet", {}, 2, 64), ("Resnet50Unet", {}, 2, 96),
+CASES = [("SwinTUperNet", {}, 4, 64), ("SwinTUperNet", {}, 2, 224), ("SwinBUperNet", {}, 2, 96), ("Resnet18Unet", {}, 2, 64), ("Resnet50Unet", {}, 2, 96),
          ("Resnet50Unet", {"decoder_norm": "gn_silu"}, 2, 64), ("DeepLabV3Plus", {}, 2, 64), ("DeepLabv3Resnet101", {}, 2, 64)]
 
 

@@ -39,7 +39,7 @@ def tok(t, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C_,M", [(96, 70), (192, 45), (384, 33), (1536, 9), (768, 130)])
+@pytest.mark.parametrize("C_,M", [(96, 70), (192, 45), (384, 33), (1536, 9), (768, 130), (2048, 7)])
 def test_layernorm_forward_and_backward(dtype, C_, M):
     g = torch.Generator().manual_seed(C_)
     x = rq(torch.randn(M, C_, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
@@ -355,6 +355,46 @@ def test_fp32_train_steps_match_oracle(B, S, NC):
         labels = net.predict_labels(img.to(DEV)).cpu()
     close(ev, want, 1e-3, "eval logits")
     assert torch.equal(labels.long(), ev.argmax(1))
+
+
+def test_swin_base_variant_matches_oracle():
+    """`BSwin` (configs/train/README.txt:45): Swin-B encoder (embed 128, depths 2/2/18/2, heads 4/8/16/32) + UPerNet - train-mode logits,
+    loss and the first SGD2 update against the oracle in f32; eval logits; bf16 logits RMS"""
+    NC, B, S = 5, 4, 64
+    net = utils.load_network({"net": "BSwin", "num_classes": NC - 1, "precision": "fp32"}, DEV)
+    assert isinstance(net, nets.SwinBUperNet) and utils.count_params(net) == 119_986_621 - 0   # Swin-B 88 M + UPerNet head
+    p0 = W.init_params(NC, seed=3, variant="base")
+    net.load_state_dict(p0, strict=False)
+    tr = W.OracleTrainer(NC, "SGD2", ignore_index=0, seed=3, variant="base")
+    crit = utils.CrossEntropyLoss(ignore_index=0)
+    optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
+    img, lab = O.synthetic_tiles(B, S, NC, seed=5, structured=True)
+    net.train()
+    logits = net(img.to(DEV), None)
+    loss = crit(logits, lab.to(DEV))
+    optim.zero_grad()
+    loss.backward()
+    optim.step()
+    torch.cuda.synchronize()
+    want_loss, want_logits, _ = tr.step(img, lab)
+    close(logits.detach().cpu(), want_logits, 1e-3, "Swin-B train logits")
+    assert abs(loss.item() - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    sd = net.state_dict()
+    worst = max((rel_l2(sd[k].cpu(), tr.p[k].detach()), k) for k in tr.p)
+    assert worst[0] <= 2e-4, worst
+    net.eval()
+    final = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+    with torch.no_grad():
+        ev = net(img.to(DEV), None).cpu()
+        want = W.forward(final, img.float(), train=False)
+    close(ev, want, 1e-3, "Swin-B eval logits")
+    nb = nets.SwinBUperNet(NC, "bf16")
+    nb.load_state_dict(p0, strict=False)
+    nb = nb.to(DEV).eval()
+    with torch.no_grad():
+        evb = nb(img.to(DEV), None).cpu()
+        want0 = W.forward(p0, img.float(), train=False)
+    assert (evb - want0).pow(2).mean().sqrt().item() <= 1e-2 * want0.abs().max().item()
 
 
 def test_fp32_forward_without_window_padding():
