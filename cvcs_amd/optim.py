@@ -31,12 +31,17 @@ class PolynomialLR:
         return [self.optimizer.lr]
 
     def state_dict(self):
-        return {"total_iters": self.total_iters, "power": self.power, "base_lr": self.base_lr,
-                "last_epoch": self.last_epoch}
+        """the keys torch.optim.lr_scheduler.PolynomialLR saves (its load_state_dict updates __dict__: a reference run can resume from
+        this) plus `base_lr`"""
+        return {"total_iters": self.total_iters, "power": self.power, "base_lr": self.base_lr, "base_lrs": [self.base_lr],
+                "last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1, "_last_lr": [self.optimizer.lr],
+                "_get_lr_called_within_step": False, "verbose": False}
 
     def load_state_dict(self, sd):
+        """accepts this class's dictionary or torch's (S/train.py resume: `scheduler.load_state_dict(checkpoint[...])`)"""
         self.total_iters, self.power = sd["total_iters"], sd["power"]
-        self.base_lr, self.last_epoch = sd["base_lr"], sd["last_epoch"]
+        self.base_lr = sd["base_lr"] if "base_lr" in sd else sd["base_lrs"][0]
+        self.last_epoch = sd["last_epoch"]
         self._apply()
 
 
@@ -60,6 +65,30 @@ class _FusedOptimizer:
             self.pre_step()
         return p, g
 
+    # ---- torch.optim state_dict format: {"state": {i: {...}}, "param_groups": [{..., "params": [0..n-1]}]}, parameter i = the i-th of
+    # net.parameters() (what the reference hands to torch.optim, S/utils.py:208-221).  The flat state buffers mirror the flat parameter
+    # buffer, so parameter i's slice sits at the offset of its data inside the flat parameters.
+    def _slices(self):
+        flat, _ = self.net.flat_parameters()
+        out = []
+        for prm in self.net.parameters():
+            off = (prm.data_ptr() - flat.data_ptr()) // 4
+            out.append((off, prm.numel(), tuple(prm.shape)))
+        return flat, out
+
+    def _export(self, buf):
+        _, sl = self._slices()
+        return [buf[off:off + n].view(shape).detach().cpu().clone() for off, n, shape in sl]
+
+    def _import(self, tensors, name):
+        flat, sl = self._slices()
+        buf = torch.zeros_like(flat)
+        assert len(tensors) == len(sl), f"optimizer state holds {len(tensors)} '{name}' tensors, the network has {len(sl)} parameters"
+        for t, (off, n, shape) in zip(tensors, sl):
+            assert tuple(t.shape) == shape, (name, tuple(t.shape), shape)
+            buf[off:off + n].copy_(t.reshape(-1).to(flat.device, torch.float32))
+        return buf
+
 
 class FusedSGD(_FusedOptimizer):
     """torch.optim.SGD(lr, momentum, weight_decay) semantics (S/utils.py:211,214)."""
@@ -78,11 +107,25 @@ class FusedSGD(_FusedOptimizer):
         self.steps += 1
 
     def state_dict(self):
-        return {"kind": "SGD", "lr": self.lr, "momentum": self.momentum, "weight_decay": self.weight_decay,
-                "steps": self.steps, "momentum_buffer": None if self.buf is None else self.buf.detach().cpu()}
+        """torch.optim.SGD's format (a reference run can resume from it, and this class loads the reference's)"""
+        n = sum(1 for _ in self.net.parameters())
+        state = {} if self.buf is None else {i: {"momentum_buffer": t} for i, t in enumerate(self._export(self.buf))}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay, "nesterov": False,
+                 "maximize": False, "foreach": None, "differentiable": False, "fused": None, "params": list(range(n))}
+        return {"state": state, "param_groups": [group], "steps": self.steps}
 
     def load_state_dict(self, sd):
-        self.lr, self.momentum, self.weight_decay, self.steps = sd["lr"], sd["momentum"], sd["weight_decay"], sd["steps"]
+        if "param_groups" in sd:      # torch format (the reference's checkpoints, and this class's own)
+            g = sd["param_groups"][0]
+            self.lr, self.momentum, self.weight_decay = g["lr"], g["momentum"], g["weight_decay"]
+            st = sd["state"]
+            if len(st):
+                self.buf = self._import([st[i]["momentum_buffer"] for i in range(len(st))], "momentum_buffer")
+                self.steps = sd.get("steps", 1)      # (only "first step or not" matters to the SGD update)
+            else:
+                self.buf, self.steps = None, 0
+            return
+        self.lr, self.momentum, self.weight_decay, self.steps = sd["lr"], sd["momentum"], sd["weight_decay"], sd["steps"]   # round-1 format
         if sd["momentum_buffer"] is not None:
             p, _ = self.net.flat_parameters()
             self.buf = sd["momentum_buffer"].to(p.device)
@@ -106,13 +149,32 @@ class FusedAdam(_FusedOptimizer):
                       self.grad_scale, self.steps)
 
     def state_dict(self):
-        return {"kind": "Adam", "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
-                "steps": self.steps, "exp_avg": None if self.m is None else self.m.detach().cpu(),
-                "exp_avg_sq": None if self.v is None else self.v.detach().cpu()}
+        """torch.optim.Adam's format"""
+        n = sum(1 for _ in self.net.parameters())
+        state = {}
+        if self.m is not None:
+            for i, (m, v) in enumerate(zip(self._export(self.m), self._export(self.v))):
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m, "exp_avg_sq": v}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(n))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        if "param_groups" in sd:
+            g = sd["param_groups"][0]
+            self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+            st = sd["state"]
+            if len(st):
+                self.m = self._import([st[i]["exp_avg"] for i in range(len(st))], "exp_avg")
+                self.v = self._import([st[i]["exp_avg_sq"] for i in range(len(st))], "exp_avg_sq")
+                self.steps = int(float(st[0]["step"]))
+            else:
+                self.m = self.v = None
+                self.steps = 0
+            return
         self.lr, self.betas, self.eps, self.weight_decay, self.steps = sd["lr"], tuple(sd["betas"]), sd["eps"], \
-            sd["weight_decay"], sd["steps"]
+            sd["weight_decay"], sd["steps"]                                                                          # round-1 format
         if sd["exp_avg"] is not None:
             p, _ = self.net.flat_parameters()
             self.m, self.v = sd["exp_avg"].to(p.device), sd["exp_avg_sq"].to(p.device)

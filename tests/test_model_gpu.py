@@ -476,3 +476,49 @@ def test_config5_shape_1024_tiles_21_classes():
     assert all(np.isfinite(l0)) and l0[-1] < l0[0]
     assert l0 == l1 and torch.equal(a0, a1)
     assert int(a0.max()) < NC
+
+
+@pytest.mark.parametrize("netname,optname", [("Unetv2", "SGD2"), ("Unetv2", "ADAM1"), ("TSwin", "SGD2")])
+def test_optimizer_and_scheduler_state_in_torch_format_resumes_bit_exactly(netname, optname):
+    """checkpoint compatibility (S/train.py resume, S/utils.py:128-142): `opt.state_dict()` / `scheduler.state_dict()` are torch.optim's
+    dictionaries - a torch optimiser over tensors of the same shapes loads them - and a run resumed from them continues bit for bit
+    (Swin's flat parameter order differs from net.parameters(): the per-parameter slices must still line up)"""
+    NC, B, S = 5, 4, 64
+    img, lab = O.synthetic_tiles(B, S, NC, seed=4, structured=True)
+
+    def make():
+        torch.manual_seed(0)
+        net = utils.load_network({"net": netname, "num_classes": NC - 1, "precision": "bf16"}, DEV)
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        opt, sched = utils.load_optimizer({"opt": optname, "epochs": 5}, net)
+        net.train()
+        return net, crit, opt, sched
+
+    def steps(net, crit, opt, n):
+        for _ in range(n):
+            loss = crit(net(img.to(DEV), None), lab.to(DEV))
+            opt.zero_grad(); loss.backward(); opt.step()
+
+    net, crit, opt, sched = make()
+    steps(net, crit, opt, 2)
+    sched.step()
+    ck = {"model": {k: v.clone() for k, v in net.state_dict().items()}, "opt": opt.state_dict(), "sched": sched.state_dict()}
+    steps(net, crit, opt, 2)
+    straight = net.flat_parameters()[0].clone()
+    # (a) torch's own optimiser / scheduler accept the dictionaries
+    shadow = [torch.nn.Parameter(torch.zeros(p.shape)) for p in net.parameters()]
+    topt = torch.optim.SGD(shadow, lr=0.1, momentum=0.9) if optname == "SGD2" else torch.optim.Adam(shadow, lr=0.1)
+    topt.load_state_dict({"state": ck["opt"]["state"], "param_groups": ck["opt"]["param_groups"]})
+    tsched = torch.optim.lr_scheduler.PolynomialLR(topt, total_iters=5, power=1.0)
+    tsched.load_state_dict(ck["sched"])
+    assert tsched.last_epoch == 1 and abs(topt.param_groups[0]["lr"] - opt.lr) < 1e-12
+    key = "momentum_buffer" if optname == "SGD2" else "exp_avg"
+    assert all(tuple(topt.state[q][key].shape) == tuple(q.shape) for q in shadow)
+    # (b) resume from torch's re-export of them
+    net2, crit2, opt2, sched2 = make()
+    net2.load_state_dict(ck["model"])
+    opt2.load_state_dict(topt.state_dict())
+    sched2.load_state_dict(tsched.state_dict())
+    assert sched2.last_epoch == 1 and opt2.lr == opt.lr
+    steps(net2, crit2, opt2, 2)
+    assert torch.equal(net2.flat_parameters()[0], straight)
