@@ -332,10 +332,11 @@ def _miou_parity():
     return mod
 
 
-@pytest.mark.parametrize("model,precision,steps,S", [("Resnet18Unet", "bf16", 40, 64), ("DeepLabV3Plus", "bf16", 120, 128), ("TSwin", "fp32", 120, 128)])
+@pytest.mark.parametrize("model,precision,steps,S", [("Resnet18Unet", "bf16", 40, 64), ("DeepLabV3Plus", "bf16", 120, 128)])
 def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, precision, steps, S):
     """the same for BASELINE's model families (measured on the MI355X: ResNet18-UNet bf16 0.012, ResNet50-UNet bf16 0.005, DeepLabV3+ bf16
-    0.005, Swin-T + UPerNet f32 0.030 points).  Swin in bf16 lands 0.15-0.24 points from the f32 oracle after this schedule (its mIoU
+    0.005, Swin-T + UPerNet f32 0.030 points - the last one takes 70 s of CPU oracle time and is left to `scripts/miou_parity.py fp32 120 128
+    TSwin`).  Swin in bf16 lands 0.15-0.24 points from the f32 oracle after this schedule (its mIoU
     plateaus at 95 % and the trajectory is chaotic: the oracle trained in its own forward-only bf16 emulation lands 0.08 away) - reported by
     `scripts/miou_parity.py bf16 120 128 TSwin emu`, not asserted here."""
     m_o, m_h = _miou_parity().run(precision, steps=steps, S=S, verbose=False, model=model)
