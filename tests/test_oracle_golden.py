@@ -50,6 +50,7 @@ def test_blocks_reference_vectors(golden_dir):
     ("unetv2_sgd2", "Unetv2", "SGD2", 0, 20),
     ("unetv2_adam1_wcel", "Unetv2", "ADAM1", -100, 4),
     ("unet_sgd2_wcel", "Unet", "SGD2", 0, 20),
+    ("unetv2_sgd2_4x128", "Unetv2", "SGD2", 0, 20),      # round 2: 4 x 128 x 128, every BatchNorm averages >= 256 values
 ])
 def test_nets_reference_vectors(golden_dir, tag, variant, opt, ignore, epochs):
     """nets.Urnet / nets.Urnetv2 (S/nets.py:34-199), CE loss (S/utils.py:230,238), SGD2 / ADAM1 +
