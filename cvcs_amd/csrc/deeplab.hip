@@ -102,8 +102,55 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const char* g, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------ NCHW f32 resize (logits)
+// Both kernels were VALU-instruction-bound (a float division and two integer divisions per output element; ~100 taps with a division each per
+// input element in the backward): four outputs per thread with one 16-byte store, and tap weights from a multiplication by 1/s.
+__device__ __forceinline__ void bil_taps_mul(int o, float inv_s, int n, int& i0, int& i1, float& w0, float& w1) {
+  float src = ((float)o + 0.5f) * inv_s - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  w1 = src - (float)i0;
+  w0 = 1.f - w1;
+}
+__device__ __forceinline__ float bil_weight_mul(int o, float inv_s, int n, int i) {
+  int i0, i1;
+  float w0, w1;
+  bil_taps_mul(o, inv_s, n, i0, i1, w0, w1);
+  return (i0 == i ? w0 : 0.f) + (i1 == i ? w1 : 0.f);
+}
+
+// s % 4 == 0: a thread writes 4 consecutive outputs of a row
 __global__ __launch_bounds__(256) void resize_nchw_fwd_kernel(const float* __restrict__ in, int64_t planes, int H, int W, int s,
                                                              float* __restrict__ out) {
+  const int Ho = H * s, Wo = W * s, Wq = Wo / 4;
+  const float inv_s = 1.f / (float)s;
+  const int64_t total = planes * Ho * Wq;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int ox0 = (int)(id % Wq) * 4;
+    const int64_t t = id / Wq;
+    const int oy = (int)(t % Ho);
+    const int64_t pl = t / Ho;
+    int y0, y1;
+    float wy0, wy1;
+    bil_taps_mul(oy, inv_s, H, y0, y1, wy0, wy1);
+    const float* r0 = in + pl * H * W + (int64_t)y0 * W;
+    const float* r1 = in + pl * H * W + (int64_t)y1 * W;
+    float4 o;
+    float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      float wx0, wx1;
+      bil_taps_mul(ox0 + j, inv_s, W, x0, x1, wx0, wx1);
+      ov[j] = wy0 * (wx0 * r0[x0] + wx1 * r0[x1]) + wy1 * (wx0 * r1[x0] + wx1 * r1[x1]);
+    }
+    *reinterpret_cast<float4*>(out + (pl * Ho + oy) * Wo + ox0) = o;
+  }
+}
+
+// any s: one output per thread
+__global__ __launch_bounds__(256) void resize_nchw_fwd1_kernel(const float* __restrict__ in, int64_t planes, int H, int W, int s,
+                                                              float* __restrict__ out) {
   const int Ho = H * s, Wo = W * s;
   const int64_t total = planes * Ho * Wo;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
@@ -120,9 +167,11 @@ __global__ __launch_bounds__(256) void resize_nchw_fwd_kernel(const float* __res
   }
 }
 
+template <bool MUL>
 __global__ __launch_bounds__(256) void resize_nchw_bwd_kernel(const float* __restrict__ g, int64_t planes, int H, int W, int s,
                                                              float* __restrict__ gin) {
   const int Ho = H * s, Wo = W * s;
+  const float inv_s = 1.f / (float)s;
   const int64_t total = planes * H * W;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int ix = (int)(id % W);
@@ -136,9 +185,12 @@ __global__ __launch_bounds__(256) void resize_nchw_bwd_kernel(const float* __res
     const float* p = g + pl * Ho * Wo;
     float acc = 0.f;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      const float wy = bil_weight(oy, s, H, iy);
+      const float wy = MUL ? bil_weight_mul(oy, inv_s, H, iy) : bil_weight(oy, s, H, iy);
       if (wy == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += wy * bil_weight(ox, s, W, ix) * p[(int64_t)oy * Wo + ox];
+      const float* row = p + (int64_t)oy * Wo;
+      float racc = 0.f;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) racc += (MUL ? bil_weight_mul(ox, inv_s, W, ix) : bil_weight(ox, s, W, ix)) * row[ox];
+      acc += wy * racc;
     }
     gin[id] = acc;
   }
@@ -505,7 +557,11 @@ extern "C" int cvcs_resize_bilinear_bwd(const void* gout, int64_t gout_ld, int B
 extern "C" int cvcs_resize_bilinear_nchw_fwd(const float* in, int64_t planes, int H, int W, int scale, float* out, void* stream) {
   const char* fn = "cvcs_resize_bilinear_nchw_fwd";
   CVCS_CHECK_ARG(in && out && planes > 0 && H > 0 && W > 0 && scale >= 1 && scale <= 32, "%s: bad arguments", fn);
-  hipLaunchKernelGGL(resize_nchw_fwd_kernel, dim3(dl_grid(planes * H * W * scale * scale)), dim3(256), 0, (hipStream_t)stream, in, planes, H, W, scale, out);
+  // (1/s is exact for the powers of two the networks use - the multiplication then gives the division's taps bit for bit; other scales keep the division)
+  if (scale % 4 == 0 && (scale & (scale - 1)) == 0 && ((uintptr_t)out % 16) == 0)
+    hipLaunchKernelGGL(resize_nchw_fwd_kernel, dim3(dl_grid(planes * H * W * scale * scale / 4)), dim3(256), 0, (hipStream_t)stream, in, planes, H, W, scale, out);
+  else
+    hipLaunchKernelGGL(resize_nchw_fwd1_kernel, dim3(dl_grid(planes * H * W * scale * scale)), dim3(256), 0, (hipStream_t)stream, in, planes, H, W, scale, out);
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
@@ -513,7 +569,10 @@ extern "C" int cvcs_resize_bilinear_nchw_fwd(const float* in, int64_t planes, in
 extern "C" int cvcs_resize_bilinear_nchw_bwd(const float* gout, int64_t planes, int H, int W, int scale, float* gin, void* stream) {
   const char* fn = "cvcs_resize_bilinear_nchw_bwd";
   CVCS_CHECK_ARG(gout && gin && planes > 0 && H > 0 && W > 0 && scale >= 1 && scale <= 32, "%s: bad arguments", fn);
-  hipLaunchKernelGGL(resize_nchw_bwd_kernel, dim3(dl_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, gout, planes, H, W, scale, gin);
+  if ((scale & (scale - 1)) == 0)
+    hipLaunchKernelGGL(resize_nchw_bwd_kernel<true>, dim3(dl_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, gout, planes, H, W, scale, gin);
+  else
+    hipLaunchKernelGGL(resize_nchw_bwd_kernel<false>, dim3(dl_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, gout, planes, H, W, scale, gin);
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
