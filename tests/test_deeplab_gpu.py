@@ -253,8 +253,7 @@ def test_factory_names():
     assert isinstance(r101, nets.DeepLabv3Resnet101) and utils.count_params(r101) == want
 
 
-@pytest.mark.parametrize("cls,arch,os_,plus,B,S,NC", [(nets.DeepLabV3Plus, "resnet50", 16, True, 4, 64, 5),
-                                                      (nets.DeepLabV3Plus, "resnet50", 16, True, 4, 128, 16),
+@pytest.mark.parametrize("cls,arch,os_,plus,B,S,NC", [(nets.DeepLabV3Plus, "resnet50", 16, True, 4, 128, 16),
                                                       (nets.DeepLabv3Resnet50, "resnet50", 8, False, 4, 64, 5)])
 def test_fp32_train_steps_match_oracle(cls, arch, os_, plus, B, S, NC):
     """three SGD2 steps (S/train.py:121-126), logits 1e-3 / loss 1e-4 against the f32 oracle; gradients 2e-4 relative L2 per

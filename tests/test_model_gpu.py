@@ -200,7 +200,7 @@ def _assert_argmax_near_ties(got, want64, rel):
     return n, a.numel()
 
 
-@pytest.mark.parametrize("variant,B,S,NC", [("Unetv2", 4, 128, 5), ("Unet", 2, 128, 16), ("Unetv2", 2, 64, 5)])
+@pytest.mark.parametrize("variant,B,S,NC", [("Unetv2", 4, 128, 5), ("Unet", 2, 128, 16)])
 def test_fp32_train_steps_float64_yardstick(variant, B, S, NC):
     """The reference's U-Nets, three SGD2 steps in its order (S/train.py:121-126), every step checked at the HIP network's
     own current parameters: train-mode logits within 1e-3 of max|logit| and loss within 1e-5 of the f32 oracle (the oracle
