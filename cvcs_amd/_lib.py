@@ -56,6 +56,7 @@ class WgradDesc(C.Structure):
         ("aniso", C.c_int32), ("stride_w", C.c_int32), ("pad_w", C.c_int32),
         ("x_row_pitch", C.c_int64), ("x_img_pitch", C.c_int64),
         ("dil", C.c_int32),
+        ("dbias", C.c_void_p),
     ]
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "cvcs_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "cvcs_wgrad_workspace_floats": (_i64, [C.POINTER(WgradDesc)]),
+    "cvcs_wgrad_takes_bias": (_i, [C.POINTER(WgradDesc)]),
     "cvcs_bn_add_act": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp]),
     "cvcs_relu_bwd_sum": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_maxpool3x3s2_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
@@ -153,7 +155,7 @@ SIGNATURES = {
 _lib = None
 _recording = None          # the Recording that is capturing launches right now (None: plain eager calls)
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_conv_stat_rows",
-            "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
+            "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
             "cvcs_window_attention_bwd_workspace_floats"}
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
@@ -323,7 +325,7 @@ def _load():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 8:
+        if h.cvcs_abi_version() != 9:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
         if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")

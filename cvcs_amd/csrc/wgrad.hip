@@ -39,6 +39,7 @@ struct WgradArgs {
   int ktiles, per_slice;      // total K-tiles, K-tiles per slice
   int ntile_n;                // Cin tiles
   int tiles_mn, xcd_order;    // GEMM kernel: (co, ci) tiles per K-slice; XCD-aware workgroup order (CVCS_XCD_ORDER=0: off)
+  float* bias_ws;             // GEMM kernel: partial bias gradients [slice][Cout] (NULL: none)
 };
 
 __device__ uint4 g_wzero16;  // zero word: LDS-DMA source of padding pixels / absent channels
@@ -328,6 +329,12 @@ __global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgra
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient (cvcs_wgrad_desc.dbias): the ci-tile-0 workgroups of every K-slice also sum their dy fragments over the pixels
+  // (lane = channel fr of fragment i, eight pixels per fragment; the four lane groups hold different pixels)
+  const bool do_bias = p.bias_ws != nullptr && tn == 0 && wn == 0;
+  float bsum[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) bsum[i] = 0.f;
 
   const int fr = lane & 15, fg = lane >> 4;
   const int q = fr >> 2, pp = fr & 3;
@@ -370,10 +377,28 @@ __global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgra
     for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        float f[8];
+        Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, af[i]), f);
+        bsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+      }
+    }
     wait_vm_barrier_n(issued);
     if (++st == NS) st = 0;
   }
   // partials ws[slice][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int co = co0 + wm * (BM / WMV) + i * 16 + fr;
+      if (fg == 0 && co < p.Cout) p.bias_ws[(int64_t)kslice * p.Cout + co] = v;
+    }
+  }
   float* ws = p.ws + (int64_t)kslice * (p.slice_stride ? p.slice_stride : (int64_t)p.Cout * p.Cin);
 #pragma unroll
   for (int i = 0; i < MR; ++i)
@@ -877,6 +902,15 @@ static int fast_path(const cvcs_wgrad_desc* d) {
   return (d->Cout % 128 == 0 && !force64) ? 2 : 1;
 }
 
+// db[co] = sum over the K-slices of the partial bias gradients, slice 0 first
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ part, int nslice, int Cout, float* __restrict__ db) {
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= Cout) return;
+  float a = 0.f;
+  for (int s = 0; s < nslice; ++s) a += part[(int64_t)s * Cout + co];
+  db[co] = a;
+}
+
 static int wgrad_xcd_order() {
   static const int on = getenv("CVCS_XCD_ORDER") ? atoi(getenv("CVCS_XCD_ORDER")) : 1;   // tuning knob
   return on;
@@ -950,7 +984,7 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
   CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0 &&
                  ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad(dilated): views");
   WgradArgs a;
-  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order();
+  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order(); a.bias_ws = nullptr;
   a.x = (const char*)d->x; a.dy = (const char*)d->dy;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -1009,8 +1043,24 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
 }
 
 // exact workspace size of one descriptor (covers the anisotropic / pitched case, which cvcs_wgrad_slices cannot express)
+extern "C" int cvcs_wgrad_takes_bias(const cvcs_wgrad_desc* d) {
+  if (!d) return 0;
+  const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
+  return d->dtype == CVCS_BF16 && d->dil <= 1 && !special && d->pad == 0 && d->H == d->Ho && d->W == d->Wo &&
+         gemm_shape(d->KH, d->KW, d->stride, d->Cout, d->Cin);
+}
+
+// floats of the dW partial slabs (the bias partials of cvcs_wgrad_desc.dbias follow them)
+static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d);
+
 extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 32 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
+  int64_t n = wgrad_slab_floats(d);
+  if (d->dbias && cvcs_wgrad_takes_bias(d)) n += (int64_t)gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice * d->Cout;
+  return n;
+}
+
+static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d) {
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   int n;
   if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
@@ -1034,7 +1084,10 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   const int taps = d->KH * d->KW;
   CVCS_CHECK_ARG((d->KH == 3 && d->KW == 3) || (d->KH == 2 && d->KW == 2) || (d->KH == 1 && d->KW == 1) || (d->KH == 7 && d->KW == 1),
                  "cvcs_conv2d_wgrad: filter %dx%d not built (3x3, 2x2, 1x1, 7x1)", d->KH, d->KW);
-  if (d->dil > 1) return wgrad_dilated(d, (hipStream_t)stream);
+  if (d->dil > 1) {
+    CVCS_CHECK_ARG(d->dbias == nullptr, "cvcs_conv2d_wgrad: no dbias with dilation");
+    return wgrad_dilated(d, (hipStream_t)stream);
+  }
   const bool aniso = d->aniso != 0, pitched = d->x_row_pitch != 0 || d->x_img_pitch != 0;
   const int stride_w = aniso ? d->stride_w : d->stride, pad_w = aniso ? d->pad_w : d->pad;
   CVCS_CHECK_ARG(d->stride >= 1 && d->stride <= 2 && d->pad >= 0 && stride_w >= 1 && stride_w <= 2 && pad_w >= 0, "cvcs_conv2d_wgrad: stride/pad");
@@ -1051,7 +1104,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, fastp, stride_w);
   CVCS_CHECK_ARG(pl.HR * pl.HC <= (fastp ? 128 : kXRows), "cvcs_conv2d_wgrad: halo tile too large");
   WgradArgs a;
-  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order();
+  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order(); a.bias_ws = nullptr;
   a.x = (const char*)d->x; a.dy = (const char*)d->dy; a.ws = d->workspace;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -1070,6 +1123,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     a.ktiles = g.ktiles; a.per_slice = g.per_slice; a.ntile_n = g.ntile_n;
     nslice_used = g.nslice;
     a.tiles_mn = g.tiles_mn;
+    if (d->dbias) a.bias_ws = d->workspace + wgrad_slab_floats(d);
     const dim3 grid((unsigned)(g.tiles_mn * g.nslice));
 #define LAUNCH_GEMM(BM_, BN_, WMV_)                                                                                             \
   do {                                                                                                                          \
@@ -1087,8 +1141,13 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     else if (g.BM == 128) LAUNCH_GEMM(128, 64, 2);
     else LAUNCH_GEMM(64, 128, 2);
 #undef LAUNCH_GEMM
+    if (d->dbias)
+      hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)cdiv(d->Cout, 256)), dim3(256), 0, st, a.bias_ws, g.nslice, d->Cout, d->dbias);
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(gemm)");
     rc = CVCS_OK;
+  } else if (d->dbias) {
+    set_error("cvcs_conv2d_wgrad: dbias is built for the descriptors cvcs_wgrad_takes_bias() accepts (bf16 1x1 / stride 1 GEMM path)");
+    return CVCS_EUNSUPPORTED;
   } else if (d->dtype == CVCS_F32)
     rc = taps == 9 ? launch<float, 9>(a, pl, st) : taps == 7 ? launch<float, 7>(a, pl, st) : taps == 4 ? launch<float, 4>(a, pl, st) : launch<float, 1>(a, pl, st);
   else if (fastp && s2_shape(d)) {

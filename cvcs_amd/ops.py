@@ -230,9 +230,15 @@ def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1):
     return d
 
 
-def wgrad_workspace_floats_for(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1) -> int:
-    """exact split-K workspace (floats) of one weight-gradient launch"""
+def wgrad_takes_bias(x: View, dy: View, KH, KW, stride, pad, dil=1) -> bool:
+    return bool(_lib.lib().cvcs_wgrad_takes_bias(C.byref(_wgrad_desc(x, dy, KH, KW, stride, pad, None, dil))))
+
+
+def wgrad_workspace_floats_for(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1, with_bias=False) -> int:
+    """exact split-K workspace (floats) of one weight-gradient launch (with_bias: the launch also produces the bias gradient)"""
     d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt, dil)
+    if with_bias:
+        d.dbias = 16      # (any non-null value: only its presence matters to the size query)
     n = _lib.lib().cvcs_wgrad_workspace_floats(C.byref(d))
     if n < 0:
         raise _lib.CvcsError("cvcs_wgrad_workspace_floats: bad shape")
@@ -240,11 +246,15 @@ def wgrad_workspace_floats_for(x: View, dy: View, KH, KW, stride, pad, virt=None
 
 
 def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, workspace: torch.Tensor, cin_real=None, virt=None,
-                 dil=1):
-    """dw[Cout][Cin_real][KH][KW] (f32, contiguous) = sum_p dy[p] (x) x[pix(p, tap)]."""
+                 dil=1, dbias: torch.Tensor | None = None):
+    """dw[Cout][Cin_real][KH][KW] (f32, contiguous) = sum_p dy[p] (x) x[pix(p, tap)]; dbias (optional, f32 [Cout]) = sum_p dy[p]
+    out of the same launch where wgrad_takes_bias() says so."""
     d = _wgrad_desc(x, dy, KH, KW, stride, pad, virt, dil)
     cin_real = d.Cin if cin_real is None else cin_real
     d.dw, d.Cin_real = dw.data_ptr(), cin_real
+    if dbias is not None:
+        assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == dy.C
+        d.dbias = dbias.data_ptr()
     d.workspace = workspace.data_ptr()
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.C * cin_real * KH * KW
     assert workspace.dtype == torch.float32 and \

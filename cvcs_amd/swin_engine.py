@@ -109,16 +109,21 @@ class SwinUPerNetEngine(ResNetUNetEngine):
     def _lin_bwd(self, x: View, g: View, key, gx_name, bias=True, want_dx=True):
         """weight (and bias) gradient of a linear layer; returns the data gradient"""
         ops.SCOPE = "enc" if key.startswith("backbone") else "dec"
-        need = ops.wgrad_workspace_floats_for(x, g, 1, 1, 1, 0)
         gw = self.GW4[key]
-        # (x and g are per-layer buffers that nothing overwrites during this backward: no hazard on the side lane)
-        side = self.overlap_wgrad and _lib._recording is not None
-        with (_lib.side_lane() if side else contextlib.nullcontext()):
-            ops.conv2d_wgrad(x, g, gw, 1, 1, 1, 0, self._scratch("wg_ws_side" if side else "wg_ws", need), cin_real=48 if key == PE else None)
+        gb = None
         if bias:
             gb = self.GW4.get(key + ".bias")
             if gb is None:
                 gb = self.G[key + ".bias"]
+        # the bias gradient (column sums of g) comes out of the weight-gradient GEMM, which streams g anyway (bf16; the f32 path sums apart)
+        fused_bias = bias and ops.wgrad_takes_bias(x, g, 1, 1, 1, 0)
+        need = ops.wgrad_workspace_floats_for(x, g, 1, 1, 1, 0, with_bias=fused_bias)
+        # (x and g are per-layer buffers that nothing overwrites during this backward: no hazard on the side lane)
+        side = self.overlap_wgrad and _lib._recording is not None
+        with (_lib.side_lane() if side else contextlib.nullcontext()):
+            ops.conv2d_wgrad(x, g, gw, 1, 1, 1, 0, self._scratch("wg_ws_side" if side else "wg_ws", need), cin_real=48 if key == PE else None,
+                             dbias=gb if fused_bias else None)
+        if bias and not fused_bias:
             M = g.B * g.H * g.W
             rows = ops.bn_bwd_rows(M)
             part = self._scratch("bias_part", rows * g.C)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 8
+#define CVCS_ABI_VERSION 9
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
@@ -122,8 +122,15 @@ typedef struct {
   /* ABI 5: dilation (0 / 1 = none).  dil > 1 is built for 3x3 / stride 1 / pad = dil (DeepLabV3+: ASPP rates, dilated last
    * stage): nine shifted 1x1 weight gradients into one partial slab (workspace: cvcs_wgrad_workspace_floats).       */
   int32_t dil;
+  /* ABI 9: optional bias gradient db[n] = sum_p dy[p, n] (f32 [Cout]) out of the SAME launch - the weight-gradient GEMM already streams dy
+   * once, a separate column-sum pass would read it again (nn.Linear layers of the Swin encoder).  Built for the descriptors
+   * cvcs_wgrad_takes_bias() accepts (bf16, 1x1 / stride 1 on the GEMM kernel); NULL = none.  The workspace grows by slices * Cout floats
+   * (cvcs_wgrad_workspace_floats accounts for it when dbias is set).                                                                       */
+  float* dbias;
 } cvcs_wgrad_desc;
 int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
+/* 1 if cvcs_conv2d_wgrad can also produce `dbias` for this descriptor, else 0 */
+int cvcs_wgrad_takes_bias(const cvcs_wgrad_desc* d);
 /* exact workspace size (floats) of one descriptor; covers the anisotropic / pitched case cvcs_wgrad_slices cannot express */
 int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d);
 

@@ -177,6 +177,14 @@ def test_pointwise_conv_statistics_and_gemm_weight_gradient(cin, cout, S, off):
     ops.conv2d_wgrad(xv, ops.view(dyd), dw, 1, 1, 1, 0, ws)
     torch.cuda.synchronize()
     close(dw.cpu(), wq.grad, 1e-4, "weight gradient (exact bf16 products, f32 accumulate)")
+    # ... and with the bias gradient out of the same launch (cvcs_wgrad_desc.dbias: the nn.Linear layers of the Swin encoder)
+    assert ops.wgrad_takes_bias(xv, ops.view(dyd), 1, 1, 1, 0)
+    dw2, db = torch.empty_like(dw), torch.empty(cout, device=DEV)
+    ws2 = torch.empty(ops.wgrad_workspace_floats_for(xv, ops.view(dyd), 1, 1, 1, 0, with_bias=True), device=DEV)
+    ops.conv2d_wgrad(xv, ops.view(dyd), dw2, 1, 1, 1, 0, ws2, dbias=db)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, dw)
+    close(db.cpu(), rq(dy, dtype).sum(dim=(0, 2, 3)), 1e-5, "bias gradient")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
