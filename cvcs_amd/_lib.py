@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcvcs_hip.so")
 
 F32, BF16 = 0, 1
+E4M3, E5M2 = 0, 1          # fp8 formats (CVCS_E4M3 / CVCS_E5M2)
+ABI_VERSION = 10
 
 
 class CvcsError(RuntimeError):
@@ -36,6 +38,20 @@ class ConvDesc(C.Structure):
         ("bwd_part_dz", C.c_void_p), ("bwd_part_dzx", C.c_void_p),
         ("aniso", C.c_int32), ("stride_w", C.c_int32), ("pad_w", C.c_int32),
         ("in_row_pitch", C.c_int64), ("in_img_pitch", C.c_int64),
+    ]
+
+
+class Conv8Desc(C.Structure):
+    """cvcs_conv8_desc (include/cvcs_hip.h): the fp8 3x3 convolution"""
+    _fields_ = [
+        ("in_", C.c_void_p), ("in_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("in_fmt", C.c_int32),
+        ("wt", C.c_void_p),
+        ("out", C.c_void_p), ("out_ld", C.c_int64), ("Cout", C.c_int32),
+        ("scale_in", C.c_void_p), ("scale_w", C.c_void_p),
+        ("relu", C.c_int32),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p),
+        ("stat_sum", C.c_void_p), ("stat_m2", C.c_void_p), ("stat_cnt", C.c_void_p),
     ]
 
 
@@ -68,6 +84,10 @@ SIGNATURES = {
     "cvcs_abi_version": (_i, []),
     "cvcs_sizeof_conv_desc": (_i, []),
     "cvcs_sizeof_wgrad_desc": (_i, []),
+    "cvcs_sizeof_conv8_desc": (_i, []),
+    "cvcs_conv3x3_fp8": (_i, [C.POINTER(Conv8Desc), _vp]),
+    "cvcs_quantize_fp8": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _vp]),
+    "cvcs_fp8_update_scales": (_i, [_vp, _i, _f, _vp]),
     "cvcs_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "cvcs_wgrad_slices": (_i, [_i] * 8),
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
@@ -154,7 +174,7 @@ SIGNATURES = {
 
 _lib = None
 _recording = None          # the Recording that is capturing launches right now (None: plain eager calls)
-_QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_conv_stat_rows",
+_QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_sizeof_conv8_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
             "cvcs_window_attention_bwd_workspace_floats"}
@@ -325,9 +345,10 @@ def _load():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.cvcs_abi_version() != 9:
+        if h.cvcs_abi_version() != ABI_VERSION:
             raise CvcsError("libcvcs_hip.so ABI version mismatch")
-        if h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc):
+        if (h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc) or
+                h.cvcs_sizeof_conv8_desc() != C.sizeof(Conv8Desc)):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")
         _lib = h
         _proxy = _Proxy(h)

@@ -17,3 +17,4 @@ extern "C" const char* cvcs_last_error(void) { return cvcs::g_err; }
 extern "C" int cvcs_abi_version(void) { return CVCS_ABI_VERSION; }
 extern "C" int cvcs_sizeof_conv_desc(void) { return (int)sizeof(cvcs_conv_desc); }
 extern "C" int cvcs_sizeof_wgrad_desc(void) { return (int)sizeof(cvcs_wgrad_desc); }
+extern "C" int cvcs_sizeof_conv8_desc(void) { return (int)sizeof(cvcs_conv8_desc); }

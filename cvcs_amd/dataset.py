@@ -44,6 +44,7 @@ class SyntheticLoader:
         self.patch_size, self.NC, self.tpi = patch_size, num_classes, tiles_per_image
         self.chunk_size, self.seed = chunk_size, seed
         self.idxs = list(range(n_images))
+        self._base_idxs = list(self.idxs)
         self.epoch = 0
         self._gen_chunks()
         g = torch.Generator().manual_seed(99)
@@ -61,11 +62,13 @@ class SyntheticLoader:
         the SAME permutation (the reference shuffles with the process-global `random`, S/dataset.py:289-291, which is only
         right for its single process)"""
         self.epoch += 1
-        random.Random(self.seed * 1000003 + self.epoch).shuffle(self.idxs)
+        self.idxs = list(self._base_idxs)      # a PURE function of (seed, epoch): a run resumed at epoch k (train.py sets
+        random.Random(self.seed * 1000003 + self.epoch).shuffle(self.idxs)   # .epoch) draws the orders of epochs k+1.. again
         self._gen_chunks()
 
     def specify(self, targets):
         self.idxs = [self.idxs[i] for i in targets]
+        self._base_idxs = list(self.idxs)
         self._gen_chunks()
 
     def _tile(self, g):
@@ -122,6 +125,7 @@ class Loader:
         self.tpi = (H // patch_size) * (W // patch_size)
         self.H, self.W = H, W
         self.idxs = list(range(len(self.images)))
+        self._base_idxs = list(self.idxs)
         self.seed, self.epoch = seed, 0
         self.device = None     # set (make_loader(device=...)) to count the class pixels with the device histogram
         self._gen_chunks()
@@ -136,20 +140,27 @@ class Loader:
     def shuffle(self):
         """a function of (seed, epoch): identical on every rank of a data-parallel job (see SyntheticLoader.shuffle)"""
         self.epoch += 1
-        random.Random(self.seed * 1000003 + self.epoch).shuffle(self.idxs)
+        self.idxs = list(self._base_idxs)      # a PURE function of (seed, epoch): a run resumed at epoch k (train.py sets
+        random.Random(self.seed * 1000003 + self.epoch).shuffle(self.idxs)   # .epoch) draws the orders of epochs k+1.. again
         self._gen_chunks()
 
     def specify(self, targets):
         self.idxs = [self.idxs[i] for i in targets]
+        self._base_idxs = list(self.idxs)
         self._gen_chunks()
 
     def _decode(self, i):
         from PIL import Image
         img = torch.from_numpy(np.array(Image.open(self.images[i]).convert("RGB"))).permute(2, 0, 1).contiguous()
+        return img, self._decode_mask(i)
+
+    def _decode_mask(self, i):
+        """the index mask alone (the class-weight scan, S/dataset.py:346-384, never needs the RGB image)"""
+        from PIL import Image
         mask = torch.from_numpy(np.array(Image.open(self.index_masks[i])))
         if mask.dim() == 3:
             mask = mask[..., 0]
-        return img, mask.to(torch.uint8).contiguous()
+        return mask.to(torch.uint8).contiguous()
 
     def plan_items(self, idx):
         """(position in the chunk, top, left) of every tile of chunk idx in the order they are served: the +-20 px random
@@ -188,12 +199,12 @@ class Loader:
                 from . import ops
                 counts = torch.zeros(classes, dtype=torch.int64, device=self.device)
                 for i in range(len(self.index_masks)):
-                    ops.label_histogram(self._decode(i)[1].to(self.device), counts)
+                    ops.label_histogram(self._decode_mask(i).to(self.device), counts)
                 self.count = counts.cpu().float()
             else:
                 self.count = torch.zeros(classes, dtype=torch.float32)
                 for i in range(len(self.index_masks)):
-                    m = self._decode(i)[1].reshape(-1).long()
+                    m = self._decode_mask(i).reshape(-1).long()
                     self.count += torch.bincount(m, minlength=classes)[:classes].float()
         return class_weights_from_counts(self.count, ignore_background)
 

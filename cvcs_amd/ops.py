@@ -270,6 +270,92 @@ def conv2d_wgrad(x: View, dy: View, dw: torch.Tensor, KH, KW, stride, pad, works
         ev[1].record()
 
 
+# ------------------------------------------------------------------------------------------------ fp8 convolutions
+FP8_MAX = {_lib.E4M3: 448.0, _lib.E5M2: 57344.0}
+FP8_TORCH = {_lib.E4M3: torch.float8_e4m3fn, _lib.E5M2: torch.float8_e5m2}
+FP8_MARGIN = 2.0      # delayed scaling: scale = FP8_MARGIN * amax(previous step) / fmax - one binade of headroom for the next step
+
+
+class Fp8Slots:
+    """per-tensor scale slots of the fp8 path, one device table [n][4] f32 = (amax of this step, scale, 1 / scale, fmax): the kernels
+    read scale / 1/scale through pointers into it, cvcs_fp8_update_scales turns the step's amax into the next step's scale"""
+
+    def __init__(self, device, capacity=256):
+        self.t = torch.zeros((capacity, 4), dtype=torch.float32, device=device)
+        self.t[:, 1:3] = 1.0
+        self.names, self.fresh = {}, set()
+
+    def slot(self, name, fmt):
+        """index of the slot called `name` (created on first use: scale 1, no history)"""
+        i = self.names.get(name)
+        if i is None:
+            i = self.names[name] = len(self.names)
+            assert i < self.t.shape[0], "Fp8Slots capacity"
+            self.t[i, 3] = FP8_MAX[fmt]
+            self.fresh.add(i)
+        return i
+
+    def ptr(self, i, field=0):
+        return self.t.data_ptr() + (4 * i + field) * 4
+
+    def update(self):
+        check(_lib.lib().cvcs_fp8_update_scales(self.t.data_ptr(), max(len(self.names), 1), FP8_MARGIN, _stream()), "cvcs_fp8_update_scales")
+
+
+def quantize_fp8(x: View, q: View | None, fmt: int, slots: Fp8Slots, i: int):
+    """q = fmt(x / scale_i) (bf16 view -> fp8 view) and amax_i = max(amax_i, max|x|).  A slot without history is CALIBRATED first, outside
+    any recording: the amax of this very tensor becomes its scale (current scaling for a slot's first use, delayed scaling afterwards)"""
+    M = x.B * x.H * x.W
+    assert x.code == BF16 and x.C % 16 == 0
+    if i in slots.fresh:
+        h = _lib._load()      # (the raw handle: calibration launches are not part of a recorded plan)
+        check(h.cvcs_quantize_fp8(x.ptr, x.ld, M, x.C, 0, 0, fmt, slots.ptr(i), _stream()), "cvcs_quantize_fp8(amax)")
+        check(h.cvcs_fp8_update_scales(slots.ptr(i), 1, FP8_MARGIN, _stream()), "cvcs_fp8_update_scales")
+        slots.fresh.discard(i)
+    if q is None:
+        return
+    assert q.t.dtype == torch.uint8 and (q.B, q.H, q.W, q.C) == (x.B, x.H, x.W, x.C)
+    _tag_hbm("quantize_fp8", M * x.C * 3)
+    check(_lib.lib().cvcs_quantize_fp8(x.ptr, x.ld, M, x.C, q.ptr, q.ld, fmt, slots.ptr(i), _stream()), "cvcs_quantize_fp8")
+
+
+def conv3x3_fp8(x8: View, fmt: int, wt8: torch.Tensor, out: View, slots: Fp8Slots, ix: int, iw: int, stats=None, relu=False, pre_affine=None):
+    """out (bf16) = act(s_x s_w conv3x3(x8, wt8)) on the block-scaled fp8 MFMA; wt8 u8 [9][Cout][Cin] (e4m3); x8 u8 view"""
+    Cout, Cin = wt8.shape[1], wt8.shape[2]
+    assert x8.t.dtype == torch.uint8 and wt8.dtype == torch.uint8 and wt8.shape[0] == 9 and x8.C == Cin and out.code == BF16
+    assert (out.B, out.H, out.W, out.C) == (x8.B, x8.H, x8.W, Cout)
+    d = _lib.Conv8Desc()
+    d.in_, d.in_ld, d.B, d.H, d.W, d.Cin, d.in_fmt = x8.ptr, x8.ld, x8.B, x8.H, x8.W, Cin, fmt
+    d.wt, d.out, d.out_ld, d.Cout = wt8.data_ptr(), out.ptr, out.ld, Cout
+    d.scale_in, d.scale_w = slots.ptr(ix, 1), slots.ptr(iw, 1)
+    d.relu = int(relu)
+    if pre_affine is not None:
+        d.pre_scale, d.pre_shift = pre_affine[0].data_ptr(), pre_affine[1].data_ptr()
+    if stats is not None:
+        d.stat_sum, d.stat_m2, d.stat_cnt = (_ptr(t) for t in stats)
+    fam = "conv3x3_fp8" + (f":{SCOPE}" if SCOPE else "")
+    tag = (fam, 2.0 * x8.B * x8.H * x8.W * Cout * Cin * 9)
+    if _lib._recording is not None:
+        _lib.pending_tag = tag
+    elif TIMERS is not None:
+        ev = TIMERS.bracket(*tag)
+        ev[0].record()
+    check(_lib.lib().cvcs_conv3x3_fp8(C.byref(d), _stream()), "cvcs_conv3x3_fp8")
+    if TIMERS is not None and _lib._recording is None:
+        ev[1].record()
+
+
+def fp8_stat_rows(x: View) -> int:
+    return x.B * -(-x.H // 16) * -(-x.W // 16)
+
+
+def _tag_hbm(family, nbytes):
+    """timer family of an HBM-bound pass inside a recorded plan: `work` is its ALGORITHMIC byte count (every input read once, every
+    output written once at storage precision) - bench.py prices these families against the 8 TB/s HBM peak"""
+    if _lib._recording is not None:
+        _lib.pending_tag = ("hbm_" + family + (f":{SCOPE}" if SCOPE else ""), float(nbytes))
+
+
 # ------------------------------------------------------------------------------------------------ batch norm
 def bn_finalize_workspace_floats(rows: int, C_: int) -> int:
     return _lib.lib().cvcs_bn_finalize_workspace_floats(rows, C_)

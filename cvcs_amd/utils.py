@@ -143,6 +143,15 @@ class CrossEntropyLoss:
         return _CEFunction.apply(logits, target, self)
 
 
+class MSELoss:
+    """nn.MSELoss() (S/utils.py:239-240).  The reference builds it but cannot train with it (its loop hands it an int64
+    [B,H,W] target against [B,C,H,W] logits, S/train.py:122); kept for the factory surface: mean squared error with torch's
+    broadcasting rules, evaluated on the device by elementwise torch ops (not a hot-path kernel), differentiable through autograd."""
+
+    def __call__(self, pred, target):
+        return torch.nn.functional.mse_loss(pred, target.to(pred.dtype))
+
+
 def load_loss(config, device, dataset=None):
     """S/utils.py:223-242: 'CEL' | 'wCEL' (class-balanced weights from the Loader) ; ignore_index 0 or -100."""
     classes = config["num_classes"] + 1
@@ -158,7 +167,7 @@ def load_loss(config, device, dataset=None):
             print(f"{labels.get(i, i):>22s} {score.item():.6f}")
         return CrossEntropyLoss(weight=weights, ignore_index=ignore_index, unit_grad=True)
     elif name == "MSE":
-        raise NotImplementedError("MSE loss is not on the HIP path (the reference never trains with it)")
+        return MSELoss()                         # S/utils.py:239-240 (nn.MSELoss(); the reference never trains with it)
     else:
         raise Exception
 
@@ -344,16 +353,24 @@ class NormalizedConfusion:
         return c / c.sum(dim=1, keepdim=True).clamp_min(1)
 
 
+def _takes_device(loader) -> bool:
+    """does this loader's get_iterable_chunk offer the device-resident route (keywords device / batch_size / shard)?  Decided from
+    the signature, not by catching TypeError: an error raised INSIDE the device route must surface, not fall back silently"""
+    import inspect
+    try:
+        names = inspect.signature(loader.get_iterable_chunk).parameters
+    except (TypeError, ValueError):
+        return False
+    return all(k in names for k in ("device", "batch_size", "shard"))
+
+
 def chunk_batches(loader, c, batch_size, device, random_tps=None, shard=None):
     """batches of chunk c on `device`.  On the GPU the loader keeps the chunk's decoded images (or tiles) resident and
     produces every batch with one gather launch (dataset.DeviceChunk / DeviceTiles - SURVEY section 8 f1); otherwise (and
     for foreign loaders without the `device` keyword) the reference's route: per-tile iterable -> DataLoader -> `.to(device)`
     (S/train.py:107-115).  shard=(rank, world): this rank's slice of every global batch of `batch_size` tiles."""
-    if torch.device(device).type == "cuda":
-        try:
-            return loader.get_iterable_chunk(c, random_tps, device=device, batch_size=batch_size, shard=shard)
-        except TypeError:
-            pass
+    if torch.device(device).type == "cuda" and _takes_device(loader):
+        return loader.get_iterable_chunk(c, random_tps, device=device, batch_size=batch_size, shard=shard)
     ds = loader.get_iterable_chunk(c, random_tps) if random_tps is not None else loader.get_iterable_chunk(c)
     dl = torch.utils.data.DataLoader(ds, batch_size=batch_size, drop_last=shard is not None)
     if shard is None:

@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 9
+#define CVCS_ABI_VERSION 10
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
+enum { CVCS_E4M3 = 0, CVCS_E5M2 = 1 };   /* OCP fp8 formats of the fp8 convolution path (gfx950: e4m3fn / e5m2, not the MI300 fnuz forms) */
 enum { CVCS_OK = 0, CVCS_EINVAL = -1, CVCS_EHIP = -2, CVCS_EUNSUPPORTED = -3 };
 
 const char* cvcs_last_error(void);
@@ -432,6 +433,36 @@ int cvcs_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
                   float weight_decay, float grad_scale, int first_step, void* stream);
 int cvcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float grad_scale, int step, void* stream);
+
+/* ---- ABI 10: fp8 convolutions (BASELINE.json configs[4]: "mixed bf16/fp8 convs") ---------------------------------------
+ * replaces: the same nn.Conv2d k3 p1 (S/blocks.py:3-4) and the input-gradient half of its convolution_backward (S/train.py:125) as
+ * cvcs_conv2d, for 3x3 / stride 1 / pad 1 layers whose channel counts are multiples of 128 - on the block-scaled matrix instruction
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the bf16 rate).  The reference computes in f32 only; this is the reduced-precision
+ * throughput path the north star names, checked against the oracle's fp8-emulation mode.
+ *   out[p, n] (bf16) = act( s_in * s_w * sum_{kh,kw,c} in8[pix(p,kh,kw), c] * wt8[kh*3+kw][n][c] )
+ * in8: fp8 NHWC view (e4m3 for activations, e5m2 for gradients; in_ld in BYTES = elements), wt8: e4m3 [9][Cout][Cin];
+ * scale_in / scale_w: DEVICE scalars (f32) holding the dequantisation scales s_in, s_w (element [1] of a scale slot, below).
+ * stat_*: BatchNorm partial statistics of the bf16 values written, one row per 16x16 tile (B * ceil(H/16) * ceil(W/16) rows) as
+ * the bf16 kernel of cvcs_conv2d writes them.  pre_scale / pre_shift / relu: the eval-mode BatchNorm fold of cvcs_conv_desc.  */
+typedef struct {
+  const void* in;   int64_t in_ld;  int32_t B, H, W, Cin;   int32_t in_fmt;   /* CVCS_E4M3 | CVCS_E5M2 */
+  const void* wt;
+  void* out;        int64_t out_ld; int32_t Cout;
+  const float* scale_in;  const float* scale_w;
+  int32_t relu;
+  const float* pre_scale;  const float* pre_shift;
+  float* stat_sum;  float* stat_m2;  float* stat_cnt;
+} cvcs_conv8_desc;
+int cvcs_sizeof_conv8_desc(void);
+int cvcs_conv3x3_fp8(const cvcs_conv8_desc* d, void* stream);
+/* A scale slot is float[4] = { amax of the tensor this step, scale, 1 / scale, fmax of its format (448 | 57344) }.
+ * cvcs_quantize_fp8: q (fp8 view, ld in bytes) = fmt(clamp(x * slot[2], +-slot[3])) of a bf16 view x [M pixels][C], round to nearest
+ * even, and slot[0] = max(slot[0], max|x|) (atomic max on the float's bits: order-independent, so a step stays reproducible).
+ * q == NULL: the amax only (calibration of a slot without history).  C % 16 == 0.
+ * cvcs_fp8_update_scales: delayed scaling at the end of a step - for each of n slots with amax > 0: scale = margin * amax / fmax,
+ * then amax = 0.  (margin >= 1 leaves headroom for the next step's growth; values beyond saturate.)                          */
+int cvcs_quantize_fp8(const void* x, int64_t x_ld, int64_t M, int C, void* q, int64_t q_ld, int fmt, float* slot, void* stream);
+int cvcs_fp8_update_scales(float* slots, int n, float margin, void* stream);
 
 #ifdef __cplusplus
 }

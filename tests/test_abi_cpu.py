@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.cvcs_abi_version() == 9
+    assert lib.cvcs_abi_version() == _lib.ABI_VERSION
     import ctypes as C
     from cvcs_amd import _lib
     assert lib.cvcs_sizeof_conv_desc() == C.sizeof(_lib.ConvDesc) and lib.cvcs_sizeof_wgrad_desc() == C.sizeof(_lib.WgradDesc)

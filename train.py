@@ -62,6 +62,7 @@ if "load_checkpoint" in config:
         except Exception:
             print(f"{key} not compatible; {type(obj).__name__} starts fresh.")
     last_epoch = ck["epoch"] + 1
+    Loader_train.epoch = last_epoch   # image order, tile order and shifts are functions of (seed, epoch): resume continues the sequence
     training_loss_values, validation_loss_values = ck["training_loss_values"], ck["validation_loss_values"]
 assert Path(config["checkpoint_directory"]).is_dir(), "Please provide a valid directory to save checkpoints in."
 
