@@ -25,7 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 peak (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4; same table)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0      # HBM3E spec (6.3 TB/s is what a streaming copy reaches on this chip: MI355X_MICROARCH.md, HBM)
 PMC_FILES = {"Resnet50Unet": "r02_pmc_traffic_resnet50unet_b32_s512_bf16.json", "DeepLabV3Plus": "r02_pmc_traffic_deeplabv3plus_b32_s512_bf16.json", "SwinTUperNet": "r02_pmc_traffic_swintupernet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json"}
 FAMILY_KERNEL = {
     "conv3x3_halo": "conv3x3_halo_kernel (3x3 / stride 1 forward and data-gradient launches; strided 3x3 data gradients run it on the zero-dilated gradient, counted at their algorithmic FLOPs)",
@@ -35,6 +37,12 @@ FAMILY_KERNEL = {
     "wgrad": "wgrad_* kernels (all weight gradients, split-K reduce included)",
     "window_attention": "attn_fwd_kernel / attn_bwd_kernel (7x7-window attention, one wavefront per (window, head), VALU; scores recomputed in backward)",
     "wgrad_1x1": "wgrad_gemm_kernel (1x1 weight gradients as one transposed GEMM)",
+    "conv3x3_fp8": "conv3x3_fp8_kernel (3x3 / stride 1 forward and data gradient of the layers with channel counts % 128 == 0 on v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 x e4m3 forward, e5m2 x e4m3 data gradient)",
+    "hbm_bn_bwd": "bn_bwd_kernel (BatchNorm backward: reduce pass reads y, g; apply pass reads y, g and writes dy - algorithmic bytes = 5 tensor passes)",
+    "hbm_bn_act": "bn_act_kernel (BatchNorm apply + ReLU: read y, write the activation)",
+    "hbm_residual": "bn_add_act_kernel / relu_bwd_sum_kernel (residual block tail forward and backward)",
+    "hbm_resize": "upsample2x_fwd / upsample2x_bwd (bilinear x2 of the decoder)",
+    "hbm_quantize_fp8": "quantize_fp8_kernel (bf16 -> fp8 image + amax of the tensors the fp8 convolutions read)",
 }
 
 
@@ -79,6 +87,43 @@ def cpu_baseline(net, nc, tile, tiles, steps):
             "sample": f"{what} NC={nc}, CE ignore_index=0, SGD2): {steps} train steps of {tiles} tiles {tile}x{tile} after 1 warm-up step"}
 
 
+def parity_at_dtype(net, name, nc, tile, dev):
+    """eval-mode logits and labels of the benchmarked network AT THE BENCHMARKED PRECISION against the f32 CPU oracle evaluated at the same
+    (current) parameters, on one structured synthetic tile of the benchmarked size - the figures tests/test_named_configs_gpu.py asserts.
+    The north star's "1e-3 on logits, bit-exact argmax" is met by the f32 path only (that test); bf16 / fp8 storage cannot reach it."""
+    import torch
+    from oracle import unet_oracle as O
+    p = {k: v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu() for k, v in net.state_dict().items()}
+    if name in ("Resnet50Unet", "Resnet18Unet", "Resnet34Unet"):
+        from oracle import resnet_unet_oracle as R
+        arch = {"Resnet50Unet": "resnet50", "Resnet18Unet": "resnet18", "Resnet34Unet": "resnet34"}[name]
+        fwd = lambda x: R.forward(p, x, arch, train=False)          # noqa: E731
+    elif name in ("DeepLabV3Plus", "Resnet101"):
+        from oracle import deeplab_oracle as D
+        plus = name == "DeepLabV3Plus"
+        fwd = lambda x: D.forward(p, x, "resnet50" if plus else "resnet101", train=False, output_stride=16 if plus else 8, plus=plus)   # noqa: E731
+    elif name in ("SwinTUperNet", "SwinBUperNet"):
+        from oracle import swin_upernet_oracle as W
+        fwd = lambda x: W.forward(p, x, train=False)   # noqa: E731
+    else:
+        fwd = lambda x: O.unet_forward(p, x, name, train=False)   # noqa: E731
+    img, _ = O.synthetic_tiles(1, tile, nc, seed=11, structured=True)
+    net.eval()
+    with torch.no_grad():
+        want = fwd(img.float())
+        got = net(img.to(dev), None).float().cpu()
+    scale = want.abs().max().item()
+    d = got - want
+    lab, ref = got.argmax(1), want.argmax(1)
+    top2 = want.topk(2, dim=1).values
+    bad = lab != ref
+    return {"against": "f32 CPU oracle at the same parameters, eval mode, 1 structured synthetic tile of the benchmarked size",
+            "logit_err_max": round(d.abs().max().item() / scale, 6), "logit_err_rms": round(d.pow(2).mean().sqrt().item() / scale, 6),
+            "unit": "fraction of max|logit|", "labels_differing": int(bad.sum()), "labels_total": int(lab.numel()),
+            "largest_oracle_top2_margin_among_them": round(((top2[:, 0] - top2[:, 1])[bad].max().item() / scale) if bool(bad.any()) else 0.0, 6),
+            "north_star_tolerance": "1e-3 on logits / bit-exact argmax: met by --precision fp32 (tests/test_named_configs_gpu.py), not reachable in bf16 / fp8 storage"}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a child (this process has not touched the
     GPU, and it does not exec - it waits and exits with the child's code)"""
@@ -100,7 +145,8 @@ def main():
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
     ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "SwinBUperNet", "Unetv2", "Unet"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 = mixed bf16 / fp8 convolutions (BASELINE configs[4]; ResNet-UNets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     a = ap.parse_args()
@@ -170,11 +216,10 @@ def main():
             step()
         probe = ops.TIMERS.summary()
         pf = {}
-        for kind, t in probe.items():
-            if kind.startswith("conv"):
-                pf[kind.split(":")[0]] = pf.get(kind.split(":")[0], 0.0) + t["total_ms"]
+        for kind, t in probe.items():          # EVERY tagged family competes: convolutions, weight gradients, the HBM-bound passes
+            pf[kind.split(":")[0]] = pf.get(kind.split(":")[0], 0.0) + t["total_ms"]
         dom_family = max(pf, key=pf.get)
-        ops.TIMERS = ops.KernelTimers(only={dom_family, "conv3x3_halo"})
+        ops.TIMERS = ops.KernelTimers(only={dom_family, "conv3x3_halo", "conv3x3_fp8"})
         fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
@@ -194,7 +239,7 @@ def main():
         dt = t.item()
 
     if rank == 0:
-        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         model = {"Resnet50Unet": "ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder 256/128/64/64/64, 1x1 head)",
                  "Resnet18Unet": "ResNet18-UNet", "Resnet34Unet": "ResNet34-UNet",
                  "DeepLabV3Plus": "DeepLabV3+ (ResNet-50 v1.5 at output stride 16, ASPP rates 6/12/18, 64-channel low-level branch)",
@@ -207,13 +252,17 @@ def main():
             "value": round(world * a.batch * a.steps / dt, 3), "unit": "tiles/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.precision, "data": "synthetic",
+            "dtype": "bf16 + fp8 (e4m3 activations / weights, e5m2 gradients; f32 accumulate)" if a.precision == "fp8" else a.precision,
+            "data": "synthetic",
             "config": {"workload": f"{model}, NC={NC}, train step: fwd + CE(ignore_index=0) + bwd + SGD2, "
-                                   f"{a.tile}x{a.tile} u8 tiles, batch {a.batch}/GPU, {a.precision} MFMA convs, f32 accumulate/master",
+                                   f"{a.tile}x{a.tile} u8 tiles, batch {a.batch}/GPU, "
+                                   + ("mixed bf16 / fp8 MFMA convs (fp8: 3x3 stride-1 layers with channel counts % 128 == 0, forward + data gradient)"
+                                      if a.precision == "fp8" else f"{a.precision} MFMA convs") + ", f32 accumulate/master",
                        "global_batch": world * a.batch, "tile": a.tile, "num_classes": NC,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "loss": round(last_loss, 5),
             "median_ms_per_step": round(statistics.median(per_step), 3),
+            "timed_region_s": round(dt, 3),
         }
         if timers:
             # kernel families (HIP-event brackets on the launch stream); scopes: enc / dec.  `live`: inside the timed region
@@ -227,36 +276,51 @@ def main():
             live, fams = families(timers), families(probe)
             psteps = 2
 
-            def line(f, kernel, nsteps):
-                tf = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else 0.0
-                return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tf / peak, 4), "launches_per_step": f["launches"] // nsteps,
+            def line(f, kernel, nsteps, fam=""):
+                sec = f["ms"] * 1e-3
+                if fam.startswith("hbm_"):     # `flops` of these families is their algorithmic BYTE count (ops._tag_hbm)
+                    gbs = f["flops"] / sec / 1e9 if sec > 0 else 0.0
+                    return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": f["launches"] // nsteps,
+                            "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
+                            "algorithmic_mbytes_per_step": round(f["flops"] / nsteps / 1e6, 1), "ms_per_step": round(f["ms"] / nsteps, 3)}
+                pk = PEAK_FP8_TFLOPS if fam == "conv3x3_fp8" else peak
+                tf = f["flops"] / sec / 1e12 if sec > 0 else 0.0
+                return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 2), "peak": pk, "unit": "TFLOP/s",
+                        "frac": round(tf / pk, 4), "launches_per_step": f["launches"] // nsteps,
                         "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                         "algorithmic_gflop_per_step": round(f["flops"] / nsteps / 1e9, 1),
                         "ms_per_step": round(f["ms"] / nsteps, 3)}
-            dom = max((k for k in fams if k.startswith("conv")), key=lambda k: fams[k]["ms"])
-            out["roofline"] = line(live[dom], FAMILY_KERNEL.get(dom, dom), a.steps)
+            dom = max(fams, key=lambda k: fams[k]["ms"])     # the family with the largest time over ALL tagged families
+            out["roofline"] = line(live[dom], FAMILY_KERNEL.get(dom, dom), a.steps, dom)
             out["roofline"]["measured"] = f"HIP events on the launch stream around every launch of this family in the {a.steps} timed steps"
             out["roofline"]["traffic"] = None
-            out["kernel_families"] = {k: line(f, FAMILY_KERNEL.get(k, k), psteps) for k, f in fams.items() if k != dom}
+            out["kernel_families"] = {k: line(f, FAMILY_KERNEL.get(k, k), psteps, k) for k, f in fams.items() if k != dom}
             out["kernel_families_measured"] = f"{psteps} fully instrumented steps before the timed region (bracketing all ~600 launches costs the step 2.5 %)"
             # the 3x3 ENCODER convolutions (the set the north star's >= 50 % target is written for), forward + data gradient
             enc = [t for kind, t in timers.items() if kind.startswith("conv3x3_halo") and kind.endswith(":enc")]
             if enc:
                 e = dict(ms=sum(t["total_ms"] for t in enc), flops=sum(t["flops"] for t in enc), launches=sum(t["launches"] for t in enc))
                 out["roofline_encoder"] = line(e, "conv3x3_halo_kernel, encoder 3x3 convolutions only (forward + data gradient)", a.steps)
+            enc8 = [t for kind, t in timers.items() if kind.startswith("conv3x3_fp8") and kind.endswith(":enc")]
+            if enc8:
+                e = dict(ms=sum(t["total_ms"] for t in enc8), flops=sum(t["flops"] for t in enc8), launches=sum(t["launches"] for t in enc8))
+                out["roofline_encoder_fp8"] = line(e, "conv3x3_fp8_kernel, encoder 3x3 convolutions only (forward + data gradient)", a.steps, "conv3x3_fp8")
             pmc = os.path.join(ROOT, "profiles", PMC_FILES.get(a.net, ""))
             if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and os.path.isfile(pmc):
-                kern = {"conv3x3_halo": "conv3x3_halo_kernel", "conv_taps": "conv_taps_kernel", "conv_igemm": "conv_igemm_kernel"}.get(dom)
+                kern = {"conv3x3_halo": "conv3x3_halo_kernel", "conv_taps": "conv_taps_kernel", "conv_igemm": "conv_igemm_kernel",
+                        "hbm_bn_bwd": "bn_bwd_kernel", "wgrad": "wgrad"}.get(dom)
                 pm = json.load(open(pmc)).get(kern)
                 if pm:
                     out["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
                     out["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{PMC_FILES[a.net]})"
-            tot = sum(f["ms"] for f in fams.values()) / psteps
+            mf = {k: f for k, f in fams.items() if not k.startswith("hbm_")}
+            tot = sum(f["ms"] for f in mf.values()) / psteps
             out["mfma_kernels_share_of_step"] = round(tot / (1e3 * dt / a.steps), 3)
-            out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in fams.values()) / psteps / 1e9, 1)
-            out["step_tflops"] = round(sum(f["flops"] for f in fams.values()) / psteps * a.steps / dt / 1e12, 1)
+            out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in mf.values()) / psteps / 1e9, 1)
+            out["step_tflops"] = round(sum(f["flops"] for f in mf.values()) / psteps * a.steps / dt / 1e12, 1)
         if world == 1 and not a.no_cpu_baseline:
+            out["parity_at_dtype"] = parity_at_dtype(net, a.net, NC, a.tile, dev)
             out["cpu_baseline"] = cpu_baseline(a.net, NC, a.tile, 2, 2)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -86,8 +86,13 @@ SIGNATURES = {
     "cvcs_sizeof_wgrad_desc": (_i, []),
     "cvcs_sizeof_conv8_desc": (_i, []),
     "cvcs_conv3x3_fp8": (_i, [C.POINTER(Conv8Desc), _vp]),
-    "cvcs_quantize_fp8": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _vp]),
+    "cvcs_quantize_fp8": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i, _vp]),
     "cvcs_fp8_update_scales": (_i, [_vp, _i, _f, _vp]),
+    "cvcs_bn_act_q8": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]),
+    "cvcs_bn_bwd_apply_q8": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i,
+                                  _i, _vp]),
+    "cvcs_upsample2x_fwd_q8": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]),
+    "cvcs_bn_add_act_q8": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]),
     "cvcs_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "cvcs_wgrad_slices": (_i, [_i] * 8),
     "cvcs_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),

@@ -108,6 +108,49 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave
                : "memory");
 }
 
+// ---- optional fp8 side output of a producer pass (the tensors the fp8 convolutions of conv_fp8.hip read): besides its bf16 output the
+// pass writes the e4m3 / e5m2 image of THE SAME (bf16-rounded) values and feeds the tensor's amax - no separate quantisation sweep.
+// slot = { amax, scale, 1 / scale, fmax } + the partial amax lines (cvcs_hip.h, kF8SlotFloats).  q == NULL: none.
+struct Q8Out { char* q; int64_t ld; float* slot; int fmt; int take_amax; };
+
+// eight bf16 values as stored (one 16-byte chunk) -> eight fp8 bytes; am <- max(am, |values|)
+__device__ __forceinline__ uint2 q8_pack8(const uint4& packed, float inv, float fmax, int fmt, float& am) {
+  float f[8];
+  f[0] = __uint_as_float(packed.x << 16); f[1] = __uint_as_float(packed.x & 0xffff0000u);
+  f[2] = __uint_as_float(packed.y << 16); f[3] = __uint_as_float(packed.y & 0xffff0000u);
+  f[4] = __uint_as_float(packed.z << 16); f[5] = __uint_as_float(packed.z & 0xffff0000u);
+  f[6] = __uint_as_float(packed.w << 16); f[7] = __uint_as_float(packed.w & 0xffff0000u);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    am = fmaxf(am, fabsf(f[k]));
+    f[k] = fminf(fmaxf(f[k] * inv, -fmax), fmax);
+  }
+  unsigned lo = 0, hi = 0;
+  if (fmt == CVCS_E4M3) {
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  } else {
+    lo = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], hi, true);
+  }
+  return make_uint2(lo, hi);
+}
+
+// a thread's running amax -> the slot: wave maximum, then ONE atomic per wave into one of kF8Parts partial words, each on a 64-byte line of
+// its own behind the slot's state (thousands of waves finishing together on ONE word queue at the memory side, ~12 ns each: measured
+// +75 us per producer launch); cvcs_fp8_update_scales takes the maximum over the words.  atomicMax on the bits of a non-negative float is
+// exact and order-independent, so the step stays bitwise reproducible.  Every lane of the wave must call it.
+constexpr int kF8Parts = 64;            // partial amax words per slot
+constexpr int kF8SlotFloats = 16 * (1 + kF8Parts);   // a slot: one 64-byte line of state + kF8Parts lines of one partial word each
+__device__ __forceinline__ void q8_commit_amax(float am, float* slot) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+  if ((threadIdx.x & 63) == 0 && am == am && am > 0.f) {
+    const unsigned w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) + blockIdx.y * 7u) & (kF8Parts - 1);
+    atomicMax(reinterpret_cast<unsigned*>(slot + 16 * (1 + w)), __float_as_uint(am));
+  }
+}
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace cvcs

@@ -334,7 +334,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fp8_kernel(Conv8Args p) {
 }
 
 // ------------------------------------------------------------------------------------------------ quantisation
-// state of one per-tensor scale ("slot"): float[4] = { amax (running, this step), scale, 1 / scale, fmax of the format }
+// state of one per-tensor scale ("slot", kF8SlotFloats floats): { amax, scale, 1 / scale, fmax, amax the scale was made from } on the first
+// 64-byte line, then kF8Parts lines holding one partial amax word each (q8_commit_amax)
 template <int FMT>
 __device__ __forceinline__ unsigned pack4_f8(float a, float b, float c, float d, float fmax) {
   a = fminf(fmaxf(a, -fmax), fmax); b = fminf(fmaxf(b, -fmax), fmax);
@@ -354,7 +355,7 @@ __device__ __forceinline__ unsigned pack4_f8(float a, float b, float c, float d,
 // non-negative float).  q == NULL: the amax only (calibration of a slot that has no history yet).
 template <int FMT>
 __global__ __launch_bounds__(256) void quantize_fp8_kernel(const char* __restrict__ x, int64_t x_ld, int64_t M, int C, char* __restrict__ q,
-                                                           int64_t q_ld, float* __restrict__ slot) {
+                                                           int64_t q_ld, float* __restrict__ slot, int take_amax) {
   const int CC = C / 16;
   const int64_t total = M * CC;
   const float inv = slot[2], fmax = slot[3];
@@ -378,15 +379,8 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const char* __restric
       *reinterpret_cast<uint4*>(q + pix * q_ld + cc * 16) = o;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (am == am && am > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(am));   // (a NaN never enters the scale)
-  }
+  if (!take_amax) return;      // (kernel argument: uniform)
+  q8_commit_amax(am, slot);
 }
 
 // delayed scaling: scale <- margin * amax / fmax of the step that just ended (kept when the tensor was not produced: amax == 0),
@@ -394,8 +388,13 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const char* __restric
 __global__ void fp8_update_scales_kernel(float* slots, int n, float margin) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float* s = slots + 4 * (int64_t)i;
-  const float am = s[0];
+  float* s = slots + (int64_t)kF8SlotFloats * i;
+  float am = s[0];
+  for (int j = 0; j < kF8Parts; ++j) {
+    am = fmaxf(am, s[16 * (1 + j)]);
+    s[16 * (1 + j)] = 0.f;
+  }
+  s[4] = am;                   // (kept for inspection: the amax the current scale was made from)
   if (am > 0.f) {
     const float sc = margin * am / s[3];
     s[1] = sc;
@@ -443,18 +442,20 @@ extern "C" int cvcs_conv3x3_fp8(const cvcs_conv8_desc* d, void* stream) {
   return CVCS_OK;
 }
 
-extern "C" int cvcs_quantize_fp8(const void* x, int64_t x_ld, int64_t M, int C, void* q, int64_t q_ld, int fmt, float* slot, void* stream) {
+extern "C" int cvcs_quantize_fp8(const void* x, int64_t x_ld, int64_t M, int C, void* q, int64_t q_ld, int fmt, float* slot, int take_amax,
+                                 void* stream) {
   CVCS_CHECK_ARG(x && slot && M > 0 && C > 0 && C % 16 == 0, "cvcs_quantize_fp8: bad argument (C must be a multiple of 16)");
   CVCS_CHECK_ARG(fmt == CVCS_E4M3 || fmt == CVCS_E5M2, "cvcs_quantize_fp8: fmt");
+  CVCS_CHECK_ARG(q || take_amax, "cvcs_quantize_fp8: nothing to do (no output view and no amax)");
   CVCS_CHECK_ARG(x_ld >= C && (x_ld * 2) % 16 == 0 && ((uintptr_t)x % 16) == 0, "cvcs_quantize_fp8: x view");
   CVCS_CHECK_ARG(!q || (q_ld >= C && q_ld % 16 == 0 && ((uintptr_t)q % 16) == 0), "cvcs_quantize_fp8: q view");
   const int64_t total = M * (C / 16);
   int64_t blocks = cdiv(total, 256);
   blocks = blocks > 256 * 8 ? 256 * 8 : blocks;
   if (fmt == CVCS_E4M3)
-    hipLaunchKernelGGL((quantize_fp8_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, (char*)q, q_ld, slot);
+    hipLaunchKernelGGL((quantize_fp8_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, (char*)q, q_ld, slot, take_amax);
   else
-    hipLaunchKernelGGL((quantize_fp8_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, (char*)q, q_ld, slot);
+    hipLaunchKernelGGL((quantize_fp8_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, M, C, (char*)q, q_ld, slot, take_amax);
   CVCS_CHECK_LAUNCH("cvcs_quantize_fp8");
   return CVCS_OK;
 }

@@ -159,6 +159,7 @@ struct BnActArgs {
   int64_t y_ld, out_ld, pool_ld;
   const float* scale; const float* shift;
   int B, H, W, C, relu;
+  Q8Out q8;
 };
 
 template <typename T, bool POOL>
@@ -167,6 +168,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
   const int CC = p.C / V;
   const int64_t items = POOL ? (int64_t)p.B * (p.H / 2) * (p.W / 2) : (int64_t)p.B * p.H * p.W;
   const int64_t total = items * CC;
+  float am = 0.f;
+  const float q_inv = p.q8.q ? p.q8.slot[2] : 0.f, q_fmax = p.q8.q ? p.q8.slot[3] : 0.f;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int cc = (int)(id % CC);
     const int64_t it = id / CC;
@@ -181,7 +184,11 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
         f[k] = f[k] * sc[k] + sh[k];
         if (p.relu) f[k] = fmaxf(f[k], 0.f);
       }
-      *reinterpret_cast<uint4*>(p.out + (it * p.out_ld) * ES + cc * 16) = Elem<T>::pack(f);
+      const uint4 pk = Elem<T>::pack(f);
+      *reinterpret_cast<uint4*>(p.out + (it * p.out_ld) * ES + cc * 16) = pk;
+      if constexpr (ES == 2) {
+        if (p.q8.q) *reinterpret_cast<uint2*>(p.q8.q + it * p.q8.ld + cc * 8) = q8_pack8(pk, q_inv, q_fmax, p.q8.fmt, am);
+      }
     } else {
       const int W2 = p.W / 2, H2 = p.H / 2;
       const int px = (int)(it % W2);
@@ -207,6 +214,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
       *reinterpret_cast<uint4*>(p.pool + (it * p.pool_ld) * ES + cc * 16) = Elem<T>::pack(mx);
     }
   }
+  if constexpr (ES == 2 && !POOL) {
+    if (p.q8.q && p.q8.take_amax) q8_commit_amax(am, p.q8.slot);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
@@ -217,6 +227,7 @@ struct BnBwdArgs {
   const float* ca; const float* cb;
   float* part0; float* part1;   // reduce: (dz, dz*xhat); apply: (db, unused)
   int B, H, W, C, mode;
+  Q8Out q8;                     // apply: fp8 image of dy (the data gradient of an fp8 convolution reads it)
 };
 
 // One work item = one pixel (POOL=false) or one 2x2 window (POOL=true) x one 16-byte channel chunk.
@@ -243,6 +254,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   float s0[V], s1[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) { s0[k] = 0.f; s1[k] = 0.f; }
+  float am = 0.f;
+  const float q_inv = (APPLY && p.q8.q) ? p.q8.slot[2] : 0.f, q_fmax = (APPLY && p.q8.q) ? p.q8.slot[3] : 0.f;
 
   for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < items; it += (int64_t)gridDim.x * PL) {
     int64_t pix[NPIX];
@@ -304,9 +317,17 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
           s0[k] += d;
         }
       }
-      if constexpr (APPLY)
-        *reinterpret_cast<uint4*>(p.dy + (pix[w] * p.dy_ld) * ES + cc * 16) = Elem<T>::pack(out);
+      if constexpr (APPLY) {
+        const uint4 pk = Elem<T>::pack(out);
+        *reinterpret_cast<uint4*>(p.dy + (pix[w] * p.dy_ld) * ES + cc * 16) = pk;
+        if constexpr (ES == 2) {
+          if (p.q8.q) *reinterpret_cast<uint2*>(p.q8.q + pix[w] * p.q8.ld + cc * 8) = q8_pack8(pk, q_inv, q_fmax, p.q8.fmt, am);
+        }
+      }
     }
+  }
+  if constexpr (APPLY && ES == 2) {
+    if (p.q8.q && p.q8.take_amax) q8_commit_amax(am, p.q8.slot);
   }
   // ---- combine the PL pixel lanes
 #pragma unroll
@@ -408,10 +429,12 @@ __device__ __forceinline__ void up_taps(int o, int n, int& i0, int& i1, float& w
 
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const char* in, int64_t in_ld, int B, int H, int W, int C,
-                                                            char* out, int64_t out_ld) {
+                                                            char* out, int64_t out_ld, Q8Out q8) {
   constexpr int ES = sizeof(T), V = 16 / ES;
   const int CC = C / V;
   const int64_t total = (int64_t)B * 2 * H * 2 * W * CC;
+  float am = 0.f;
+  const float q_inv = q8.q ? q8.slot[2] : 0.f, q_fmax = q8.q ? q8.slot[3] : 0.f;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int cc = (int)(id % CC);
     int64_t t = id / CC;
@@ -428,7 +451,15 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const char* in, int
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(in + (((b * H + y1) * W + x1) * in_ld) * ES + cc * 16), d);
 #pragma unroll
     for (int k = 0; k < V; ++k) o[k] = wy0 * (wx0 * a[k] + wx1 * bb[k]) + wy1 * (wx0 * c[k] + wx1 * d[k]);
-    *reinterpret_cast<uint4*>(out + ((((b * 2 * H) + oy) * (2 * W) + ox) * out_ld) * ES + cc * 16) = Elem<T>::pack(o);
+    const int64_t opix = ((b * 2 * H) + oy) * (2 * W) + ox;
+    const uint4 pk = Elem<T>::pack(o);
+    *reinterpret_cast<uint4*>(out + (opix * out_ld) * ES + cc * 16) = pk;
+    if constexpr (ES == 2) {
+      if (q8.q) *reinterpret_cast<uint2*>(q8.q + opix * q8.ld + cc * 8) = q8_pack8(pk, q_inv, q_fmax, q8.fmt, am);
+    }
+  }
+  if constexpr (ES == 2) {
+    if (q8.q && q8.take_amax) q8_commit_amax(am, q8.slot);
   }
 }
 
@@ -686,9 +717,33 @@ static int check_view(const char* fn, const void* p, int64_t ld, int C, int es) 
   return CVCS_OK;
 }
 
+static int check_q8(const char* fn, const Q8Out& q, int C, int dtype) {
+  if (!q.q) return CVCS_OK;
+  CVCS_CHECK_ARG(dtype == CVCS_BF16, "%s: the fp8 side output goes with bf16 storage", fn);
+  CVCS_CHECK_ARG(q.slot && (q.fmt == CVCS_E4M3 || q.fmt == CVCS_E5M2), "%s: fp8 side output needs a scale slot and a format", fn);
+  CVCS_CHECK_ARG(q.ld >= C && q.ld % 8 == 0 && ((uintptr_t)q.q % 8) == 0, "%s: fp8 view", fn);
+  return CVCS_OK;
+}
+
+static int bn_act_impl(const void* y, int64_t y_ld, int B, int H, int W, int C, const float* scale, const float* shift,
+                       int relu, void* out, int64_t out_ld, void* pool, int64_t pool_ld, int dtype, void* stream, Q8Out q8);
+
 extern "C" int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C, const float* scale, const float* shift,
                            int relu, void* out, int64_t out_ld, void* pool, int64_t pool_ld, int dtype, void* stream) {
+  return bn_act_impl(y, y_ld, B, H, W, C, scale, shift, relu, out, out_ld, pool, pool_ld, dtype, stream, Q8Out{nullptr, 0, nullptr, 0, 0});
+}
+
+extern "C" int cvcs_bn_act_q8(const void* y, int64_t y_ld, int B, int H, int W, int C, const float* scale, const float* shift,
+                              int relu, void* out, int64_t out_ld, void* q8, int64_t q8_ld, int fmt, float* slot, int take_amax, int dtype,
+                              void* stream) {
+  CVCS_CHECK_ARG(q8 != nullptr && out != nullptr, "cvcs_bn_act_q8: null output");
+  return bn_act_impl(y, y_ld, B, H, W, C, scale, shift, relu, out, out_ld, nullptr, 0, dtype, stream, Q8Out{(char*)q8, q8_ld, slot, fmt, take_amax});
+}
+
+static int bn_act_impl(const void* y, int64_t y_ld, int B, int H, int W, int C, const float* scale, const float* shift,
+                       int relu, void* out, int64_t out_ld, void* pool, int64_t pool_ld, int dtype, void* stream, Q8Out q8) {
   CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_bn_act: bad dtype");
+  { int rq = check_q8("cvcs_bn_act", q8, C, dtype); if (rq) return rq; }
   const int es = dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "cvcs_bn_act: bad shape");
   int rc;
@@ -700,7 +755,7 @@ extern "C" int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int
     CVCS_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "cvcs_bn_act: pooling needs even H, W");
   }
   CVCS_CHECK_ARG(scale && shift, "cvcs_bn_act: null scale/shift");
-  BnActArgs a{(const char*)y, (char*)out, (char*)pool, y_ld, out_ld, pool_ld, scale, shift, B, H, W, C, relu};
+  BnActArgs a{(const char*)y, (char*)out, (char*)pool, y_ld, out_ld, pool_ld, scale, shift, B, H, W, C, relu, q8};
   const int64_t total = (pool ? (int64_t)B * (H / 2) * (W / 2) : (int64_t)B * H * W) * (C / (16 / es));
   dim3 grid(grid_for(total, 256, 256 * 32));
   hipStream_t st = (hipStream_t)stream;
@@ -724,8 +779,10 @@ extern "C" int cvcs_bn_bwd_rows(int64_t M) {
 static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld, const void* g1, int64_t g1_ld,
                          const void* g2, int64_t g2_ld, int B, int H, int W, int C, const float* scale, const float* shift,
                          const float* mean, const float* invstd, const float* ca, const float* cb, int mode, void* dy,
-                         int64_t dy_ld, float* part0, float* part1, int dtype, void* stream) {
+                         int64_t dy_ld, float* part0, float* part1, int dtype, void* stream, Q8Out q8 = Q8Out{nullptr, 0, nullptr, 0, 0}) {
   CVCS_CHECK_ARG(DT_OK(dtype), "%s: bad dtype", fn);
+  { int rq = check_q8(fn, q8, C, dtype); if (rq) return rq; }
+  CVCS_CHECK_ARG(!q8.q || (apply && !g2), "%s: the fp8 side output belongs to the apply pass without pooling", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2;
   const int V = 16 / es;
   CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0, "%s: bad shape", fn);
@@ -743,7 +800,7 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   if (apply && (rc = check_view(fn, dy, dy_ld, C, es))) return rc;
   CVCS_CHECK_ARG(scale && shift && mean && invstd && part0 && (apply ? (ca && cb) : part1 != nullptr), "%s: null argument", fn);
   BnBwdArgs a{(const char*)y, (const char*)g1, (const char*)g2, (char*)dy, y_ld, g1_ld, g2_ld, dy_ld, scale, shift, mean,
-              invstd, ca, cb, part0, part1, B, H, W, C, mode};
+              invstd, ca, cb, part0, part1, B, H, W, C, mode, q8};
   const int ccw = CC < 256 ? CC : 256;
   dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)B * H * W), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;
@@ -787,6 +844,15 @@ extern "C" int cvcs_bn_bwd_apply(const void* y, int64_t y_ld, const void* g1, in
                        save_invstd, coef_a, coef_b, mode, dy, dy_ld, part_db, nullptr, dtype, stream);
 }
 
+extern "C" int cvcs_bn_bwd_apply_q8(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, int B, int H, int W, int C, const float* scale,
+                                    const float* shift, const float* save_mean, const float* save_invstd, const float* coef_a,
+                                    const float* coef_b, int mode, void* dy, int64_t dy_ld, float* part_db, void* q8, int64_t q8_ld, int fmt,
+                                    float* slot, int take_amax, int dtype, void* stream) {
+  CVCS_CHECK_ARG(q8 != nullptr, "cvcs_bn_bwd_apply_q8: null fp8 output");
+  return bn_bwd_common("cvcs_bn_bwd_apply_q8", true, y, y_ld, g1, g1_ld, nullptr, 0, B, H, W, C, scale, shift, save_mean, save_invstd, coef_a,
+                       coef_b, mode, dy, dy_ld, part_db, nullptr, dtype, stream, Q8Out{(char*)q8, q8_ld, slot, fmt, take_amax});
+}
+
 extern "C" int cvcs_colsum_finalize(const float* part, int rows, int C, float* out, void* stream) {
   CVCS_CHECK_ARG(part && out && rows > 0 && C > 0, "cvcs_colsum_finalize: bad argument");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(16 * kRL), 0, (hipStream_t)stream, part, rows, C, out);
@@ -812,22 +878,34 @@ extern "C" int cvcs_colsum_partial(const void* x, int64_t x_ld, int64_t M, int C
   return CVCS_OK;
 }
 
-extern "C" int cvcs_upsample2x_fwd(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
-                                   int dtype, void* stream) {
-  CVCS_CHECK_ARG(DT_OK(dtype), "cvcs_upsample2x_fwd: bad dtype");
+static int upsample2x_fwd_impl(const char* fn, const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
+                               int dtype, void* stream, Q8Out q8) {
+  CVCS_CHECK_ARG(DT_OK(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2;
-  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "cvcs_upsample2x_fwd: bad shape");
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
   int rc;
-  if ((rc = check_view("cvcs_upsample2x_fwd", in, in_ld, C, es))) return rc;
-  if ((rc = check_view("cvcs_upsample2x_fwd", out, out_ld, C, es))) return rc;
+  if ((rc = check_view(fn, in, in_ld, C, es))) return rc;
+  if ((rc = check_view(fn, out, out_ld, C, es))) return rc;
+  if ((rc = check_q8(fn, q8, C, dtype))) return rc;
   const int64_t total = (int64_t)B * 4 * H * W * (C / (16 / es));
   dim3 grid(grid_for(total, 256, 256 * 32));
   if (dtype == CVCS_F32)
-    hipLaunchKernelGGL((upsample2x_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
+    hipLaunchKernelGGL((upsample2x_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld, q8);
   else
-    hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld);
-  CVCS_CHECK_LAUNCH("cvcs_upsample2x_fwd");
+    hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, B, H, W, C, (char*)out, out_ld, q8);
+  CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
+}
+
+extern "C" int cvcs_upsample2x_fwd(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld,
+                                   int dtype, void* stream) {
+  return upsample2x_fwd_impl("cvcs_upsample2x_fwd", in, in_ld, B, H, W, C, out, out_ld, dtype, stream, Q8Out{nullptr, 0, nullptr, 0, 0});
+}
+
+extern "C" int cvcs_upsample2x_fwd_q8(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld, void* q8,
+                                      int64_t q8_ld, int fmt, float* slot, int take_amax, int dtype, void* stream) {
+  CVCS_CHECK_ARG(q8 != nullptr, "cvcs_upsample2x_fwd_q8: null fp8 output");
+  return upsample2x_fwd_impl("cvcs_upsample2x_fwd_q8", in, in_ld, B, H, W, C, out, out_ld, dtype, stream, Q8Out{(char*)q8, q8_ld, slot, fmt, take_amax});
 }
 
 extern "C" int cvcs_upsample2x_bwd(const void* gout, int64_t gout_ld, int B, int H, int W, int C, void* gin, int64_t gin_ld,

@@ -21,7 +21,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_add_act_kernel(const char* y1, int64_t y1_ld, const float* __restrict__ s1,
                                                         const float* __restrict__ b1, const char* y2, int64_t y2_ld,
                                                         const float* __restrict__ s2, const float* __restrict__ b2, int64_t M,
-                                                        int C, char* out, int64_t out_ld) {
+                                                        int C, char* out, int64_t out_ld, Q8Out q8) {
   constexpr int ES = sizeof(T), V = 16 / ES;
   const int CC = C / V;
   const int ccw = CC < 256 ? CC : 256;
@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const char* y1, int64_t
   const int cl = threadIdx.x % ccw, pl = threadIdx.x / ccw;
   const int cc = blockIdx.y * ccw + cl;
   if (cc >= CC) return;
+  float am = 0.f;
+  const float q_inv = q8.q ? q8.slot[2] : 0.f, q_fmax = q8.q ? q8.slot[3] : 0.f;
   float a1[V], c1[V], a2[V], c2[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) {
@@ -42,7 +44,14 @@ __global__ __launch_bounds__(256) void bn_add_act_kernel(const char* y1, int64_t
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(y2 + pix * y2_ld * ES + cc * 16), b);
 #pragma unroll
     for (int k = 0; k < V; ++k) a[k] = fmaxf((a[k] * a1[k] + c1[k]) + (b[k] * a2[k] + c2[k]), 0.f);
-    *reinterpret_cast<uint4*>(out + pix * out_ld * ES + cc * 16) = Elem<T>::pack(a);
+    const uint4 pk = Elem<T>::pack(a);
+    *reinterpret_cast<uint4*>(out + pix * out_ld * ES + cc * 16) = pk;
+    if constexpr (ES == 2) {
+      if (q8.q) *reinterpret_cast<uint2*>(q8.q + pix * q8.ld + cc * 8) = q8_pack8(pk, q_inv, q_fmax, q8.fmt, am);
+    }
+  }
+  if constexpr (ES == 2) {
+    if (q8.q && q8.take_amax) q8_commit_amax(am, q8.slot);
   }
 }
 
@@ -295,10 +304,8 @@ using namespace cvcs;
 
 #define RES_DT_OK(dt) ((dt) == CVCS_F32 || (dt) == CVCS_BF16)
 
-extern "C" int cvcs_bn_add_act(const void* y1, int64_t y1_ld, const float* s1, const float* b1, const void* y2, int64_t y2_ld,
-                               const float* s2, const float* b2, int64_t M, int C, void* out, int64_t out_ld, int dtype,
-                               void* stream) {
-  const char* fn = "cvcs_bn_add_act";
+static int bn_add_act_impl(const char* fn, const void* y1, int64_t y1_ld, const float* s1, const float* b1, const void* y2, int64_t y2_ld,
+                           const float* s2, const float* b2, int64_t M, int C, void* out, int64_t out_ld, int dtype, void* stream, Q8Out q8) {
   CVCS_CHECK_ARG(RES_DT_OK(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(M > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
@@ -307,17 +314,35 @@ extern "C" int cvcs_bn_add_act(const void* y1, int64_t y1_ld, const float* s1, c
   if ((rc = res_check_view(fn, y1, y1_ld, C, es)) || (rc = res_check_view(fn, y2, y2_ld, C, es)) ||
       (rc = res_check_view(fn, out, out_ld, C, es)))
     return rc;
+  if (q8.q) {
+    CVCS_CHECK_ARG(dtype == CVCS_BF16 && q8.slot && (q8.fmt == CVCS_E4M3 || q8.fmt == CVCS_E5M2), "%s: fp8 side output (bf16 storage, slot, format)", fn);
+    CVCS_CHECK_ARG(q8.ld >= C && q8.ld % 8 == 0 && ((uintptr_t)q8.q % 8) == 0, "%s: fp8 view", fn);
+  }
   const int CC = C / (16 / es), ccw = CC < 256 ? CC : 256;
   CVCS_CHECK_ARG(256 % ccw == 0 && CC % ccw == 0, "%s: C/%d must divide 256 or be a multiple of 256", fn, 16 / es);
   int64_t gx = cdiv(M, (256 / ccw) * 4);   // ~4 pixels per thread
   const dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 8192 ? 8192 : gx)), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CVCS_F32)
-    hipLaunchKernelGGL((bn_add_act_kernel<float>), grid, dim3(256), 0, st, (const char*)y1, y1_ld, s1, b1, (const char*)y2, y2_ld, s2, b2, M, C, (char*)out, out_ld);
+    hipLaunchKernelGGL((bn_add_act_kernel<float>), grid, dim3(256), 0, st, (const char*)y1, y1_ld, s1, b1, (const char*)y2, y2_ld, s2, b2, M, C, (char*)out, out_ld, q8);
   else
-    hipLaunchKernelGGL((bn_add_act_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)y1, y1_ld, s1, b1, (const char*)y2, y2_ld, s2, b2, M, C, (char*)out, out_ld);
+    hipLaunchKernelGGL((bn_add_act_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)y1, y1_ld, s1, b1, (const char*)y2, y2_ld, s2, b2, M, C, (char*)out, out_ld, q8);
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_add_act(const void* y1, int64_t y1_ld, const float* s1, const float* b1, const void* y2, int64_t y2_ld,
+                               const float* s2, const float* b2, int64_t M, int C, void* out, int64_t out_ld, int dtype,
+                               void* stream) {
+  return bn_add_act_impl("cvcs_bn_add_act", y1, y1_ld, s1, b1, y2, y2_ld, s2, b2, M, C, out, out_ld, dtype, stream, Q8Out{nullptr, 0, nullptr, 0, 0});
+}
+
+extern "C" int cvcs_bn_add_act_q8(const void* y1, int64_t y1_ld, const float* s1, const float* b1, const void* y2, int64_t y2_ld,
+                                  const float* s2, const float* b2, int64_t M, int C, void* out, int64_t out_ld, void* q8, int64_t q8_ld,
+                                  int fmt, float* slot, int take_amax, int dtype, void* stream) {
+  CVCS_CHECK_ARG(q8 != nullptr, "cvcs_bn_add_act_q8: null fp8 output");
+  return bn_add_act_impl("cvcs_bn_add_act_q8", y1, y1_ld, s1, b1, y2, y2_ld, s2, b2, M, C, out, out_ld, dtype, stream,
+                         Q8Out{(char*)q8, q8_ld, slot, fmt, take_amax});
 }
 
 extern "C" int cvcs_relu_bwd_sum(const void* out, int64_t out_ld, const void* g0, int64_t g0_ld, int g0_half, const void* g1,

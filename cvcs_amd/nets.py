@@ -21,7 +21,9 @@ from .deeplab_engine import LOW_LEVEL_CHANNELS, DeepLabEngine
 from .resnet_engine import ARCHS as RESNET_ARCHS, DECODER_CHANNELS, ResNetUNetEngine
 from .swin_engine import HIDDEN as UPER_HIDDEN, POOL_SCALES, VARIANTS as SWIN_VARIANTS, SwinUPerNetEngine
 
-PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
+PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16,
+              # "fp8" = BASELINE configs[4] "mixed bf16/fp8 convs": bf16 storage, the qualifying 3x3 convolutions on the fp8 MFMA (ResNet-UNets)
+              "fp8": torch.bfloat16}
 
 
 def unet_param_spec(variant: str, num_classes: int):
@@ -99,6 +101,7 @@ class _HipUNet(nn.Module):
     def __init__(self, num_classes: int, precision: str = "bf16"):
         super().__init__()
         assert precision in PRECISIONS, f"precision must be one of {list(PRECISIONS)}"
+        assert precision != "fp8" or self.variant == "ResnetUnet", "precision 'fp8' (mixed bf16 / fp8 convolutions) is built for the ResNet-UNets"
         self.requires_context = False   # S/nets.py:37,120
         self.wrapper = False
         self.returns_logits = True
@@ -314,7 +317,8 @@ class ResnetUnet(_HipUNet):
         return resnet_unet_param_spec(self.arch, self.num_classes, decoder_norm=self.decoder_norm)
 
     def _build_engine(self, dev):
-        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, decoder_norm=self.decoder_norm)
+        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, decoder_norm=self.decoder_norm,
+                                fp8=self.precision == "fp8")
 
 
 class Resnet18Unet(ResnetUnet):

@@ -277,11 +277,13 @@ FP8_MARGIN = 2.0      # delayed scaling: scale = FP8_MARGIN * amax(previous step
 
 
 class Fp8Slots:
-    """per-tensor scale slots of the fp8 path, one device table [n][4] f32 = (amax of this step, scale, 1 / scale, fmax): the kernels
-    read scale / 1/scale through pointers into it, cvcs_fp8_update_scales turns the step's amax into the next step's scale"""
+    """per-tensor scale slots of the fp8 path: one device table [n][SLOT] f32, a slot = (-, scale, 1 / scale, fmax, amax the scale came from)
+    on its first 64-byte line + 64 partial amax words on lines of their own (include/cvcs_hip.h).  The kernels read scale / 1/scale through
+    pointers into it; cvcs_fp8_update_scales turns the step's amax into the next step's scale."""
+    SLOT = 1040
 
     def __init__(self, device, capacity=256):
-        self.t = torch.zeros((capacity, 4), dtype=torch.float32, device=device)
+        self.t = torch.zeros((capacity, self.SLOT), dtype=torch.float32, device=device)
         self.t[:, 1:3] = 1.0
         self.names, self.fresh = {}, set()
 
@@ -296,27 +298,34 @@ class Fp8Slots:
         return i
 
     def ptr(self, i, field=0):
-        return self.t.data_ptr() + (4 * i + field) * 4
+        return self.t.data_ptr() + (self.SLOT * i + field) * 4
+
+    def amax_now(self, i) -> float:
+        """the amax collected so far in this step (maximum over the partial words)"""
+        return float(self.t[i, 16::16].max())
+
+    def scale(self, i) -> float:
+        return float(self.t[i, 1])
 
     def update(self):
         check(_lib.lib().cvcs_fp8_update_scales(self.t.data_ptr(), max(len(self.names), 1), FP8_MARGIN, _stream()), "cvcs_fp8_update_scales")
 
 
-def quantize_fp8(x: View, q: View | None, fmt: int, slots: Fp8Slots, i: int):
+def quantize_fp8(x: View, q: View | None, fmt: int, slots: Fp8Slots, i: int, take_amax=True):
     """q = fmt(x / scale_i) (bf16 view -> fp8 view) and amax_i = max(amax_i, max|x|).  A slot without history is CALIBRATED first, outside
     any recording: the amax of this very tensor becomes its scale (current scaling for a slot's first use, delayed scaling afterwards)"""
     M = x.B * x.H * x.W
     assert x.code == BF16 and x.C % 16 == 0
     if i in slots.fresh:
         h = _lib._load()      # (the raw handle: calibration launches are not part of a recorded plan)
-        check(h.cvcs_quantize_fp8(x.ptr, x.ld, M, x.C, 0, 0, fmt, slots.ptr(i), _stream()), "cvcs_quantize_fp8(amax)")
+        check(h.cvcs_quantize_fp8(x.ptr, x.ld, M, x.C, 0, 0, fmt, slots.ptr(i), 1, _stream()), "cvcs_quantize_fp8(amax)")
         check(h.cvcs_fp8_update_scales(slots.ptr(i), 1, FP8_MARGIN, _stream()), "cvcs_fp8_update_scales")
         slots.fresh.discard(i)
     if q is None:
         return
     assert q.t.dtype == torch.uint8 and (q.B, q.H, q.W, q.C) == (x.B, x.H, x.W, x.C)
     _tag_hbm("quantize_fp8", M * x.C * 3)
-    check(_lib.lib().cvcs_quantize_fp8(x.ptr, x.ld, M, x.C, q.ptr, q.ld, fmt, slots.ptr(i), _stream()), "cvcs_quantize_fp8")
+    check(_lib.lib().cvcs_quantize_fp8(x.ptr, x.ld, M, x.C, q.ptr, q.ld, fmt, slots.ptr(i), int(take_amax), _stream()), "cvcs_quantize_fp8")
 
 
 def conv3x3_fp8(x8: View, fmt: int, wt8: torch.Tensor, out: View, slots: Fp8Slots, ix: int, iw: int, stats=None, relu=False, pre_affine=None):
@@ -395,8 +404,22 @@ def bn_bwd_coeffs(sums, M, C_, ca, cb):
     check(_lib.lib().cvcs_bn_bwd_coeffs(sums.data_ptr(), M, C_, ca.data_ptr(), cb.data_ptr(), _stream()), "cvcs_bn_bwd_coeffs")
 
 
-def bn_act(y: View, scale, shift, relu: bool, out: View | None, pool: View | None = None):
-    """out = relu?(scale*y + shift) (+ pool = 2x2 max of it); out=None with a pool view: pooling only"""
+def _q8_args(q8):
+    """q8 = (fp8 view, format, Fp8Slots, slot index, take_amax) -> the trailing C arguments of a *_q8 producer"""
+    qv, fmt, slots, i, take = q8
+    assert qv.t.dtype == torch.uint8
+    return qv.ptr, qv.ld, fmt, slots.ptr(i), int(take)
+
+
+def bn_act(y: View, scale, shift, relu: bool, out: View | None, pool: View | None = None, q8=None):
+    """out = relu?(scale*y + shift) (+ pool = 2x2 max of it); out=None with a pool view: pooling only.
+    q8 = (fp8 view, format, slots, slot, take_amax): also the fp8 image of out (cvcs_bn_act_q8)"""
+    _tag_hbm("bn_act", y.B * y.H * y.W * y.C * (y.t.element_size() * (2 if pool is None else 2.25) + (1 if q8 is not None else 0)))
+    if q8 is not None:
+        assert pool is None and out is not None and (q8[0].B, q8[0].H, q8[0].W, q8[0].C) == (y.B, y.H, y.W, y.C)
+        check(_lib.lib().cvcs_bn_act_q8(y.ptr, y.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(relu), out.ptr, out.ld,
+                                        *_q8_args(q8), y.code, _stream()), "cvcs_bn_act_q8")
+        return
     check(_lib.lib().cvcs_bn_act(y.ptr, y.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), int(relu),
                                  0 if out is None else out.ptr, 0 if out is None else out.ld,
                                  0 if pool is None else pool.ptr, 0 if pool is None else pool.ld, y.code,
@@ -408,6 +431,7 @@ def bn_bwd_rows(M: int) -> int:
 
 
 def bn_bwd_reduce(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, mode, part_dz, part_dzx):
+    _tag_hbm("bn_bwd", y.B * y.H * y.W * y.C * y.t.element_size() * 2)
     check(_lib.lib().cvcs_bn_bwd_reduce(y.ptr, y.ld, g1.ptr, g1.ld, 0 if g2 is None else g2.ptr, 0 if g2 is None else g2.ld,
                                         y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                         invstd.data_ptr(), mode, part_dz.data_ptr(), part_dzx.data_ptr(), y.code, _stream()),
@@ -420,7 +444,14 @@ def bn_bwd_finalize(part_dz, part_dzx, rows, M, C_, gamma, invstd, dgamma, dbeta
                                           cb.data_ptr(), _stream()), "cvcs_bn_bwd_finalize")
 
 
-def bn_bwd_apply(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, ca, cb, mode, dy: View, part_db):
+def bn_bwd_apply(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, ca, cb, mode, dy: View, part_db, q8=None):
+    _tag_hbm("bn_bwd", y.B * y.H * y.W * y.C * (y.t.element_size() * 3 + (1 if q8 is not None else 0)))
+    if q8 is not None:      # also the fp8 image of dy (cvcs_bn_bwd_apply_q8)
+        assert g2 is None
+        check(_lib.lib().cvcs_bn_bwd_apply_q8(y.ptr, y.ld, g1.ptr, g1.ld, y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                              invstd.data_ptr(), ca.data_ptr(), cb.data_ptr(), mode, dy.ptr, dy.ld, part_db.data_ptr(),
+                                              *_q8_args(q8), y.code, _stream()), "cvcs_bn_bwd_apply_q8")
+        return
     check(_lib.lib().cvcs_bn_bwd_apply(y.ptr, y.ld, g1.ptr, g1.ld, 0 if g2 is None else g2.ptr, 0 if g2 is None else g2.ld,
                                        y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                        invstd.data_ptr(), ca.data_ptr(), cb.data_ptr(), mode, dy.ptr, dy.ld,
@@ -437,10 +468,15 @@ def colsum_partial(x: View, part):
 
 
 # ------------------------------------------------------------------------------------------------ residual networks
-def bn_add_act(y1: View, s1, b1, y2: View, s2, b2, out: View):
-    """out = relu(s1*y1 + b1 + (s2*y2 + b2 | y2)): the tail of a residual block in one pass"""
+def bn_add_act(y1: View, s1, b1, y2: View, s2, b2, out: View, q8=None):
+    """out = relu(s1*y1 + b1 + (s2*y2 + b2 | y2)): the tail of a residual block in one pass (q8: also its fp8 image, cvcs_bn_add_act_q8)"""
     M = y1.B * y1.H * y1.W
     assert (y2.B, y2.H, y2.W, y2.C) == (y1.B, y1.H, y1.W, y1.C) == (out.B, out.H, out.W, out.C)
+    _tag_hbm("residual", M * y1.C * (y1.t.element_size() * 3 + (1 if q8 is not None else 0)))
+    if q8 is not None:
+        check(_lib.lib().cvcs_bn_add_act_q8(y1.ptr, y1.ld, s1.data_ptr(), b1.data_ptr(), y2.ptr, y2.ld, _ptr(s2), _ptr(b2), M, y1.C, out.ptr, out.ld,
+                                            *_q8_args(q8), y1.code, _stream()), "cvcs_bn_add_act_q8")
+        return
     check(_lib.lib().cvcs_bn_add_act(y1.ptr, y1.ld, s1.data_ptr(), b1.data_ptr(), y2.ptr, y2.ld, _ptr(s2), _ptr(b2), M, y1.C,
                                      out.ptr, out.ld, y1.code, _stream()), "cvcs_bn_add_act")
 
@@ -455,6 +491,7 @@ def relu_bwd_sum(out: View | None, grads, dz: View):
     a = []
     for v, half in g:
         a += [0 if v is None else v.ptr, 0 if v is None else v.ld, int(half)]
+    _tag_hbm("residual", dz.B * dz.H * dz.W * dz.C * dz.t.element_size() * (1 + (out is not None) + sum(0.25 if half else 1.0 for _, half in grads)))
     check(_lib.lib().cvcs_relu_bwd_sum(0 if out is None else out.ptr, 0 if out is None else out.ld, *a, dz.B, dz.H, dz.W, dz.C,
                                        dz.ptr, dz.ld, dz.code, _stream()), "cvcs_relu_bwd_sum")
 
@@ -688,12 +725,18 @@ def linear_head_bwd(x: View, dlogits, w, dx: View, part_dw):
 
 
 # ------------------------------------------------------------------------------------------------ bilinear
-def upsample2x_fwd(x: View, out: View):
+def upsample2x_fwd(x: View, out: View, q8=None):
+    _tag_hbm("resize", out.B * out.H * out.W * out.C * (out.t.element_size() * 1.25 + (1 if q8 is not None else 0)))
+    if q8 is not None:
+        check(_lib.lib().cvcs_upsample2x_fwd_q8(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, *_q8_args(q8), x.code, _stream()),
+              "cvcs_upsample2x_fwd_q8")
+        return
     check(_lib.lib().cvcs_upsample2x_fwd(x.ptr, x.ld, x.B, x.H, x.W, x.C, out.ptr, out.ld, x.code, _stream()),
           "cvcs_upsample2x_fwd")
 
 
 def upsample2x_bwd(gout: View, gin: View):
+    _tag_hbm("resize", gout.B * gout.H * gout.W * gout.C * gout.t.element_size() * 1.25)
     check(_lib.lib().cvcs_upsample2x_bwd(gout.ptr, gout.ld, gin.B, gin.H, gin.W, gin.C, gin.ptr, gin.ld, gin.code, _stream()),
           "cvcs_upsample2x_bwd")
 

@@ -89,8 +89,18 @@ class Unit:
 
 class ResNetUNetEngine:
     def __init__(self, arch: str, num_classes: int, dtype: torch.dtype, device, decoder_channels=DECODER_CHANNELS,
-                 decoder_norm="bn_relu"):
+                 decoder_norm="bn_relu", fp8=False):
         assert arch in ARCHS and decoder_norm in ("bn_relu", "gn_silu")
+        assert not fp8 or dtype == torch.bfloat16, "the fp8 convolutions live beside bf16 storage (precision 'fp8' = mixed bf16 / fp8)"
+        # fp8 = BASELINE configs[4] "mixed bf16/fp8 convs": the 3x3 / stride 1 convolutions whose channel counts are multiples of 128 run
+        # forward AND data gradient on the block-scaled fp8 MFMA (csrc/conv_fp8.hip); everything else, the weight gradients included, bf16
+        self.fp8 = bool(fp8)
+        self.f8 = None                   # ops.Fp8Slots: per-tensor scales (delayed scaling)
+        self._q8 = {}                    # bf16 buffer address -> (fp8 buffer, slot, format) of the tensors an fp8 convolution reads
+        self._train_pass = True
+        # evaluation passes run the bf16 kernels by default: in eval mode the BatchNorms are folded into the conv epilogues, so no producer
+        # pass exists to write the fp8 images for free, and fp8 is a TRAINING-throughput feature (CVCS_FP8_EVAL=1: fp8 with the trained scales)
+        self.fp8_eval = os.environ.get("CVCS_FP8_EVAL", "0") == "1"
         self.decoder_norm = decoder_norm
         self.arch, self.NC, self.dtype, self.dev = arch, num_classes, dtype, torch.device(device)
         self.kind, self.depths, self.widths = ARCHS[arch]
@@ -137,6 +147,12 @@ class ResNetUNetEngine:
             self.packed[name[:-len(".weight")]] = pk
             entries.append((w, pk["wf"], pk["wd"]))
         self._pack_table = ops.pack_table(entries, dev)
+        if self.fp8:
+            self.f8 = ops.Fp8Slots(dev)
+            for name, pk in self.packed.items():
+                _, cout, cin = pk["wf"].shape
+                if pk["wf"].shape[0] == 9 and cout % 128 == 0 and cin % 128 == 0:      # (which of them run fp8 is decided per launch: _fp8_ok)
+                    pk["wf8"], pk["wd8"] = (torch.empty(t.shape, dtype=torch.uint8, device=dev) for t in (pk["wf"], pk["wd"]))
         self.stem_wf = torch.empty(7, 64, 32, dtype=dt, device=dev)
         self.stem_dw_tmp = torch.empty(64 * 32 * 7, dtype=torch.float32, device=dev)
         self.bn = {n[:-len(".weight")]: _BN(p.numel(), dev) for n, p in params.items() if p.dim() == 1 and n.endswith(".weight")}
@@ -150,9 +166,63 @@ class ResNetUNetEngine:
         raise NotImplementedError("exact (SyncBN) data-parallel mode is built for the reference's U-Nets only so far; "
                                   "ResNet-UNets train with per-rank BatchNorm statistics (torch-DDP semantics)")
 
-    def refresh_weights(self):
+    def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
         ops.pack_stem_weight(self.P["encoder.conv1.weight"], self.stem_wf)
+        if self.fp8:
+            # e4m3 images of the packed bf16 weights, one scale per layer (forward and data-gradient image hold the same values)
+            for name, pk in self.packed.items():
+                if "wf8" in pk:
+                    i = self.f8.slot("w:" + name, _lib.E4M3)
+                    for src, dst in ((pk["wf"], pk["wf8"]), (pk["wd"], pk["wd8"])):
+                        rows, k = src.shape[0] * src.shape[1], src.shape[2]
+                        ops.quantize_fp8(View(src.view(1, rows, 1, k), 0, k), View(dst.view(1, rows, 1, k), 0, k), _lib.E4M3, self.f8, i,
+                                         take_amax=train and src is pk["wf"])
+
+    def _fp8_ok(self, conv, x: View, k, stride, dil, virt=False):
+        """does this convolution run on the fp8 kernel?  3x3 / stride 1 / no dilation on maps of at least 8 pixels, both channel counts
+        multiples of 128 (one MFMA K-step = 128 input channels; 128 output channels per workgroup)"""
+        pk = self.packed.get(conv)
+        return (self.fp8 and not virt and pk is not None and "wf8" in pk and k == 3 and stride == 1 and dil == 1 and x.H >= 8 and x.W >= 8 and
+                x.C % 128 == 0 and (self._train_pass or self.fp8_eval))
+
+    # The fp8 image of a tensor is written by the pass that PRODUCES the tensor (bn_act / the block tail / the bilinear up-sampling /
+    # the BatchNorm-backward apply: ops.*(..., q8=...)), not by a sweep of its own.  A tensor that an fp8 convolution will read is registered
+    # before its producers run; producers and the consumer look it up by the bf16 buffer's address.
+    def _register_q8(self, t: torch.Tensor, tag, fmt=_lib.E4M3, buf=None):
+        q = self._buf("f8." + (buf or tag), tuple(t.shape), torch.uint8)
+        self._q8[t.data_ptr()] = (q, self.f8.slot(tag, fmt), fmt)
+
+    def _q8_of(self, v: View, train=True):
+        """the q8 argument of a producer that writes the view v, or None"""
+        if not self.fp8 or v is None:
+            return None
+        r = self._q8.get(v.t.data_ptr())
+        if r is None:
+            return None
+        q, i, fmt = r
+        return (View(q, v.off, v.C), fmt, self.f8, i, train)
+
+    def _fp8_input(self, x: View, tag, fmt, train, buf=None):
+        """(fp8 view, slot) of the convolution input x.  Registered tensors were written by their producers; a slot WITHOUT history is
+        calibrated here, outside the recording: the producers have already fed its amax (which does not depend on the scale), so the scale
+        is set from it and the image is taken again once with that scale - later steps run on the delayed scale alone.  Unregistered
+        tensors (no fused producer) get a quantisation pass of their own."""
+        r = self._q8.get(x.t.data_ptr())
+        if r is None:
+            q = self._buf("f8." + (buf or tag), tuple(x.t.shape), torch.uint8)
+            i = self.f8.slot(tag, fmt)
+            qv = View(q, x.off, x.C)
+            ops.quantize_fp8(x, qv, fmt, self.f8, i, take_amax=train)
+            return qv, i
+        q, i, _ = r
+        qv = View(q, x.off, x.C)
+        if i in self.f8.fresh:
+            h, st = _lib._load(), torch.cuda.current_stream().cuda_stream
+            _lib.check(h.cvcs_fp8_update_scales(self.f8.ptr(i), 1, ops.FP8_MARGIN, st), "cvcs_fp8_update_scales")
+            _lib.check(h.cvcs_quantize_fp8(x.ptr, x.ld, x.B * x.H * x.W, x.C, qv.ptr, qv.ld, fmt, self.f8.ptr(i), 1, st), "cvcs_quantize_fp8")
+            self.f8.fresh.discard(i)
+        return qv, i
 
     # ------------------------------------------------------------------------------------------------ buffers
     def _buf(self, name, shape, dtype=None):
@@ -192,20 +262,31 @@ class ResNetUNetEngine:
             ops.bn_finalize(None, 0, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
                             self.Bf[bn + ".running_var"], False, st.scale, st.shift, None, None)
             out = act_out if act_out is not None else ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
-            ops.conv2d(x, wf, None, out, kh, kw, stride, pad, dil, relu=relu and act_out is not None, pre_affine=(st.scale, st.shift),
-                       virt=virt or None)
+            if self._fp8_ok(conv, x, k, stride, dil, virt):
+                x8, ix = self._fp8_input(x, "a:" + conv, _lib.E4M3, False)
+                ops.conv3x3_fp8(x8, _lib.E4M3, self.packed[conv]["wf8"], out, self.f8, ix, self.f8.slot("w:" + conv, _lib.E4M3),
+                                relu=relu and act_out is not None, pre_affine=(st.scale, st.shift))
+            else:
+                ops.conv2d(x, wf, None, out, kh, kw, stride, pad, dil, relu=relu and act_out is not None, pre_affine=(st.scale, st.shift),
+                           virt=virt or None)
             return Unit(x, out, conv, bn, k, stride, pad, virt, dil)
         y = ops.view(self._act(conv + ".y", B, Ho, Wo, cout))
-        rows = ops.conv_stat_rows(x, cout, kh, kw, stride, pad, dil, virt=virt or None)
+        f8 = self._fp8_ok(conv, x, k, stride, dil, virt)
+        rows = ops.fp8_stat_rows(x) if f8 else ops.conv_stat_rows(x, cout, kh, kw, stride, pad, dil, virt=virt or None)
         stats = (self._scratch("stat_sum", rows * cout), self._scratch("stat_m2", rows * cout), self._scratch("stat_cnt", rows))
-        ops.conv2d(x, wf, None, y, kh, kw, stride, pad, dil, stats=stats, virt=virt or None)
+        if f8:
+            x8, ix = self._fp8_input(x, "a:" + conv, _lib.E4M3, True)
+            ops.conv3x3_fp8(x8, _lib.E4M3, self.packed[conv]["wf8"], y, self.f8, ix, self.f8.slot("w:" + conv, _lib.E4M3), stats=stats)
+        else:
+            ops.conv2d(x, wf, None, y, kh, kw, stride, pad, dil, stats=stats, virt=virt or None)
         need = ops.bn_finalize_workspace_floats(rows, cout)
         ops.bn_finalize(stats, rows, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
                         self.Bf[bn + ".running_var"], True, st.scale, st.shift, st.mean, st.invstd,
                         workspace=self._scratch("bn_ws", max(need, 4)))
         if act_out is not None:
-            ops.bn_act(y, st.scale, st.shift, relu, act_out)
+            ops.bn_act(y, st.scale, st.shift, relu, act_out, q8=self._q8_of(act_out))
         u = Unit(x, y, conv, bn, k, stride, pad, virt, dil)
+        u.fp8 = f8
         self.units[conv] = (u, act_out)     # persistent views of this shape's plan (layer-wise parity tests read them)
         if act_out is not None and relu:
             self.relu_order.append(act_out if self._grid == 1 else GridView(act_out, self._grid))
@@ -235,11 +316,12 @@ class ResNetUNetEngine:
         s3 = self.bn[u3.bn]
         C_ = out.C
         if train:
+            q8 = self._q8_of(out)
             if ud is not None:
                 sd = self.bn[ud.bn]
-                ops.bn_add_act(u3.y, s3.scale, s3.shift, ud.y, sd.scale, sd.shift, out)
+                ops.bn_add_act(u3.y, s3.scale, s3.shift, ud.y, sd.scale, sd.shift, out, q8=q8)
             else:
-                ops.bn_add_act(u3.y, s3.scale, s3.shift, h.v, None, None, out)
+                ops.bn_add_act(u3.y, s3.scale, s3.shift, h.v, None, None, out, q8=q8)
         else:   # the BatchNorms are already inside the conv epilogues
             ops.bn_add_act(u3.y, self.one[:C_], self.zero[:C_], ud.y if ud is not None else h.v, None, None, out)
 
@@ -259,6 +341,8 @@ class ResNetUNetEngine:
             Ho, Wo = h.v.H // stride, h.v.W // stride
             a1 = Act(ops.view(self._act(p + ".a1", B, h.v.H, h.v.W, mid)))
             a2 = Act(ops.view(self._act(p + ".a2", B, Ho, Wo, mid)))
+            if train and self._fp8_ok(p + ".conv2", a1.v, 3, stride, dil):
+                self._register_q8(a1.v.t, "a:" + p + ".conv2")
             u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 1, 1, 0, train, a1.v)
             u2 = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, stride, dil, train, a2.v, dil=dil)
             ut = self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
@@ -303,6 +387,8 @@ class ResNetUNetEngine:
         reduce pass of consumer's BatchNorm backward?  (cvcs_conv_desc.bwd_y: bf16 3x3 / stride 1 launches on the three-
         workgroup narrow tiles, i.e. up to 128 channels - on the wide kernel the longer epilogue is exposed)"""
         y = consumer.y
+        if getattr(producer, "fp8", False):      # the fp8 kernel has no fused reduce epilogue
+            return False
         return (self.fuse_bn_bwd and not getattr(consumer, "gn", False) and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
                 producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128)
 
@@ -346,7 +432,11 @@ class ResNetUNetEngine:
         rec = _lib._recording
         if self.overlap_wgrad and rec is not None and dyname in self._dy_reader:
             rec.wait_side(self._dy_reader[dyname])
-        ops.bn_bwd_apply(y, g, None, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, dy, p2)
+        q8 = None
+        if getattr(u, "fp8", False):      # the data gradient of this unit runs fp8: dy leaves the pass with its e5m2 image
+            self._register_q8(dy.t, "g:" + u.conv, _lib.E5M2, buf=None if self.keep_all else "dy")
+            q8 = self._q8_of(dy)
+        ops.bn_bwd_apply(y, g, None, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, dy, p2, q8=q8)
         side = self.overlap_wgrad and rec is not None
         ws_name = "wg_ws_side" if side else "wg_ws"      # (the side lane's launches share one workspace: their stream serialises them)
         with (_lib.side_lane() if side else contextlib.nullcontext()):
@@ -386,7 +476,11 @@ class ResNetUNetEngine:
                 self.bwd_units[u.conv]["gx"] = gx
             return gx, u.stride == 2
         gx = ops.view(self._act(name, B, x.H, x.W, cin))
-        if u.stride == 1:
+        if getattr(u, "fp8", False):
+            # e5m2 gradient (range over precision) x e4m3 flipped weights on the same kernel
+            dy8, ig = self._fp8_input(dy, "g:" + u.conv, _lib.E5M2, True, buf="dy" if not self.keep_all else None)
+            ops.conv3x3_fp8(dy8, _lib.E5M2, self.packed[u.conv]["wd8"], gx, self.f8, ig, self.f8.slot("w:" + u.conv, _lib.E4M3))
+        elif u.stride == 1:
             ops.conv2d(dy, wd, None, gx, 3, 3, 1, u.dil, u.dil)   # (dilated: the generic gather kernel, see wgrad_dilated)
         else:
             # 3x3 / stride 2 / pad 1: dx = conv3x3/s1/p1(zero-dilated dy, flipped weights) - on the halo kernel
@@ -407,7 +501,8 @@ class ResNetUNetEngine:
         train mode, fills self._tape with the backward closures (run in reverse by backward())"""
         tape = []
         self.units, self.relu_order = {}, []     # relu_order: every ReLU output in execution order (tests)
-        self.refresh_weights()
+        self._q8, self._train_pass = {}, train
+        self.refresh_weights(train)
         dec, widths = self.dec, self.widths
         skipc = [widths[2], widths[1], widths[0], 64, 0]
         # decoder input buffers: [up-sampled | skip] channel ranges; the encoder writes its features into the skip ranges
@@ -415,6 +510,8 @@ class ResNetUNetEngine:
         for i in range(5):
             s = S >> (4 - i)
             cat.append(self._act(f"cat{i}", B, s, s, cin + skipc[i]))
+            if train and self._fp8_ok(f"decoder.blocks.{i}.conv1.0", ops.view(cat[i]), 3, 1, 1):
+                self._register_q8(cat[i], f"a:decoder.blocks.{i}.conv1.0")      # both producers (up-sampling, encoder block tail) write into it
             cin = dec[i]
         upc = [widths[3]] + list(dec[:4])                    # channels of the up-sampled part of cat[i]
         skip_view = lambda i: View(cat[i], upc[i], skipc[i])  # noqa: E731
@@ -425,10 +522,12 @@ class ResNetUNetEngine:
         for i in range(5):
             s = S >> (4 - i)
             up = View(cat[i], 0, upc[i])
-            ops.upsample2x_fwd(h.v, up)
+            ops.upsample2x_fwd(h.v, up, q8=self._q8_of(up))
             pre = f"decoder.blocks.{i}"
             a1 = Act(ops.view(self._act(pre + ".a1", B, s, s, dec[i])))
             a2 = Act(ops.view(self._act(pre + ".a2", B, s, s, dec[i])))
+            if train and self._fp8_ok(pre + ".conv2.0", a1.v, 3, 1, 1):
+                self._register_q8(a1.v.t, "a:" + pre + ".conv2.0")
             xin = ops.view(cat[i])
             u1 = self._unit(xin, pre + ".conv1.0", pre + ".conv1.1", 3, 1, 1, train, a1.v)
             u2 = self._unit(a1.v, pre + ".conv2.0", pre + ".conv2.1", 3, 1, 1, train, a2.v)
@@ -602,4 +701,6 @@ class ResNetUNetEngine:
             h.grads = [(gh, False)]
             for fn in reversed(self._tape):
                 fn()
+            if self.fp8:
+                self.f8.update()      # delayed scaling: this step's amax of every quantised tensor becomes the next step's scale
         self._run("bwd", run_tape)

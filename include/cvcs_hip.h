@@ -455,14 +455,33 @@ typedef struct {
 } cvcs_conv8_desc;
 int cvcs_sizeof_conv8_desc(void);
 int cvcs_conv3x3_fp8(const cvcs_conv8_desc* d, void* stream);
-/* A scale slot is float[4] = { amax of the tensor this step, scale, 1 / scale, fmax of its format (448 | 57344) }.
+#define CVCS_FP8_SLOT_FLOATS 1040
+/* A scale slot is CVCS_FP8_SLOT_FLOATS floats: [0..4] = { amax (unused by the kernels: 0), scale, 1 / scale, fmax of its format (448 | 57344),
+ * the amax the current scale was made from }, then 64 partial amax words, one per 64-byte line at [16 * (1 + j)] - producers
+ * atomically raise ONE of them per wave, cvcs_fp8_update_scales takes the maximum over all and clears them.
  * cvcs_quantize_fp8: q (fp8 view, ld in bytes) = fmt(clamp(x * slot[2], +-slot[3])) of a bf16 view x [M pixels][C], round to nearest
- * even, and slot[0] = max(slot[0], max|x|) (atomic max on the float's bits: order-independent, so a step stays reproducible).
+ * even, and the slot's amax words are raised to max|x| (atomic max on the float's bits: order-independent, so a step stays reproducible).
+ * take_amax = 0: slot[0] is left alone (evaluation passes use the trained scales without feeding the next step's).
  * q == NULL: the amax only (calibration of a slot without history).  C % 16 == 0.
- * cvcs_fp8_update_scales: delayed scaling at the end of a step - for each of n slots with amax > 0: scale = margin * amax / fmax,
- * then amax = 0.  (margin >= 1 leaves headroom for the next step's growth; values beyond saturate.)                          */
-int cvcs_quantize_fp8(const void* x, int64_t x_ld, int64_t M, int C, void* q, int64_t q_ld, int fmt, float* slot, void* stream);
+ * cvcs_fp8_update_scales: delayed scaling at the end of a step - for each of n consecutive slots with amax > 0: scale = margin * amax / fmax,
+ * then the amax words are cleared.  (margin >= 1 leaves headroom for the next step's growth; values beyond saturate.)                          */
+int cvcs_quantize_fp8(const void* x, int64_t x_ld, int64_t M, int C, void* q, int64_t q_ld, int fmt, float* slot, int take_amax, void* stream);
 int cvcs_fp8_update_scales(float* slots, int n, float margin, void* stream);
+/* Producer passes WITH an fp8 side output: exactly cvcs_bn_act (no pooling) / cvcs_bn_bwd_apply (no pooled gradient) / cvcs_upsample2x_fwd /
+ * cvcs_bn_add_act, which besides their bf16 output write the fp8 image q8 (view, ld in bytes) of the SAME bf16-rounded values, quantised with
+ * `slot` as cvcs_quantize_fp8 does, and feed the slot's amax (take_amax) - the tensor an fp8 convolution reads never gets a sweep of its
+ * own.  Several producers may share one slot (the two channel ranges of a decoder's concat buffer are one tensor with one scale).  bf16 only. */
+int cvcs_bn_act_q8(const void* y, int64_t y_ld, int B, int H, int W, int C, const float* scale, const float* shift, int relu, void* out,
+                   int64_t out_ld, void* q8, int64_t q8_ld, int fmt, float* slot, int take_amax, int dtype, void* stream);
+int cvcs_bn_bwd_apply_q8(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, int B, int H, int W, int C, const float* scale,
+                         const float* shift, const float* save_mean, const float* save_invstd, const float* coef_a, const float* coef_b,
+                         int mode, void* dy, int64_t dy_ld, float* part_db, void* q8, int64_t q8_ld, int fmt, float* slot, int take_amax,
+                         int dtype, void* stream);
+int cvcs_upsample2x_fwd_q8(const void* in, int64_t in_ld, int B, int H, int W, int C, void* out, int64_t out_ld, void* q8, int64_t q8_ld,
+                           int fmt, float* slot, int take_amax, int dtype, void* stream);
+int cvcs_bn_add_act_q8(const void* y1, int64_t y1_ld, const float* s1, const float* b1, const void* y2, int64_t y2_ld, const float* s2,
+                       const float* b2, int64_t M, int C, void* out, int64_t out_ld, void* q8, int64_t q8_ld, int fmt, float* slot,
+                       int take_amax, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

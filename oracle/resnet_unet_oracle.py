@@ -170,9 +170,50 @@ def _bn(x, p, prefix, train):
                         eps=BN_EPS)
 
 
+# --------------------------------------------------------------------------- fp8 emulation (BASELINE configs[4]: "mixed bf16/fp8 convs")
+_FP8_BOOK = None      # oracle.fp8_emulation.ScaleBook while forward(..., emulate_fp8=book) runs, else None
+
+
+def fp8_eligible(w, x, stride, pad, dil):
+    """the layers cvcs_amd.resnet_engine._fp8_ok sends to the fp8 kernel: 3x3 / stride 1 / pad 1, both channel counts multiples of 128,
+    maps of at least 8 pixels"""
+    return (w.shape[2] == 3 and w.shape[3] == 3 and stride == 1 and pad == 1 and dil == 1 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0 and
+            x.shape[2] >= 8 and x.shape[3] >= 8)
+
+
+class _Fp8Conv(torch.autograd.Function):
+    """3x3 convolution as the MI355X fp8 path computes it: forward e4m3(x / s_x) * e4m3(bf16(w) / s_w), products exact, f32 accumulate;
+    data gradient e5m2(dy / s_g) against the SAME e4m3 weights; the weight gradient stays on the bf16 operands (x, dy as stored)."""
+
+    @staticmethod
+    def forward(ctx, x, w, name):
+        from oracle import fp8_emulation as F8
+        book = _FP8_BOOK
+        wb = w.to(torch.bfloat16).to(torch.float32)
+        sx = book.scale("a:" + name, x, F8.E4M3)
+        sw = book.scale("w:" + name, wb, F8.E4M3)
+        xq, wq = F8.fake_quant(x, sx, F8.E4M3), F8.fake_quant(wb, sw, F8.E4M3)
+        ctx.save_for_backward(x, wq)
+        ctx.name, ctx.book = name, book
+        return F.conv2d(xq, wq, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import fp8_emulation as F8
+        x, wq = ctx.saved_tensors
+        sg = ctx.book.scale("g:" + ctx.name, g, F8.E5M2)
+        gq = F8.fake_quant(g, sg, F8.E5M2)
+        dx = torch.nn.grad.conv2d_input(x.shape, wq, gq, padding=1)
+        dw = torch.nn.grad.conv2d_weight(x, wq.shape, g, padding=1)
+        return dx, dw, None
+
+
 def _conv(x, p, name, stride=1, pad=0, q=False, dil=1):
     # x is already bf16-representable in emulation mode (every stored activation is rounded where it is produced)
-    return _q(F.conv2d(x, _qw(p[name + ".weight"], q), p.get(name + ".bias"), stride=stride, padding=pad, dilation=dil), q)
+    w = p[name + ".weight"]
+    if _FP8_BOOK is not None and fp8_eligible(w, x, stride, pad, dil):
+        return _q(_Fp8Conv.apply(x, w, name), True)
+    return _q(F.conv2d(x, _qw(w, q), p.get(name + ".bias"), stride=stride, padding=pad, dilation=dil), q)
 
 
 def _cbr(x, p, conv, bn, stride, pad, q, train, relu=True, dil=1):
@@ -234,8 +275,16 @@ def _cgs(x, p, conv, gn, q):
     return _q(F.silu(F.group_norm(y, GN_GROUPS, p[gn + ".weight"], p[gn + ".bias"], eps=BN_EPS)), q)
 
 
-def forward(p, x, arch="resnet50", train=False, emulate_bf16=False, return_acts=False):
-    """x f32 [B,3,S,S] raw 0..255 (S % 32 == 0) -> logits f32 [B,NC,S,S]"""
+def forward(p, x, arch="resnet50", train=False, emulate_bf16=False, return_acts=False, emulate_fp8=None):
+    """x f32 [B,3,S,S] raw 0..255 (S % 32 == 0) -> logits f32 [B,NC,S,S].  emulate_fp8: an oracle.fp8_emulation.ScaleBook - the bf16
+    emulation with the qualifying 3x3 convolutions in fp8 (precision "fp8" of cvcs_amd; the caller ends the book's step)"""
+    global _FP8_BOOK
+    if emulate_fp8 is not None:
+        prev, _FP8_BOOK = _FP8_BOOK, emulate_fp8
+        try:
+            return forward(p, x, arch, train, True, return_acts, None)
+        finally:
+            _FP8_BOOK = prev
     q = emulate_bf16
     feats = encoder_features(p, x, arch, train, q)
     skips = [feats[3], feats[2], feats[1], feats[0], None]
@@ -298,7 +347,11 @@ class OracleTrainer:
     """forward -> loss -> zero_grad -> backward -> opt.step (S/train.py:121-126) on the ResNet-UNet definition above"""
 
     def __init__(self, arch, num_classes, opt="SGD2", epochs=20, ignore_index=-100, weight=None, seed=0, params=None,
-                 emulate_bf16=False, decoder_norm="bn_relu"):
+                 emulate_bf16=False, decoder_norm="bn_relu", emulate_fp8=False):
+        self.book = None
+        if emulate_fp8:
+            from oracle import fp8_emulation as F8
+            self.book, emulate_bf16 = F8.ScaleBook(), True
         self.arch = arch
         self.p = params if params is not None else init_params(arch, num_classes, seed, decoder_norm=decoder_norm)
         self.trainable = [k for k in self.p if not is_buffer(k)]
@@ -314,9 +367,16 @@ class OracleTrainer:
         return U.polynomial_lr(self.cfg["lr"], self.epoch, self.cfg["total_iters"], self.cfg["power"])
 
     def step(self, x_u8, target_u8):
-        logits = forward(self.p, x_u8.to(torch.float32), self.arch, train=True, emulate_bf16=self.emulate_bf16)
+        global _FP8_BOOK
+        logits = forward(self.p, x_u8.to(torch.float32), self.arch, train=True, emulate_bf16=self.emulate_bf16, emulate_fp8=self.book)
         loss = U.cross_entropy(logits, target_u8.long(), self.weight, self.ignore_index)
-        grads = torch.autograd.grad(loss, [self.p[k] for k in self.trainable])
+        prev, _FP8_BOOK = _FP8_BOOK, self.book       # (the data gradients of the fp8 layers quantise dy with the same book)
+        try:
+            grads = torch.autograd.grad(loss, [self.p[k] for k in self.trainable])
+        finally:
+            _FP8_BOOK = prev
+        if self.book is not None:
+            self.book.end_step()
         self.nstep += 1
         lr = self.lr()
         with torch.no_grad():
