@@ -32,9 +32,10 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.cvcs_abi_version() == _lib.ABI_VERSION
     import ctypes as C
     from cvcs_amd import _lib
+    assert lib.cvcs_abi_version() == _lib.ABI_VERSION and lib.cvcs_sizeof_conv8_desc() == C.sizeof(_lib.Conv8Desc)
+    assert lib.cvcs_conv3x3_fp8(None, None) == -1 and b"null descriptor" in lib.cvcs_last_error()
     assert lib.cvcs_sizeof_conv_desc() == C.sizeof(_lib.ConvDesc) and lib.cvcs_sizeof_wgrad_desc() == C.sizeof(_lib.WgradDesc)
     # argument validation happens on the host, before any HIP call: usable without a GPU
     assert lib.cvcs_conv2d(None, None) == -1
