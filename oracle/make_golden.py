@@ -179,6 +179,10 @@ if __name__ == "__main__":
         # above average 8, and torch-CPU f32 is itself percent-level away from float64 on them
         nets = import_nets()
         nets_golden(nets, "Unetv2", nets.Urnetv2, 5, 4, 128, "SGD2", 0, False, "unetv2_sgd2_4x128")
+        # round 3: the other two configurations of the small fixtures (Adam + weighted CE without ignore_index; the bilinear-upsampling
+        # Urnet with weighted CE) at the same well-conditioned size, so that the loose 2 x 32 x 32 bounds can go
+        nets_golden(nets, "Unetv2", nets.Urnetv2, 5, 4, 128, "ADAM1", -100, True, "unetv2_adam1_wcel_4x128")
+        nets_golden(nets, "Unet", nets.Urnet, 5, 4, 128, "SGD2", 0, True, "unet_sgd2_wcel_4x128")
         sys.exit(0)
     blocks_golden()
     converter_golden()

@@ -47,8 +47,37 @@ def test_state_dict_keys_match_reference(golden_dir):
     ("unetv2_adam1_wcel", "Unetv2", "ADAM1", -100, 4),
     ("unet_sgd2_wcel", "Unet", "SGD2", 0, 20),
 ])
-def test_fp32_path_replays_reference_golden(golden_dir, tag, variant, opt, ignore, epochs):
-    """three training steps + eval forward of the reference (fixtures from its own Python) on the HIP fp32 path."""
+def test_fp32_path_replays_reference_golden_first_step(golden_dir, tag, variant, opt, ignore, epochs):
+    """The 2 x 32 x 32 fixtures of round 1 (the reference's own Python): their FIRST training step is a pure function of the inputs and is
+    held to 1e-3 on the logits and 1e-5 on the loss.  Everything later on these tiny tiles (deepest BatchNorm over 8 values) inherits the
+    reference's own f32 noise - torch-CPU f32 is percent-level away from its float64 run there - so the loose later-step / gradient /
+    eval bounds they carried in rounds 1-2 are gone: the 4 x 128 x 128 fixtures below cover those parts with tight bounds."""
+    g = np.load(os.path.join(golden_dir, f"nets_{tag}.npz"))
+    NC = int(g["NC"])
+    net = _build(variant, NC, "fp32", seed=int(g["seed"]))
+    w = torch.tensor(g["class_weight"]).to(DEV) if "class_weight" in g.files else None
+    crit = utils.CrossEntropyLoss(weight=w, ignore_index=ignore)
+    img, lab = torch.tensor(g["img"]).to(DEV), torch.tensor(g["lab"]).to(DEV)
+    net.train()
+    pred = net(img.type(torch.float32), None)
+    loss = crit(pred, lab.type(torch.long))
+    ref = g["logits_train0"]
+    err = np.abs(pred.detach().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+    assert err < 1e-3, f"train logits rel err {err:.2e}"
+    assert abs(loss.item() - g["losses"][0]) < 1e-5 * abs(g["losses"][0])
+
+
+@pytest.mark.parametrize("tag,variant,opt,ignore,epochs", [
+    ("unetv2_sgd2_4x128", "Unetv2", "SGD2", 0, 20),
+    ("unetv2_adam1_wcel_4x128", "Unetv2", "ADAM1", -100, 4),
+    ("unet_sgd2_wcel_4x128", "Unet", "SGD2", 0, 20),
+])
+def test_fp32_path_replays_the_large_reference_golden(golden_dir, tag, variant, opt, ignore, epochs):
+    """the reference's own Python (torch-CPU f32) on 4 x 128 x 128 tiles - every BatchNorm averages >= 256 values - replayed on the HIP
+    f32 path: three train steps + eval, for the three configurations of the fixtures (SGD2 / plain CE with ignore_index 0; ADAM1 / weighted
+    CE; the bilinear-upsampling Urnet / weighted CE).  Measured on the MI355X for the first (round 2): train logits 3.7e-5, losses exact /
+    8e-6 / 1.5e-4, gradient norms 2.3e-3, parameters after three steps 4.8e-5, eval logits 4.6e-3 of max|logit|, 151 of 65 536 eval labels
+    differ - each on a pixel whose reference top-2 margin is inside the logit error."""
     g = np.load(os.path.join(golden_dir, f"nets_{tag}.npz"))
     NC = int(g["NC"])
     net = _build(variant, NC, "fp32", seed=int(g["seed"]))
@@ -56,64 +85,11 @@ def test_fp32_path_replays_reference_golden(golden_dir, tag, variant, opt, ignor
     crit = utils.CrossEntropyLoss(weight=w, ignore_index=ignore)
     optim, sched = utils.load_optimizer({"opt": opt, "epochs": epochs}, net)
     img, lab = torch.tensor(g["img"]).to(DEV), torch.tensor(g["lab"]).to(DEV)
+    adam = opt == "ADAM1"
     net.train()
-    for step in range(3):
-        pred = net(img.type(torch.float32), None)
-        loss = crit(pred, lab.type(torch.long))
-        lv = loss.item()
-        optim.zero_grad()
-        loss.backward()
-        if step == 0:
-            ref = g["logits_train0"]
-            err = np.abs(pred.detach().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
-            assert err < 1e-3, f"train logits rel err {err:.2e}"
-            for k, p in net.named_parameters():
-                s = g[f"grad0.sum.{k}"]
-                if k.startswith("encode") and k.endswith(".layer.0.bias"):
-                    continue  # exactly-zero true gradient (bias in front of a train-mode BN): rounding noise only
-                # the golden gradients are torch-CPU fp32: against an fp64 run they carry ~1-5e-2 relative error
-                # themselves (scripts/grad_noise_probe.py; the HIP path is at ~2e-5).  Hence the loose bound
-                # here and the tight fp64 comparison in test_fp32_gradients_vs_f64_oracle.
-                gn = p.grad.double().norm().item()
-                assert abs(gn - s[1]) <= 3e-2 * s[1] + 1e-6, f"{k}: |grad| {gn} vs {s[1]}"
-                np.testing.assert_allclose(p.grad.reshape(-1)[:64].cpu().numpy(), g[f"grad0.head.{k}"], rtol=0,
-                                           atol=0.15 * s[2] + 1e-7, err_msg=k)
-        optim.step()
-        # step 0 is a pure function of the inputs; later steps inherit the reference's own fp32 gradient noise
-        # (torch-CPU fp32 is ~1e-2 from an fp64 run on this tiny 2x32x32 fixture, scripts/train_noise_probe.py)
-        ltol = 1e-5 if step == 0 else 2e-2
-        assert abs(lv - g["losses"][step]) < ltol * abs(g["losses"][step]), (step, lv, g["losses"][step])
-        if step == 1:
-            sched.step()
-    net.eval()
-    with torch.no_grad():
-        ev = net(img.type(torch.float32), None)
-    ref = g["logits_eval"]
-    scale = max(1.0, np.abs(ref).max())
-    err = np.abs(ev.cpu().numpy() - ref).max() / scale
-    # eval mode after only 3 running-stat updates is ill-conditioned (running_var still ~0.73): against fp64 the
-    # reference's fp32 run itself is off by 8e-2 (SGD2) / 5e-1 (ADAM1) here, the HIP path by 2e-2 / 2e-1.
-    if opt != "ADAM1":
-        assert err < 0.15, f"eval logits rel err after 3 steps {err:.2e}"
-        lab_hip = torch.argmax(ev, 1).cpu().numpy()
-        top2 = np.sort(ref, axis=1)[:, -2:]
-        decided = (top2[:, 1] - top2[:, 0]) > 4 * err * scale  # pixels whose reference margin exceeds the logit error
-        assert (lab_hip[decided] == g["labels_eval"][decided]).all()
-
-
-def test_fp32_path_replays_the_large_reference_golden(golden_dir):
-    """the reference's own Python (torch-CPU f32) on 4 x 128 x 128 tiles - every BatchNorm averages >= 256 values, unlike the 2 x 32 x 32
-    fixtures above whose f32 noise forces their loose bounds - replayed on the HIP f32 path: three train steps + eval.  Measured on the
-    MI355X: train logits 3.7e-5, losses exact / 8e-6 / 1.5e-4, gradient norms 2.3e-3, parameters after three steps 4.8e-5, eval logits
-    4.6e-3 of max|logit|, 151 of 65 536 eval labels differ - each on a pixel whose reference top-2 margin is inside the logit error."""
-    g = np.load(os.path.join(golden_dir, "nets_unetv2_sgd2_4x128.npz"))
-    NC = int(g["NC"])
-    net = _build("Unetv2", NC, "fp32", seed=int(g["seed"]))
-    crit = utils.CrossEntropyLoss(ignore_index=0)
-    optim, sched = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
-    img, lab = torch.tensor(g["img"]).to(DEV), torch.tensor(g["lab"]).to(DEV)
-    net.train()
-    for step, ltol in enumerate((1e-6, 1e-4, 1e-3)):
+    # Adam turns the rounding noise of exactly-zero gradients (conv biases in front of a train-mode BatchNorm) into +-lr steps: its
+    # later losses follow the reference to 1e-2 instead of 1e-3 (torch itself does not reproduce them across thread counts)
+    for step, ltol in enumerate((1e-6, 1e-4 if not adam else 2e-3, 1e-3 if not adam else 1e-2)):
         pred = net(img.type(torch.float32), None)
         loss = crit(pred, lab.type(torch.long))
         lv = loss.item()
@@ -134,14 +110,19 @@ def test_fp32_path_replays_the_large_reference_golden(golden_dir):
             sched.step()
     for k, v in net.state_dict().items():
         if v.dtype.is_floating_point:
+            if adam and k.startswith("encode") and k.endswith(".layer.0.bias"):
+                continue
             s = g[f"after.sum.{k}"]
-            assert abs(v.double().norm().item() - s[1]) <= 2e-4 * s[1] + 1e-7, k
+            assert abs(v.double().norm().item() - s[1]) <= (2e-4 if not adam else 2e-3) * s[1] + 1e-7, k
     net.eval()
     with torch.no_grad():
         ev = net(img.type(torch.float32), None).cpu().numpy()
     ref = g["logits_eval"]
     scale = max(1.0, np.abs(ref).max())
     err = np.abs(ev - ref).max()
+    if adam:    # eval-mode logits of 1e5 after three Adam steps, dominated by Adam's +-lr steps on zero-gradient biases (tests/test_oracle_golden.py)
+        assert err <= 1e-1 * scale
+        return
     assert err <= 1e-2 * scale
     bad = ev.argmax(1) != g["labels_eval"]
     top2 = np.sort(ref, axis=1)[:, -2:]
