@@ -88,6 +88,8 @@ SIGNATURES = {
     "cvcs_conv3x3_fp8": (_i, [C.POINTER(Conv8Desc), _vp]),
     "cvcs_quantize_fp8": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i, _vp]),
     "cvcs_fp8_update_scales": (_i, [_vp, _i, _f, _vp]),
+    "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),
+    "cvcs_counter_add": (_i, [_vp, C.c_uint64, _vp]),
     "cvcs_bn_act_q8": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]),
     "cvcs_bn_bwd_apply_q8": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i,
                                   _i, _vp]),

@@ -611,6 +611,40 @@ extern "C" int cvcs_image_broadcast(const void* v, int64_t v_ld, int B, int HW, 
   return CVCS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ dropout (counter-based mask)
+// nn.Dropout(p) of torchvision's ASPP (after the 1x1 projection; reached through S/nets.py:242-246 in train mode): out = keep ? x / (1 - p) : 0
+// with keep decided by a counter-based hash of (seed, step, logical element index) - no generator state, so the mask is replayable on the
+// host (tests) and identical in forward and backward (the backward is the same call on the gradient).  state = {seed, step} on the device:
+// a recorded launch plan replays with fixed arguments, the step advances through cvcs_counter_add.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long step, unsigned long long idx, unsigned thr24) {
+  unsigned long long z = (seed ^ (step * 0xD6E8FEB86659FD93ull)) + idx * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 40) < thr24;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const char* x, int64_t x_ld, int64_t M, int C, char* out, int64_t out_ld,
+                                                      const unsigned long long* __restrict__ state, unsigned thr24, float inv_keep) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  const unsigned long long seed = state[0], step = state[1];
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < M * CC; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;
+    float f[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (pix * x_ld) * ES + cc * 16), f);
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+      f[k] = dropout_keep(seed, step, (unsigned long long)pix * C + cc * V + k, thr24) ? f[k] * inv_keep : 0.f;
+    *reinterpret_cast<uint4*>(out + (pix * out_ld) * ES + cc * 16) = Elem<T>::pack(f);
+  }
+}
+
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
+
 static int lin_args_ok(const char* fn, int C, int NC, int dtype) {
   CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
   CVCS_CHECK_ARG(C > 0 && C % 64 == 0 && C <= 1024, "%s: C=%d must be a multiple of 64, at most 1024", fn, C);
@@ -686,5 +720,32 @@ extern "C" int cvcs_linear_head_bwd(const void* x, int64_t x_ld, const float* dl
   if (dtype == CVCS_F32) LAUNCH_LINB(float); else LAUNCH_LINB(bf16_t);
 #undef LAUNCH_LINB
   CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_dropout(const void* x, int64_t x_ld, int64_t M, int C, void* out, int64_t out_ld, const uint64_t* state, float p,
+                            int dtype, void* stream) {
+  const char* fn = "cvcs_dropout";
+  CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2;
+  CVCS_CHECK_ARG(M > 0 && C > 0 && C % (16 / es) == 0 && state && p >= 0.f && p < 1.f, "%s: bad argument", fn);
+  int rc;
+  if ((rc = dl_check_view(fn, x, x_ld, C, es)) || (rc = dl_check_view(fn, out, out_ld, C, es))) return rc;
+  const float keep = 1.f - p;
+  const unsigned thr24 = (unsigned)(keep * 16777216.0f);
+  const dim3 grid(dl_grid(M * (C / (16 / es))));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32)
+    hipLaunchKernelGGL((dropout_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, M, C, (char*)out, out_ld, (const unsigned long long*)state, thr24, 1.f / keep);
+  else
+    hipLaunchKernelGGL((dropout_kernel<bf16_t>), grid, dim3(256), 0, st, (const char*)x, x_ld, M, C, (char*)out, out_ld, (const unsigned long long*)state, thr24, 1.f / keep);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_counter_add(uint64_t* counter, uint64_t inc, void* stream) {
+  CVCS_CHECK_ARG(counter != nullptr, "cvcs_counter_add: null counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter, (unsigned long long)inc);
+  CVCS_CHECK_LAUNCH("cvcs_counter_add");
   return CVCS_OK;
 }

@@ -25,9 +25,13 @@ LOW_LEVEL_CHANNELS = 64
 
 
 class DeepLabEngine(ResNetUNetEngine):
-    def __init__(self, arch, num_classes, dtype, device, output_stride=16, plus=True):
+    def __init__(self, arch, num_classes, dtype, device, output_stride=16, plus=True, aspp_dropout=0.0, dropout_seed=0):
         super().__init__(arch, num_classes, dtype, device)
-        assert output_stride in (8, 16)
+        assert output_stride in (8, 16) and 0.0 <= aspp_dropout < 1.0
+        # nn.Dropout(p) behind the ASPP projection in train mode (torchvision's ASPP has p = 0.5: the reference's `Resnet101` trains with it,
+        # S/nets.py:242-246): a counter-based mask, state = [seed, step] on the device (ops.dropout); the step advances once per backward
+        self.aspp_dropout = float(aspp_dropout)
+        self.drop_state = torch.tensor([dropout_seed, 0], dtype=torch.int64, device=self.dev)
         self.os, self.plus = output_stride, plus
         self.rates = (6, 12, 18) if output_stride == 16 else (12, 24, 36)
         self.head_name = "classifier"
@@ -55,9 +59,14 @@ class DeepLabEngine(ResNetUNetEngine):
         ops.image_broadcast(pa.v, br[4].v, 1.0)
         a = Act(ops.view(self._act("aspp.out", B, h5, h5, 256)))
         uproj = self._unit(ops.view(cat), "aspp.project.0", "aspp.project.1", 1, 1, 0, train, a.v)
+        drop = train and self.aspp_dropout > 0.0
+        if drop:      # in place: the projection's own backward reads its conv output, not `a`; every consumer of `a` sees the dropped tensor
+            ops.dropout(a.v, a.v, self.drop_state, self.aspp_dropout)
         if train:
             def aspp_bwd():
                 assert len(a.grads) == 1
+                if drop:
+                    ops.dropout(a.grads[0][0], a.grads[0][0], self.drop_state, self.aspp_dropout)   # the same mask on the gradient
                 dy = self._unit_bwd(uproj, a.grads[0][0], 0)
                 gcat, _ = self._dgrad(uproj, dy, "aspp.g_cat")
                 # image-pooling branch: broadcast^T = per-image sum; conv + BN backward on [B,1,1,256]; mean^T = broadcast / HW
@@ -168,4 +177,6 @@ class DeepLabEngine(ResNetUNetEngine):
             h.grads = [(gh, False)]
             for fn in reversed(self._tape):
                 fn()
+            if self.aspp_dropout > 0.0:
+                ops.counter_add(self.drop_state, 1)      # the next step draws a new mask
         self._run("bwd", run_tape)

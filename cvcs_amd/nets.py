@@ -372,20 +372,38 @@ class DeepLabV3Plus(_HipUNet):
     of at least 2 tiles (the image-pooling branch normalises a 1x1 map over the batch, as in torchvision)."""
     arch, output_stride, plus = "resnet50", 16, True
     variant = "DeepLab"
+    default_aspp_dropout = 0.0     # (BASELINE names the architecture only; config key `aspp_dropout` switches it on)
+
+    def __init__(self, num_classes: int, precision: str = "bf16", aspp_dropout=None, dropout_seed: int = 0):
+        """aspp_dropout: p of the nn.Dropout behind the ASPP projection in train mode (None: the class default - 0.5 for the reference's
+        torchvision DeepLabV3 wrappers, as torchvision's DeepLabHead has it; 0 for DeepLabV3+).  The mask is counter-based:
+        (dropout_seed, step, element) -> keep, replayable on the host (ops.dropout_mask_host)."""
+        self.aspp_dropout = self.default_aspp_dropout if aspp_dropout is None else float(aspp_dropout)
+        self.dropout_seed = int(dropout_seed)
+        super().__init__(num_classes, precision)
 
     def _build_spec(self):
         return deeplab_param_spec(self.arch, self.num_classes, self.plus)
 
     def _build_engine(self, dev):
-        return DeepLabEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, self.output_stride, self.plus)
+        return DeepLabEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, self.output_stride, self.plus,
+                             aspp_dropout=self.aspp_dropout, dropout_seed=self.dropout_seed)
 
 
 class _TorchvisionDeepLabKeys:
     """`state_dict()` / `load_state_dict()` in the key names of the reference's wrapper modules (S/nets.py:234-275: `self.model =
     torchvision deeplabv3_resnet*`, so a reference checkpoint reads `model.backbone.layer3.0.conv1.weight`,
-    `model.classifier.0.convs.1.0.weight`, `model.classifier.4.bias` ...): checkpoints written by the reference load here and the
-    ones written here load in the reference.  torchvision's auxiliary FCN head (`model.aux_classifier.*`, present when the reference
-    starts from the COCO weights; its forward never uses it, S/nets.py:248-250) is accepted and dropped on load."""
+    `model.classifier.0.convs.1.0.weight`, `model.classifier.4.bias` ...).
+    Reference -> here: loads as is (`module.` prefix accepted).  torchvision's auxiliary FCN head (`model.aux_classifier.*`, present when
+    the reference starts from the COCO weights; its forward never uses it, S/nets.py:248-250) takes no part in this network: its
+    tensors are KEPT as loaded and written back by `state_dict()`, so a reference checkpoint survives a round trip through this class
+    key for key and loads back into the reference's module strictly.
+    Here -> reference, for a network that never saw a reference checkpoint: the aux head's keys are absent, so the reference's
+    `custom_load` (a strict `load_state_dict`, S/nets.py:252-257) needs `strict=False` for them (or `aux_loss=None` at construction);
+    the torch-format optimiser state covers this network's parameters only (the reference's optimiser also holds the aux head's), so the
+    reference starts its optimiser fresh.  Train mode applies the nn.Dropout(0.5) torchvision's ASPP ends with (see `aspp_dropout`)."""
+    default_aspp_dropout = 0.5
+    _aux_state = None
     _KEYS = (("encoder.", "model.backbone."), ("aspp.convs.", "model.classifier.0.convs."), ("aspp.project.", "model.classifier.0.project."),
              ("head.0.", "model.classifier.1."), ("head.1.", "model.classifier.2."), ("classifier.", "model.classifier.4."))
 
@@ -408,11 +426,16 @@ class _TorchvisionDeepLabKeys:
     def state_dict(self, *args, **kwargs):
         sd = super().state_dict(*args, **kwargs)
         out = type(sd)((self._to_reference(k), v) for k, v in sd.items())
+        if self._aux_state:
+            out.update(self._aux_state)
         if hasattr(sd, "_metadata"):
             out._metadata = sd._metadata
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        aux = OrderedDict((k[len("module."):] if k.startswith("module.") else k, v.detach().clone()) for k, v in state_dict.items()
+                          if ".aux_classifier." in k)
+        self._aux_state = aux or None
         sd = OrderedDict((self._from_reference(k), v) for k, v in state_dict.items() if ".aux_classifier." not in k)
         return super().load_state_dict(sd, strict=strict, **kwargs)
 

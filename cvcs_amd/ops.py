@@ -706,6 +706,30 @@ def image_broadcast(v: View, out: View, scale: float):
           "cvcs_image_broadcast")
 
 
+def dropout(x: View, out: View, state: torch.Tensor, p: float):
+    """out = x * mask / (1 - p), mask from the counter-based hash of (state = [seed, step] int64 on the device, element index); the same call
+    on a gradient is the backward"""
+    assert state.dtype == torch.int64 and state.numel() == 2 and (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+    check(_lib.lib().cvcs_dropout(x.ptr, x.ld, x.B * x.H * x.W, x.C, out.ptr, out.ld, state.data_ptr(), float(p), x.code, _stream()), "cvcs_dropout")
+
+
+def counter_add(state: torch.Tensor, index: int, inc: int = 1):
+    check(_lib.lib().cvcs_counter_add(state.data_ptr() + 8 * index, inc, _stream()), "cvcs_counter_add")
+
+
+def dropout_mask_host(seed: int, step: int, n: int, p: float):
+    """the mask cvcs_dropout applies to elements 0..n-1, replayed on the host (numpy uint64 arithmetic wraps like the device's)"""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        z = (np.uint64(seed) ^ (np.uint64(step) * np.uint64(0xD6E8FEB86659FD93))) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        thr = np.uint64(int((np.float32(1.0) - np.float32(p)) * np.float32(16777216.0)))
+        return torch.from_numpy(((z >> np.uint64(40)) < thr))
+
+
 def linear_head_fwd(x: View, w, bias, logits=None, labels=None):
     """1x1 classifier on any channel count: NCHW f32 logits, or (labels given) the fused argmax"""
     NC = w.shape[0]

@@ -163,8 +163,16 @@ class ResNetUNetEngine:
         self.gn = {}                     # GroupNorm state per layer (allocated per batch size at plan time)
 
     def enable_sync_bn(self, sync):
-        raise NotImplementedError("exact (SyncBN) data-parallel mode is built for the reference's U-Nets only so far; "
-                                  "ResNet-UNets train with per-rank BatchNorm statistics (torch-DDP semantics)")
+        """exact data-parallel mode for every network on this engine (ResNet-UNets, DeepLab, Swin + UPerNet):
+        `sync` has .world and .all_reduce(tensor) (sum over ranks, in place, ordered on the current stream).  Each BatchNorm's batch moments
+        (forward) and its two backward sums are summed over ranks, so N ranks x B tiles normalise like one process on N*B tiles.  A
+        BatchNorm's statistics depend on the previous layer's normalised output, so these are one small collective per BatchNorm and
+        direction (<= 3 x 2048 doubles), issued from host callbacks recorded INSIDE the launch plans at the point of use."""
+        self.sync_bn = sync
+        cmax = max(p.numel() for n, p in self.P.items() if p.dim() == 1)
+        self._sync_mom = torch.empty(3 * cmax, dtype=torch.float64, device=self.dev)
+        self._sync_sums = torch.empty(2 * cmax, dtype=torch.float32, device=self.dev)
+        self._rec = {}            # plans recorded without the exchanges are stale
 
     def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
@@ -280,9 +288,17 @@ class ResNetUNetEngine:
         else:
             ops.conv2d(x, wf, None, y, kh, kw, stride, pad, dil, stats=stats, virt=virt or None)
         need = ops.bn_finalize_workspace_floats(rows, cout)
-        ops.bn_finalize(stats, rows, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
-                        self.Bf[bn + ".running_var"], True, st.scale, st.shift, st.mean, st.invstd,
-                        workspace=self._scratch("bn_ws", max(need, 4)))
+        if self.sync_bn is None:
+            ops.bn_finalize(stats, rows, M, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
+                            self.Bf[bn + ".running_var"], True, st.scale, st.shift, st.mean, st.invstd,
+                            workspace=self._scratch("bn_ws", max(need, 4)))
+        else:
+            # batch statistics over the tiles of ALL ranks: this rank's (n, sum, sum of squares) per channel in f64, one sum-all-reduce
+            mom = self._sync_mom[:3 * cout]
+            ops.bn_moments(stats, rows, cout, mom, workspace=self._scratch("bn_ws", max(need, 4)))
+            self._host(lambda mom=mom: self.sync_bn.all_reduce(mom))
+            ops.bn_finalize_moments(mom, cout, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"],
+                                    self.Bf[bn + ".running_var"], st.scale, st.shift, st.mean, st.invstd)
         if act_out is not None:
             ops.bn_act(y, st.scale, st.shift, relu, act_out, q8=self._q8_of(act_out))
         u = Unit(x, y, conv, bn, k, stride, pad, virt, dil)
@@ -423,6 +439,18 @@ class ResNetUNetEngine:
             ops.bn_bwd_reduce(y, g, None, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
             ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
                                 st.ca, st.cb)
+        if self.sync_bn is not None:
+            # dgamma / dbeta stay this rank's sums (the gradient all-reduce adds them up); the two coefficients of the apply pass are
+            # means over every rank's pixels
+            sums = self._sync_sums[:2 * C_]
+            gb, gw = self.G[u.bn + ".bias"], self.G[u.bn + ".weight"]
+
+            def exchange(sums=sums, gb=gb, gw=gw, n=C_):
+                sums[:n].copy_(gb)
+                sums[n:].copy_(gw)
+                self.sync_bn.all_reduce(sums)
+            self._host(exchange)
+            ops.bn_bwd_coeffs(sums, M * self.sync_bn.world, C_, st.ca, st.cb)
         # two dy buffers in turn: the weight gradient of unit k (side lane) may still read its dy while unit k + 1 writes the other one
         self._dy_toggle ^= 1
         dyname = u.conv + ".dy" if self.keep_all else ("dy" if not self.overlap_wgrad else f"dy{self._dy_toggle}")
@@ -490,6 +518,13 @@ class ResNetUNetEngine:
         if self.keep_all:
             self.bwd_units[u.conv]["gx"] = gx
         return gx, False
+
+    def _host(self, fn):
+        """run fn() now and at this point of every replay of the plan being recorded (eager pass outside a recording: just now)"""
+        if _lib._recording is not None:
+            _lib._recording.host(fn)
+        else:
+            fn()
 
     def _ready(self, name):
         off = self._goff[name]   # (the hook is looked up at replay time: a data-parallel wrapper may be attached later)

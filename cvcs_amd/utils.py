@@ -65,11 +65,11 @@ def load_network(config, device):
         return nets.SwinBUperNet(classes, precision).to(device)   # configs/train/README.txt:45
     elif netname == "DeepLabV3Plus":
         # BASELINE.json configs[2]: DeepLabV3+ (ResNet-50, ASPP 6/12/18) - a new factory name behind the same seam
-        return nets.DeepLabV3Plus(classes, precision).to(device)
+        return nets.DeepLabV3Plus(classes, precision, config.get("aspp_dropout"), config.get("seed", 0)).to(device)
     elif netname == "Resnet101":
         # S/utils.py:180-181 -> nets.DeepLabv3Resnet101: DeepLabV3 on a dilated ResNet-101, on the HIP kernels (random-init:
         # the reference's COCO weights come from a network fetch)
-        return nets.DeepLabv3Resnet101(classes, precision).to(device)
+        return nets.DeepLabv3Resnet101(classes, precision, config.get("aspp_dropout"), config.get("seed", 0)).to(device)
     elif netname in ("MobileNet", "SegformerMod"):
         raise NotImplementedError(f"network '{netname}' wraps third-party pretrained models in the reference "
                                   "(S/nets.py:234-356) and is outside the MI355X hot path of this build")

@@ -483,6 +483,17 @@ int cvcs_bn_add_act_q8(const void* y1, int64_t y1_ld, const float* s1, const flo
                        const float* b2, int64_t M, int C, void* out, int64_t out_ld, void* q8, int64_t q8_ld, int fmt, float* slot,
                        int take_amax, int dtype, void* stream);
 
+/* ---- ABI 10: dropout with a counter-based mask --------------------------------------------------------------------------------
+ * replaces: the nn.Dropout(0.5) of torchvision's DeepLabHead / ASPP (after the 1x1 projection) that the reference's `Resnet101` trains with
+ * (S/nets.py:242-246 builds torchvision.models.segmentation.deeplabv3_resnet101; net.train() at S/train.py:113 switches it on).
+ * out[i] = keep(i) ? x[i] / (1 - p) : 0, keep(i) = (splitmix64(seed ^ step * 0xD6E8FEB86659FD93 + i * 0x9E3779B97F4A7C15) >> 40) < (1 - p) * 2^24,
+ * i = pixel * C + channel; state = {seed, step} (two uint64 on the device).  The same call on the gradient is the backward; the mask is
+ * a pure function of (seed, step, i), so a test replays it on the host.  cvcs_counter_add advances `step` (a recorded plan replays with
+ * fixed arguments).  In place (out == x) is allowed.                                                                            */
+int cvcs_dropout(const void* x, int64_t x_ld, int64_t M, int C, void* out, int64_t out_ld, const uint64_t* state, float p, int dtype,
+                 void* stream);
+int cvcs_counter_add(uint64_t* counter, uint64_t inc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

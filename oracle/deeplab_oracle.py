@@ -9,8 +9,8 @@ weights, so no reference output can pin these models.  This file restates the PU
     `replace_stride_with_dilation` rule (output stride 16: last stage dilated; 8: last two);
   * ASPP (Chen et al. 2017, torchvision.models.segmentation.deeplabv3.ASPP): 1x1 branch, three 3x3 atrous branches (rates
     6/12/18 at OS 16; 12/24/36 at OS 8), image pooling branch (AdaptiveAvgPool2d(1) -> 1x1 conv -> BN -> ReLU -> bilinear
-    resize = broadcast), concat -> 1x1 projection -> BN -> ReLU.  The Dropout(0.5) after the projection is left out
-    (stochastic; it cannot be checked against anything and is irrelevant to throughput);
+    resize = broadcast), concat -> 1x1 projection -> BN -> ReLU -> Dropout(0.5) in train mode: `forward(..., aspp_keep=mask)`
+    takes the keep mask as an input (the HIP path's mask is a counter-based hash the tests replay on the host);
   * DeepLabV3 head (plus=False; torchvision DeepLabHead): ASPP -> 3x3 conv 256 -> BN -> ReLU -> 1x1 classifier -> bilinear
     resize (align_corners=False) to the input size;
   * DeepLabV3+ decoder (plus=True; Chen et al. 2018): 1x1 reduction of the stride-4 feature (64 channels here instead of the
@@ -90,8 +90,11 @@ def init_params(arch, num_classes, seed=0, plus=True):
 is_buffer = R.is_buffer
 
 
-def forward(p, x, arch="resnet50", train=False, output_stride=16, plus=True, emulate_bf16=False, return_acts=False):
-    """x f32 [B,3,S,S] raw 0..255 (S % 32 == 0) -> logits f32 [B,NC,S,S]"""
+def forward(p, x, arch="resnet50", train=False, output_stride=16, plus=True, emulate_bf16=False, return_acts=False, aspp_keep=None,
+            aspp_dropout=0.5):
+    """x f32 [B,3,S,S] raw 0..255 (S % 32 == 0) -> logits f32 [B,NC,S,S].  aspp_keep: bool [B,256,h,w] - the keep mask of the
+    nn.Dropout(aspp_dropout) torchvision's ASPP ends with (train mode); None: no dropout (eval mode, or the deterministic parity runs).
+    The mask itself is an INPUT here: the HIP path draws it from a counter-based hash that the tests replay on the host."""
     q = emulate_bf16
     feats = R.encoder_features(p, x, arch, train, q, output_stride)
     f5 = feats[4]
@@ -102,6 +105,8 @@ def forward(p, x, arch="resnet50", train=False, output_stride=16, plus=True, emu
     g = R._cbr(g, p, "aspp.convs.4.1", "aspp.convs.4.2", 1, 0, q, train)
     branches.append(g.expand(-1, -1, f5.shape[2], f5.shape[3]))        # bilinear resize of a 1x1 map = broadcast
     a = R._cbr(torch.cat(branches, dim=1), p, "aspp.project.0", "aspp.project.1", 1, 0, q, train)
+    if aspp_keep is not None:
+        a = R._q(a * aspp_keep.to(a.dtype) * (1.0 / (1.0 - aspp_dropout)), q)
     acts = {"features": feats, "aspp": a}
     if plus:
         low = R._cbr(feats[1], p, "low_level.0", "low_level.1", 1, 0, q, train)

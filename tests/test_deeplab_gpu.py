@@ -184,8 +184,8 @@ def test_sub_grid_layout_change_and_dilated_conv_as_plain_conv(dtype, H, W, a, b
 
 
 # ---------------------------------------------------------------------------------------------------- whole networks
-def _build(cls, arch, NC, precision, plus, seed=3):
-    net = cls(NC, precision)
+def _build(cls, arch, NC, precision, plus, seed=3, aspp_dropout=0.0):
+    net = cls(NC, precision, aspp_dropout=aspp_dropout)      # (0: the deterministic parity runs; the dropout has its own test below)
     missing, unexpected = net.load_state_dict(D.init_params(arch, NC, seed=seed, plus=plus), strict=False)
     assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
     return net.to(DEV)
@@ -364,3 +364,84 @@ def test_deeplab_trains_reproducibly():
         runs.append((losses, net.flat_parameters()[0].clone()))
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert runs[0][0][-1] < 0.7 * runs[0][0][0], runs[0][0]
+
+
+def test_aspp_dropout_mask_is_counter_based_and_the_train_step_matches_the_oracle_under_the_replayed_mask():
+    """The reference's `Resnet101` trains with torchvision's nn.Dropout(0.5) behind the ASPP projection (S/nets.py:242-246; S/train.py:113).
+    Here the mask is a counter-based hash of (seed, step, element): (1) the kernel against the host replay, bit for bit, forward = backward
+    mask, ~half kept; (2) two f32 train steps of DeepLabV3 (OS 8, the wrapper's key names) against the oracle given the REPLAYED masks of
+    steps 0 and 1: logits 1e-3, loss 1e-4, and the steps draw different masks; eval mode applies none."""
+    from cvcs_amd import ops
+    B, H, W, C = 2, 5, 7, 64
+    x = torch.randn(B, H, W, C, device=DEV)
+    state = torch.tensor([1234, 3], dtype=torch.int64, device=DEV)
+    out = torch.empty_like(x)
+    ops.dropout(ops.view(x), ops.view(out), state, 0.5)
+    keep = ops.dropout_mask_host(1234, 3, x.numel(), 0.5).view(B, H, W, C)
+    assert torch.equal(out.cpu(), torch.where(keep, x.cpu() * 2.0, torch.zeros(())))
+    assert 0.45 < keep.float().mean().item() < 0.55
+    ops.counter_add(state, 1)
+    torch.cuda.synchronize()
+    assert state.tolist() == [1234, 4]
+    # the network
+    NC, S, seed = 5, 64, 77
+    arch, os_ = "resnet50", 8
+    net = nets.DeepLabv3Resnet50(NC, "fp32", dropout_seed=seed)          # class default: p = 0.5
+    assert net.aspp_dropout == 0.5
+    net.load_state_dict({net._to_reference(k): v for k, v in D.init_params(arch, NC, seed=3, plus=False).items()}, strict=False)
+    net = net.to(DEV)
+    tr = D.OracleTrainer(arch, NC, "SGD2", ignore_index=0, seed=3, output_stride=os_, plus=False)
+    img, lab = O.synthetic_tiles(4, S, NC, seed=5, structured=True)
+    crit = utils.CrossEntropyLoss(ignore_index=0)
+    opt, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
+    net.train()
+    h5 = S // os_
+    masks = []
+    for step in range(2):
+        keep = ops.dropout_mask_host(seed, step, 4 * h5 * h5 * 256, 0.5).view(4, h5, h5, 256).permute(0, 3, 1, 2)
+        masks.append(keep)
+        logits = net(img.to(DEV), None)
+        loss = crit(logits, lab.to(DEV))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        # the oracle, same step, the replayed mask as an input
+        z = D.forward(tr.p, img.float(), arch, train=True, output_stride=os_, plus=False, aspp_keep=keep)
+        lo = O.cross_entropy(z, lab.long(), None, 0)
+        grads = torch.autograd.grad(lo, [tr.p[k] for k in tr.trainable])
+        scale = z.abs().max().item()
+        err = (logits.detach().cpu() - z.detach()).abs().max().item() / scale
+        assert err <= 1e-3 and abs(loss.item() - lo.item()) <= 1e-4 * max(1.0, abs(lo.item())), (step, err, loss.item(), lo.item())
+        tr.nstep += 1
+        with torch.no_grad():
+            for k, g in zip(tr.trainable, grads):
+                newp, buf = O.sgd_step(tr.p[k], g, tr.state.get(k), tr.lr(), tr.cfg["momentum"], tr.cfg["weight_decay"], k not in tr.state)
+                tr.state[k] = buf
+                tr.p[k].copy_(newp)
+    assert not torch.equal(masks[0], masks[1])
+    assert net._engine.drop_state.tolist() == [seed, 2]
+    net.eval()
+    with torch.no_grad():
+        ev = net(img.to(DEV), None).cpu()
+        want = D.forward({k: v.detach() for k, v in tr.p.items()}, img.float(), arch, train=False, output_stride=os_, plus=False)
+    assert (ev - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+
+
+def test_reference_checkpoint_with_the_aux_head_survives_a_round_trip(tmp_path):
+    """a checkpoint of the reference's `Resnet101` holds torchvision's auxiliary FCN head (`model.aux_classifier.{0,1,4}.*`, built with the
+    COCO weights; unused by its forward, S/nets.py:248-250): loading it here and saving again must give back EVERY key, so the reference's
+    strict `custom_load` (S/nets.py:252-257) takes the result"""
+    net = utils.load_network({"net": "Resnet101", "num_classes": 15, "precision": "bf16"}, DEV)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    aux = {"model.aux_classifier.0.weight": torch.randn(256, 1024, 3, 3), "model.aux_classifier.1.weight": torch.ones(256),
+           "model.aux_classifier.1.bias": torch.zeros(256), "model.aux_classifier.1.running_mean": torch.zeros(256),
+           "model.aux_classifier.1.running_var": torch.ones(256), "model.aux_classifier.1.num_batches_tracked": torch.tensor(0),
+           "model.aux_classifier.4.weight": torch.randn(21, 256, 1, 1), "model.aux_classifier.4.bias": torch.zeros(21)}
+    assert not any(k in sd for k in aux)              # a fresh network has no aux head (documented: strict=False on the reference side)
+    ref_ck = {"module." + k: v for k, v in {**sd, **aux}.items()}
+    other = utils.load_network({"net": "Resnet101", "num_classes": 15, "precision": "bf16"}, DEV)
+    other.custom_load({"model_state_dict": ref_ck})
+    back = other.state_dict()
+    assert set(back) == set(sd) | set(aux)
+    for k, v in aux.items():
+        assert torch.equal(back[k].cpu(), v), k
