@@ -240,7 +240,7 @@ def main():
 
     if rank == 0:
         peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
-        model = {"Resnet50Unet": "ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder 256/128/64/64/64, 1x1 head)",
+        model = {"Resnet50Unet": "ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder 256/128/64/32/16 - the common public widths -, 1x1 head)",
                  "Resnet18Unet": "ResNet18-UNet", "Resnet34Unet": "ResNet34-UNet",
                  "DeepLabV3Plus": "DeepLabV3+ (ResNet-50 v1.5 at output stride 16, ASPP rates 6/12/18, 64-channel low-level branch)",
                  "Resnet101": "DeepLabV3-ResNet101 (the reference's factory name Resnet101, S/nets.py:234-257; output stride 8, ASPP 12/24/36)",

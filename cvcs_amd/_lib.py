@@ -58,7 +58,7 @@ class Conv8Desc(C.Structure):
 class PackItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("Cin_pad", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("Cout_pad", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

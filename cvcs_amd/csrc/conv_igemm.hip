@@ -492,25 +492,30 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
   f32x4 bias0[NREP];
 #pragma unroll
   for (int j = 0; j < NREP; ++j)
-    bias0[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WNC + j * 16 + (lane >> 4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bias0[j] = (p.bias && n0 + wn * WNC + j * 16 + (lane >> 4) * 4 < p.Cout)
+                   ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WNC + j * 16 + (lane >> 4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   // ---- prologue: the weight tiles of step 0 go out FIRST (their addresses cost a few instructions), the halo pieces of
   // slice 0 one by one as their per-lane source offsets are computed (the address unit works while the VALU computes;
   // the prologue's issue phase was a sixth of a 64-channel tile's life), the weight tiles of step 1 last - those stay in
   // flight across the first barrier (the loop's counted waits only exempt operations YOUNGER than them).
   // weight pieces of this wave: piece g = wave + NW*j of a step = tap tt = g / (BN/16), rows (g % (BN/16))*16 ..
+  // (thin layers - Cout = 16 | 32 inside the 64-channel tile, the light U-Net decoder stages - read ZERO weights for the tile rows beyond
+  //  Cout: their accumulators stay 0 and neither their statistics nor their channels are written)
   const char* bsrc[BPW];
+  bool bok[BPW];
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
     const int g = wave + NW * j;
     const int tt = g / (BN / 16);
     const int row = (g - tt * (BN / 16)) * 16 + rr;
+    bok[j] = n0 + row < p.Cout;
     bsrc[j] = p.wt + ((int64_t)tt * wt_tap_stride + (int64_t)(n0 + row) * p.Cin) * ES + swz(row, pc) * 16;
   }
   auto dma_b = [&](int cs, int st, int slot) {
     const int64_t soff = ((int64_t)(st * TPS) * wt_tap_stride + (int64_t)cs * KG) * ES;   // wave-uniform
 #pragma unroll
     for (int j = 0; j < BPW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + soff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bok[j] ? bsrc[j] + soff : reinterpret_cast<const char*>(&g_zero16)),
                                        (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + (wave + NW * j) * 1024),
                                        16, 0, 0);
   };
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
       const int64_t soff = ((int64_t)(st * TPS) * wt_tap_stride + (int64_t)cs * KG) * ES;   // wave-uniform
 #pragma unroll
       for (int j = 0; j < BPW; ++j)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + soff),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bok[j] ? bsrc[j] + soff : reinterpret_cast<const char*>(&g_zero16)),
                                          (__attribute__((address_space(3))) void*)(sB + slot * B_BYTES + (wave + NW * j) * 1024),
                                          16, 0, 0);
     };
@@ -783,11 +788,11 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
       for (int j = 0; j < NREP; ++j) {
         const int nb = n0 + wn * WNC + j * 16 + fg * 4;
         float s1[4] = {1.f, 1.f, 1.f, 1.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {1.f, 1.f, 1.f, 1.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.pre_scale) {
+        if (p.pre_scale && nb < p.Cout) {
           const float4 a = *reinterpret_cast<const float4*>(p.pre_scale + nb), c = *reinterpret_cast<const float4*>(p.pre_shift + nb);
           s1[0] = a.x; s1[1] = a.y; s1[2] = a.z; s1[3] = a.w; t1[0] = c.x; t1[1] = c.y; t1[2] = c.z; t1[3] = c.w;
         }
-        if (p.post_scale) {
+        if (p.post_scale && nb < p.Cout) {
           const float4 a = *reinterpret_cast<const float4*>(p.post_scale + nb), c = *reinterpret_cast<const float4*>(p.post_shift + nb);
           s2[0] = a.x; s2[1] = a.y; s2[2] = a.z; s2[3] = a.w; t2[0] = c.x; t2[1] = c.y; t2[2] = c.z; t2[3] = c.w;
         }
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
             }
           q[r] = row_sum16(t);
         }
-        if (fr == 0) {
+        if (fr == 0 && n0 + wn * WNC + j * 16 + fg * 4 < p.Cout) {
           const int n = n0 + wn * WNC + j * 16 + fg * 4;
           *reinterpret_cast<float4*>(p.stat_sum + row * p.Cout + n) = make_float4(s[0], s[1], s[2], s[3]);
           *reinterpret_cast<float4*>(p.stat_m2 + row * p.Cout + n) = make_float4(q[0], q[1], q[2], q[3]);
@@ -900,11 +905,11 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
           float bound = 0.f;
           if constexpr (MODE == 2) {
             const int nb = n0 + wn * WNC + j * 16 + fg * 4;
-            if (p.pre_scale) {
+            if (p.pre_scale && nb < p.Cout) {
               const float4 a = *reinterpret_cast<const float4*>(p.pre_scale + nb), c = *reinterpret_cast<const float4*>(p.pre_shift + nb);
               s1[0] = a.x; s1[1] = a.y; s1[2] = a.z; s1[3] = a.w; t1[0] = c.x; t1[1] = c.y; t1[2] = c.z; t1[3] = c.w;
             }
-            if (p.post_scale) {
+            if (p.post_scale && nb < p.Cout) {
               const float4 a = *reinterpret_cast<const float4*>(p.post_scale + nb), c = *reinterpret_cast<const float4*>(p.post_shift + nb);
               s2[0] = a.x; s2[1] = a.y; s2[2] = a.z; s2[3] = a.w; t2[0] = c.x; t2[1] = c.y; t2[2] = c.z; t2[3] = c.w;
             }
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
           int nyt = p.H - ty0; nyt = nyt > 16 ? 16 : nyt;
           const int nvalid = nyt * nx;
           const int64_t row = blockIdx.x;
-          if (fg == q) {                                   // lane fr of group fr>>2 holds the diagonal entry of its channel
+          if (fg == q && n0 + wave * 16 + fr < p.Cout) {   // lane fr of group fr>>2 holds the diagonal entry of its channel
             const float sx = ssum[0];
             const float s2 = pp == 0 ? ssq[0] : (pp == 1 ? ssq[1] : (pp == 2 ? ssq[2] : ssq[3]));
             float m2 = s2 - sx * sx / (float)nvalid;
@@ -1000,13 +1005,14 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
       }
       const bool full = ty0 + 16 <= p.H && tx0 + 16 <= p.W;
-      if (full) {
+      const bool cok = n0 + c * (16 / ES) < p.Cout;      // thin layers: the chunks beyond Cout do not exist in `out`
+      if (full && n0 + BN <= p.Cout) {
 #pragma unroll
         for (int k = 0; k < ITERS; ++k) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
       } else {
 #pragma unroll
         for (int k = 0; k < ITERS; ++k)
-          if (y0 + k * RPI < p.H && x < p.W) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
+          if (cok && y0 + k * RPI < p.H && x < p.W) *reinterpret_cast<u32x4*>(dst + k * dstep) = v[k];
       }
       if constexpr (ES == 2) {
         if (p.bwd_y) {
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
         const int pr = id / CPR, c = id - pr * CPR;
         const int py = pr >> 3, px = pr & 7;
         const int oy = ((ty0 + h * PR) >> 1) + py, ox = (tx0 >> 1) + px;
-        if (oy >= HP || ox >= WP) continue;
+        if (oy >= HP || ox >= WP || n0 + c * (16 / ES) >= p.Cout) continue;
         constexpr int V = 16 / ES;
         float mx[V];
 #pragma unroll
@@ -1326,7 +1332,7 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)(a.Cout / BN));
+  dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)cdiv(a.Cout, BN));
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, WM, WN, TPS, PIPE>), grid, dim3(WM * WN * 64), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d(halo)");
   return CVCS_OK;
@@ -1359,8 +1365,9 @@ extern "C" int cvcs_probe_read(void* host, size_t bytes) { return (int)hipMemcpy
 #endif
 
 // 3x3 / stride 1 / pad 1 / dil 1 convolutions whose image is at least half a tile wide take the halo kernel
+static bool thin_cout(const cvcs_conv_desc* d) { return d->Cout < 64 && d->Cout % 16 == 0; }   // 16 | 32 | 48 output channels in one masked 64-channel tile
 static bool use_halo(const cvcs_conv_desc* d) {
-  return d->Cout % 64 == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
+  return (d->Cout % 64 == 0 || thin_cout(d)) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle && d->H >= 8 &&
          d->W >= 8;
 }
 // bf16 1x1/s1 and 2x2/s2 convolutions without padding (1x1 forward / data gradient of the residual blocks, the
@@ -1399,8 +1406,9 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->Cin > 0 && d->Cin % kg == 0, "cvcs_conv2d: Cin=%d must be a multiple of %d", d->Cin, kg);
   // (a multiple of 32 that is no multiple of 64 - the 96 / 288 widths of Swin-T's first stage - runs on the generic kernel,
   //  whose last column tile masks the channels beyond Cout)
-  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 32 == 0, "cvcs_conv2d: Cout=%d must be a multiple of 32", d->Cout);
-  const bool ragged_n = d->Cout % 64 != 0;
+  const bool thin = use_halo(d) && thin_cout(d) && !d->aniso && !d->in_row_pitch && !d->in_img_pitch;
+  CVCS_CHECK_ARG(d->Cout > 0 && (d->Cout % 32 == 0 || thin), "cvcs_conv2d: Cout=%d must be a multiple of 32 (16 for 3x3 / stride 1 / pad 1 layers below 64 channels)", d->Cout);
+  const bool ragged_n = d->Cout % 64 != 0 && !thin;
   CVCS_CHECK_ARG(!ragged_n || !d->pixel_shuffle, "cvcs_conv2d: pixel_shuffle needs Cout %% 64 == 0");
   CVCS_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "cvcs_conv2d: bad filter geometry");
   // output extent must match the filter geometry (every gathered pixel is range-checked in the kernel, but the
@@ -1451,7 +1459,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.bwd_y = (const char*)d->bwd_y; a.bwd_y_ld = d->bwd_y_ld; a.bwd_scale = d->bwd_scale; a.bwd_shift = d->bwd_shift;
   a.bwd_mean = d->bwd_mean; a.bwd_invstd = d->bwd_invstd; a.bwd_p0 = d->bwd_part_dz; a.bwd_p1 = d->bwd_part_dzx; a.bwd_mode = d->bwd_mode;
   if (d->bwd_y) {
-    CVCS_CHECK_ARG(use_halo(d) && d->dtype == CVCS_BF16, "cvcs_conv2d: the fused BatchNorm-backward reduce is built for bf16 3x3 / stride 1 / pad 1 launches");
+    CVCS_CHECK_ARG(use_halo(d) && d->dtype == CVCS_BF16 && !thin, "cvcs_conv2d: the fused BatchNorm-backward reduce is built for bf16 3x3 / stride 1 / pad 1 launches of at least 64 output channels");
     CVCS_CHECK_ARG(d->bwd_scale && d->bwd_shift && d->bwd_mean && d->bwd_invstd && d->bwd_part_dz && d->bwd_part_dzx,
                    "cvcs_conv2d: bwd_y needs its four per-channel vectors and both partial-sum buffers");
     CVCS_CHECK_ARG(d->bwd_mode == 0 || d->bwd_mode == 1, "cvcs_conv2d: bwd_mode");
@@ -1472,7 +1480,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     // a launch that carries the fused BatchNorm-backward reduce needs neighbours on its CU to hide the longer epilogue: up to
     // narrow_bwd output channels it takes the three-workgroup narrow tiles (two column tiles for 128 channels)
     static const int narrow_bwd = getenv("CVCS_HALO_NARROW_BWD") ? atoi(getenv("CVCS_HALO_NARROW_BWD")) : 128;    // tuning knob
-    const bool wide = d->Cout % 128 == 0 && !(d->dtype == CVCS_BF16 && (d->Cin <= narrow_cin || (d->bwd_y && d->Cout <= narrow_bwd)));
+    const bool wide = !thin && d->Cout % 128 == 0 && !(d->dtype == CVCS_BF16 && (d->Cin <= narrow_cin || (d->bwd_y && d->Cout <= narrow_bwd)));
     static const int waves = getenv("CVCS_HALO_WAVES") ? atoi(getenv("CVCS_HALO_WAVES")) : 8;   // tuning knob (4 | 8)
     if (d->dtype == CVCS_F32) return wide ? launch_halo<float, 128, 4, 2, 1>(a, st) : launch_halo<float, 64, 4, 1, 3>(a, st);
     static const int pipe = getenv("CVCS_HALO_PIPE") ? atoi(getenv("CVCS_HALO_PIPE")) : 1;               // tuning knob

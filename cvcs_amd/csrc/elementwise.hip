@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
   T* wf = reinterpret_cast<T*>(it.w_fwd);
   T* wd = reinterpret_cast<T*>(it.w_dgrad);
   const int Cout = it.Cout, Cin = it.Cin, Cin_pad = it.Cin_pad, taps = it.KH * it.KW;
+  const int Cout_pad = it.Cout_pad > 0 ? it.Cout_pad : Cout;      // row length of the data-gradient image (columns Cout.. stay as allocated: zero)
   const int nci = (Cin_pad + CI - 1) / CI, nco = Cout / CO;
   for (int blk = blockIdx.x; blk < nco * nci; blk += gridDim.x) {
     const int co0 = (blk / nci) * CO, ci0 = (blk % nci) * CI;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
         float f[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) f[k] = sw[cv * V + k][ci * taps + (taps - 1 - tp)];
-        *reinterpret_cast<uint4*>(wd + ((int64_t)tp * Cin + ci0 + ci) * Cout + co0 + cv * V) = Elem<T>::pack(f);
+        *reinterpret_cast<uint4*>(wd + ((int64_t)tp * Cin + ci0 + ci) * Cout_pad + co0 + cv * V) = Elem<T>::pack(f);
       }
     }
   }

@@ -614,20 +614,142 @@ static inline int pix_grid(int64_t P, int cap = 256 * 16) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+
+// ------------------------------------------------------------------------------------------------ thin heads (C = 16 | 32 input channels)
+// The light U-Net decoders end in 16 (or 32) channels at full resolution (decoder widths 256/128/64/32/16): the head is then even more
+// HBM-bound than the 64-channel one (2*C*NC FLOP against C + NC elements per pixel) and runs on the VALU.  Forward / argmax: one lane
+// owns one pixel, weights in LDS.  Backward: 256-pixel tiles staged in LDS (x as f32 [pixel][C], dl as [class][pixel]); dx per pixel by
+// its lane; dW: each thread owns (class, channel) pairs and sums over the tile's pixels; one partial row per workgroup in the layout of
+// the 64-channel head (part[row][c*C + k], then part[row][NC*C + c]) for the same fixed-order finalize.
+template <typename T, int C>
+__device__ __forceinline__ void load_pixel_c(const char* base, float* x) {
+  constexpr int V = 16 / sizeof(T);
+#pragma unroll
+  for (int c = 0; c < C / V; ++c) Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + c * 16), x + c * V);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void thin_head_fwd_kernel(const char* x, int64_t x_ld, int64_t P, int64_t HW, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int NC, float* logits, uint8_t* labels) {
+  __shared__ float sw[kMaxNC * C + kMaxNC];
+  for (int i = threadIdx.x; i < NC * C; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < NC; i += 256) sw[kMaxNC * C + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  for (int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x; pidx < P; pidx += (int64_t)gridDim.x * 256) {
+    float xv[C];
+    load_pixel_c<T, C>(x + pidx * x_ld * sizeof(T), xv);
+    const int64_t b = pidx / HW, hw = pidx - b * HW;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < NC; ++c) {
+      float s = sw[kMaxNC * C + c];
+#pragma unroll
+      for (int k = 0; k < C; ++k) s += xv[k] * sw[c * C + k];
+      if (logits) logits[(b * NC + c) * HW + hw] = s;
+      if (s > best || c == 0) { best = s; arg = c; }   // strict '>' keeps the FIRST maximum
+    }
+    if (labels) labels[pidx] = (uint8_t)arg;
+  }
+}
+
+constexpr int kThinTile = 256;
+template <typename T, int C>
+__global__ __launch_bounds__(256) void thin_head_bwd_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P, int64_t HW,
+                                                           const float* __restrict__ w, int NC, char* dx, int64_t dx_ld, float* part) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  constexpr int XP = C + 1;                       // pitch of the x tile (floats): lanes walk pixels, +1 keeps the banks apart
+  __shared__ float sw[kMaxNC * C];
+  __shared__ float sx[kThinTile * XP];
+  __shared__ float sd[kMaxNC * kThinTile];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NC * C; i += 256) sw[i] = w[i];
+  // (class, channel) pairs of this thread: pair q = tid + 256 j; the bias sums ride as channel index C
+  constexpr int NPAIR = (kMaxNC * (C + 1) + 255) / 256;
+  float acc[NPAIR];
+#pragma unroll
+  for (int j = 0; j < NPAIR; ++j) acc[j] = 0.f;
+  const int npairs = NC * (C + 1);
+  const int64_t ntiles = (P + kThinTile - 1) / kThinTile;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t p0 = t * kThinTile;
+    const int64_t pidx = p0 + tid;
+    const bool ok = pidx < P;
+    __syncthreads();                              // the previous tile's readers are done
+    float xv[C];
+    if (ok) load_pixel_c<T, C>(x + pidx * x_ld * ES, xv);
+#pragma unroll
+    for (int k = 0; k < C; ++k) sx[tid * XP + k] = ok ? xv[k] : 0.f;
+    const int64_t b = ok ? pidx / HW : 0, hw = ok ? pidx - b * HW : 0;
+    float dlv[kMaxNC];
+#pragma unroll 4
+    for (int c = 0; c < NC; ++c) {
+      dlv[c] = ok ? dl[(b * NC + c) * HW + hw] : 0.f;
+      sd[c * kThinTile + tid] = dlv[c];
+    }
+    __syncthreads();
+    if (ok) {                                     // dx[p][k] = sum_c dl[p][c] w[c][k]
+      float o[C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) o[k] = 0.f;
+      for (int c = 0; c < NC; ++c) {
+        const float d = sd[c * kThinTile + tid];
+#pragma unroll
+        for (int k = 0; k < C; ++k) o[k] += d * sw[c * C + k];
+      }
+#pragma unroll
+      for (int k = 0; k < C / V; ++k) *reinterpret_cast<uint4*>(dx + pidx * dx_ld * ES + k * 16) = Elem<T>::pack(o + k * V);
+    }
+#pragma unroll
+    for (int j = 0; j < NPAIR; ++j) {
+      const int q = tid + 256 * j;
+      if (q < npairs) {
+        const int c = q / (C + 1), k = q - c * (C + 1);
+        float a = 0.f;
+        if (k < C) {
+          for (int pp = 0; pp < kThinTile; ++pp) a += sd[c * kThinTile + pp] * sx[pp * XP + k];
+        } else {
+          for (int pp = 0; pp < kThinTile; ++pp) a += sd[c * kThinTile + pp];
+        }
+        acc[j] += a;
+      }
+    }
+  }
+  float* row = part + (int64_t)blockIdx.x * (NC * C + NC);
+#pragma unroll
+  for (int j = 0; j < NPAIR; ++j) {
+    const int q = tid + 256 * j;
+    if (q < npairs) {
+      const int c = q / (C + 1), k = q - c * (C + 1);
+      if (k < C) row[c * C + k] = acc[j];
+      else row[NC * C + c] = acc[j];
+    }
+  }
+}
+
 }  // namespace cvcs
 
 using namespace cvcs;
+
+static bool thin_c(int C) { return C == 16 || C == 32; }
 
 extern "C" int cvcs_head_fwd(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
                              float* logits, int dtype, void* stream) {
   CVCS_CHECK_ARG(dtype == CVCS_F32 || dtype == CVCS_BF16, "cvcs_head_fwd: bad dtype");
   const int es = dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(x && w && logits && B > 0 && H > 0 && W > 0, "cvcs_head_fwd: null argument");
-  CVCS_CHECK_ARG(C == kHeadC, "cvcs_head_fwd: head is built for %d input channels (S/nets.py:172), got %d", kHeadC, C);
+  CVCS_CHECK_ARG(C == kHeadC || thin_c(C), "cvcs_head_fwd: head is built for %d (S/nets.py:172), 32 or 16 input channels, got %d", kHeadC, C);
   CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_fwd: NC=%d out of [1,%d]", NC, kMaxNC);
   CVCS_CHECK_ARG(((uintptr_t)x % 16) == 0 && (x_ld * es) % 16 == 0 && x_ld >= C, "cvcs_head_fwd: x view alignment");
   const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
   dim3 grid(pix_grid(P));
+  if (thin_c(C)) {
+#define THIN_FWD(TT, CC) hipLaunchKernelGGL((thin_head_fwd_kernel<TT, CC>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, logits, (uint8_t*)nullptr)
+    if (dtype == CVCS_F32) { if (C == 16) THIN_FWD(float, 16); else THIN_FWD(float, 32); }
+    else { if (C == 16) THIN_FWD(bf16_t, 16); else THIN_FWD(bf16_t, 32); }
+#undef THIN_FWD
+    CVCS_CHECK_LAUNCH("cvcs_head_fwd(thin)");
+    return CVCS_OK;
+  }
   if (dtype == CVCS_F32)
     hipLaunchKernelGGL((head_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, logits);
   else
@@ -656,10 +778,19 @@ extern "C" int cvcs_head_argmax(const void* x, int64_t x_ld, int B, int H, int W
   CVCS_CHECK_ARG(dtype == CVCS_F32 || dtype == CVCS_BF16, "cvcs_head_argmax: bad dtype");
   const int es = dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(x && w && labels && B > 0 && H > 0 && W > 0, "cvcs_head_argmax: null argument");
-  CVCS_CHECK_ARG(C == kHeadC, "cvcs_head_argmax: head is built for %d input channels, got %d", kHeadC, C);
+  CVCS_CHECK_ARG(C == kHeadC || thin_c(C), "cvcs_head_argmax: head is built for %d, 32 or 16 input channels, got %d", kHeadC, C);
   CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_argmax: NC=%d out of [1,%d]", NC, kMaxNC);
   CVCS_CHECK_ARG(((uintptr_t)x % 16) == 0 && (x_ld * es) % 16 == 0 && x_ld >= C, "cvcs_head_argmax: view alignment");
   const int64_t P = (int64_t)B * H * W;
+  if (thin_c(C)) {
+    const int64_t HW = (int64_t)H * W;
+#define THIN_ARG(TT, CC) hipLaunchKernelGGL((thin_head_fwd_kernel<TT, CC>), dim3(pix_grid(P)), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, HW, w, bias, NC, (float*)nullptr, labels)
+    if (dtype == CVCS_F32) { if (C == 16) THIN_ARG(float, 16); else THIN_ARG(float, 32); }
+    else { if (C == 16) THIN_ARG(bf16_t, 16); else THIN_ARG(bf16_t, 32); }
+#undef THIN_ARG
+    CVCS_CHECK_LAUNCH("cvcs_head_argmax(thin)");
+    return CVCS_OK;
+  }
   if (dtype == CVCS_F32)
     hipLaunchKernelGGL((head_argmax_kernel<float>), dim3(pix_grid(P)), dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, P, w, bias, NC, labels);
   else
@@ -690,13 +821,21 @@ extern "C" int cvcs_head_bwd(const void* x, int64_t x_ld, const float* dlogits, 
   CVCS_CHECK_ARG(dtype == CVCS_F32 || dtype == CVCS_BF16, "cvcs_head_bwd: bad dtype");
   const int es = dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(x && dlogits && w && dx && part_dw && B > 0 && H > 0 && W > 0, "cvcs_head_bwd: null argument");
-  CVCS_CHECK_ARG(C == kHeadC, "cvcs_head_bwd: head is built for %d input channels, got %d", kHeadC, C);
+  CVCS_CHECK_ARG(C == kHeadC || thin_c(C), "cvcs_head_bwd: head is built for %d, 32 or 16 input channels, got %d", kHeadC, C);
   CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_bwd: NC=%d out of [1,%d]", NC, kMaxNC);
   CVCS_CHECK_ARG(((uintptr_t)x % 16) == 0 && (x_ld * es) % 16 == 0 && x_ld >= C && ((uintptr_t)dx % 16) == 0 &&
                      (dx_ld * es) % 16 == 0 && dx_ld >= C, "cvcs_head_bwd: view alignment");
   const int64_t P = (int64_t)B * H * W, HW = (int64_t)H * W;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)cvcs_head_bwd_rows(P));
+  if (thin_c(C)) {
+#define THIN_BWD(TT, CC) hipLaunchKernelGGL((thin_head_bwd_kernel<TT, CC>), grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw)
+    if (dtype == CVCS_F32) { if (C == 16) THIN_BWD(float, 16); else THIN_BWD(float, 32); }
+    else { if (C == 16) THIN_BWD(bf16_t, 16); else THIN_BWD(bf16_t, 32); }
+#undef THIN_BWD
+    CVCS_CHECK_LAUNCH("cvcs_head_bwd(thin)");
+    return CVCS_OK;
+  }
   if (dtype == CVCS_F32)
     hipLaunchKernelGGL((head_bwd_kernel<float>), grid, dim3(256), 0, st, (const char*)x, x_ld, dlogits, P, HW, w, NC, (char*)dx, dx_ld, part_dw);
   else if (HW % kDwTile == 0)   // tiles of 64 pixels inside one image (every tile side that is a multiple of 16)

@@ -248,11 +248,19 @@ class Urnetv2(_HipUNet):
 
 
 # ---------------------------------------------------------------------------------------------------- ResNet-encoder U-Nets
-def resnet_unet_param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS, decoder_norm="bn_relu"):
+GN_DECODER_CHANNELS = (256, 128, 64, 64, 64)      # GroupNorm(32) needs multiples of 32 channels: the gn_silu decoder keeps the wide last stages
+
+
+def default_decoder_channels(decoder_norm="bn_relu"):
+    return DECODER_CHANNELS if decoder_norm == "bn_relu" else GN_DECODER_CHANNELS
+
+
+def resnet_unet_param_spec(arch: str, num_classes: int, decoder_channels=None, decoder_norm="bn_relu"):
     """(name, shape, kind) in forward order.  Encoder names are torchvision's ResNet names under `encoder.` (ImageNet /
     torchvision checkpoints map one to one); decoder / head names follow the common `decoder.blocks.N.convK.{0,1}` /
     `segmentation_head.0` scheme.  No conv of the encoder or decoder has a bias (each is followed by a BatchNorm)."""
     kind, depths, widths = RESNET_ARCHS[arch]
+    decoder_channels = tuple(decoder_channels) if decoder_channels is not None else default_decoder_channels(decoder_norm)
     spec = []
 
     def conv(p, cin, cout, k, bias=False):
@@ -306,19 +314,21 @@ class ResnetUnet(_HipUNet):
     arch = "resnet50"
     variant = "ResnetUnet"
 
-    def __init__(self, num_classes: int, precision: str = "bf16", decoder_norm: str = "bn_relu"):
+    def __init__(self, num_classes: int, precision: str = "bf16", decoder_norm: str = "bn_relu", decoder_channels=None):
         """decoder_norm: "bn_relu" (default: conv -> BatchNorm -> ReLU) | "gn_silu" (conv -> GroupNorm(32) -> SiLU, normalisation and
-        activation fused in one pass; config key `decoder_norm`)"""
+        activation fused in one pass; config key `decoder_norm`).  decoder_channels: the five decoder widths (config key `decoder_channels`;
+        default (256, 128, 64, 32, 16), the common public U-Net-on-ResNet layout; multiples of 16, the last one 16 / 32 / 64)"""
         assert decoder_norm in ("bn_relu", "gn_silu")
         self.decoder_norm = decoder_norm
+        self.decoder_channels = tuple(decoder_channels) if decoder_channels is not None else default_decoder_channels(decoder_norm)
         super().__init__(num_classes, precision)
 
     def _build_spec(self):
-        return resnet_unet_param_spec(self.arch, self.num_classes, decoder_norm=self.decoder_norm)
+        return resnet_unet_param_spec(self.arch, self.num_classes, self.decoder_channels, decoder_norm=self.decoder_norm)
 
     def _build_engine(self, dev):
-        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, decoder_norm=self.decoder_norm,
-                                fp8=self.precision == "fp8")
+        return ResNetUNetEngine(self.arch, self.num_classes, PRECISIONS[self.precision], dev, decoder_channels=self.decoder_channels,
+                                decoder_norm=self.decoder_norm, fp8=self.precision == "fp8")
 
 
 class Resnet18Unet(ResnetUnet):

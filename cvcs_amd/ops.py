@@ -799,6 +799,7 @@ def pack_table(entries, device):
         assert wf.shape[2] % 16 == 0 and wf.data_ptr() % 16 == 0 and (wd is None or wd.data_ptr() % 16 == 0)
         it.w, it.w_fwd, it.w_dgrad = w.data_ptr(), wf.data_ptr(), _ptr(wd)
         it.Cout, it.Cin, it.KH, it.KW, it.Cin_pad = Cout, Cin, KH, KW, wf.shape[2]
+        it.Cout_pad = 0 if wd is None else wd.shape[2]      # (a data-gradient image wider than Cout must have been zero-filled by its owner)
     raw = bytes(arr)
     return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device), len(entries)
 

@@ -55,7 +55,10 @@ def stage_plan(arch, output_stride=32):
         for b in range(n):
             plan.append((s, b, first_stride if b == 0 else 1, first_dil if b == 0 else dil))
     return plan
-DECODER_CHANNELS = (256, 128, 64, 64, 64)
+# decoder widths: the common public U-Net-on-ResNet layout (segmentation_models_pytorch's default (256, 128, 64, 32, 16)).  Rounds 1-2 kept the
+# last two stages at 64 channels because no kernel tiled output channels below 64; the 3x3 halo kernel now masks 16 / 32 / 48-channel tiles,
+# the head takes 16 / 32 / 64 input channels (config key `decoder_channels` restores any other widths, e.g. [256, 128, 64, 64, 64])
+DECODER_CHANNELS = (256, 128, 64, 32, 16)
 GN_GROUPS = 32
 
 
@@ -105,7 +108,8 @@ class ResNetUNetEngine:
         self.arch, self.NC, self.dtype, self.dev = arch, num_classes, dtype, torch.device(device)
         self.kind, self.depths, self.widths = ARCHS[arch]
         self.dec = tuple(decoder_channels)
-        assert self.dec[-1] == 64, "the 1x1 head kernels take 64 input channels"
+        assert len(self.dec) == 5 and all(c % 16 == 0 for c in self.dec) and self.dec[-1] in (16, 32, 64), \
+            "decoder widths: five multiples of 16, the last one 16 / 32 / 64 (the 1x1 head kernels)"
         self.head_name = "segmentation_head.0"
         self.code = ops.dtype_code(dtype)
         self.P = self.G = self.Bf = None
@@ -143,7 +147,8 @@ class ResNetUNetEngine:
             if w.dim() != 4 or name in ("encoder.conv1.weight", self.head_name + ".weight"):
                 continue
             cout, cin, kh, kw = w.shape
-            pk = dict(wf=torch.empty(kh * kw, cout, cin, dtype=dt, device=dev), wd=torch.empty(kh * kw, cin, cout, dtype=dt, device=dev))
+            kg = 64 // (2 if dt == torch.bfloat16 else 4)      # channels per 64-byte K-step: a thinner contraction axis is zero-padded to one
+            pk = dict(wf=torch.zeros(kh * kw, cout, max(cin, kg), dtype=dt, device=dev), wd=torch.zeros(kh * kw, cin, max(cout, kg), dtype=dt, device=dev))
             self.packed[name[:-len(".weight")]] = pk
             entries.append((w, pk["wf"], pk["wd"]))
         self._pack_table = ops.pack_table(entries, dev)
@@ -238,6 +243,14 @@ class ResNetUNetEngine:
         t = self._bufs.get(key)
         if t is None:
             t = self._bufs[key] = torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+        return t
+
+    def _zbuf(self, name, shape, dtype=None):
+        """like _buf, zero-filled at allocation (buffers whose padding must read as zero)"""
+        key = (name, tuple(shape), dtype or self.dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.zeros(shape, dtype=dtype or self.dtype, device=self.dev)
         return t
 
     def _act(self, name, B, H, W, C_):
@@ -406,7 +419,7 @@ class ResNetUNetEngine:
         if getattr(producer, "fp8", False):      # the fp8 kernel has no fused reduce epilogue
             return False
         return (self.fuse_bn_bwd and not getattr(consumer, "gn", False) and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
-                producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128)
+                producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128 and y.C % 64 == 0)
 
     def _unit_bwd(self, u: Unit, g: View, mode, fused=None) -> View:
         """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
@@ -454,7 +467,12 @@ class ResNetUNetEngine:
         # two dy buffers in turn: the weight gradient of unit k (side lane) may still read its dy while unit k + 1 writes the other one
         self._dy_toggle ^= 1
         dyname = u.conv + ".dy" if self.keep_all else ("dy" if not self.overlap_wgrad else f"dy{self._dy_toggle}")
-        dy = ops.view(self._scratch(dyname, M * C_, self.dtype).view(y.B, y.H, y.W, C_))
+        thin16 = C_ % 32 != 0      # 16 (or 48) output channels: the weight-gradient kernels take multiples of 32 -> dy lives in a buffer
+        if thin16:                 # whose upper channels stay zero, the weight gradient of the padded rows is dropped (see below)
+            cpad = (C_ + 31) // 32 * 32
+            dy = View(self._zbuf(u.conv + ".dy_pad", (y.B, y.H, y.W, cpad)), 0, C_)
+        else:
+            dy = ops.view(self._scratch(dyname, M * C_, self.dtype).view(y.B, y.H, y.W, C_))
         if self.keep_all:
             self.bwd_units[u.conv] = dict(unit=u, g=g, mode=mode, dy=dy)
         rec = _lib._recording
@@ -472,6 +490,13 @@ class ResNetUNetEngine:
                 need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
                 ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch(ws_name, need), cin_real=32, virt=True)
                 ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
+            elif thin16:
+                dyp = ops.view(dy.t)                                  # all cpad channels: rows C_.. of the result are zero and dropped
+                gw = self.G[u.conv + ".weight"]
+                tmp = self._scratch("wg_thin", dyp.C * gw[0].numel())
+                need = ops.wgrad_workspace_floats_for(u.x, dyp, u.k, u.k, u.stride, u.pad, dil=u.dil)
+                ops.conv2d_wgrad(u.x, dyp, tmp, u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)
+                ops.colsum_finalize(tmp, 1, gw.numel(), gw)          # (one "row": a device copy of the first C_ output channels)
             else:
                 need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
                 ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)
@@ -704,14 +729,14 @@ class ResNetUNetEngine:
         if self.shape != (x.shape[0], x.shape[2]):
             self._last_act = {}
         h = self._forward_backbone(x, train)
-        ops.head_fwd(h.v, self.P["segmentation_head.0.weight"].view(self.NC, 64), self.P["segmentation_head.0.bias"], self.logits)
+        ops.head_fwd(h.v, self.P["segmentation_head.0.weight"].view(self.NC, self.dec[-1]), self.P["segmentation_head.0.bias"], self.logits)
         return self.logits
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
         if self.shape != (x.shape[0], x.shape[2]):
             self._last_act = {}
         h = self._forward_backbone(x, False)
-        ops.head_argmax(h.v, self.P["segmentation_head.0.weight"].view(self.NC, 64), self.P["segmentation_head.0.bias"], labels)
+        ops.head_argmax(h.v, self.P["segmentation_head.0.weight"].view(self.NC, self.dec[-1]), self.P["segmentation_head.0.bias"], labels)
         return labels
 
     def backward(self, dlogits: torch.Tensor):
@@ -722,13 +747,14 @@ class ResNetUNetEngine:
         B, S = self.shape
         NC = self.NC
         h = self._last_act["fwd_train"]
+        CH = self.dec[-1]
         rows = ops.head_bwd_rows(B * S * S)
-        part = self._scratch("head_part", rows * (NC * 64 + NC))
-        gh = ops.view(self._act("head.gx", B, S, S, 64))
-        ops.head_bwd(h.v, dlogits.contiguous(), self.P["segmentation_head.0.weight"].view(NC, 64), gh, part)
+        part = self._scratch("head_part", rows * (NC * CH + NC))
+        gh = ops.view(self._act("head.gx", B, S, S, CH))
+        ops.head_bwd(h.v, dlogits.contiguous(), self.P["segmentation_head.0.weight"].view(NC, CH), gh, part)
         gw, gb = self.G["segmentation_head.0.weight"], self.G["segmentation_head.0.bias"]
         assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4
-        ops.colsum_finalize(part, rows, NC * 64 + NC, gw)
+        ops.colsum_finalize(part, rows, NC * CH + NC, gw)
         if self.on_grad_ready is not None:
             self.on_grad_ready(self._goff["segmentation_head.0.weight"], [])
 

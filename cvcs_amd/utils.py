@@ -51,7 +51,7 @@ def load_network(config, device):
         return nets.Urnetv2(classes, precision).to(device)
     elif netname in ("Resnet18Unet", "Resnet34Unet", "Resnet50Unet"):
         # BASELINE.json's ResNet-encoder U-Nets: new factory names behind the same seam (the reference has no such model)
-        return getattr(nets, netname)(classes, precision, config.get("decoder_norm", "bn_relu")).to(device)
+        return getattr(nets, netname)(classes, precision, config.get("decoder_norm", "bn_relu"), config.get("decoder_channels")).to(device)
     elif netname == "Ensemble":
         try:
             return Ensemble(classes, device, config.get("ensemble_config"), precision=precision)

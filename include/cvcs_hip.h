@@ -209,7 +209,8 @@ int cvcs_pack_input(const void* src, int src_is_u8, int B, int C, int H, int W, 
 typedef struct {
   const float* w;   void* w_fwd;   void* w_dgrad;   /* w_dgrad may be NULL */
   int32_t Cout, Cin, KH, KW, Cin_pad;
-  int32_t reserved;
+  int32_t Cout_pad;   /* row length of w_dgrad ([flipped tap][Cin][Cout_pad]); 0 = Cout.  Cout_pad > Cout: the layer's data gradient contracts
+                         over a K-group wider than its output channels (thin layers, Cout = 16): the caller zero-fills the columns once */
 } cvcs_pack_item;
 int cvcs_pack_conv_weights(const cvcs_pack_item* items_device, int n_items, int dtype, void* stream);
 

@@ -45,14 +45,21 @@ ARCHS = {
     "resnet50": ("bottleneck", (3, 4, 6, 3), (256, 512, 1024, 2048)),
     "resnet101": ("bottleneck", (3, 4, 23, 3), (256, 512, 1024, 2048)),
 }
-DECODER_CHANNELS = (256, 128, 64, 64, 64)
+DECODER_CHANNELS = (256, 128, 64, 32, 16)         # the common public layout (segmentation_models_pytorch's Unet default)
+GN_DECODER_CHANNELS = (256, 128, 64, 64, 64)      # decoder_norm="gn_silu": GroupNorm(32) needs multiples of 32 channels
+
+
+def _dec_channels(decoder_channels, decoder_norm="bn_relu"):
+    if decoder_channels is not None:
+        return tuple(decoder_channels)
+    return DECODER_CHANNELS if decoder_norm == "bn_relu" else GN_DECODER_CHANNELS
 
 
 # --------------------------------------------------------------------------- parameter table
 GN_GROUPS = 32
 
 
-def param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS, decoder_norm="bn_relu"):
+def param_spec(arch: str, num_classes: int, decoder_channels=None, decoder_norm="bn_relu"):
     """ordered (name, shape); encoder names are torchvision's ResNet names under `encoder.`, so ImageNet / torchvision
     checkpoints map one to one.  decoder_norm="gn_silu": the decoder's conv -> BatchNorm -> ReLU pairs become
     conv -> GroupNorm(32) -> SiLU (north star "fused BN/GN+SiLU"); a GroupNorm has no running statistics."""
@@ -92,7 +99,7 @@ def param_spec(arch: str, num_classes: int, decoder_channels=DECODER_CHANNELS, d
                 conv(p + ".downsample.0", cin, w, 1); bn(p + ".downsample.1", w)
             cin = w
     skips = [widths[2], widths[1], widths[0], 64, 0]
-    for i, (dc, sk) in enumerate(zip(decoder_channels, skips)):
+    for i, (dc, sk) in enumerate(zip(_dec_channels(decoder_channels, decoder_norm), skips)):
         p = f"decoder.blocks.{i}"
         conv(p + ".conv1.0", cin + sk, dc, 3); dnorm(p + ".conv1.1", dc)
         conv(p + ".conv2.0", dc, dc, 3); dnorm(p + ".conv2.1", dc)
@@ -105,7 +112,7 @@ def is_buffer(name):
     return name.endswith("running_mean") or name.endswith("running_var")
 
 
-def init_params(arch, num_classes, seed=0, decoder_channels=DECODER_CHANNELS, decoder_norm="bn_relu"):
+def init_params(arch, num_classes, seed=0, decoder_channels=None, decoder_norm="bn_relu"):
     """deterministic synthetic weights, independent of torch's default init: conv ~ N(0, 2/fan_in); BN gamma in [0.5,1.5]
     (the last BN of every residual block in [0.2,0.6] so that 16 stacked blocks keep O(1) activations), beta small."""
     g = torch.Generator().manual_seed(seed)
@@ -310,7 +317,7 @@ def forward(p, x, arch="resnet50", train=False, emulate_bf16=False, return_acts=
 
 
 # --------------------------------------------------------------------------- algorithmic work (bench.py, DESIGN.md)
-def conv_table(arch, num_classes, S, decoder_channels=DECODER_CHANNELS):
+def conv_table(arch, num_classes, S, decoder_channels=None):
     """[(name, Cin, Cout, K, stride, Hout)] of every convolution at tile side S - the layer table behind
     `algorithmic_gflop_per_step` (FLOPs = 2*Cin*Cout*K*K*Hout*Hout per tile)."""
     kind, depths, widths = ARCHS[arch]
@@ -330,7 +337,7 @@ def conv_table(arch, num_classes, S, decoder_channels=DECODER_CHANNELS):
                 rows.append((p + ".downsample.0", cin, w, 1, stride, ho))
             cin, h = w, ho
     skips = [widths[2], widths[1], widths[0], 64, 0]
-    for i, (dc, sk) in enumerate(zip(decoder_channels, skips)):
+    for i, (dc, sk) in enumerate(zip(_dec_channels(decoder_channels), skips)):
         h *= 2
         rows += [(f"decoder.blocks.{i}.conv1.0", cin + sk, dc, 3, 1, h), (f"decoder.blocks.{i}.conv2.0", dc, dc, 3, 1, h)]
         cin = dc
@@ -338,7 +345,7 @@ def conv_table(arch, num_classes, S, decoder_channels=DECODER_CHANNELS):
     return rows
 
 
-def forward_gflop_per_tile(arch, num_classes, S, decoder_channels=DECODER_CHANNELS):
+def forward_gflop_per_tile(arch, num_classes, S, decoder_channels=None):
     return sum(2.0 * ci * co * k * k * ho * ho for _, ci, co, k, _, ho in conv_table(arch, num_classes, S, decoder_channels)) / 1e9
 
 

@@ -39,7 +39,7 @@ def _desc(a, **kw):
 @pytest.mark.parametrize("kw,msg", [
     (dict(dtype=7), b"bad dtype"),
     (dict(Cin=24, in_ld=24), b"Cin=24 must be a multiple of 32"),
-    (dict(Cout=48), b"Cout=48 must be a multiple of 32"),
+    (dict(Cout=40), b"Cout=40 must be a multiple of 32"),      # (16 | 32 | 48 run as masked thin tiles of the 3x3 halo kernel)
     (dict(Ho=7), b"geometry gives 8,8"),
     (dict(B=0), b"bad shape"),
     (dict(in_ld=16), b"in_ld"),
@@ -78,7 +78,7 @@ def test_wgrad_rejects_unbuilt_filters_and_bad_shapes(lib):
 
 def test_other_entry_points_reject_bad_arguments(lib):
     keep, a = _buf()
-    assert lib.cvcs_head_fwd(a, 32, 1, 4, 4, 32, a, a, 5, a, 1, None) == -1 and b"64 input channels" in lib.cvcs_last_error()
+    assert lib.cvcs_head_fwd(a, 48, 1, 4, 4, 48, a, a, 5, a, 1, None) == -1 and b"input channels, got 48" in lib.cvcs_last_error()
     assert lib.cvcs_head_argmax(a, 64, 1, 4, 4, 64, a, a, 40, a, 1, None) == -1 and b"NC=40" in lib.cvcs_last_error()
     assert lib.cvcs_ce_fwd_bwd(a, a, 1, 1, 33, 16, None, 0, 1.0, a, a, a, 0, None) == -1 and b"NC=33" in lib.cvcs_last_error()
     assert lib.cvcs_vote_labels(a, 0, 16, a, None) == -1 and b"voters" in lib.cvcs_last_error()

@@ -55,6 +55,9 @@ CONV_CASES = [
     (1, 28, 20, 128, 64, 3, 1, 1, 1, False),   # halo kernel, ragged tiles (28x20), BN=64, 4 channel slices
     (3, 14, 14, 96, 192, 3, 1, 1, 1, True),    # halo kernel, 14x14 maps (224-tile level 5), Cout % 128 != 0
     (1, 40, 24, 64, 256, 3, 1, 1, 1, False),   # halo kernel, two column tiles of weights
+    (2, 32, 32, 128, 32, 3, 1, 1, 1, False),   # thin output (light decoder stage 128 -> 32): masked 64-channel tile of the halo kernel
+    (1, 24, 40, 32, 16, 3, 1, 1, 1, True),     # thin 32 -> 16, ragged tiles
+    (2, 16, 16, 64, 48, 3, 1, 1, 1, False),    # 48 channels (the DeepLabV3+ paper's low-level width)
 ]
 
 
@@ -465,6 +468,41 @@ def test_head_forward_backward(NC, B, H, W, dtype):
     torch.cuda.synchronize()
     close(logits.cpu(), ref.detach().float(), 1e-5, "logits")
     close(from_nhwc(dx), xr.grad.float(), 1e-5 if dtype == torch.float32 else 8e-3, "head dx")
+    close(dwb[:NC * C].cpu().reshape(NC, C), wr.grad.float(), 1e-4, "head dW")
+    close(dwb[NC * C:].cpu(), br.grad.float(), 1e-4, "head db")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,NC,B,H,W", [(16, 16, 2, 24, 40), (32, 5, 1, 17, 13), (16, 21, 3, 32, 32), (32, 32, 1, 40, 40)])
+def test_thin_head_forward_argmax_backward(C, NC, B, H, W, dtype):
+    """the head on 16 / 32 input channels (decoder widths 256/128/64/32/16): logits, fused argmax = argmax of the logits, dx, dW, db;
+    ragged last 256-pixel tile and more tiles than workgroup rows"""
+    g = torch.Generator().manual_seed(C + NC)
+    x = rq(torch.randn(B, C, H, W, generator=g), dtype)
+    w = torch.randn(NC, C, generator=g) / 4
+    b = torch.randn(NC, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr[:, :, None, None], br)
+    dl = torch.randn(B, NC, H, W, generator=g)
+    ref.backward(dl.double())
+    xd = torch.full((B, H, W, C + 16), 9.0, dtype=dtype, device=DEV)       # a view with a leading dimension
+    xd[..., :C] = to_nhwc(x, dtype)
+    xv = ops.View(xd, 0, C)
+    logits = torch.empty(B, NC, H, W, device=DEV)
+    ops.head_fwd(xv, w.to(DEV), b.to(DEV), logits)
+    labels = torch.empty(B, H, W, dtype=torch.uint8, device=DEV)
+    ops.head_argmax(xv, w.to(DEV), b.to(DEV), labels)
+    dx = torch.full((B, H, W, C + 16), 3.0, dtype=dtype, device=DEV)
+    rows = ops.head_bwd_rows(B * H * W)
+    part = torch.zeros(rows, NC * C + NC, device=DEV)
+    ops.head_bwd(xv, dl.to(DEV), w.to(DEV), ops.View(dx, 0, C), part)
+    dwb = torch.empty(NC * C + NC, device=DEV)
+    ops.colsum_finalize(part, rows, NC * C + NC, dwb)
+    torch.cuda.synchronize()
+    close(logits.cpu(), ref.detach().float(), 1e-5, "logits")
+    assert torch.equal(labels.cpu().long(), logits.argmax(1).cpu())
+    close(from_nhwc(dx[..., :C]), xr.grad.float(), 1e-5 if dtype == torch.float32 else 8e-3, "head dx")
+    assert (dx[..., C:].float() == 3.0).all()
     close(dwb[:NC * C].cpu().reshape(NC, C), wr.grad.float(), 1e-4, "head dW")
     close(dwb[NC * C:].cpu(), br.grad.float(), 1e-4, "head db")
 

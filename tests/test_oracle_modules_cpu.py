@@ -183,7 +183,7 @@ class DecoderBlock(nn.Module):
 
 
 class ResNetUNetModule(nn.Module):
-    def __init__(self, block, layers, nc, dec=R.DECODER_CHANNELS):
+    def __init__(self, block, layers, nc, dec=R.DECODER_CHANNELS):      # (256, 128, 64, 32, 16)
         super().__init__()
         self.encoder = TVResNet(block, layers)
         w = [64 * block.expansion * m for m in (1, 2, 4, 8)]

@@ -110,7 +110,7 @@ def test_decoder_and_head_match_module_code():
         blk.load_state_dict(sd, strict=False)
         blk.train()
         h = blk.conv2(blk.conv1(h))
-    head = nn.Conv2d(64, 4, 1)
+    head = nn.Conv2d(p["segmentation_head.0.weight"].shape[1], 4, 1)
     head.load_state_dict({"weight": p["segmentation_head.0.weight"], "bias": p["segmentation_head.0.bias"]})
     ref = head(h)
     assert (ref - logits).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
