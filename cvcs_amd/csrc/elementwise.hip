@@ -69,14 +69,15 @@ __global__ __launch_bounds__(1024) void bn_stats_reduce_kernel(const float* __re
                                                              float* out_sum, float* out_m2, float* out_cnt) {
   __shared__ double sh[3][16][65];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
+  const int cx = blockIdx.y * 64 + cl;
+  const int c = cx < C ? cx : C - 1;             // thin layers (C = 16 | 32 | 48): the lanes beyond C repeat the last channel, write nothing
   const int r0 = blockIdx.x * R;
   int r1 = r0 + R;
   if (r1 > rows) r1 = rows;
   Moments a = merge_rows(ssum, sm2, scnt, r0 + rl, r1, 16, C, c);
   sh[0][rl][cl] = a.n; sh[1][rl][cl] = a.mean; sh[2][rl][cl] = a.m2;
   __syncthreads();
-  if (rl == 0) {
+  if (rl == 0 && cx < C) {
     Moments t{0.0, 0.0, 0.0};
     for (int q = 0; q < 16; ++q) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
     out_sum[(int64_t)blockIdx.x * C + c] = (float)(t.mean * t.n);
@@ -647,13 +648,13 @@ static int bn_stage1(const char* fn, const float*& stat_sum, const float*& stat_
                      float* workspace, hipStream_t st) {
   if (rows <= kDirectRows) return CVCS_OK;
   CVCS_CHECK_ARG(workspace != nullptr, "%s: %d partial rows need the workspace", fn, rows);
-  CVCS_CHECK_ARG(C % 64 == 0, "%s: the two-stage merge needs C %% 64 == 0", fn);
+  CVCS_CHECK_ARG(C % 16 == 0, "%s: the two-stage merge needs C %% 16 == 0", fn);
   const int R = (int)cdiv(rows, 1024);
   const int nblk = (int)cdiv(rows, R);
   float* o_sum = workspace;
   float* o_m2 = workspace + (int64_t)nblk * C;
   float* o_cnt = workspace + (int64_t)2 * nblk * C;
-  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)(C / 64)), dim3(1024), 0, st, stat_sum, stat_m2,
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)nblk, (unsigned)cdiv(C, 64)), dim3(1024), 0, st, stat_sum, stat_m2,
                      stat_cnt, rows, R, C, o_sum, o_m2, o_cnt);
   stat_sum = o_sum; stat_m2 = o_m2; stat_cnt = o_cnt; rows = nblk;
   return CVCS_OK;

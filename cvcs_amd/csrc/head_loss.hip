@@ -657,35 +657,32 @@ template <typename T, int C>
 __global__ __launch_bounds__(256) void thin_head_bwd_kernel(const char* x, int64_t x_ld, const float* __restrict__ dl, int64_t P, int64_t HW,
                                                            const float* __restrict__ w, int NC, char* dx, int64_t dx_ld, float* part) {
   constexpr int ES = sizeof(T), V = 16 / ES;
-  constexpr int XP = C + 1;                       // pitch of the x tile (floats): lanes walk pixels, +1 keeps the banks apart
-  __shared__ float sw[kMaxNC * C];
-  __shared__ float sx[kThinTile * XP];
+  constexpr int XP = C + 4;                       // pitch of the x tile (floats): 16-byte aligned rows, the +4 keeps pixel lanes on different banks
+  constexpr int KG = C / 4;                       // 4-channel groups
+  __shared__ __attribute__((aligned(16))) float sx[kThinTile * XP];
   __shared__ float sd[kMaxNC * kThinTile];
+  __shared__ float sw[kMaxNC * C];
   const int tid = threadIdx.x;
   for (int i = tid; i < NC * C; i += 256) sw[i] = w[i];
-  // (class, channel) pairs of this thread: pair q = tid + 256 j; the bias sums ride as channel index C
-  constexpr int NPAIR = (kMaxNC * (C + 1) + 255) / 256;
-  float acc[NPAIR];
-#pragma unroll
-  for (int j = 0; j < NPAIR; ++j) acc[j] = 0.f;
-  const int npairs = NC * (C + 1);
+  // dW: a thread owns one (class, 4-channel group) block and every Q-th pixel of a tile: ONE dl read (shared by the block's 4 FMAs) and
+  // ONE 16-byte x read per pixel; the Q pixel phases of a block are summed at the end.  nblk = NC * C / 4 <= 256.
+  const int nblk = NC * KG;
+  const int Q = 256 / nblk;                       // pixel phases (>= 1)
+  const int blk = tid % nblk, q = tid / nblk;     // threads beyond Q * nblk idle in the dW part
+  const int bc = blk / KG, bk = (blk - bc * KG) * 4;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
   const int64_t ntiles = (P + kThinTile - 1) / kThinTile;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int64_t p0 = t * kThinTile;
-    const int64_t pidx = p0 + tid;
+    const int64_t pidx = t * kThinTile + tid;
     const bool ok = pidx < P;
     __syncthreads();                              // the previous tile's readers are done
     float xv[C];
     if (ok) load_pixel_c<T, C>(x + pidx * x_ld * ES, xv);
 #pragma unroll
-    for (int k = 0; k < C; ++k) sx[tid * XP + k] = ok ? xv[k] : 0.f;
+    for (int k = 0; k < C; k += 4)
+      *reinterpret_cast<float4*>(&sx[tid * XP + k]) = ok ? make_float4(xv[k], xv[k + 1], xv[k + 2], xv[k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t b = ok ? pidx / HW : 0, hw = ok ? pidx - b * HW : 0;
-    float dlv[kMaxNC];
-#pragma unroll 4
-    for (int c = 0; c < NC; ++c) {
-      dlv[c] = ok ? dl[(b * NC + c) * HW + hw] : 0.f;
-      sd[c * kThinTile + tid] = dlv[c];
-    }
+    for (int c = 0; c < NC; ++c) sd[c * kThinTile + tid] = ok ? dl[(b * NC + c) * HW + hw] : 0.f;
     __syncthreads();
     if (ok) {                                     // dx[p][k] = sum_c dl[p][c] w[c][k]
       float o[C];
@@ -699,30 +696,32 @@ __global__ __launch_bounds__(256) void thin_head_bwd_kernel(const char* x, int64
 #pragma unroll
       for (int k = 0; k < C / V; ++k) *reinterpret_cast<uint4*>(dx + pidx * dx_ld * ES + k * 16) = Elem<T>::pack(o + k * V);
     }
-#pragma unroll
-    for (int j = 0; j < NPAIR; ++j) {
-      const int q = tid + 256 * j;
-      if (q < npairs) {
-        const int c = q / (C + 1), k = q - c * (C + 1);
-        float a = 0.f;
-        if (k < C) {
-          for (int pp = 0; pp < kThinTile; ++pp) a += sd[c * kThinTile + pp] * sx[pp * XP + k];
-        } else {
-          for (int pp = 0; pp < kThinTile; ++pp) a += sd[c * kThinTile + pp];
-        }
-        acc[j] += a;
+    if (q < Q) {
+      for (int pp = q; pp < kThinTile; pp += Q) {
+        const float d = sd[bc * kThinTile + pp];
+        const float4 xx = *reinterpret_cast<const float4*>(&sx[pp * XP + bk]);
+        a0 += d * xx.x; a1 += d * xx.y; a2 += d * xx.z; a3 += d * xx.w;
+        ab += d;
       }
     }
   }
+  // sum the Q pixel phases of every block through LDS (the x tile is free), fixed order
+  __syncthreads();
+  float* red = sx;                                // [Q][nblk][5]
+  if (q < Q) {
+    float* r = red + ((int64_t)q * nblk + blk) * 5;
+    r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3; r[4] = ab;
+  }
+  __syncthreads();
   float* row = part + (int64_t)blockIdx.x * (NC * C + NC);
-#pragma unroll
-  for (int j = 0; j < NPAIR; ++j) {
-    const int q = tid + 256 * j;
-    if (q < npairs) {
-      const int c = q / (C + 1), k = q - c * (C + 1);
-      if (k < C) row[c * C + k] = acc[j];
-      else row[NC * C + c] = acc[j];
+  if (tid < nblk) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sb = 0.f;
+    for (int j = 0; j < Q; ++j) {
+      const float* r = red + ((int64_t)j * nblk + tid) * 5;
+      s0 += r[0]; s1 += r[1]; s2 += r[2]; s3 += r[3]; sb += r[4];
     }
+    row[bc * C + bk] = s0; row[bc * C + bk + 1] = s1; row[bc * C + bk + 2] = s2; row[bc * C + bk + 3] = s3;
+    if (bk == 0) row[NC * C + bc] = sb;
   }
 }
 

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const int cout_rem = p.Cout - co0;            // < 64 in the last row tile of a Cout that is no multiple of 64 (Swin's 96 / 288)
   const int rr = lane / CPR, pc = lane % CPR;   // row / physical 16-byte chunk of this lane inside a DMA piece
   const int my_pieces = DYP / 4 + (xpieces - wave + 3) / 4;   // DMA instructions this wave issues per K-tile
+  const bool m0ok = wm * 32 < cout_rem, m1ok = wm * 32 + 16 < cout_rem, n0ok = wn * 32 < cin_rem, n1ok = wn * 32 + 16 < cin_rem;
 
   auto swz_chunk = [&](int row, int chunk) -> int {   // logical <-> physical 16-byte chunk (involution)
     if constexpr (ES == 2) return chunk ^ (((row >> 1) & 3) << 1);
@@ -190,10 +191,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
                  addr(xb, hb1 + off, wn * 2 + 1));
         const bf16x8 bf0 = __builtin_bit_cast(bf16x8, make_uint4(b0l.x, b0l.y, b0h.x, b0h.y));
         const bf16x8 bf1 = __builtin_bit_cast(bf16x8, make_uint4(b1l.x, b1l.y, b1h.x, b1h.y));
-        acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
-        acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
-        acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
-        acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
+        // thin layers (Cout / Cin of 16 | 32 inside the 64 x 64 tile): the 16 x 16 blocks that lie wholly in the zero padding are skipped
+        // (wave-uniform tests; a 16 -> 16 layer leaves ONE of the sixteen blocks of a tile)
+        if (m0ok && n0ok) acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
+        if (m0ok && n1ok) acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
+        if (m1ok && n0ok) acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
+        if (m1ok && n1ok) acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
       }
     } else {
       // f32 (parity path): plain LDS reads; MFMA pass s contracts tile pixels k = 4s + g (g = lane>>4)
@@ -951,7 +954,7 @@ static GemmPlan gemm_plan(int B, int Ho, int Wo, int Cout, int Cin) {
 
 // worst case over both kernels (the slice count of the generic and of the fast plan can differ)
 extern "C" int cvcs_wgrad_slices(int B, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride) {
-  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 32 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout < 16 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CVCS_EINVAL;
   int n = make_plan(B, Ho, Wo, Cout, Cin, KH, KW, stride, 0).nslice;
   if (gemm_shape(KH, KW, stride, Cout, Cin)) {
     const int g = gemm_plan(B, Ho, Wo, Cout, Cin).nslice;
@@ -1054,7 +1057,7 @@ extern "C" int cvcs_wgrad_takes_bias(const cvcs_wgrad_desc* d) {
 static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d);
 
 extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
-  if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 32 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
+  if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout < 16 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return CVCS_EINVAL;
   int64_t n = wgrad_slab_floats(d);
   if (d->dbias && cvcs_wgrad_takes_bias(d)) n += (int64_t)gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice * d->Cout;
   return n;
@@ -1078,7 +1081,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->dtype == CVCS_F32 || d->dtype == CVCS_BF16, "cvcs_conv2d_wgrad: bad dtype");
   const int es = d->dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(d->x && d->dy && d->dw && d->workspace, "cvcs_conv2d_wgrad: null tensor");
-  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 32 == 0, "cvcs_conv2d_wgrad: Cout=%d must be a multiple of 32", d->Cout);
+  CVCS_CHECK_ARG(d->Cout > 0 && d->Cout % 16 == 0, "cvcs_conv2d_wgrad: Cout=%d must be a multiple of 16", d->Cout);
   CVCS_CHECK_ARG(d->Cin > 0 && d->Cin % (16 / es) == 0, "cvcs_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, 16 / es);
   CVCS_CHECK_ARG(d->Cin_real > 0 && d->Cin_real <= d->Cin, "cvcs_conv2d_wgrad: Cin_real");
   const int taps = d->KH * d->KW;

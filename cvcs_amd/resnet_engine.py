@@ -467,12 +467,7 @@ class ResNetUNetEngine:
         # two dy buffers in turn: the weight gradient of unit k (side lane) may still read its dy while unit k + 1 writes the other one
         self._dy_toggle ^= 1
         dyname = u.conv + ".dy" if self.keep_all else ("dy" if not self.overlap_wgrad else f"dy{self._dy_toggle}")
-        thin16 = C_ % 32 != 0      # 16 (or 48) output channels: the weight-gradient kernels take multiples of 32 -> dy lives in a buffer
-        if thin16:                 # whose upper channels stay zero, the weight gradient of the padded rows is dropped (see below)
-            cpad = (C_ + 31) // 32 * 32
-            dy = View(self._zbuf(u.conv + ".dy_pad", (y.B, y.H, y.W, cpad)), 0, C_)
-        else:
-            dy = ops.view(self._scratch(dyname, M * C_, self.dtype).view(y.B, y.H, y.W, C_))
+        dy = ops.view(self._scratch(dyname, M * C_, self.dtype).view(y.B, y.H, y.W, C_))
         if self.keep_all:
             self.bwd_units[u.conv] = dict(unit=u, g=g, mode=mode, dy=dy)
         rec = _lib._recording
@@ -490,13 +485,6 @@ class ResNetUNetEngine:
                 need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
                 ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch(ws_name, need), cin_real=32, virt=True)
                 ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
-            elif thin16:
-                dyp = ops.view(dy.t)                                  # all cpad channels: rows C_.. of the result are zero and dropped
-                gw = self.G[u.conv + ".weight"]
-                tmp = self._scratch("wg_thin", dyp.C * gw[0].numel())
-                need = ops.wgrad_workspace_floats_for(u.x, dyp, u.k, u.k, u.stride, u.pad, dil=u.dil)
-                ops.conv2d_wgrad(u.x, dyp, tmp, u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)
-                ops.colsum_finalize(tmp, 1, gw.numel(), gw)          # (one "row": a device copy of the first C_ output channels)
             else:
                 need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
                 ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)

@@ -71,8 +71,8 @@ def test_wgrad_rejects_unbuilt_filters_and_bad_shapes(lib):
     d.KH = d.KW = 3
     d.pad = 0
     assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"geometry gives 6,6" in lib.cvcs_last_error()
-    d.pad, d.Cout = 1, 48
-    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"Cout=48" in lib.cvcs_last_error()
+    d.pad, d.Cout = 1, 40
+    assert lib.cvcs_conv2d_wgrad(C.byref(d), None) == -1 and b"Cout=40" in lib.cvcs_last_error()
     assert lib.cvcs_wgrad_slices(0, 8, 8, 64, 64, 3, 3, 1) == -1
 
 
