@@ -682,16 +682,29 @@ __global__ __launch_bounds__(256) void thin_head_bwd_kernel(const char* x, int64
     for (int k = 0; k < C; k += 4)
       *reinterpret_cast<float4*>(&sx[tid * XP + k]) = ok ? make_float4(xv[k], xv[k + 1], xv[k + 2], xv[k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t b = ok ? pidx / HW : 0, hw = ok ? pidx - b * HW : 0;
-    for (int c = 0; c < NC; ++c) sd[c * kThinTile + tid] = ok ? dl[(b * NC + c) * HW + hw] : 0.f;
+    // the NC class planes of this pixel: eight loads in flight at a time (a loop of load -> LDS store pays the HBM latency per class)
+    float dlv[kMaxNC];
+#pragma unroll
+    for (int c0 = 0; c0 < kMaxNC; c0 += 8) {
+      if (c0 < NC) {
+#pragma unroll
+        for (int c = c0; c < c0 + 8; ++c) dlv[c] = (ok && c < NC) ? dl[(b * NC + c) * HW + hw] : 0.f;
+#pragma unroll
+        for (int c = c0; c < c0 + 8; ++c)
+          if (c < NC) sd[c * kThinTile + tid] = dlv[c];
+      }
+    }
     __syncthreads();
-    if (ok) {                                     // dx[p][k] = sum_c dl[p][c] w[c][k]
+    if (ok) {                                     // dx[p][k] = sum_c dl[p][c] w[c][k]  (w by wave-uniform scalar loads, dl from registers)
       float o[C];
 #pragma unroll
       for (int k = 0; k < C; ++k) o[k] = 0.f;
-      for (int c = 0; c < NC; ++c) {
-        const float d = sd[c * kThinTile + tid];
 #pragma unroll
-        for (int k = 0; k < C; ++k) o[k] += d * sw[c * C + k];
+      for (int c = 0; c < kMaxNC; ++c) {
+        if (c < NC) {
+#pragma unroll
+          for (int k = 0; k < C; ++k) o[k] += dlv[c] * w[c * C + k];
+        }
       }
 #pragma unroll
       for (int k = 0; k < C / V; ++k) *reinterpret_cast<uint4*>(dx + pidx * dx_ld * ES + k * 16) = Elem<T>::pack(o + k * V);

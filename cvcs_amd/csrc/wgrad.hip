@@ -897,6 +897,156 @@ static bool s2_shape(const cvcs_wgrad_desc* d) {
          d->Cout % 128 == 0 && d->H == 2 * d->Ho && d->W == 2 * d->Wo &&
          (int64_t)d->H * d->W * d->x_ld * 2 < (1ll << 31) && (int64_t)d->Ho * d->Wo * d->dy_ld * 2 < (1ll << 31);
 }
+
+// ===================================================================================================================
+// Thin weight gradient (bf16, 3x3 / stride 1 / pad 1, Cout and Cin in {16, 32}): the light U-Net decoder stages at 256^2 / 512^2 pixels.
+// These layers are HBM-bound (a 16 -> 16 layer at 512^2 x 32 tiles reads 0.54 GB for 39 GFLOP); on the generic kernel above they ran
+// 4-5 x over their HBM floor (64 x 64 channel tiles that are 15/16 padding, 32-pixel K-tiles with a barrier each).  Here:
+//   * a workgroup takes 4 x 64-pixel tiles of one image (grid-stride over all tiles); the dy tile and the 6 x 66-pixel x halo are
+//     staged by LDS-DMA as pixel-major rows of C * 2 bytes (the tensors' own layout: whole 1 KiB pieces are contiguous runs);
+//   * wave w owns tile row w: K = 32 consecutive pixels of the row per MFMA, operands by transposed LDS reads (ds_read_b64_tr_b16 turns
+//     4 pixels x 16 channels into the k-major fragment; a tap is a pixel offset into the halo rows) - one dy fragment pair serves all
+//     nine taps;
+//   * every wave keeps its own [9][Cout][Cin] accumulators over all its tiles and writes ONE partial slab (slice = 4 * workgroup + wave);
+//     the fixed-order reduce kernel above sums the slabs - no atomics, bitwise reproducible.
+// Single-buffered: several workgroups per CU overlap each other's DMA waits (21.5 KB of LDS for 16 / 16 channels, 42 KB for 32 / 32).
+struct ThinWgArgs {
+  const char* x; const char* dy; float* ws;
+  int64_t x_ld, dy_ld;       // elements
+  int B, H, W, Cin, Cout;
+  int tiles_x, tiles_y, ntiles;
+};
+constexpr int kThinTH = 4, kThinTW = 64, kThinHC = kThinTW + 2, kThinHR = kThinTH + 2;
+
+__device__ uint4 g_tzero16;
+
+template <int CO, int CI>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWgArgs p) {
+  constexpr int DYB = kThinTH * kThinTW * CO * 2;                      // bytes of the dy tile
+  constexpr int XPIX = kThinHR * kThinHC;                              // 396 halo pixels
+  constexpr int XB = (XPIX * CI * 2 + 1023) / 1024 * 1024;
+  constexpr int NDY = DYB / 1024, NX = XB / 1024;
+  constexpr int MB = CO / 16, NB = CI / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tpi = p.tiles_x * p.tiles_y;
+  f32x4 acc[9][MB][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane position inside a DMA piece: byte offset 16 * lane of 1 KiB = (pixel, 16-byte chunk) of a pixel-major image
+  constexpr int DPP = 1024 / (CO * 2), DCH = CO * 2 / 16;             // dy pixels per piece, chunks per pixel
+  constexpr int XPP = 1024 / (CI * 2), XCH = CI * 2 / 16;
+  const int dpx = lane / DCH, dch = lane % DCH;
+  const int xpx = lane / XCH, xch = lane % XCH;
+  // fragment addresses: lane (i = fr, g = fg) of a transposed read supplies row q = i >> 2 (a pixel), 8 bytes at channel 4 * (i & 3)
+  const int q = fr >> 2, pp = fr & 3;
+
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    const int b = t / tpi, tr = t - b * tpi;
+    const int ty0 = (tr / p.tiles_x) * kThinTH, tx0 = (tr % p.tiles_x) * kThinTW;
+    // ---- stage the tile (every wave its share of the pieces)
+    for (int pi = wave; pi < NDY; pi += 4) {
+      const int k = pi * DPP + dpx;                                    // tile pixel: row k / 64, column k % 64
+      const int oy = ty0 + (k >> 6), ox = tx0 + (k & 63);
+      const char* src = (oy < p.H && ox < p.W) ? p.dy + ((((int64_t)b * p.H + oy) * p.W + ox) * p.dy_ld) * 2 + dch * 16
+                                               : reinterpret_cast<const char*>(&g_tzero16);
+      dma16(src, lds0 + pi * 1024);
+    }
+    for (int pi = wave; pi < NX; pi += 4) {
+      const int r = pi * XPP + xpx;                                    // halo pixel: row r / 66, column r % 66
+      const int hy = r / kThinHC, hx = r - hy * kThinHC;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      const char* src = (r < XPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                            ? p.x + ((((int64_t)b * p.H + iy) * p.W + ix) * p.x_ld) * 2 + xch * 16
+                            : reinterpret_cast<const char*>(&g_tzero16);
+      dma16(src, lds0 + DYB + pi * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- wave `wave` = tile row `wave`: two K-steps of 32 pixels
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int px0 = wave * kThinTW + ks * 32 + 8 * fg + q;           // dy tile pixel of this lane's first transposed read
+      bf16x8 af[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+        af[i] = tr_pair(smem, px0 * (CO * 2) + i * 32 + pp * 8, (px0 + 4) * (CO * 2) + i * 32 + pp * 8);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int hp = (wave + kh) * kThinHC + ks * 32 + 8 * fg + q + kw;   // halo pixel under tile pixel px0 for this tap
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const bf16x8 bf = tr_pair(smem, DYB + hp * (CI * 2) + j * 32 + pp * 8, DYB + (hp + 4) * (CI * 2) + j * 32 + pp * 8);
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[tap][i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();            // every wave is done with the tile before the next one is staged over it
+  }
+  // ---- this wave's partial slab: ws[slice][tap][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
+  float* ws = p.ws + (int64_t)(blockIdx.x * 4 + wave) * 9 * CO * CI;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[((int64_t)tap * CO + i * 16 + fg * 4 + r) * CI + j * 16 + fr] = acc[tap][i][j][r];
+}
+
+// sum of the thin kernel's S partial slabs ws[s][tap][co][ci] -> dw[co][ci][tap] (OIHW), fixed order: 1024 threads = 16 slice lanes x 64
+// consecutive slab elements (a wave reads 256 contiguous bytes of one slab); slice lane l sums slabs l, l + 16, ... eight loads in
+// flight, then the 16 lanes are added in order.  (The generic reduce kernel above walks the slices with 16 lanes per OUTPUT PAIR: with
+// thousands of slabs of a few thousand elements it took 0.3 ms - 3 x the thin kernel itself.)
+__global__ __launch_bounds__(1024) void wgrad_thin_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int CO, int CI) {
+  __shared__ float sh[16][64];
+  const int n = 9 * CO * CI;
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
+  float a = 0.f;
+  if (e < n) {
+    int s = l;
+    for (; s + 7 * 16 < S; s += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(s + u * 16) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s < S; s += 16) a += ws[(int64_t)s * n + e];
+  }
+  sh[l][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (l == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+    const int ci = e % CI, r = e / CI, co = r % CO, tap = r / CO;
+    dw[((int64_t)co * CI + ci) * 9 + tap] = t;
+  }
+}
+
+static bool thin_wgrad_shape(const cvcs_wgrad_desc* d) {
+  static const int on = getenv("CVCS_WGRAD_THIN") ? atoi(getenv("CVCS_WGRAD_THIN")) : 1;   // tuning knob
+  const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
+  return on && d->dtype == CVCS_BF16 && !special && d->dil <= 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+         (d->Cout == 16 || d->Cout == 32) && (d->Cin == 16 || d->Cin == 32) && d->Cin_real == d->Cin && d->H == d->Ho && d->W == d->Wo &&
+         d->H >= 4 && d->W >= 32;
+}
+static int thin_wgrad_groups(const cvcs_wgrad_desc* d) {
+  const int64_t ntiles = (int64_t)d->B * cdiv(d->H, kThinTH) * cdiv(d->W, kThinTW);
+  return (int)(ntiles < 768 ? ntiles : 768);       // three workgroups per CU
+}
+
 static int fast_path(const cvcs_wgrad_desc* d) {
   if (d->Cout % 64 != 0) return 0;   // a last row tile that is not full: the generic kernel masks it
   static const int force64 = getenv("CVCS_WGRAD_64") ? atoi(getenv("CVCS_WGRAD_64")) : 0;   // tuning knob
@@ -1066,6 +1216,7 @@ extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
 static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d) {
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   int n;
+  if (thin_wgrad_shape(d)) return (int64_t)thin_wgrad_groups(d) * 4 * 9 * d->Cout * d->Cin;
   if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
     const int a = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 1, 0).nslice;
     const int g = gemm_shape(1, 1, 1, d->Cout, d->Cin) ? gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice : 0;
@@ -1103,6 +1254,29 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   const int64_t row_pitch = d->x_row_pitch ? d->x_row_pitch : (int64_t)d->W * d->x_ld;
   const int64_t img_pitch = d->x_img_pitch ? d->x_img_pitch : (int64_t)d->H * row_pitch;
   CVCS_CHECK_ARG(row_pitch * es % 16 == 0 && img_pitch * es % 16 == 0 && row_pitch > 0 && img_pitch >= row_pitch, "cvcs_conv2d_wgrad: pitches of x");
+  if (thin_wgrad_shape(d)) {
+    ThinWgArgs ta;
+    ta.x = (const char*)d->x; ta.dy = (const char*)d->dy; ta.ws = d->workspace; ta.x_ld = d->x_ld; ta.dy_ld = d->dy_ld;
+    ta.B = d->B; ta.H = d->H; ta.W = d->W; ta.Cin = d->Cin; ta.Cout = d->Cout;
+    ta.tiles_x = (int)cdiv(d->W, kThinTW); ta.tiles_y = (int)cdiv(d->H, kThinTH); ta.ntiles = d->B * ta.tiles_x * ta.tiles_y;
+    const int groups = thin_wgrad_groups(d);
+    hipStream_t tst = (hipStream_t)stream;
+#define LAUNCH_THIN(CO_, CI_)                                                                                              \
+  do {                                                                                                                     \
+    const int lds = kThinTH * kThinTW * (CO_) * 2 + (kThinHR * kThinHC * (CI_) * 2 + 1023) / 1024 * 1024;                  \
+    hipLaunchKernelGGL((wgrad_thin_kernel<CO_, CI_>), dim3((unsigned)groups), dim3(256), lds, tst, ta);                    \
+  } while (0)
+    if (d->Cout == 16 && d->Cin == 16) LAUNCH_THIN(16, 16);
+    else if (d->Cout == 16) LAUNCH_THIN(16, 32);
+    else if (d->Cin == 16) LAUNCH_THIN(32, 16);
+    else LAUNCH_THIN(32, 32);
+#undef LAUNCH_THIN
+    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin)");
+    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)cdiv(9 * d->Cout * d->Cin, 64)), dim3(1024), 0, tst, d->workspace, d->dw, groups * 4,
+                       d->Cout, d->Cin);
+    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin reduce)");
+    return CVCS_OK;
+  }
   const int fastp = (aniso || pitched) ? 0 : fast_path(d);
   WgradPlan pl = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, d->KH, d->KW, d->stride, fastp, stride_w);
   CVCS_CHECK_ARG(pl.HR * pl.HC <= (fastp ? 128 : kXRows), "cvcs_conv2d_wgrad: halo tile too large");

@@ -226,6 +226,7 @@ def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1):
         d.x, d.x_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
     d.dy, d.dy_ld, d.Ho, d.Wo, d.Cout = dy.ptr, dy.ld, dy.H, dy.W, dy.C
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.Cin_real = d.Cin         # (conv2d_wgrad overrides it for the zero-padded first layer; the workspace query sees the same value)
     d.dtype = x.code
     return d
 

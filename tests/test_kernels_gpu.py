@@ -294,6 +294,12 @@ WGRAD_CASES = [
     (2, 16, 32, 64, 64, 128, 2, 2, 0),   # stride-2 fast path (ConvTranspose weight gradient): whole 4x8 K-tiles
     (1, 24, 20, 128, 128, 256, 2, 2, 0), # stride-2 fast path: ragged K-tiles (Wo = 10), two Cout x two Cin tiles
     (3, 16, 16, 72, 72, 128, 2, 2, 0),   # stride-2 fast path: Cin not a multiple of 64
+    (2, 32, 64, 16, 16, 16, 3, 1, 1),    # thin kernel (light decoder stages): 16 -> 16, whole 4 x 64 tiles
+    (1, 21, 100, 32, 32, 16, 3, 1, 1),   # thin 32 -> 16, ragged tiles in both directions
+    (2, 16, 72, 32, 32, 32, 3, 1, 1),    # thin 32 -> 32
+    (1, 12, 40, 16, 16, 32, 3, 1, 1),    # thin 16 -> 32
+    (2, 8, 24, 128, 128, 32, 3, 1, 1),   # Cout = 32 on the generic kernel (masked row tile, skipped zero blocks), narrow map
+    (1, 16, 16, 64, 64, 16, 3, 1, 1),    # Cout = 16 on the generic kernel
 ]
 
 
@@ -309,9 +315,10 @@ def test_wgrad_matches_autograd(case, dtype):
     gy = rq(torch.randn(B, Cout, Ho, Wo, generator=g), dtype)
     w = torch.zeros(Cout, Cin_real, K, K, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.double(), w, None, stride=stride, padding=pad).backward(gy.double())
-    ws = torch.empty(ops.wgrad_workspace_floats(B, Ho, Wo, Cout, Cin, K, K, stride), device=DEV)
+    xv, gv = ops.view(to_nhwc(x, dtype, Cin)), ops.view(to_nhwc(gy, dtype))
+    ws = torch.empty(max(ops.wgrad_workspace_floats(B, Ho, Wo, Cout, Cin, K, K, stride), ops.wgrad_workspace_floats_for(xv, gv, K, K, stride, pad)), device=DEV)
     dw = torch.empty(Cout, Cin_real, K, K, device=DEV)
-    ops.conv2d_wgrad(ops.view(to_nhwc(x, dtype, Cin)), ops.view(to_nhwc(gy, dtype)), dw, K, K, stride, pad, ws, cin_real=Cin_real)
+    ops.conv2d_wgrad(xv, gv, dw, K, K, stride, pad, ws, cin_real=Cin_real)
     torch.cuda.synchronize()
     close(dw.cpu(), w.grad.float(), 1e-4 if dtype == torch.float32 else 1e-3, "dW")  # exact products, f32 sums
 
