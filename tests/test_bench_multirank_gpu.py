@@ -29,6 +29,6 @@ def test_bench_two_ranks_prints_one_aggregate_line():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "tiles/s"
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] == pytest.approx(2 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-3)   # whole-job tiles / max-over-ranks time
-    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
+    assert d["roofline"]["bound"] in ("mfma", "hbm") and d["roofline"]["achieved"] > 0      # the family with the largest time, whatever bounds it
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
     assert d["loss"] == d["loss"]           # finite
