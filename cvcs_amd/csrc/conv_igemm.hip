@@ -1305,6 +1305,146 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
   }
 }
 
+
+// ===================================================================================================================
+// Thin 3x3 convolution (bf16, stride 1 / pad 1, Cin and Cout in {16, 32}): the light U-Net decoder stages at 256^2 / 512^2 pixels and
+// their data gradients.  HBM-bound layers (16 -> 16 at 512^2 x 32 tiles: 0.54 GB for 39 GFLOP) that ran at a third of their HBM floor
+// as masked 64-channel tiles of the halo kernel.  A workgroup walks 4 x 64-pixel tiles (grid-stride); the 6 x 66-pixel halo of a tile is
+// staged by LDS-DMA as pixel-major rows in the tensor's own layout; the nine weight fragments of every 16-channel block live in
+// REGISTERS for the whole kernel (A operand = weights [co][32 K], a 16-channel input contracts over a half-empty K: the matrix cores are
+// idle anyway); wave w owns tile row w, 16 pixels per MFMA column block, and stores four consecutive channels per lane.  BatchNorm
+// partial statistics: one row per wave (64 pixels), sum and M2 centred on the row's own mean, from the f32 accumulators.
+struct ThinConvArgs {
+  const char* in; const char* wt; char* out;
+  const float* bias; const float* pre_scale; const float* pre_shift;
+  float* stat_sum; float* stat_m2; float* stat_cnt;
+  int64_t in_ld, out_ld;
+  int B, H, W, Cin, Cout, relu;
+  int tiles_x, tiles_y, ntiles;
+};
+constexpr int kTcTH = 4, kTcTW = 64, kTcHC = kTcTW + 2, kTcHR = kTcTH + 2;
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
+  constexpr int XPIX = kTcHR * kTcHC;
+  constexpr int XB = (XPIX * CI * 2 + 1023) / 1024 * 1024, NX = XB / 1024;
+  constexpr int XPP = 1024 / (CI * 2), XCH = CI * 2 / 16;             // halo pixels per DMA piece, 16-byte chunks per pixel
+  constexpr int MB = CO / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tpi = p.tiles_x * p.tiles_y;
+  // weight fragments: wt is [9][CO][32] (rows of one 64-byte K-group; channels CI.. are zero), lane (co = fr, k-group fg) takes 16 bytes
+  bf16x8 wf[9][MB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+      wf[t][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p.wt + ((int64_t)(t * CO + i * 16 + fr) * 32 + fg * 8) * 2));
+  f32x4 sc[MB], sh[MB], b0[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    b0[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + i * 16 + fg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sc[i] = p.pre_scale ? *reinterpret_cast<const f32x4*>(p.pre_scale + i * 16 + fg * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    sh[i] = p.pre_scale ? *reinterpret_cast<const f32x4*>(p.pre_shift + i * 16 + fg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float lo = p.relu ? 0.f : -INFINITY;
+  const int xpx = lane / XCH, xch = lane % XCH;
+  const bool kvalid = fg * 16 < CI * 2;            // this lane's 16 bytes of K exist in the input (a 16-channel input fills k-groups 0, 1)
+
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    const int b = t / tpi, tr = t - b * tpi;
+    const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
+    for (int pi = wave; pi < NX; pi += 4) {
+      const int r = pi * XPP + xpx;
+      const int hy = r / kTcHC, hx = r - hy * kTcHC;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      const char* src = (r < XPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                            ? p.in + ((((int64_t)b * p.H + iy) * p.W + ix) * p.in_ld) * 2 + xch * 16
+                            : reinterpret_cast<const char*>(&g_zero16);
+      dma16(src, lds0 + pi * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const int y = ty0 + wave;
+    f32x4 acc[4][MB];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[g][i] = b0[i];      // the accumulators start at the bias
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int hp = (wave + kh) * kTcHC + g * 16 + fr + kw;
+        uint4 xv = make_uint4(0u, 0u, 0u, 0u);
+        if (kvalid) xv = *reinterpret_cast<const uint4*>(smem + hp * (CI * 2) + fg * 16);
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, xv);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][i], bfr, acc[g][i], 0, 0, 0);   // D[co][pixel]
+      }
+    }
+    // ---- statistics of this wave's row (the conv output before any fold), then the stores
+    if (p.stat_sum) {
+      const int nvalid = y < p.H ? (p.W - tx0 < kTcTW ? p.W - tx0 : kTcTW) : 0;
+      const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
+      const int64_t srow = (int64_t)t * kTcTH + wave;
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) s += (g * 16 + fr < nvalid) ? acc[g][i][r] : 0.f;
+          s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+          const float mean = s * inv;
+          float q = 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float dlt = acc[g][i][r] - mean;
+            q += (g * 16 + fr < nvalid) ? dlt * dlt : 0.f;
+          }
+          q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+          if (fr == 0) {
+            p.stat_sum[srow * CO + i * 16 + fg * 4 + r] = s;
+            p.stat_m2[srow * CO + i * 16 + fg * 4 + r] = q;
+          }
+        }
+      if (lane == 0) p.stat_cnt[srow] = (float)nvalid;
+    }
+    if (y < p.H) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int x = tx0 + g * 16 + fr;
+        if (x < p.W) {
+          char* dst = p.out + ((((int64_t)b * p.H + y) * p.W + x) * p.out_ld) * 2;
+#pragma unroll
+          for (int i = 0; i < MB; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[g][i][r] * sc[i][r] + sh[i][r], lo);
+            uint2 u;
+            u.x = pack2_bf16(v[0], v[1]);
+            u.y = pack2_bf16(v[2], v[3]);
+            *reinterpret_cast<uint2*>(dst + (i * 16 + fg * 4) * 2) = u;
+          }
+        }
+      }
+    }
+    __syncthreads();            // the halo is free again
+  }
+}
+
+static bool thin_conv_shape(const cvcs_conv_desc* d) {
+  static const int on = getenv("CVCS_CONV_THIN") ? atoi(getenv("CVCS_CONV_THIN")) : 1;   // tuning knob
+  const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
+  return on && d->dtype == CVCS_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle &&
+         !d->aniso && !d->in_row_pitch && !d->in_img_pitch && d->Cin == 32 && (cin_valid == 16 || cin_valid == 32) &&
+         (d->Cout == 16 || d->Cout == 32) && d->H >= 4 && d->W >= 16 && !d->post_scale && !d->pool_out && !d->bwd_y;
+}
+
 template <int TAPS>
 static int launch_taps(const ConvArgs& a, hipStream_t st) {
   const size_t lds = 3 * (size_t)(256 * 64 + 128 * 64);   // the ring; the staged output tile (256 x 272 B) aliases it
@@ -1386,6 +1526,7 @@ static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 1 :
 
 extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
+  if (thin_conv_shape(d)) return d->B * (int)cdiv(d->H, kTcTH) * (int)cdiv(d->W, kTcTW) * kTcTH;      // one row per wave = tile row
   if (use_halo(d) && !d->aniso && !d->in_row_pitch && !d->in_img_pitch)
     return d->B * (int)cdiv(d->H, 16) * (int)cdiv(d->W, 16) * halo_wm(d);
   // (the statistics pointers of the descriptor are not set by every caller of this query: the row count is that of the
@@ -1474,6 +1615,25 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.relu = d->relu; a.pixel_shuffle = d->pixel_shuffle; a.M = (int)M;
   a.stride_w = stride_w; a.pad_w = pad_w; a.in_row_pitch = row_pitch; a.in_img_pitch = img_pitch;
   hipStream_t st = (hipStream_t)stream;
+  if (thin_conv_shape(d)) {
+    ThinConvArgs ta;
+    ta.in = (const char*)d->in; ta.wt = (const char*)d->wt; ta.out = (char*)d->out;
+    ta.bias = d->bias; ta.pre_scale = d->pre_scale; ta.pre_shift = d->pre_shift;
+    ta.stat_sum = d->stat_sum; ta.stat_m2 = d->stat_m2; ta.stat_cnt = d->stat_cnt;
+    ta.in_ld = d->in_ld; ta.out_ld = d->out_ld;
+    ta.B = d->B; ta.H = d->H; ta.W = d->W; ta.Cin = cin_valid; ta.Cout = d->Cout; ta.relu = d->relu;
+    ta.tiles_x = (int)cdiv(d->W, kTcTW); ta.tiles_y = (int)cdiv(d->H, kTcTH); ta.ntiles = d->B * ta.tiles_x * ta.tiles_y;
+    const int groups = ta.ntiles < 1024 ? ta.ntiles : 1024;
+#define LAUNCH_TC(CI_, CO_)                                                                                              \
+  hipLaunchKernelGGL((conv3x3_thin_kernel<CI_, CO_>), dim3((unsigned)groups), dim3(256), (kTcHR * kTcHC * (CI_) * 2 + 1023) / 1024 * 1024, st, ta)
+    if (cin_valid == 16 && d->Cout == 16) LAUNCH_TC(16, 16);
+    else if (cin_valid == 16) LAUNCH_TC(16, 32);
+    else if (d->Cout == 16) LAUNCH_TC(32, 16);
+    else LAUNCH_TC(32, 32);
+#undef LAUNCH_TC
+    CVCS_CHECK_LAUNCH("cvcs_conv2d(thin)");
+    return CVCS_OK;
+  }
   const bool plain = !aniso && !pitched && !ragged_n;   // the specialised kernels assume the isotropic, densely packed case
   if (plain && use_halo(d)) {
     static const int narrow_cin = getenv("CVCS_HALO_NARROW_CIN") ? atoi(getenv("CVCS_HALO_NARROW_CIN")) : 64;   // tuning knob

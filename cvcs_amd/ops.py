@@ -144,7 +144,8 @@ class _Shape:
 
 def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None) -> int:
     """number of partial-statistics rows cvcs_conv2d writes for this geometry"""
-    d, _, _, _ = _conv_desc(x, _Shape(KH * KW, Cout, 32 if virt else x.C), None, None, KH, KW, stride, pad, dil, False, False, None,
+    # (the weight image's contraction axis is at least one K-group wide: a 16-channel bf16 input runs under a zero-padded 32-channel K-group)
+    d, _, _, _ = _conv_desc(x, _Shape(KH * KW, Cout, 32 if virt else max(x.C, KGROUP[x.code])), None, None, KH, KW, stride, pad, dil, False, False, None,
                             virt=virt)
     n = _lib.lib().cvcs_conv_stat_rows(C.byref(d))
     if n < 0:

@@ -58,6 +58,9 @@ CONV_CASES = [
     (2, 32, 32, 128, 32, 3, 1, 1, 1, False),   # thin output (light decoder stage 128 -> 32): masked 64-channel tile of the halo kernel
     (1, 24, 40, 32, 16, 3, 1, 1, 1, True),     # thin 32 -> 16, ragged tiles
     (2, 16, 16, 64, 48, 3, 1, 1, 1, False),    # 48 channels (the DeepLabV3+ paper's low-level width)
+    (2, 32, 64, 16, 16, 3, 1, 1, 1, False),    # thin kernel 16 -> 16, whole 4 x 64 tiles
+    (1, 21, 100, 16, 32, 3, 1, 1, 1, True),    # thin 16 -> 32, ragged tiles both ways, ReLU
+    (2, 18, 40, 32, 32, 3, 1, 1, 1, False),    # thin 32 -> 32
 ]
 
 
@@ -75,7 +78,7 @@ def test_conv2d_matches_aten(case, dtype):
         ref = ref.relu()
     ref = ref.float()
     xd = to_nhwc(x, dtype)
-    wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype, want_dgrad=False)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), max(Cin, ops.KGROUP[ops.dtype_code(dtype)]), dtype, want_dgrad=False)
     Ho, Wo = ops.conv_out_hw(H, W, K, K, stride, pad, dil)
     out = torch.full((B, Ho, Wo, Cout + 64), 7.0, dtype=dtype, device=DEV)  # wider buffer: checks ld / channel offset
     M = B * Ho * Wo
