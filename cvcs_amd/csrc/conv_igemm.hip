@@ -1386,7 +1386,14 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
         for (int i = 0; i < MB; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][i], bfr, acc[g][i], 0, 0, 0);   // D[co][pixel]
       }
     }
-    // ---- statistics of this wave's row (the conv output before any fold), then the stores
+    // ---- output transform in place (eval-mode fold / ReLU; train-mode launches carry neither), statistics of the values written,
+    //      then the stores
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[g][i][r] = fmaxf(acc[g][i][r] * sc[i][r] + sh[i][r], lo);
     if (p.stat_sum) {
       const int nvalid = y < p.H ? (p.W - tx0 < kTcTW ? p.W - tx0 : kTcTW) : 0;
       const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
@@ -1422,12 +1429,9 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
           char* dst = p.out + ((((int64_t)b * p.H + y) * p.W + x) * p.out_ld) * 2;
 #pragma unroll
           for (int i = 0; i < MB; ++i) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[g][i][r] * sc[i][r] + sh[i][r], lo);
             uint2 u;
-            u.x = pack2_bf16(v[0], v[1]);
-            u.y = pack2_bf16(v[2], v[3]);
+            u.x = pack2_bf16(acc[g][i][0], acc[g][i][1]);
+            u.y = pack2_bf16(acc[g][i][2], acc[g][i][3]);
             *reinterpret_cast<uint2*>(dst + (i * 16 + fg * 4) * 2) = u;
           }
         }

@@ -193,6 +193,9 @@ def _exact_train(name, img, lab, wrap):
     return losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
 
 
+S_EXACT = 128      # (at 64 x 64 the last ResNet stage is a 2 x 2 map: its BatchNorms average 16 values and amplify summation-order noise to percents)
+
+
 def _exact_worker(rank, world, port, path, name):
     import torch.distributed as dist
     from oracle import unet_oracle as O
@@ -201,7 +204,7 @@ def _exact_worker(rank, world, port, path, name):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        img, lab = O.synthetic_tiles(B, S, NC, seed=23, structured=True)
+        img, lab = O.synthetic_tiles(B, S_EXACT, NC, seed=23, structured=True)
         lo, hi = shard_batch(B, rank, world)
         losses, sd = _exact_train(name, img[lo:hi], lab[lo:hi], lambda n, o, c: DataParallel(n, o, bucket_mb=8.0, exact=True, criterion=c))
         torch.save({"losses": losses, "sd": sd}, f"{path}/rank{rank}.pt")
@@ -219,24 +222,28 @@ def test_exact_mode_on_the_launch_plan_engines_two_ranks_equal_one_process_on_th
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_exact_worker, args=(2, _free_port(), tmp, name), nprocs=2, join=True)
         r0, r1 = (torch.load(f"{tmp}/rank{r}.pt") for r in range(2))
-    img, lab = O.synthetic_tiles(B, S, NC, seed=23, structured=True)
+    img, lab = O.synthetic_tiles(B, S_EXACT, NC, seed=23, structured=True)
     losses, sd = _exact_train(name, img, lab, None)
     assert r0["losses"] == pytest.approx(r1["losses"], rel=1e-6)
     for k in sd:
         assert torch.allclose(r0["sd"][k].float(), r1["sd"][k].float(), rtol=1e-6, atol=1e-7), k
-    # (steps 0 and 1 agree to 1e-6: the exchange is exact; the third loss sits behind two optimiser steps of a 50-layer network, which
-    #  amplify the summation-order differences of the first - measured 2.6e-4 on ResNet50-UNet)
-    assert r0["losses"][:2] == pytest.approx(losses[:2], rel=2e-5) and r0["losses"] == pytest.approx(losses, rel=1e-3), (r0["losses"], losses)
-    rows = []
+    # Yardstick for "up to summation order": the SAME single-process run with the four tiles in reverse order - mathematically the same
+    # step (BatchNorm and the loss mean are permutation-invariant), a different floating-point summation order.  Three SGD2 steps of a
+    # 50-layer network with BatchNorms over 64-value maps turn that into percent-level differences of the deepest running means and
+    # of near-zero BatchNorm biases; the sharded run may not be further from the single-process one than a few times that.
+    losses_perm, sd_perm = _exact_train(name, img.flip(0), lab.flip(0), None)
+    print(f"{name} losses: sharded {r0['losses']} | single {losses} | single, tiles reversed {losses_perm}")
+    assert r0["losses"][0] == pytest.approx(losses[0], rel=2e-5)                 # the first step is a pure function of the inputs
+    for a, b, c in zip(r0["losses"], losses, losses_perm):
+        assert abs(a - b) <= 4.0 * abs(c - b) + 2e-5 * abs(b), (r0["losses"], losses, losses_perm)
+    worst = (0.0, "")
     for k, v in sd.items():
         if v.dtype != torch.float32:
             continue
-        diff = r0["sd"][k] - v
-        rows.append((diff.norm().item() / (v.norm().item() + 1e-12), diff.abs().max().item(), k))
-    rows.sort(reverse=True)
-    for r in rows[:5]:
-        print("rel %.2e  absmax %.2e  %s" % r)
-    bad = [r for r in rows if not (r[0] < 1e-2 or r[1] < 2e-4)]      # (three steps of a 50-layer network amplify summation-order differences:
-    assert not bad, bad[:6]                                           #  the exactness of the exchange shows in the first two losses above)
-    # and WITHOUT the exchange the two differ visibly (the test would otherwise pass for the wrong reason): per-rank statistics of 2 tiles
-    assert losses[0] == losses[0]
+        noise = (sd_perm[k] - v).abs().max().item()
+        diff = (r0["sd"][k] - v).abs().max().item()
+        rel = diff / (v.abs().max().item() + 1e-12)
+        ok = diff <= 4.0 * noise + 1e-6 or rel < 2e-4
+        worst = max(worst, (diff / (noise + 1e-12) if not rel < 2e-4 else 0.0, k))
+        assert ok, (k, diff, noise, rel)
+    print(f"{name}: largest (sharded - single) / (permuted - single) parameter difference ratio {worst[0]:.2f} ({worst[1]})")

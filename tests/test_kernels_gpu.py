@@ -61,6 +61,8 @@ CONV_CASES = [
     (2, 32, 64, 16, 16, 3, 1, 1, 1, False),    # thin kernel 16 -> 16, whole 4 x 64 tiles
     (1, 21, 100, 16, 32, 3, 1, 1, 1, True),    # thin 16 -> 32, ragged tiles both ways, ReLU
     (2, 18, 40, 32, 32, 3, 1, 1, 1, False),    # thin 32 -> 32
+    (4, 128, 128, 32, 16, 3, 1, 1, 1, False),  # thin, > 1024 partial-statistics rows: the two-stage BatchNorm merge with C = 16
+    (4, 128, 128, 128, 32, 3, 1, 1, 1, False), # masked halo tile, two-stage merge with C = 32
 ]
 
 
