@@ -233,13 +233,15 @@ struct BnBwdArgs {
 
 // One work item = one pixel (POOL=false) or one 2x2 window (POOL=true) x one 16-byte channel chunk.
 // APPLY=false: accumulate sum(dz), sum(dz*xhat).  APPLY=true: write dy, accumulate sum(dy).
+constexpr int kBnBwdChunks = 32;
 template <typename T, bool POOL, bool APPLY>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   constexpr int ES = sizeof(T), V = 16 / ES;
   constexpr int NPIX = POOL ? 4 : 1;
   __shared__ float red[2][256 * V];
   const int CC = p.C / V;
-  const int ccw = CC < 256 ? CC : 256;      // chunk lanes per workgroup
+  const int ccw = CC < kBnBwdChunks ? CC : kBnBwdChunks;   // chunk lanes per workgroup (a 512-byte slab of a pixel at most: wide layers
+                                                           // spread over blockIdx.y, so that small maps still fill the chip)
   const int PL = 256 / ccw;                 // pixel lanes per workgroup
   const int tid = threadIdx.x;
   const int cl = tid % ccw, pl = tid / ccw;
@@ -258,7 +260,52 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   float am = 0.f;
   const float q_inv = (APPLY && p.q8.q) ? p.q8.slot[2] : 0.f, q_fmax = (APPLY && p.q8.q) ? p.q8.slot[3] : 0.f;
 
-  for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < items; it += (int64_t)gridDim.x * PL) {
+  // U independent work items per trip: all their 16-byte loads are issued before the first use (a single item in flight per
+  // thread left the small layers latency-bound: 0.8-3 TB/s)
+  constexpr int U = POOL ? 1 : 4;
+  const int64_t step = (int64_t)gridDim.x * PL;
+  int64_t it = (int64_t)blockIdx.x * PL + pl;
+  if constexpr (!POOL) {
+    for (; it + (U - 1) * step < items; it += U * step) {
+      uint4 yr[U], gr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t px = it + u * step;
+        yr[u] = *reinterpret_cast<const uint4*>(p.y + (px * p.y_ld) * ES + cc * 16);
+        gr[u] = *reinterpret_cast<const uint4*>(p.g1 + (px * p.g1_ld) * ES + cc * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t px = it + u * step;
+        float yv[V], gv[V], out[V];
+        Elem<T>::unpack(yr[u], yv);
+        Elem<T>::unpack(gr[u], gv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float xh = (yv[k] - mu[k]) * is[k];
+          float dz = gv[k];
+          if (p.mode == 0) dz = (yv[k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;
+          if constexpr (!APPLY) {
+            s0[k] += dz;
+            s1[k] += dz * xh;
+          } else {
+            float d = sc[k] * (dz - ca[k] - xh * cb[k]);
+            if (p.mode == 1) d = (yv[k] > 0.f) ? d : 0.f;
+            out[k] = d;
+            s0[k] += d;
+          }
+        }
+        if constexpr (APPLY) {
+          const uint4 pk = Elem<T>::pack(out);
+          *reinterpret_cast<uint4*>(p.dy + (px * p.dy_ld) * ES + cc * 16) = pk;
+          if constexpr (ES == 2) {
+            if (p.q8.q) *reinterpret_cast<uint2*>(p.q8.q + px * p.q8.ld + cc * 8) = q8_pack8(pk, q_inv, q_fmax, p.q8.fmt, am);
+          }
+        }
+      }
+    }
+  }
+  for (; it < items; it += step) {
     int64_t pix[NPIX];
     if constexpr (POOL) {
       const int W2 = p.W / 2, H2 = p.H / 2;
@@ -307,13 +354,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
           s0[k] += dz;
           s1[k] += dz * xh;
         } else {
-#ifdef CVCS_PROBE_BN_COPY   // scripts/bn_probe.py ablation: the same traffic with (almost) no arithmetic
-          float d = gv[w][k] + yv[w][k];
-          (void)xh; (void)dz;
-#else
           float d = sc[k] * (dz - ca[k] - xh * cb[k]);
           if (p.mode == 1) d = (yv[w][k] > 0.f) ? d : 0.f;                  // decoder: ReLU before BN
-#endif
           out[k] = d;
           s0[k] += d;
         }
@@ -774,7 +816,7 @@ static int bn_act_impl(const void* y, int64_t y_ld, int B, int H, int W, int C, 
 
 extern "C" int cvcs_bn_bwd_rows(int64_t M) {
   static const int cap = getenv("CVCS_BN_BWD_ROWS") ? atoi(getenv("CVCS_BN_BWD_ROWS")) : 1024;   // tuning knob: workgroups (= partial rows)
-  int64_t r = cdiv(M, 256);
+  int64_t r = cdiv(M, 64);       // >= 64 pixels per workgroup row; maps of 16^2 x 32 tiles still get 128 rows x C/256 slabs
   return (int)(r < 1 ? 1 : (r > cap ? cap : r));
 }
 
@@ -803,7 +845,7 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   CVCS_CHECK_ARG(scale && shift && mean && invstd && part0 && (apply ? (ca && cb) : part1 != nullptr), "%s: null argument", fn);
   BnBwdArgs a{(const char*)y, (const char*)g1, (const char*)g2, (char*)dy, y_ld, g1_ld, g2_ld, dy_ld, scale, shift, mean,
               invstd, ca, cb, part0, part1, B, H, W, C, mode, q8};
-  const int ccw = CC < 256 ? CC : 256;
+  const int ccw = CC < kBnBwdChunks ? CC : kBnBwdChunks;
   dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)B * H * W), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BNB(TT)                                                                                      \

@@ -799,9 +799,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const int ci = (int)(id % Cin_real);
       const int co = (int)(id / Cin_real);
       const float* src = ws + (int64_t)co * Cin + ci;
-      for (int k = kg; k < nslice; k += KS) {
+      // four slices' loads in flight per thread (a single slice per trip left the reduce latency-bound: 0.5 TB/s over the
+      // 512 partial slabs of a 64 x 64 layer); summed in slice order all the same
+      constexpr int UK = TAPS > 1 ? 4 : 8;
+      int k = kg;
+      for (; k + (UK - 1) * KS < nslice; k += UK * KS) {
+        float v[UK][TAPS];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) s[t] += src[k * slice_stride + t * tap_stride];
+        for (int u = 0; u < UK; ++u) {
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) v[u][t] = src[(int64_t)(k + u * KS) * slice_stride + t * tap_stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) s[t] += v[u][t];
+        }
+      }
+      for (; k < nslice; k += KS) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) s[t] += src[(int64_t)k * slice_stride + t * tap_stride];
       }
     }
     if constexpr (KS > 1) {

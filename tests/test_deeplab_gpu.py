@@ -216,7 +216,9 @@ def test_reference_checkpoint_key_names_of_the_deeplabv3_wrappers(tmp_path):
     torch.save(ck, path)
     other = utils.load_network({"net": "Resnet101", "num_classes": 15, "precision": "bf16"}, DEV)
     utils.load_checkpoint({"load_checkpoint": path}, other)
-    assert all((v == 0.25).all() for k, v in other.state_dict().items() if v.dtype == torch.float32)
+    out = other.state_dict()
+    assert all((v == 0.25).all() for k, v in out.items() if v.dtype == torch.float32 and "aux_classifier" not in k)
+    assert (out["model.aux_classifier.4.weight"] == 0).all()          # the unused auxiliary head travels with the checkpoint
 
 
 def _f64_gradients(arch, p32, img, lab, os_, plus, relu_masks):

@@ -159,8 +159,8 @@ def test_host_only_c_abi_sizing_functions():
         assert 1 <= n <= 32 * S * S // 32
         if Cin * Cout >= 512 * 512:
             assert n <= 8
-    assert lib.cvcs_wgrad_slices(0, 8, 8, 64, 64, 3, 3, 1) < 0 and lib.cvcs_wgrad_slices(1, 8, 8, 16, 64, 3, 3, 1) < 0
+    assert lib.cvcs_wgrad_slices(0, 8, 8, 64, 64, 3, 3, 1) < 0 and lib.cvcs_wgrad_slices(1, 8, 8, 8, 64, 3, 3, 1) < 0
     for M in (1, 255, 256, 257, 1 << 23):
-        assert lib.cvcs_bn_bwd_rows(M) == min(1024, max(1, -(-M // 256)))
+        assert lib.cvcs_bn_bwd_rows(M) == min(1024, max(1, -(-M // 64)))
         assert lib.cvcs_head_bwd_rows(M) == min(1024, max(1, -(-M // 64)))
         assert lib.cvcs_ce_workspace_floats(M) == 2 + 2 * min(4096, max(1, -(-M // 1024)))
