@@ -1,0 +1,893 @@
+// Kernels of the reference's `SegformerMod` (/root/reference/source/scripts/nets.py:313-349: transformers' Mix-Transformer segmentation
+// model + the reference's ConvTranspose tail) that the ResNet / Swin kernels do not cover.  gfx950 only.
+//
+//   * patch matrices: every convolution of this model whose filter is neither 1x1 nor 3x3 / stride 1 (the 7x7 / stride 4 and 3x3 / stride 2
+//     overlapping patch embeddings, the k = s = 8 | 4 | 2 sequence-reduction convolutions, the two ConvTranspose2d of the tail taken phase
+//     by phase) is ONE gather of its patches into rows (`cvcs_im2col`, zero-padded to a K-group) followed by the GEMM kernels of the 1x1
+//     convolutions; `cvcs_col2im` is the transposed gather (data gradient).  These layers work on 3 ... 320 channels at 1/4 ... 1/32 of
+//     the tile (and on NC <= 32 channels in the tail): HBM-bound byte shuffling, no case for a dedicated MFMA pipeline each.
+//   * depthwise 3x3 of the Mix-FFN (forward, data gradient = the same kernel on the flipped filter, weight + bias gradient partial rows);
+//   * spatial-reduction attention: N queries x Nk = N / sr^2 keys per image and head, head dimension 32 (forward with the log-sum-exp
+//     saved; backward recomputes the probabilities: a query-major kernel for dQ, a key-major kernel for dK / dV partials, fixed-order sum);
+//   * DropPath as a per-sample scale (counter-based, replayable on the host) fused into the residual add;
+//   * table-driven weight gather: f32 master tensors in the reference's layouts -> the GEMM operands of the patch-matrix layers.
+#include "common.h"
+
+namespace cvcs {
+
+#define SF_DT(dt) ((dt) == CVCS_F32 || (dt) == CVCS_BF16)
+
+static int sf_view(const char* fn, const void* p, int64_t ld, int C, int es) {
+  CVCS_CHECK_ARG(p != nullptr, "%s: null tensor", fn);
+  CVCS_CHECK_ARG(ld >= C && (ld * es) % 16 == 0 && ((uintptr_t)p % 16) == 0, "%s: view (ld=%lld, C=%d) must be 16-byte aligned", fn, (long long)ld, C);
+  return CVCS_OK;
+}
+static inline unsigned sf_grid(int64_t items, int cap = 256 * 32) {
+  int64_t g = cdiv(items, 256);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------------ patch gather / scatter
+// col[b, oy, ox, (ky*KW + kx)*C + c] = in[b, oy*s + oy0 + ky*dir, ox*s + ox0 + kx*dir, c]   (0 outside the map, 0 in the K padding)
+// a convolution: oy0 = ox0 = -pad, dir = +1; phase (a, b) of a stride-2 ConvTranspose2d(k, p): s = 1, dir = -1, oy0 = (a + p) >> 1
+struct ColArgs {
+  const char* in; char* col;
+  int64_t in_ld, col_ld;
+  int B, H, W, C, Ho, Wo, KH, KW, s, oy0, ox0, dir;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(ColArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int cpt = p.C / V;                                   // chunks per tap
+  const int cpr = (int)(p.col_ld / V);                       // chunks per row (K padding included)
+  const int64_t total = (int64_t)p.B * p.Ho * p.Wo * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(id % cpr);
+    const int64_t pix = id / cpr;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    const int tap = ch / cpt;
+    if (tap < p.KH * p.KW) {
+      const int cc = ch - tap * cpt;
+      const int ox = (int)(pix % p.Wo);
+      const int64_t t = pix / p.Wo;
+      const int oy = (int)(t % p.Ho);
+      const int64_t b = t / p.Ho;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const int iy = oy * p.s + p.oy0 + ky * p.dir, ix = ox * p.s + p.ox0 + kx * p.dir;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4*>(p.in + (((b * p.H + iy) * p.W + ix) * p.in_ld) * ES + cc * 16);
+    }
+    *reinterpret_cast<uint4*>(p.col + (pix * p.col_ld) * ES + ch * 16) = v;
+  }
+}
+
+// the first patch embedding reads the tile itself: planar u8 / f32 [B,3,H,W], normalised as nets.py:337-340 does ((x - mean) / std on the
+// raw 0..255 scale, f32 division), K index (ky*KW + kx)*3 + c
+struct StemColArgs {
+  const void* src; char* col;
+  int64_t col_ld;
+  int B, H, W, Ho, Wo, KH, KW, s, pad, is_u8;
+  float mean[3], std[3];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(StemColArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int cpr = (int)(p.col_ld / V);
+  const int K = p.KH * p.KW * 3;
+  const int64_t total = (int64_t)p.B * p.Ho * p.Wo * cpr;
+  const int64_t plane = (int64_t)p.H * p.W;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(id % cpr);
+    const int64_t pix = id / cpr;
+    const int ox = (int)(pix % p.Wo);
+    const int64_t t = pix / p.Wo;
+    const int oy = (int)(t % p.Ho);
+    const int64_t b = t / p.Ho;
+    float f[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int kk = ch * V + k;
+      float v = 0.f;
+      if (kk < K) {
+        const int c = kk % 3, tap = kk / 3;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int iy = oy * p.s - p.pad + ky, ix = ox * p.s - p.pad + kx;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          const int64_t o = (b * 3 + c) * plane + (int64_t)iy * p.W + ix;
+          const float x = p.is_u8 ? (float)reinterpret_cast<const uint8_t*>(p.src)[o] : reinterpret_cast<const float*>(p.src)[o];
+          v = (x - p.mean[c]) / p.std[c];
+        }
+      }
+      f[k] = v;
+    }
+    *reinterpret_cast<uint4*>(p.col + (pix * p.col_ld) * ES + ch * 16) = Elem<T>::pack(f);
+  }
+}
+
+// dx[b, iy, ix, c] = sum over phases and taps of col_ph[b, oy, ox, tap*C + c] with oy*s + oy0[ph] + ky*dir == iy (f32 sum, fixed order)
+struct Col2imArgs {
+  const char* col; char* dx;
+  int64_t col_ld, dx_ld, phase_bytes;
+  int B, H, W, C, Ho, Wo, KH, KW, s, dir, nph;
+  int oy0[4], ox0[4];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(Col2imArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int cpt = p.C / V;
+  const int64_t total = (int64_t)p.B * p.H * p.W * cpt;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % cpt);
+    const int64_t pix = id / cpt;
+    const int ix = (int)(pix % p.W);
+    const int64_t t = pix / p.W;
+    const int iy = (int)(t % p.H);
+    const int64_t b = t / p.H;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int ph = 0; ph < p.nph; ++ph) {
+      const char* col = p.col + ph * p.phase_bytes;
+      for (int ky = 0; ky < p.KH; ++ky) {
+        const int ny = iy - p.oy0[ph] - ky * p.dir;
+        if (ny < 0 || ny % p.s) continue;
+        const int oy = ny / p.s;
+        if (oy >= p.Ho) continue;
+        for (int kx = 0; kx < p.KW; ++kx) {
+          const int nx = ix - p.ox0[ph] - kx * p.dir;
+          if (nx < 0 || nx % p.s) continue;
+          const int ox = nx / p.s;
+          if (ox >= p.Wo) continue;
+          float f[V];
+          Elem<T>::unpack(*reinterpret_cast<const uint4*>(col + (((b * p.Ho + oy) * p.Wo + ox) * p.col_ld + (int64_t)(ky * p.KW + kx) * p.C) * ES + cc * 16), f);
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[k] += f[k];
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(p.dx + (pix * p.dx_ld) * ES + cc * 16) = Elem<T>::pack(acc);
+  }
+}
+
+// the four phase outputs [4][B,H,W,C] of a stride-2 ConvTranspose2d -> [B,2H,2W,C] (+ReLU); the transposed move (ReLU mask from the output)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void phase_shuffle_kernel(const char* ph, int64_t ph_ld, int64_t phase_bytes, int B, int H, int W, int C, char* full,
+                                                            int64_t full_ld, const char* mask, int64_t mask_ld, int relu) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int cpt = C / V;
+  const int64_t total = (int64_t)B * 4 * H * W * cpt;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % cpt);
+    const int64_t pix = id / cpt;                         // pixel of the full-resolution map
+    const int ox = (int)(pix % (2 * W));
+    const int64_t t = pix / (2 * W);
+    const int oy = (int)(t % (2 * H));
+    const int64_t b = t / (2 * H);
+    const int phase = (oy & 1) * 2 + (ox & 1);
+    const int64_t lo = (b * H + (oy >> 1)) * W + (ox >> 1);
+    char* pp = const_cast<char*>(ph) + phase * phase_bytes + (lo * ph_ld) * ES + cc * 16;
+    char* fp = full + (pix * full_ld) * ES + cc * 16;
+    float f[V];
+    if constexpr (!BWD) {
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(pp), f);
+      if (relu) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = fmaxf(f[k], 0.f);
+      }
+      *reinterpret_cast<uint4*>(fp) = Elem<T>::pack(f);
+    } else {
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(fp), f);
+      if (mask) {
+        float m[V];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(mask + (pix * mask_ld) * ES + cc * 16), m);
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = m[k] > 0.f ? f[k] : 0.f;
+      }
+      *reinterpret_cast<uint4*>(pp) = Elem<T>::pack(f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise 3x3 (Mix-FFN)
+// nn.Conv2d(C, C, 3, 1, 1, groups=C): w [C][9] f32 as stored ([C,1,3,3]); flip = 1 runs the data gradient (taps reversed, no bias).
+// A thread owns one 16-byte channel chunk (its 9 x V weights stay in registers) and walks pixels.
+constexpr int kDwChunks = 32;
+struct DwArgs {
+  const char* x; const char* dy; char* out;
+  const float* w; const float* bias; float* part;
+  int64_t x_ld, dy_ld, out_ld;
+  int B, H, W, C, flip;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = p.C / V;
+  const int ccw = CC < kDwChunks ? CC : kDwChunks;
+  const int PL = 256 / ccw;
+  const int cl = threadIdx.x % ccw, pl = threadIdx.x / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  if (pl >= PL || cc >= CC) return;
+  float wv[9][V], bv[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int c = cc * V + k;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t][k] = p.w[c * 9 + (p.flip ? 8 - t : t)];
+    bv[k] = p.bias ? p.bias[c] : 0.f;
+  }
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
+    const int x = (int)(pix % p.W);
+    const int64_t t = pix / p.W;
+    const int y = (int)(t % p.H);
+    uint4 raw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      raw[tap] = make_uint4(0u, 0u, 0u, 0u);
+      if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+        raw[tap] = *reinterpret_cast<const uint4*>(p.x + ((pix + (int64_t)(tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.x_ld) * ES + cc * 16);
+    }
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = bv[k];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      float f[V];
+      Elem<T>::unpack(raw[tap], f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += f[k] * wv[tap][k];
+    }
+    *reinterpret_cast<uint4*>(p.out + (pix * p.out_ld) * ES + cc * 16) = Elem<T>::pack(acc);
+  }
+}
+
+// partial sums of dW[c][tap] = sum dy[p] * x[p + off(tap)] and db[c] = sum dy[p]: part[blockIdx.x][c*9 + tap | 9C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  __shared__ float red[256][V + 1];
+  const int CC = p.C / V;
+  const int ccw = CC < kDwChunks ? CC : kDwChunks;
+  const int PL = 256 / ccw;
+  const int cl = threadIdx.x % ccw, pl = threadIdx.x / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  const bool live = pl < PL && cc < CC;
+  float acc[10][V];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[t][k] = 0.f;
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  if (live) {
+    for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
+      const int x = (int)(pix % p.W);
+      const int64_t t = pix / p.W;
+      const int y = (int)(t % p.H);
+      float g[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.dy + (pix * p.dy_ld) * ES + cc * 16), g);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[9][k] += g[k];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+          float f[V];
+          Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.x + ((pix + (int64_t)(tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.x_ld) * ES + cc * 16), f);
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[tap][k] += g[k] * f[k];
+        }
+      }
+    }
+  }
+  // combine the PL pixel lanes, one tap at a time, in lane order
+  float* row = p.part + (int64_t)blockIdx.x * 10 * p.C;
+  for (int t = 0; t < 10; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[threadIdx.x][k] = acc[t][k];
+    __syncthreads();
+    if (live && pl == 0) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        float s = 0.f;
+        for (int q = 0; q < PL; ++q) s += red[q * ccw + cl][k];
+        const int c = cc * V + k;
+        if (t < 9) row[c * 9 + t] = s; else row[9 * p.C + c] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ DropPath
+// SegformerDropPath: per sample, out = x / keep * floor(u + keep).  u = 24 random bits of a counter-based hash of (seed, step, call, sample):
+// scale[call][b] = (u24 < keep * 2^24) ? 1 / keep : 0   (rate 0 -> 1).  Replayed on the host by cvcs_amd.ops.drop_path_scales_host.
+__global__ void drop_path_scales_kernel(const unsigned long long* __restrict__ state, const float* __restrict__ rates, int n, int B, float* out) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n * B) return;
+  const int call = id / B;
+  const float keep = 1.f - rates[call];
+  float s = 1.f;
+  if (rates[call] > 0.f) {
+    unsigned long long z = ((state[0] ^ 0x5DEECE66Dull) ^ (state[1] * 0xD6E8FEB86659FD93ull)) + (unsigned long long)id * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const unsigned thr24 = (unsigned)(keep * 16777216.0f);
+    s = (unsigned)(z >> 40) < thr24 ? 1.f / keep : 0.f;
+  }
+  out[id] = s;
+}
+
+// out[b, n, :] = (res ? res[b, n, :] : 0) + scale[b] * x[b, n, :]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_add_kernel(const char* x, int64_t x_ld, const float* __restrict__ scale, const char* res, int64_t res_ld,
+                                                             int64_t HW, int64_t M, int C, char* out, int64_t out_ld) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  const int CC = C / V;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < M * CC; id += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(id % CC);
+    const int64_t pix = id / CC;
+    const float s = scale ? scale[pix / HW] : 1.f;
+    float f[V];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (pix * x_ld) * ES + cc * 16), f);
+    if (res) {
+      float r[V];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(res + (pix * res_ld) * ES + cc * 16), r);
+#pragma unroll
+      for (int k = 0; k < V; ++k) f[k] = r[k] + s * f[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) f[k] = s * f[k];
+    }
+    *reinterpret_cast<uint4*>(out + (pix * out_ld) * ES + cc * 16) = Elem<T>::pack(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ spatial-reduction attention
+// q [B, N, heads*32], kv [B, Nk, 2*heads*32] (keys in channels [0, C), values in [C, 2C)), out [B, N, heads*32], lse [B*heads, N] f32.
+// softmax(q k^T / sqrt(32)) v per image and head.  One thread = one query (its 32 q values and 32 accumulators in registers); the keys and
+// values of the (image, head) are staged in LDS as f32, 256 at a time, and read as broadcasts; the softmax runs online over blocks of
+// 8 keys.  (The matrix-core version is the next step: at Nk = 256 this VALU form costs ~70 instructions per query-key pair.)
+constexpr int kSrD = 32, kSrKC = 256;
+struct SrArgs {
+  const char* q; const char* kv; const char* o; const char* go; char* out; char* gq;
+  float* lse; float* delta; float* part;
+  int64_t q_ld, kv_ld, o_ld, go_ld, out_ld, gq_ld;
+  int B, N, Nk, heads, QC;
+  float scale;
+};
+
+template <typename T>
+__device__ __forceinline__ void sr_load_row(const char* base, float* f) {   // 32 consecutive channels of one token -> f32
+  constexpr int ES = sizeof(T), V = 16 / ES;
+#pragma unroll
+  for (int i = 0; i < kSrD / V; ++i) Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + i * 16), f + i * V);
+}
+template <typename T>
+__device__ __forceinline__ void sr_store_row(char* base, const float* f) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+#pragma unroll
+  for (int i = 0; i < kSrD / V; ++i) *reinterpret_cast<uint4*>(base + i * 16) = Elem<T>::pack(f + i * V);
+}
+// stage keys [j0, j0 + n) of (b, h): sk[j][32], sv[j][32] as f32
+template <typename T>
+__device__ __forceinline__ void sr_stage_kv(const SrArgs& p, int b, int h, int j0, int n, float* sk, float* sv) {
+  constexpr int ES = sizeof(T);
+  const int C = p.heads * kSrD;
+  for (int id = threadIdx.x; id < n * 2; id += blockDim.x) {
+    const int j = id >> 1, which = id & 1;
+    float f[kSrD];
+    sr_load_row<T>(p.kv + (((int64_t)b * p.Nk + j0 + j) * p.kv_ld + which * C + h * kSrD) * ES, f);
+    float* dst = (which ? sv : sk) + j * kSrD;
+#pragma unroll
+    for (int d = 0; d < kSrD; d += 4) *reinterpret_cast<f32x4*>(dst + d) = (f32x4){f[d], f[d + 1], f[d + 2], f[d + 3]};
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sr_attn_fwd_kernel(SrArgs p) {
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sr_smem[];
+  float* sk = sr_smem;
+  float* sv = sr_smem + kSrKC * kSrD;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const bool live = n < p.N;
+  float q[kSrD], acc[kSrD];
+  if (live) sr_load_row<T>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD) * ES, q);
+#pragma unroll
+  for (int d = 0; d < kSrD; ++d) { q[d] = live ? q[d] : 0.f; acc[d] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
+    const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;
+    __syncthreads();
+    sr_stage_kv<T>(p, b, h, j0, nk, sk, sv);
+    __syncthreads();
+    for (int jb = 0; jb < nk; jb += 8) {
+      float s[8];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float a = 0.f;
+        if (jb + u < nk) {
+#pragma unroll
+          for (int d = 0; d < kSrD; d += 4) {
+            const f32x4 kk = *reinterpret_cast<const f32x4*>(sk + (jb + u) * kSrD + d);
+            a += q[d] * kk[0] + q[d + 1] * kk[1] + q[d + 2] * kk[2] + q[d + 3] * kk[3];
+          }
+          a *= p.scale;
+        } else {
+          a = -INFINITY;
+        }
+        s[u] = a;
+        bm = fmaxf(bm, a);
+      }
+      const float mn = fmaxf(m, bm);
+      const float corr = __expf(m - mn);           // (m = -inf on the first block: exp(-inf) = 0)
+      l *= corr;
+#pragma unroll
+      for (int d = 0; d < kSrD; ++d) acc[d] *= corr;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (jb + u < nk) {
+          const float pr = __expf(s[u] - mn);
+          l += pr;
+#pragma unroll
+          for (int d = 0; d < kSrD; d += 4) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(sv + (jb + u) * kSrD + d);
+            acc[d] += pr * vv[0]; acc[d + 1] += pr * vv[1]; acc[d + 2] += pr * vv[2]; acc[d + 3] += pr * vv[3];
+          }
+        }
+      }
+      m = mn;
+    }
+  }
+  if (live) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < kSrD; ++d) acc[d] *= inv;
+    sr_store_row<T>(p.out + (((int64_t)b * p.N + n) * p.out_ld + h * kSrD) * ES, acc);
+    if (p.lse) p.lse[(int64_t)bh * p.N + n] = m + __logf(l);
+  }
+}
+
+// dQ (query-major, the forward's structure): p = exp(s - lse), dp = go . v, ds = p (dp - delta) scale, dq += ds k;  delta = go . o saved
+template <typename T>
+__global__ __launch_bounds__(256) void sr_attn_bwd_dq_kernel(SrArgs p) {
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sr_smem[];
+  float* sk = sr_smem;
+  float* sv = sr_smem + kSrKC * kSrD;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const bool live = n < p.N;
+  float q[kSrD], go[kSrD], dq[kSrD];
+  float delta = 0.f, lse = 0.f;
+  if (live) {
+    sr_load_row<T>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD) * ES, q);
+    sr_load_row<T>(p.go + (((int64_t)b * p.N + n) * p.go_ld + h * kSrD) * ES, go);
+    float o[kSrD];
+    sr_load_row<T>(p.o + (((int64_t)b * p.N + n) * p.o_ld + h * kSrD) * ES, o);
+#pragma unroll
+    for (int d = 0; d < kSrD; ++d) delta += go[d] * o[d];
+    lse = p.lse[(int64_t)bh * p.N + n];
+    p.delta[(int64_t)bh * p.N + n] = delta;
+  }
+#pragma unroll
+  for (int d = 0; d < kSrD; ++d) { if (!live) { q[d] = 0.f; go[d] = 0.f; } dq[d] = 0.f; }
+  for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
+    const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;
+    __syncthreads();
+    sr_stage_kv<T>(p, b, h, j0, nk, sk, sv);
+    __syncthreads();
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f, dp = 0.f;
+      f32x4 kk[kSrD / 4];
+#pragma unroll
+      for (int d = 0; d < kSrD; d += 4) {
+        kk[d / 4] = *reinterpret_cast<const f32x4*>(sk + j * kSrD + d);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(sv + j * kSrD + d);
+        s += q[d] * kk[d / 4][0] + q[d + 1] * kk[d / 4][1] + q[d + 2] * kk[d / 4][2] + q[d + 3] * kk[d / 4][3];
+        dp += go[d] * vv[0] + go[d + 1] * vv[1] + go[d + 2] * vv[2] + go[d + 3] * vv[3];
+      }
+      const float pr = __expf(s * p.scale - lse);
+      const float ds = pr * (dp - delta) * p.scale;
+#pragma unroll
+      for (int d = 0; d < kSrD; d += 4) {
+        dq[d] += ds * kk[d / 4][0]; dq[d + 1] += ds * kk[d / 4][1]; dq[d + 2] += ds * kk[d / 4][2]; dq[d + 3] += ds * kk[d / 4][3];
+      }
+    }
+  }
+  if (live) sr_store_row<T>(p.gq + (((int64_t)b * p.N + n) * p.gq_ld + h * kSrD) * ES, dq);
+}
+
+// dK / dV (key-major): one thread = one key (k, v, dk, dv in registers), the workgroup walks the queries [chunk*QC, (chunk+1)*QC) staged
+// 64 at a time; part[(bh * chunks + chunk)][key][dk 32 | dv 32]
+template <typename T>
+__global__ __launch_bounds__(256) void sr_attn_bwd_dkv_kernel(SrArgs p) {
+  constexpr int ES = sizeof(T);
+  __shared__ __attribute__((aligned(16))) float sq[64 * kSrD];
+  __shared__ __attribute__((aligned(16))) float sg[64 * kSrD];
+  __shared__ float sl[64], sd[64];
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int chunk = blockIdx.x, chunks = gridDim.x;
+  const int j = blockIdx.z * 256 + threadIdx.x;
+  const bool live = j < p.Nk;
+  const int C = p.heads * kSrD;
+  float k[kSrD], v[kSrD], dk[kSrD], dv[kSrD];
+  if (live) {
+    sr_load_row<T>(p.kv + (((int64_t)b * p.Nk + j) * p.kv_ld + h * kSrD) * ES, k);
+    sr_load_row<T>(p.kv + (((int64_t)b * p.Nk + j) * p.kv_ld + C + h * kSrD) * ES, v);
+  }
+#pragma unroll
+  for (int d = 0; d < kSrD; ++d) { if (!live) { k[d] = 0.f; v[d] = 0.f; } dk[d] = 0.f; dv[d] = 0.f; }
+  const int n0 = chunk * p.QC;
+  const int n1 = n0 + p.QC < p.N ? n0 + p.QC : p.N;
+  for (int nb = n0; nb < n1; nb += 64) {
+    const int nq = n1 - nb < 64 ? n1 - nb : 64;
+    __syncthreads();
+    for (int id = threadIdx.x; id < nq * 2; id += 256) {
+      const int r = id >> 1, which = id & 1;
+      float f[kSrD];
+      const int64_t tok = (int64_t)b * p.N + nb + r;
+      if (which) sr_load_row<T>(p.go + (tok * p.go_ld + h * kSrD) * ES, f);
+      else sr_load_row<T>(p.q + (tok * p.q_ld + h * kSrD) * ES, f);
+      float* dst = (which ? sg : sq) + r * kSrD;
+#pragma unroll
+      for (int d = 0; d < kSrD; d += 4) *reinterpret_cast<f32x4*>(dst + d) = (f32x4){f[d], f[d + 1], f[d + 2], f[d + 3]};
+    }
+    if (threadIdx.x < nq) {
+      sl[threadIdx.x] = p.lse[(int64_t)bh * p.N + nb + threadIdx.x];
+      sd[threadIdx.x] = p.delta[(int64_t)bh * p.N + nb + threadIdx.x];
+    }
+    __syncthreads();
+    if (live) {
+      for (int r = 0; r < nq; ++r) {
+        float s = 0.f, dp = 0.f;
+        f32x4 qq[kSrD / 4], gg[kSrD / 4];
+#pragma unroll
+        for (int d = 0; d < kSrD; d += 4) {
+          qq[d / 4] = *reinterpret_cast<const f32x4*>(sq + r * kSrD + d);
+          gg[d / 4] = *reinterpret_cast<const f32x4*>(sg + r * kSrD + d);
+          s += k[d] * qq[d / 4][0] + k[d + 1] * qq[d / 4][1] + k[d + 2] * qq[d / 4][2] + k[d + 3] * qq[d / 4][3];
+          dp += v[d] * gg[d / 4][0] + v[d + 1] * gg[d / 4][1] + v[d + 2] * gg[d / 4][2] + v[d + 3] * gg[d / 4][3];
+        }
+        const float pr = __expf(s * p.scale - sl[r]);
+        const float ds = pr * (dp - sd[r]) * p.scale;
+#pragma unroll
+        for (int d = 0; d < kSrD; d += 4) {
+          dv[d] += pr * gg[d / 4][0]; dv[d + 1] += pr * gg[d / 4][1]; dv[d + 2] += pr * gg[d / 4][2]; dv[d + 3] += pr * gg[d / 4][3];
+          dk[d] += ds * qq[d / 4][0]; dk[d + 1] += ds * qq[d / 4][1]; dk[d + 2] += ds * qq[d / 4][2]; dk[d + 3] += ds * qq[d / 4][3];
+        }
+      }
+    }
+  }
+  if (live) {
+    float* dst = p.part + (((int64_t)bh * chunks + chunk) * p.Nk + j) * 64;
+#pragma unroll
+    for (int d = 0; d < kSrD; d += 4) {
+      *reinterpret_cast<f32x4*>(dst + d) = (f32x4){dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
+      *reinterpret_cast<f32x4*>(dst + 32 + d) = (f32x4){dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
+    }
+  }
+}
+
+// gkv[b, j, which*C + h*32 + d] = sum over chunks (in chunk order) of part[(bh, chunk)][j][which*32 + d]
+template <typename T>
+__global__ __launch_bounds__(256) void sr_attn_dkv_reduce_kernel(const float* __restrict__ part, int chunks, int B, int Nk, int heads, char* gkv, int64_t gkv_ld) {
+  const int64_t total = (int64_t)B * heads * Nk * 64;
+  const int C = heads * kSrD;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int e = (int)(id & 63);
+    const int64_t t = id >> 6;
+    const int j = (int)(t % Nk);
+    const int bh = (int)(t / Nk);
+    const int b = bh / heads, h = bh - b * heads;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(((int64_t)bh * chunks + c) * Nk + j) * 64 + e];
+    Elem<T>::st(reinterpret_cast<T*>(gkv) + ((int64_t)b * Nk + j) * gkv_ld + (e >> 5) * C + h * kSrD + (e & 31), s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gather
+// dst[r][c] (row pitch Cp) = r < Rv && c < Cv ? src[base + idx3(r; rd1, rd2, rs*) + idx3(c; cd1, cd2, cs*)] : 0,
+// idx3(x; d1, d2, s0, s1, s2) = (x / (d1*d2)) * s0 + ((x / d2) % d1) * s1 + (x % d2) * s2
+template <typename T>
+__global__ __launch_bounds__(256) void gather_weights_kernel(const cvcs_gather_item* __restrict__ items) {
+  const cvcs_gather_item it = items[blockIdx.y];
+  const int64_t total = (int64_t)it.R * it.Cp;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int c = (int)(id % it.Cp), r = (int)(id / it.Cp);
+    float v = 0.f;
+    if (r < it.Rv && c < it.Cv) {
+      const int64_t ri = (int64_t)(r / (it.rd1 * it.rd2)) * it.rs0 + (int64_t)((r / it.rd2) % it.rd1) * it.rs1 + (int64_t)(r % it.rd2) * it.rs2;
+      const int64_t ci = (int64_t)(c / (it.cd1 * it.cd2)) * it.cs0 + (int64_t)((c / it.cd2) % it.cd1) * it.cs1 + (int64_t)(c % it.cd2) * it.cs2;
+      v = it.src[it.base + ri + ci];
+    }
+    if (it.f32_out) reinterpret_cast<float*>(it.dst)[id] = v;
+    else Elem<T>::st(reinterpret_cast<T*>(it.dst) + id, v);
+  }
+}
+
+// the transposed gather: dst (f32, the master tensor's gradient) [base + idx(r) + idx(c)] = src[r][c] for r < Rv, c < Cv (every master element is
+// hit exactly once by construction of the table: plain stores)
+__global__ __launch_bounds__(256) void scatter_weight_grads_kernel(const cvcs_gather_item* __restrict__ items) {
+  const cvcs_gather_item it = items[blockIdx.y];
+  const int64_t total = (int64_t)it.Rv * it.Cv;
+  float* master = const_cast<float*>(it.src);
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int c = (int)(id % it.Cv), r = (int)(id / it.Cv);
+    const int64_t ri = (int64_t)(r / (it.rd1 * it.rd2)) * it.rs0 + (int64_t)((r / it.rd2) % it.rd1) * it.rs1 + (int64_t)(r % it.rd2) * it.rs2;
+    const int64_t ci = (int64_t)(c / (it.cd1 * it.cd2)) * it.cs0 + (int64_t)((c / it.cd2) % it.cd1) * it.cs1 + (int64_t)(c % it.cd2) * it.cs2;
+    master[it.base + ri + ci] = reinterpret_cast<const float*>(it.dst)[(int64_t)r * it.Cp + c];
+  }
+}
+
+}  // namespace cvcs
+
+using namespace cvcs;
+
+extern "C" int cvcs_im2col(const void* in, int64_t in_ld, int B, int H, int W, int C, int KH, int KW, int stride, int oy0, int ox0, int dir, int Ho,
+                           int Wo, void* col, int64_t col_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_im2col";
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "%s: bad shape (C=%d must be a multiple of %d)", fn, C, V);
+  CVCS_CHECK_ARG(KH >= 1 && KW >= 1 && KH * KW <= 64 && stride >= 1 && (dir == 1 || dir == -1), "%s: bad filter geometry", fn);
+  CVCS_CHECK_ARG(col_ld >= (int64_t)KH * KW * C, "%s: col_ld=%lld < KH*KW*C", fn, (long long)col_ld);
+  int rc;
+  if ((rc = sf_view(fn, in, in_ld, C, es)) || (rc = sf_view(fn, col, col_ld, KH * KW * C, es))) return rc;
+  ColArgs a{(const char*)in, (char*)col, in_ld, col_ld, B, H, W, C, Ho, Wo, KH, KW, stride, oy0, ox0, dir};
+  const dim3 grid(sf_grid((int64_t)B * Ho * Wo * (col_ld / V)));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((im2col_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((im2col_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_im2col_stem(const void* src, int src_is_u8, int B, int H, int W, int KH, int KW, int stride, int pad, const float* mean3,
+                                const float* std3, int Ho, int Wo, void* col, int64_t col_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_im2col_stem";
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(src && mean3 && std3 && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "%s: bad argument", fn);
+  CVCS_CHECK_ARG(col_ld >= (int64_t)KH * KW * 3 && col_ld % V == 0, "%s: col_ld=%lld", fn, (long long)col_ld);
+  CVCS_CHECK_ARG(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1, "%s: Ho, Wo do not follow from the geometry", fn);
+  int rc;
+  if ((rc = sf_view(fn, col, col_ld, KH * KW * 3, es))) return rc;
+  StemColArgs a;
+  a.src = src; a.col = (char*)col; a.col_ld = col_ld; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.s = stride; a.pad = pad;
+  a.is_u8 = src_is_u8;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.std[i] = std3[i]; }
+  const dim3 grid(sf_grid((int64_t)B * Ho * Wo * (col_ld / V)));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((im2col_stem_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((im2col_stem_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_col2im(const void* col, int64_t col_ld, int64_t phase_elems, int nph, const int* oy0, const int* ox0, int dir, int stride, int KH,
+                           int KW, int B, int Ho, int Wo, int C, int H, int W, void* dx, int64_t dx_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_col2im";
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0, "%s: bad shape", fn);
+  CVCS_CHECK_ARG(nph >= 1 && nph <= 4 && oy0 && ox0 && KH >= 1 && KW >= 1 && KH * KW <= 64 && stride >= 1 && (dir == 1 || dir == -1), "%s: bad geometry", fn);
+  CVCS_CHECK_ARG(col_ld >= (int64_t)KH * KW * C && (nph == 1 || phase_elems >= (int64_t)B * Ho * Wo * col_ld), "%s: col_ld / phase stride", fn);
+  int rc;
+  if ((rc = sf_view(fn, col, col_ld, KH * KW * C, es)) || (rc = sf_view(fn, dx, dx_ld, C, es))) return rc;
+  CVCS_CHECK_ARG((phase_elems * es) % 16 == 0, "%s: phase stride alignment", fn);
+  Col2imArgs a;
+  a.col = (const char*)col; a.dx = (char*)dx; a.col_ld = col_ld; a.dx_ld = dx_ld; a.phase_bytes = phase_elems * es;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.s = stride; a.dir = dir; a.nph = nph;
+  for (int i = 0; i < 4; ++i) { a.oy0[i] = i < nph ? oy0[i] : 0; a.ox0[i] = i < nph ? ox0[i] : 0; }
+  const dim3 grid(sf_grid((int64_t)B * H * W * (C / V)));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((col2im_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((col2im_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+static int phase_shuffle_impl(const char* fn, bool bwd, const void* ph, int64_t ph_ld, int64_t phase_elems, int B, int H, int W, int C, void* full,
+                              int64_t full_ld, const void* mask, int64_t mask_ld, int relu, int dtype, void* stream) {
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0 && phase_elems >= (int64_t)B * H * W * ph_ld && (phase_elems * es) % 16 == 0, "%s: bad shape", fn);
+  int rc;
+  if ((rc = sf_view(fn, ph, ph_ld, C, es)) || (rc = sf_view(fn, full, full_ld, C, es))) return rc;
+  if (mask && (rc = sf_view(fn, mask, mask_ld, C, es))) return rc;
+  const dim3 grid(sf_grid((int64_t)B * 4 * H * W * (C / V)));
+  hipStream_t st = (hipStream_t)stream;
+#define PS_L(TT, BW) hipLaunchKernelGGL((phase_shuffle_kernel<TT, BW>), grid, dim3(256), 0, st, (const char*)ph, ph_ld, phase_elems * es, B, H, W, C, (char*)full, full_ld, (const char*)mask, mask_ld, relu)
+  if (dtype == CVCS_F32) { if (bwd) PS_L(float, true); else PS_L(float, false); }
+  else { if (bwd) PS_L(bf16_t, true); else PS_L(bf16_t, false); }
+#undef PS_L
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_phase_shuffle(const void* ph, int64_t ph_ld, int64_t phase_elems, int B, int H, int W, int C, void* out, int64_t out_ld, int relu,
+                                  int dtype, void* stream) {
+  return phase_shuffle_impl("cvcs_phase_shuffle", false, ph, ph_ld, phase_elems, B, H, W, C, out, out_ld, nullptr, 0, relu, dtype, stream);
+}
+
+extern "C" int cvcs_phase_unshuffle(const void* g, int64_t g_ld, const void* relu_out, int64_t relu_out_ld, int B, int H, int W, int C, void* gph,
+                                    int64_t gph_ld, int64_t phase_elems, int dtype, void* stream) {
+  return phase_shuffle_impl("cvcs_phase_unshuffle", true, gph, gph_ld, phase_elems, B, H, W, C, const_cast<void*>(g), g_ld, relu_out, relu_out_ld, 0, dtype, stream);
+}
+
+static int dw_common(const char* fn, const void* x, int64_t x_ld, int B, int H, int W, int C, int dtype) {
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0, "%s: bad shape (C=%d must be a multiple of %d)", fn, C, V);
+  return sf_view(fn, x, x_ld, C, es);
+}
+
+extern "C" int cvcs_dwconv3x3(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int flip, void* out,
+                              int64_t out_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_dwconv3x3";
+  int rc;
+  if ((rc = dw_common(fn, x, x_ld, B, H, W, C, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(w != nullptr, "%s: null weight", fn);
+  if ((rc = sf_view(fn, out, out_ld, C, es))) return rc;
+  DwArgs a{(const char*)x, nullptr, (char*)out, w, bias, nullptr, x_ld, 0, out_ld, B, H, W, C, flip};
+  const int CC = C / V, ccw = CC < kDwChunks ? CC : kDwChunks, PL = 256 / ccw;
+  const int64_t M = (int64_t)B * H * W;
+  int64_t gx = cdiv(M, (int64_t)PL * 4);
+  if (gx > 4096) gx = 4096;
+  const dim3 grid((unsigned)gx, (unsigned)cdiv(CC, ccw));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((dwconv3x3_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_dwconv3x3_wgrad_rows(int64_t M) {
+  int64_t r = cdiv(M, 256);
+  return (int)(r < 1 ? 1 : (r > 512 ? 512 : r));
+}
+
+extern "C" int cvcs_dwconv3x3_wgrad(const void* x, int64_t x_ld, const void* dy, int64_t dy_ld, int B, int H, int W, int C, float* part, int dtype,
+                                    void* stream) {
+  const char* fn = "cvcs_dwconv3x3_wgrad";
+  int rc;
+  if ((rc = dw_common(fn, x, x_ld, B, H, W, C, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  if ((rc = sf_view(fn, dy, dy_ld, C, es))) return rc;
+  CVCS_CHECK_ARG(part != nullptr, "%s: null partial buffer", fn);
+  DwArgs a{(const char*)x, (const char*)dy, nullptr, nullptr, nullptr, part, x_ld, dy_ld, 0, B, H, W, C, 0};
+  const int CC = C / V, ccw = CC < kDwChunks ? CC : kDwChunks;
+  const dim3 grid((unsigned)cvcs_dwconv3x3_wgrad_rows((int64_t)B * H * W), (unsigned)cdiv(CC, ccw));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_drop_path_scales(const uint64_t* state, const float* rates, int n, int B, float* out, void* stream) {
+  CVCS_CHECK_ARG(state && rates && out && n > 0 && B > 0, "cvcs_drop_path_scales: bad argument");
+  hipLaunchKernelGGL(drop_path_scales_kernel, dim3((unsigned)cdiv((int64_t)n * B, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)state, rates, n, B, out);
+  CVCS_CHECK_LAUNCH("cvcs_drop_path_scales");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_scale_rows_add(const void* x, int64_t x_ld, const float* scale, const void* res, int64_t res_ld, int B, int64_t HW, int C, void* out,
+                                   int64_t out_ld, int dtype, void* stream) {
+  const char* fn = "cvcs_scale_rows_add";
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % V == 0, "%s: bad shape", fn);
+  int rc;
+  if ((rc = sf_view(fn, x, x_ld, C, es)) || (rc = sf_view(fn, out, out_ld, C, es))) return rc;
+  if (res && (rc = sf_view(fn, res, res_ld, C, es))) return rc;
+  const int64_t M = (int64_t)B * HW;
+  const dim3 grid(sf_grid(M * (C / V)));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((scale_rows_add_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, scale, (const char*)res, res_ld, HW, M, C, (char*)out, out_ld);
+  else hipLaunchKernelGGL((scale_rows_add_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, x_ld, scale, (const char*)res, res_ld, HW, M, C, (char*)out, out_ld);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+static int sr_check(const char* fn, int B, int N, int Nk, int heads, int dtype) {
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  CVCS_CHECK_ARG(B > 0 && N > 0 && Nk > 0 && heads > 0 && heads <= 64 && (int64_t)B * heads <= 65535, "%s: bad shape", fn);
+  return CVCS_OK;
+}
+static int sr_chunk(int N) {     // queries per key-major workgroup
+  int qc = N / 16;
+  return qc < 256 ? 256 : qc;
+}
+
+extern "C" int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, int B, int N, int Nk, int heads, void* out,
+                                     int64_t out_ld, float* lse, int dtype, void* stream) {
+  const char* fn = "cvcs_sr_attention_fwd";
+  int rc;
+  if ((rc = sr_check(fn, B, N, Nk, heads, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2, C = heads * kSrD;
+  if ((rc = sf_view(fn, q, q_ld, C, es)) || (rc = sf_view(fn, kv, kv_ld, 2 * C, es)) || (rc = sf_view(fn, out, out_ld, C, es))) return rc;
+  SrArgs a{};
+  a.q = (const char*)q; a.kv = (const char*)kv; a.out = (char*)out; a.lse = lse; a.q_ld = q_ld; a.kv_ld = kv_ld; a.out_ld = out_ld;
+  a.B = B; a.N = N; a.Nk = Nk; a.heads = heads; a.scale = 0.17677669529663687f;   // 32^-0.5
+  const dim3 grid((unsigned)cdiv(N, 256), (unsigned)(B * heads));
+  const size_t lds = 2 * (size_t)kSrKC * kSrD * 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVCS_F32) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL((sr_attn_fwd_kernel<float>), grid, dim3(256), lds, st, a);
+  } else {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL((sr_attn_fwd_kernel<bf16_t>), grid, dim3(256), lds, st, a);
+  }
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+// floats: delta [B*heads*N] then the key-major partials [B*heads][chunks][Nk][64]
+extern "C" int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads) {
+  if (B <= 0 || N <= 0 || Nk <= 0 || heads <= 0) return CVCS_EINVAL;
+  const int64_t chunks = cdiv(N, sr_chunk(N));
+  const int64_t delta = ((int64_t)B * heads * N + 3) / 4 * 4;
+  return delta + (int64_t)B * heads * chunks * Nk * 64;
+}
+
+extern "C" int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, const void* o, int64_t o_ld, const void* go, int64_t go_ld,
+                                     const float* lse, int B, int N, int Nk, int heads, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld,
+                                     float* workspace, int dtype, void* stream) {
+  const char* fn = "cvcs_sr_attention_bwd";
+  int rc;
+  if ((rc = sr_check(fn, B, N, Nk, heads, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2, C = heads * kSrD;
+  CVCS_CHECK_ARG(lse && workspace, "%s: null argument", fn);
+  if ((rc = sf_view(fn, q, q_ld, C, es)) || (rc = sf_view(fn, kv, kv_ld, 2 * C, es)) || (rc = sf_view(fn, o, o_ld, C, es)) ||
+      (rc = sf_view(fn, go, go_ld, C, es)) || (rc = sf_view(fn, gq, gq_ld, C, es)) || (rc = sf_view(fn, gkv, gkv_ld, 2 * C, es))) return rc;
+  SrArgs a{};
+  a.q = (const char*)q; a.kv = (const char*)kv; a.o = (const char*)o; a.go = (const char*)go; a.gq = (char*)gq;
+  a.lse = const_cast<float*>(lse);
+  a.delta = workspace;
+  a.part = workspace + ((int64_t)B * heads * N + 3) / 4 * 4;
+  a.q_ld = q_ld; a.kv_ld = kv_ld; a.o_ld = o_ld; a.go_ld = go_ld; a.gq_ld = gq_ld;
+  a.B = B; a.N = N; a.Nk = Nk; a.heads = heads; a.QC = sr_chunk(N); a.scale = 0.17677669529663687f;
+  const int chunks = (int)cdiv(N, a.QC);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 gq_grid((unsigned)cdiv(N, 256), (unsigned)(B * heads));
+  const dim3 gk_grid((unsigned)chunks, (unsigned)(B * heads), (unsigned)cdiv(Nk, 256));
+  const size_t lds = 2 * (size_t)kSrKC * kSrD * 4;
+  const dim3 gr_grid(sf_grid((int64_t)B * heads * Nk * 64));
+  if (dtype == CVCS_F32) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_bwd_dq_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL((sr_attn_bwd_dq_kernel<float>), gq_grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sr_attn_bwd_dkv_kernel<float>), gk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<float>), gr_grid, dim3(256), 0, st, a.part, chunks, B, Nk, heads, (char*)gkv, gkv_ld);
+  } else {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_bwd_dq_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL((sr_attn_bwd_dq_kernel<bf16_t>), gq_grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sr_attn_bwd_dkv_kernel<bf16_t>), gk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<bf16_t>), gr_grid, dim3(256), 0, st, a.part, chunks, B, Nk, heads, (char*)gkv, gkv_ld);
+  }
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_gather_weights(const cvcs_gather_item* items_device, int n_items, int dtype, void* stream) {
+  CVCS_CHECK_ARG(SF_DT(dtype), "cvcs_gather_weights: bad dtype");
+  CVCS_CHECK_ARG(items_device && n_items > 0 && n_items <= 65535, "cvcs_gather_weights: bad table");
+  const dim3 grid(64, (unsigned)n_items);
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((gather_weights_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, items_device);
+  else hipLaunchKernelGGL((gather_weights_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, items_device);
+  CVCS_CHECK_LAUNCH("cvcs_gather_weights");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_scatter_weight_grads(const cvcs_gather_item* items_device, int n_items, void* stream) {
+  CVCS_CHECK_ARG(items_device && n_items > 0 && n_items <= 65535, "cvcs_scatter_weight_grads: bad table");
+  hipLaunchKernelGGL(scatter_weight_grads_kernel, dim3(64, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_device);
+  CVCS_CHECK_LAUNCH("cvcs_scatter_weight_grads");
+  return CVCS_OK;
+}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 10
+#define CVCS_ABI_VERSION 11
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_E4M3 = 0, CVCS_E5M2 = 1 };   /* OCP fp8 formats of the fp8 convolution path (gfx950: e4m3fn / e5m2, not the MI300 fnuz forms) */
@@ -494,6 +494,68 @@ int cvcs_bn_add_act_q8(const void* y1, int64_t y1_ld, const float* s1, const flo
 int cvcs_dropout(const void* x, int64_t x_ld, int64_t M, int C, void* out, int64_t out_ld, const uint64_t* state, float p, int dtype,
                  void* stream);
 int cvcs_counter_add(uint64_t* counter, uint64_t inc, void* stream);
+
+/* ---- ABI 11: the reference's `SegformerMod` (/root/reference/source/scripts/nets.py:313-349; factory name /root/reference/source/scripts/utils.py:191-192):
+ * transformers' Mix-Transformer segmentation model + the reference's ConvTranspose tail.  Tokens are NHWC pixels, every nn.Linear is a 1x1
+ * convolution (cvcs_conv2d / cvcs_conv2d_wgrad), LayerNorm / GELU / bilinear resizes / BatchNorm are the Swin and ResNet entry points.
+ *
+ * Patch matrices.  cvcs_im2col replaces the input side of nn.Conv2d(k, stride, padding) for the overlapping patch embeddings (7/4/3, 3/2/1),
+ * the sequence-reduction convolutions (k = s = 8 | 4 | 2) and - phase by phase - the two nn.ConvTranspose2d of the tail (nets.py:331-334):
+ *   col[b, oy, ox, (ky*KW + kx)*C + c] = in[b, oy*stride + oy0 + ky*dir, ox*stride + ox0 + kx*dir, c]    (0 outside the map and for K >= KH*KW*C)
+ * convolution: oy0 = ox0 = -padding, dir = +1.  Phase (a, b) of ConvTranspose2d(k, stride 2, padding p), i.e. the output pixels (2i + a, 2j + b):
+ * stride = 1, dir = -1, KH = KW = k / 2, oy0 = (a + p) >> 1, ox0 = (b + p) >> 1, and tap (jy, jx) multiplies w[ci][co][((a+p)&1) + 2*jy][((b+p)&1) + 2*jx].
+ * The layer is then a 1x1 convolution of `col`.  cvcs_im2col_stem is the same gather on the tile itself (planar u8 / f32 [B,3,H,W], K index
+ * (ky*KW + kx)*3 + c) with the reference's preprocessor folded in: (x - mean[c]) / std[c] on the RAW 0..255 values (nets.py:337-340, 347),
+ * padding pixels 0 AFTER the normalisation.  cvcs_col2im is the transposed gather (data gradient), summed over nph phase slabs (phase_elems
+ * elements apart) in f32 in a fixed order.  cvcs_phase_shuffle interleaves the four phase outputs [4][B,H,W,C] into [B,2H,2W,C] (+ ReLU);
+ * cvcs_phase_unshuffle is the transposed move with the ReLU mask taken from the forward output (relu_out, NULL = none).                     */
+int cvcs_im2col(const void* in, int64_t in_ld, int B, int H, int W, int C, int KH, int KW, int stride, int oy0, int ox0, int dir, int Ho, int Wo,
+                void* col, int64_t col_ld, int dtype, void* stream);
+int cvcs_im2col_stem(const void* src, int src_is_u8, int B, int H, int W, int KH, int KW, int stride, int pad, const float* mean3, const float* std3,
+                     int Ho, int Wo, void* col, int64_t col_ld, int dtype, void* stream);
+int cvcs_col2im(const void* col, int64_t col_ld, int64_t phase_elems, int nph, const int* oy0, const int* ox0, int dir, int stride, int KH, int KW,
+                int B, int Ho, int Wo, int C, int H, int W, void* dx, int64_t dx_ld, int dtype, void* stream);
+int cvcs_phase_shuffle(const void* ph, int64_t ph_ld, int64_t phase_elems, int B, int H, int W, int C, void* out, int64_t out_ld, int relu, int dtype,
+                       void* stream);
+int cvcs_phase_unshuffle(const void* g, int64_t g_ld, const void* relu_out, int64_t relu_out_ld, int B, int H, int W, int C, void* gph, int64_t gph_ld,
+                         int64_t phase_elems, int dtype, void* stream);
+/* Depthwise 3x3 of the Mix-FFN (transformers SegformerDepthWiseConv: nn.Conv2d(C, C, 3, 1, 1, groups=C)): w f32 [C][9] as the module stores it,
+ * bias f32 [C] or NULL.  flip = 1 applies the filter reversed = the data gradient.  cvcs_dwconv3x3_wgrad: partial rows
+ * part[cvcs_dwconv3x3_wgrad_rows(B*H*W)][C*9 (c-major) | C] of dW and db; cvcs_colsum_finalize sums them into a weight | bias gradient pair. */
+int cvcs_dwconv3x3(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int flip, void* out, int64_t out_ld,
+                   int dtype, void* stream);
+int cvcs_dwconv3x3_wgrad_rows(int64_t M);
+int cvcs_dwconv3x3_wgrad(const void* x, int64_t x_ld, const void* dy, int64_t dy_ld, int B, int H, int W, int C, float* part, int dtype, void* stream);
+/* DropPath (transformers SegformerDropPath, train mode): scales[call][b] = (u24 < keep * 2^24) ? 1 / keep : 0 with keep = 1 - rates[call] and
+ * u24 = splitmix64((seed ^ 0x5DEECE66D) ^ step * 0xD6E8FEB86659FD93 + (call * B + b) * 0x9E3779B97F4A7C15) >> 40; rate 0 -> 1.  state = {seed, step} as
+ * for cvcs_dropout; rates f32 [n] on the device.  cvcs_scale_rows_add: out[b, n, :] = res[b, n, :] + scale[b] * x[b, n, :] (res NULL: the scaled
+ * rows alone - the branch gradient; scale NULL = 1).                                                                                          */
+int cvcs_drop_path_scales(const uint64_t* state, const float* rates, int n, int B, float* out, void* stream);
+int cvcs_scale_rows_add(const void* x, int64_t x_ld, const float* scale, const void* res, int64_t res_ld, int B, int64_t HW, int C, void* out,
+                        int64_t out_ld, int dtype, void* stream);
+/* Spatial-reduction attention (transformers SegformerAttention + eager_attention_forward): q [B, N, heads*32], kv [B, Nk, 2*heads*32] (key
+ * projection in channels [0, C), value projection in [C, 2C): the two nn.Linear run as one GEMM), out = softmax(q k^T / sqrt(32)) v per image and
+ * head; lse f32 [B*heads][N] (log-sum-exp of the scaled scores) is what the backward recomputes the probabilities from.
+ * cvcs_sr_attention_bwd: gq, gkv from go (gradient of out); workspace of cvcs_sr_attention_bwd_workspace floats.                              */
+int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, int B, int N, int Nk, int heads, void* out, int64_t out_ld,
+                          float* lse, int dtype, void* stream);
+int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads);
+int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, const void* o, int64_t o_ld, const void* go, int64_t go_ld,
+                          const float* lse, int B, int N, int Nk, int heads, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld, float* workspace,
+                          int dtype, void* stream);
+/* Table-driven weight gather: the f32 master tensors keep the reference's layouts (Conv2d OIHW, ConvTranspose2d IOHW); the GEMM operands of the
+ * patch-matrix layers are re-gathered from them every step in ONE launch:
+ *   dst[r][c] (R rows of pitch Cp; `dtype`, or f32 when f32_out) = r < Rv && c < Cv ? src[base + idx3(r; rd1, rd2, rs0..2) + idx3(c; cd1, cd2, cs0..2)] : 0
+ *   idx3(x; d1, d2, s0, s1, s2) = (x / (d1*d2)) * s0 + ((x / d2) % d1) * s1 + (x % d2) * s2
+ * cvcs_scatter_weight_grads is the transposed move for gradients: src[base + idx3(r) + idx3(c)] = dst[r][c] (dst f32) for r < Rv, c < Cv.       */
+typedef struct {
+  const float* src;
+  void* dst;
+  int64_t base, rs0, rs1, rs2, cs0, cs1, cs2;
+  int32_t R, Cp, Rv, Cv, rd1, rd2, cd1, cd2, f32_out, pad_;
+} cvcs_gather_item;
+int cvcs_gather_weights(const cvcs_gather_item* items_device, int n_items, int dtype, void* stream);
+int cvcs_scatter_weight_grads(const cvcs_gather_item* items_device, int n_items, void* stream);
 
 #ifdef __cplusplus
 }

@@ -413,7 +413,15 @@ def test_aspp_dropout_mask_is_counter_based_and_the_train_step_matches_the_oracl
         grads = torch.autograd.grad(lo, [tr.p[k] for k in tr.trainable])
         scale = z.abs().max().item()
         err = (logits.detach().cpu() - z.detach()).abs().max().item() / scale
-        assert err <= 1e-3 and abs(loss.item() - lo.item()) <= 1e-4 * max(1.0, abs(lo.item())), (step, err, loss.item(), lo.item())
+        # step 0 is the parity statement; after one optimiser step this small network has amplified the f32 rounding differences of
+        # step 0 (the exact-mode test measures the same chaos: a permuted batch lands 2 % away): step 1 only has to tell the RIGHT mask
+        # from a wrong one, which is an O(1) error
+        etol, ltol = (1e-3, 1e-4) if step == 0 else (5e-2, 2e-3)
+        assert err <= etol and abs(loss.item() - lo.item()) <= ltol * max(1.0, abs(lo.item())), (step, err, loss.item(), lo.item())
+        if step == 1:
+            with torch.no_grad():
+                zw = D.forward({k: v.detach().clone() for k, v in tr.p.items()}, img.float(), arch, train=True, output_stride=os_, plus=False, aspp_keep=masks[0])
+            assert (logits.detach().cpu() - zw).abs().max().item() / scale > 5 * max(err, 1e-3)
         tr.nstep += 1
         with torch.no_grad():
             for k, g in zip(tr.trainable, grads):
@@ -425,7 +433,8 @@ def test_aspp_dropout_mask_is_counter_based_and_the_train_step_matches_the_oracl
     net.eval()
     with torch.no_grad():
         ev = net(img.to(DEV), None).cpu()
-        want = D.forward({k: v.detach() for k, v in tr.p.items()}, img.float(), arch, train=False, output_stride=os_, plus=False)
+        # (the oracle on THIS network's weights after its two steps: the statement is "evaluation applies no mask", not a third parity step)
+        want = D.forward(_oracle_named(net), img.float(), arch, train=False, output_stride=os_, plus=False)
     assert (ev - want).abs().max().item() <= 2e-3 * want.abs().max().item()
 
 
