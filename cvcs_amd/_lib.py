@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcvcs_hip.so")
 
 F32, BF16 = 0, 1
 E4M3, E5M2 = 0, 1          # fp8 formats (CVCS_E4M3 / CVCS_E5M2)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class CvcsError(RuntimeError):
@@ -61,6 +61,14 @@ class PackItem(C.Structure):
                 ("Cout_pad", C.c_int32)]
 
 
+class GatherItem(C.Structure):
+    """cvcs_gather_item (include/cvcs_hip.h): one matrix of the table-driven weight gather"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p),
+                ("base", C.c_int64), ("rs0", C.c_int64), ("rs1", C.c_int64), ("rs2", C.c_int64), ("cs0", C.c_int64), ("cs1", C.c_int64), ("cs2", C.c_int64),
+                ("R", C.c_int32), ("Cp", C.c_int32), ("Rv", C.c_int32), ("Cv", C.c_int32), ("rd1", C.c_int32), ("rd2", C.c_int32),
+                ("cd1", C.c_int32), ("cd2", C.c_int32), ("f32_out", C.c_int32), ("rv2", C.c_int32), ("cv2", C.c_int32), ("pad_", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
@@ -88,6 +96,21 @@ SIGNATURES = {
     "cvcs_conv3x3_fp8": (_i, [C.POINTER(Conv8Desc), _vp]),
     "cvcs_quantize_fp8": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i, _vp]),
     "cvcs_fp8_update_scales": (_i, [_vp, _i, _f, _vp]),
+    "cvcs_im2col": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_im2col_stem": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_col2im": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_phase_shuffle": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp]),
+    "cvcs_phase_unshuffle": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _i64, _i, _vp]),
+    "cvcs_dwconv3x3": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _i, _vp]),
+    "cvcs_dwconv3x3_wgrad_rows": (_i, [_i64]),
+    "cvcs_dwconv3x3_wgrad": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cvcs_drop_path_scales": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "cvcs_scale_rows_add": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i64, _i, _vp, _i64, _i, _vp]),
+    "cvcs_sr_attention_fwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_sr_attention_bwd_workspace": (_i64, [_i, _i, _i, _i]),
+    "cvcs_sr_attention_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
+    "cvcs_scatter_weight_grads": (_i, [_vp, _i, _vp]),
     "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),
     "cvcs_counter_add": (_i, [_vp, C.c_uint64, _vp]),
     "cvcs_bn_act_q8": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]),
@@ -184,7 +207,7 @@ _recording = None          # the Recording that is capturing launches right now 
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_sizeof_conv8_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
-            "cvcs_window_attention_bwd_workspace_floats"}
+            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_sr_attention_bwd_workspace"}
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 
 

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void gather_weights_kernel(const cvcs_gather_i
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int c = (int)(id % it.Cp), r = (int)(id / it.Cp);
     float v = 0.f;
-    if (r < it.Rv && c < it.Cv) {
+    if (r < it.Rv && c < it.Cv && (it.rv2 == 0 || r % it.rd2 < it.rv2) && (it.cv2 == 0 || c % it.cd2 < it.cv2)) {
       const int64_t ri = (int64_t)(r / (it.rd1 * it.rd2)) * it.rs0 + (int64_t)((r / it.rd2) % it.rd1) * it.rs1 + (int64_t)(r % it.rd2) * it.rs2;
       const int64_t ci = (int64_t)(c / (it.cd1 * it.cd2)) * it.cs0 + (int64_t)((c / it.cd2) % it.cd1) * it.cs1 + (int64_t)(c % it.cd2) * it.cs2;
       v = it.src[it.base + ri + ci];
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(256) void scatter_weight_grads_kernel(const cvcs_ga
   float* master = const_cast<float*>(it.src);
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int c = (int)(id % it.Cv), r = (int)(id / it.Cv);
+    if ((it.rv2 != 0 && r % it.rd2 >= it.rv2) || (it.cv2 != 0 && c % it.cd2 >= it.cv2)) continue;
     const int64_t ri = (int64_t)(r / (it.rd1 * it.rd2)) * it.rs0 + (int64_t)((r / it.rd2) % it.rd1) * it.rs1 + (int64_t)(r % it.rd2) * it.rs2;
     const int64_t ci = (int64_t)(c / (it.cd1 * it.cd2)) * it.cs0 + (int64_t)((c / it.cd2) % it.cd1) * it.cs1 + (int64_t)(c % it.cd2) * it.cs2;
     master[it.base + ri + ci] = reinterpret_cast<const float*>(it.dst)[(int64_t)r * it.Cp + c];

@@ -579,3 +579,115 @@ class SwinBUperNet(SwinTUperNet):
     documentation (configs/train/README.txt:45)"""
     variant = "SwinBUperNet"
     swin = "base"
+
+
+# ------------------------------------------------------------------------------------------------ SegformerMod
+def segformer_param_spec(num_classes: int, variant: str = "b0"):
+    """(name, shape, kind) under the reference wrapper's key names (S/nets.py:313-349: `self.segformer` = transformers'
+    SegformerForSemanticSegmentation, `self.seq` = the ConvTranspose / ConvTranspose / Conv tail), transformers 5.x module layout.  Key and
+    value projection weights, then their biases, are registered adjacently: the engine runs them as one [2C, C] GEMM."""
+    from .segformer_engine import CONFIGS, ENC, HEAD
+    cfg = CONFIGS[variant]
+    spec = []
+
+    def lin(p, cin, cout):
+        spec.extend([(p + ".weight", (cout, cin), "lin_w"), (p + ".bias", (cout,), "lin_b")])
+
+    def ln(p, c):
+        spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b")])
+
+    def conv(p, cin, cout, k, kind="lin_w", bias=True):
+        spec.append((p + ".weight", (cout, cin, k, k), kind))
+        if bias:
+            spec.append((p + ".bias", (cout,), "lin_b" if kind == "lin_w" else "conv_b"))
+
+    cin = 3
+    for s, (c, depth, sr, k) in enumerate(zip(cfg["hidden"], cfg["depths"], cfg["sr"], cfg["patch"])):
+        conv(f"{ENC}.{s}.patch_embeddings.proj", cin, c, k)
+        ln(f"{ENC}.{s}.patch_embeddings.layer_norm", c)
+        for b in range(depth):
+            p = f"{ENC}.{s}.blocks.{b}"
+            ln(p + ".layernorm_before", c)
+            lin(p + ".attention.q_proj", c, c)
+            for leaf, shape, kind in (("weight", (c, c), "lin_w"), ("bias", (c,), "lin_b")):
+                for n in ("k_proj", "v_proj"):
+                    spec.append((f"{p}.attention.{n}.{leaf}", shape, kind))
+            lin(p + ".attention.o_proj", c, c)
+            if sr > 1:
+                conv(p + ".attention.sequence_reduction.sequence_reduction", c, c, sr)
+                ln(p + ".attention.sequence_reduction.layer_norm", c)
+            ln(p + ".layernorm_after", c)
+            ch = cfg["mlp_ratio"] * c
+            lin(p + ".mlp.fc1", c, ch)
+            spec.extend([(p + ".mlp.dwconv.dwconv.weight", (ch, 1, 3, 3), "lin_w"), (p + ".mlp.dwconv.dwconv.bias", (ch,), "lin_b")])
+            lin(p + ".mlp.fc2", ch, c)
+        ln(f"{ENC}.{s}.layer_norm", c)
+        cin = c
+    D = cfg["decoder"]
+    for s, c in enumerate(cfg["hidden"]):
+        lin(f"{HEAD}.linear_projections.{s}.proj", c, D)
+    conv(HEAD + ".linear_fuse", D * len(cfg["hidden"]), D, 1, bias=False)
+    spec.extend([(HEAD + ".batch_norm.weight", (D,), "bn_w"), (HEAD + ".batch_norm.bias", (D,), "bn_b"), (HEAD + ".batch_norm.running_mean", (D,), "rm"),
+                 (HEAD + ".batch_norm.running_var", (D,), "rv"), (HEAD + ".batch_norm.num_batches_tracked", (), "nbt")])
+    conv(HEAD + ".classifier", D, num_classes, 1, kind="conv_w")
+    NC = num_classes
+    # nn.ConvTranspose2d weights are [in, out, k, k]; torch's default init takes its fan-in from dim 1, as for Conv2d
+    spec.extend([("seq.0.weight", (NC, NC, 8, 8), "conv_w"), ("seq.0.bias", (NC,), "conv_b"), ("seq.2.weight", (NC, NC, 4, 4), "conv_w"),
+                 ("seq.2.bias", (NC,), "conv_b")])
+    conv("seq.4", NC, NC, 3, kind="conv_w")
+    return spec
+
+
+_SEGFORMER_V4 = [
+    (r"^segformer\.segformer\.encoder\.patch_embeddings\.(\d+)\.", r"segformer.segformer.stages.\1.patch_embeddings."),
+    (r"^segformer\.segformer\.encoder\.layer_norm\.(\d+)\.", r"segformer.segformer.stages.\1.layer_norm."),
+    (r"^segformer\.segformer\.encoder\.block\.(\d+)\.(\d+)\.", r"segformer.segformer.stages.\1.blocks.\2."),
+    (r"\.layer_norm_1\.", ".layernorm_before."), (r"\.layer_norm_2\.", ".layernorm_after."),
+    (r"\.attention\.self\.query\.", ".attention.q_proj."), (r"\.attention\.self\.key\.", ".attention.k_proj."),
+    (r"\.attention\.self\.value\.", ".attention.v_proj."), (r"\.attention\.output\.dense\.", ".attention.o_proj."),
+    (r"\.attention\.self\.sr\.", ".attention.sequence_reduction.sequence_reduction."),
+    (r"\.attention\.self\.layer_norm\.", ".attention.sequence_reduction.layer_norm."),
+    (r"\.mlp\.dense1\.", ".mlp.fc1."), (r"\.mlp\.dense2\.", ".mlp.fc2."),
+    (r"^segformer\.decode_head\.linear_c\.(\d+)\.", r"segformer.decode_head.linear_projections.\1."),
+]
+
+
+class SegformerMod(_HipUNet):
+    """The reference's `SegformerMod` (S/nets.py:313-349; `load_network` name at S/utils.py:191-192): transformers' Segformer (Mix
+    Transformer encoder, all-MLP decode head) with an NC-class classifier, followed by the reference's ConvTranspose2d(NC,NC,8,2,3) - ReLU -
+    ConvTranspose2d(NC,NC,4,2,1) - ReLU - Conv2d(NC,NC,3,padding=1) tail; the input is normalised with the ImageNet constants on the RAW
+    0..255 scale, as the reference's preprocessor does.  `pretrained=False` there means `SegformerConfig()` = MiT-b0, which is what this class
+    builds (`variant="b3"`: the architecture of the checkpoint the reference fetches with pretrained=True; there is no network here to fetch
+    it, a state_dict with its tensors loads by name).  Train mode applies the library's DropPath (0 ... 0.1 over the blocks) and the head's
+    Dropout(0.1) from a counter-based generator (`stochastic=False`: off).  State-dict keys follow transformers 5.x; checkpoints written
+    under the 4.x module layout (`segformer.segformer.encoder.block.N.M.attention.self.query...`) are mapped on load.  The tile side must be
+    a multiple of 32, NC at most 64."""
+    variant = "SegformerMod"
+    mit = "b0"
+
+    def __init__(self, num_classes: int, precision: str = "bf16", stochastic: bool = True, seed: int = 0, variant: str | None = None):
+        if variant is not None:
+            self.mit = variant
+        self.stochastic, self.seed = bool(stochastic), int(seed)
+        super().__init__(num_classes, precision)
+        self.wrapper = True           # S/nets.py:318: load_checkpoint goes through custom_load
+
+    def _build_spec(self):
+        return segformer_param_spec(self.num_classes, self.mit)
+
+    def _build_engine(self, dev):
+        from .segformer_engine import SegformerEngine
+        return SegformerEngine(self.num_classes, PRECISIONS[self.precision], dev, self.mit, stochastic=self.stochastic, seed=self.seed)
+
+    @staticmethod
+    def _from_v4(k: str) -> str:
+        import re
+        for pat, rep in _SEGFORMER_V4:
+            k = re.sub(pat, rep, k)
+        return k
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        return super().load_state_dict(OrderedDict((self._from_v4(k), v) for k, v in state_dict.items()), strict=strict, **kwargs)
+
+    def custom_load(self, checkpoint):       # S/nets.py:351-356
+        self.load_state_dict({str(k).replace("module.", ""): v for k, v in checkpoint["model_state_dict"].items()})

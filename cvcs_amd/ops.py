@@ -954,3 +954,154 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale, first_step):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     check(_lib.lib().cvcs_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                                     weight_decay, grad_scale, step, _stream()), "cvcs_adam_step")
+
+
+# ------------------------------------------------------------------------------------------------ SegformerMod pieces (csrc/segformer.hip)
+def _bytes(*views):
+    return sum(v.B * v.H * v.W * v.C * v.t.element_size() for v in views)
+
+
+def im2col(x: View, col: View, KH, KW, stride, oy0, ox0, direction=1):
+    """col [B,Ho,Wo,Kp] <- patches of x [B,H,W,C]: col[.., (ky*KW+kx)*C + c] = x[oy*stride + oy0 + ky*direction, ox*stride + ox0 + kx*direction, c]"""
+    assert col.B == x.B and col.C >= KH * KW * x.C
+    _tag_hbm("patches", _bytes(col) * 2)
+    check(_lib.lib().cvcs_im2col(x.ptr, x.ld, x.B, x.H, x.W, x.C, KH, KW, stride, oy0, ox0, direction, col.H, col.W, col.ptr, col.ld, x.code,
+                                 _stream()), "cvcs_im2col")
+
+
+SEGFORMER_MEAN, SEGFORMER_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # S/nets.py:339
+
+
+def im2col_stem(x: torch.Tensor, col: View, KH, KW, stride, pad, mean=SEGFORMER_MEAN, std=SEGFORMER_STD):
+    """the first patch embedding's patches straight from the planar u8 / f32 tile, normalised as S/nets.py:337-340"""
+    import ctypes as C
+    assert x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _tag_hbm("patches", _bytes(col) + x.numel() * x.element_size())
+    check(_lib.lib().cvcs_im2col_stem(x.data_ptr(), int(x.dtype == torch.uint8), x.shape[0], x.shape[2], x.shape[3], KH, KW, stride, pad, m3, s3,
+                                      col.H, col.W, col.ptr, col.ld, col.code, _stream()), "cvcs_im2col_stem")
+
+
+def col2im(col: View, dx: View, KH, KW, stride, oy0, ox0, direction=1, phases=1, phase_elems=0):
+    """dx [B,H,W,C] <- the transposed gather of `phases` slabs col [B,Ho,Wo,Kp] (phase_elems elements apart); oy0 / ox0: int or one per phase"""
+    import ctypes as C
+    oy = [oy0] * phases if isinstance(oy0, int) else list(oy0)
+    ox = [ox0] * phases if isinstance(ox0, int) else list(ox0)
+    assert len(oy) == len(ox) == phases
+    a, b = (C.c_int * 4)(*(oy + [0] * (4 - phases))), (C.c_int * 4)(*(ox + [0] * (4 - phases)))
+    _tag_hbm("patches", _bytes(col) * phases + _bytes(dx))
+    check(_lib.lib().cvcs_col2im(col.ptr, col.ld, phase_elems, phases, a, b, direction, stride, KH, KW, col.B, col.H, col.W, dx.C, dx.H, dx.W,
+                                 dx.ptr, dx.ld, dx.code, _stream()), "cvcs_col2im")
+
+
+def phase_shuffle(ph: View, phase_elems: int, out: View, relu: bool):
+    """four phase maps [4][B,H,W,C] (ph = phase 0) -> out [B,2H,2W,C] (+ReLU)"""
+    _tag_hbm("patches", _bytes(out) * 2)
+    check(_lib.lib().cvcs_phase_shuffle(ph.ptr, ph.ld, phase_elems, ph.B, ph.H, ph.W, ph.C, out.ptr, out.ld, int(relu), ph.code, _stream()),
+          "cvcs_phase_shuffle")
+
+
+def phase_unshuffle(g: View, relu_out: View | None, gph: View, phase_elems: int):
+    _tag_hbm("patches", _bytes(g) * (3 if relu_out is not None else 2))
+    check(_lib.lib().cvcs_phase_unshuffle(g.ptr, g.ld, 0 if relu_out is None else relu_out.ptr, 0 if relu_out is None else relu_out.ld, gph.B, gph.H,
+                                          gph.W, gph.C, gph.ptr, gph.ld, phase_elems, g.code, _stream()), "cvcs_phase_unshuffle")
+
+
+def dwconv3x3(x: View, w, bias, out: View, flip=False):
+    """depthwise 3x3 / pad 1 (w f32 [C,1,3,3] as stored, bias f32 [C] | None); flip: the data gradient"""
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == 9 * x.C
+    _tag_hbm("dwconv", _bytes(x, out))
+    check(_lib.lib().cvcs_dwconv3x3(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), _ptr(bias), int(flip), out.ptr, out.ld, x.code, _stream()),
+          "cvcs_dwconv3x3")
+
+
+def dwconv3x3_wgrad_rows(M: int) -> int:
+    return _lib.lib().cvcs_dwconv3x3_wgrad_rows(M)
+
+
+def dwconv3x3_wgrad(x: View, dy: View, part):
+    _tag_hbm("dwconv", _bytes(x, dy))
+    check(_lib.lib().cvcs_dwconv3x3_wgrad(x.ptr, x.ld, dy.ptr, dy.ld, x.B, x.H, x.W, x.C, part.data_ptr(), x.code, _stream()), "cvcs_dwconv3x3_wgrad")
+
+
+def drop_path_scales(state: torch.Tensor, rates: torch.Tensor, B: int, out: torch.Tensor):
+    """out f32 [n, B]: the per-sample factors of n DropPath calls of this step (state = [seed, step] int64 on the device)"""
+    assert state.dtype == torch.int64 and rates.dtype == torch.float32 and out.dtype == torch.float32 and out.numel() == rates.numel() * B
+    check(_lib.lib().cvcs_drop_path_scales(state.data_ptr(), rates.data_ptr(), rates.numel(), B, out.data_ptr(), _stream()), "cvcs_drop_path_scales")
+
+
+def drop_path_scales_host(seed: int, step: int, rates, B: int):
+    """cvcs_drop_path_scales replayed on the host -> f32 [n, B]"""
+    import numpy as np
+    n = len(rates)
+    with np.errstate(over="ignore"):
+        idx = np.arange(n * B, dtype=np.uint64)
+        z = ((np.uint64(seed) ^ np.uint64(0x5DEECE66D)) ^ (np.uint64(step) * np.uint64(0xD6E8FEB86659FD93))) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        u = (z >> np.uint64(40)).reshape(n, B)
+    out = np.ones((n, B), dtype=np.float32)
+    for i, r in enumerate(rates):
+        if r > 0:
+            keep = np.float32(1.0) - np.float32(r)
+            thr = np.uint64(int(keep * np.float32(16777216.0)))
+            out[i] = np.where(u[i] < thr, np.float32(1.0) / keep, np.float32(0.0))
+    return torch.from_numpy(out)
+
+
+def scale_rows_add(x: View, scale, res: View | None, out: View):
+    """out[b] = (res[b] if res else 0) + scale[b] * x[b]   (scale f32 [B] on the device | None = 1)"""
+    _tag_hbm("residual", _bytes(x, out) + (_bytes(res) if res is not None else 0))
+    check(_lib.lib().cvcs_scale_rows_add(x.ptr, x.ld, _ptr(scale), 0 if res is None else res.ptr, 0 if res is None else res.ld, x.B, x.H * x.W, x.C,
+                                         out.ptr, out.ld, x.code, _stream()), "cvcs_scale_rows_add")
+
+
+def sr_attention_fwd(q: View, kv: View, heads: int, out: View, lse):
+    """q [B,H,W,heads*32], kv [B,Hk,Wk,2*heads*32] (keys | values) -> out like q; lse f32 [B*heads*N]"""
+    N, Nk = q.H * q.W, kv.H * kv.W
+    assert q.C == heads * 32 and kv.C == 2 * q.C and kv.B == q.B and lse.numel() >= q.B * heads * N
+    if _lib._recording is not None:
+        _lib.pending_tag = ("sr_attention" + (f":{SCOPE}" if SCOPE else ""), 4.0 * q.B * N * Nk * q.C)
+    check(_lib.lib().cvcs_sr_attention_fwd(q.ptr, q.ld, kv.ptr, kv.ld, q.B, N, Nk, heads, out.ptr, out.ld, lse.data_ptr(), q.code, _stream()),
+          "cvcs_sr_attention_fwd")
+
+
+def sr_attention_bwd_workspace(B, N, Nk, heads) -> int:
+    return _lib.lib().cvcs_sr_attention_bwd_workspace(B, N, Nk, heads)
+
+
+def sr_attention_bwd(q: View, kv: View, o: View, go: View, lse, heads: int, gq: View, gkv: View, workspace):
+    N, Nk = q.H * q.W, kv.H * kv.W
+    assert workspace.numel() >= sr_attention_bwd_workspace(q.B, N, Nk, heads)
+    if _lib._recording is not None:
+        _lib.pending_tag = ("sr_attention" + (f":{SCOPE}" if SCOPE else ""), 10.0 * q.B * N * Nk * q.C)
+    check(_lib.lib().cvcs_sr_attention_bwd(q.ptr, q.ld, kv.ptr, kv.ld, o.ptr, o.ld, go.ptr, go.ld, lse.data_ptr(), q.B, N, Nk, heads, gq.ptr, gq.ld,
+                                           gkv.ptr, gkv.ld, workspace.data_ptr(), q.code, _stream()), "cvcs_sr_attention_bwd")
+
+
+def gather_table(items, device):
+    """items: dicts with the fields of cvcs_gather_item (src / dst tensors, base, R, Cp, Rv, Cv, row = (d1, d2, s0, s1, s2), col = (...), f32_out)
+    -> (device-resident table, n)"""
+    arr = (_lib.GatherItem * len(items))()
+    for it, d in zip(arr, items):
+        it.src, it.dst, it.base = d["src"].data_ptr(), d["dst"].data_ptr(), d.get("base", 0)
+        it.R, it.Cp, it.Rv, it.Cv = d["R"], d["Cp"], d["Rv"], d["Cv"]
+        it.rd1, it.rd2, it.rs0, it.rs1, it.rs2 = d["row"]
+        it.cd1, it.cd2, it.cs0, it.cs1, it.cs2 = d["col"]
+        it.f32_out = int(d.get("f32_out", False))
+        it.rv2, it.cv2 = d.get("rv2", 0), d.get("cv2", 0)
+        assert d["dst"].numel() >= d["R"] * d["Cp"] and d["Rv"] <= d["R"] and d["Cv"] <= d["Cp"]
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(items)
+
+
+GATHER_ITEM_BYTES = 120
+
+
+def gather_weights(table, n, dtype, first=0):
+    check(_lib.lib().cvcs_gather_weights(table.data_ptr() + first * GATHER_ITEM_BYTES, n, dtype_code(dtype), _stream()), "cvcs_gather_weights")
+
+
+def scatter_weight_grads(table, n, first=0):
+    """items [first, first + n) of a table whose `src` fields point at master GRADIENT tensors and `dst` at f32 gathered-layout gradients"""
+    check(_lib.lib().cvcs_scatter_weight_grads(table.data_ptr() + first * GATHER_ITEM_BYTES, n, _stream()), "cvcs_scatter_weight_grads")

@@ -40,8 +40,10 @@ def load_device(config):
 def load_network(config, device):
     """S/utils.py:174-195, every network on the HIP kernels: the reference's `Unet` / `Unetv2` and `Resnet101` (DeepLabV3 on a dilated
     ResNet-101, torchvision key names), `Ensemble` (votes over HIP member networks), BASELINE.json's `Resnet18Unet` / `Resnet34Unet` /
-    `Resnet50Unet`, `DeepLabV3Plus` and `TSwin` (Swin-T + UPerNet).  `MobileNet` and `SegformerMod` (depthwise convolutions, global
-    attention, 8x8 transposed convolutions) are not built and raise."""
+    `Resnet50Unet`, `DeepLabV3Plus` and `TSwin` (Swin-T + UPerNet), and the reference's `SegformerMod` (S/utils.py:191-192: transformers'
+    Segformer + the reference's ConvTranspose tail; config keys `segformer_variant` "b0" | "b3", `stochastic` false = DropPath / Dropout off,
+    `seed`).  `MobileNet` (torchvision's DeepLabV3 on MobileNetV3-large: depthwise 5x5, squeeze-excite, 8-channel-granular widths) is
+    not built and raises."""
     netname = config["net"]
     classes = config["num_classes"] + 1
     precision = config.get("precision", "bf16")
@@ -70,9 +72,11 @@ def load_network(config, device):
         # S/utils.py:180-181 -> nets.DeepLabv3Resnet101: DeepLabV3 on a dilated ResNet-101, on the HIP kernels (random-init:
         # the reference's COCO weights come from a network fetch)
         return nets.DeepLabv3Resnet101(classes, precision, config.get("aspp_dropout"), config.get("seed", 0)).to(device)
-    elif netname in ("MobileNet", "SegformerMod"):
-        raise NotImplementedError(f"network '{netname}' wraps third-party pretrained models in the reference "
-                                  "(S/nets.py:234-356) and is outside the MI355X hot path of this build")
+    elif netname == "SegformerMod":
+        # S/utils.py:191-192 -> nets.SegformerMod (random-init MiT-b0 = the reference's pretrained=False branch; its default fetches b3 weights)
+        return nets.SegformerMod(classes, precision, config.get("stochastic", True), config.get("seed", 0), config.get("segformer_variant")).to(device)
+    elif netname == "MobileNet":
+        raise NotImplementedError("network 'MobileNet' (S/nets.py:277-311: torchvision's deeplabv3_mobilenet_v3_large) is not built on the HIP kernels yet")
     else:
         print("Invalid network name.")
         raise Exception

@@ -545,14 +545,15 @@ int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t k
                           int dtype, void* stream);
 /* Table-driven weight gather: the f32 master tensors keep the reference's layouts (Conv2d OIHW, ConvTranspose2d IOHW); the GEMM operands of the
  * patch-matrix layers are re-gathered from them every step in ONE launch:
- *   dst[r][c] (R rows of pitch Cp; `dtype`, or f32 when f32_out) = r < Rv && c < Cv ? src[base + idx3(r; rd1, rd2, rs0..2) + idx3(c; cd1, cd2, cs0..2)] : 0
+ *   dst[r][c] (R rows of pitch Cp; `dtype`, or f32 when f32_out) = valid(r, c) ? src[base + idx3(r; rd1, rd2, rs0..2) + idx3(c; cd1, cd2, cs0..2)] : 0
+ *   valid(r, c) = r < Rv && c < Cv && (rv2 == 0 || r % rd2 < rv2) && (cv2 == 0 || c % cd2 < cv2)   (rv2 / cv2: channel padding inside a tap block)
  *   idx3(x; d1, d2, s0, s1, s2) = (x / (d1*d2)) * s0 + ((x / d2) % d1) * s1 + (x % d2) * s2
  * cvcs_scatter_weight_grads is the transposed move for gradients: src[base + idx3(r) + idx3(c)] = dst[r][c] (dst f32) for r < Rv, c < Cv.       */
 typedef struct {
   const float* src;
   void* dst;
   int64_t base, rs0, rs1, rs2, cs0, cs1, cs2;
-  int32_t R, Cp, Rv, Cv, rd1, rd2, cd1, cd2, f32_out, pad_;
+  int32_t R, Cp, Rv, Cv, rd1, rd2, cd1, cd2, f32_out, rv2, cv2, pad_;
 } cvcs_gather_item;
 int cvcs_gather_weights(const cvcs_gather_item* items_device, int n_items, int dtype, void* stream);
 int cvcs_scatter_weight_grads(const cvcs_gather_item* items_device, int n_items, void* stream);
