@@ -661,7 +661,7 @@ class SegformerMod(_HipUNet):
     it, a state_dict with its tensors loads by name).  Train mode applies the library's DropPath (0 ... 0.1 over the blocks) and the head's
     Dropout(0.1) from a counter-based generator (`stochastic=False`: off).  State-dict keys follow transformers 5.x; checkpoints written
     under the 4.x module layout (`segformer.segformer.encoder.block.N.M.attention.self.query...`) are mapped on load.  The tile side must be
-    a multiple of 32, NC at most 64."""
+    a multiple of 32, NC at most 32."""
     variant = "SegformerMod"
     mit = "b0"
 
@@ -678,6 +678,22 @@ class SegformerMod(_HipUNet):
     def _build_engine(self, dev):
         from .segformer_engine import SegformerEngine
         return SegformerEngine(self.num_classes, PRECISIONS[self.precision], dev, self.mit, stochastic=self.stochastic, seed=self.seed)
+
+    def _flat_order(self, params):
+        # key | value projection weights, then their biases, adjacent: the engine runs the two projections as one [2C, C] GEMM
+        out = OrderedDict()
+        for name, p in params.items():
+            if name.endswith(".attention.k_proj.weight"):
+                att = name[:-len("k_proj.weight")]
+                for leaf in ("weight", "bias"):
+                    for n in ("k_proj", "v_proj"):
+                        out[f"{att}{n}.{leaf}"] = params[f"{att}{n}.{leaf}"]
+            elif ".attention.k_proj." in name or ".attention.v_proj." in name:
+                continue
+            else:
+                out[name] = p
+        assert len(out) == len(params)
+        return out
 
     @staticmethod
     def _from_v4(k: str) -> str:

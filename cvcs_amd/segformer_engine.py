@@ -9,11 +9,11 @@ MI355X-first choices:
     convolutions (k = s = 8 | 4 | 2), the two ConvTranspose2d taken phase by phase - is ONE patch gather (`cvcs_im2col`) + the same GEMM
     kernels (forward, data gradient, weight gradient); the reference's input normalisation is folded into the first gather;
   * the master parameters keep the reference's shapes (Conv2d OIHW, ConvTranspose2d IOHW, NC channels): the GEMM operands (K-major patch
-    order, channels padded to 16 / 32) are re-gathered from them each step by one table-driven launch, their gradients scattered back;
+    order, channels padded to 32) are re-gathered from them each step by one table-driven launch, their gradients scattered back;
   * attention never materialises the N x Nk probabilities: the forward keeps the log-sum-exp, the backward recomputes;
   * DropPath is a per-sample factor drawn by a counter-based generator (replayable on the host) and fused into the residual adds; the
     head's Dropout is `cvcs_dropout`;
-  * the NC-channel tail runs NHWC with channels padded to 16 / 32 / 64; the NCHW f32 logits leave through the 1x1 head kernel with an
+  * the NC-channel tail runs NHWC with channels padded to 32; the NCHW f32 logits leave through the 1x1 head kernel with an
     identity matrix (an exact transposition), the gradient comes back the same way;
   * recorded launch plans as in resnet_engine.py.
 """
@@ -51,8 +51,8 @@ class SegformerEngine(SwinUPerNetEngine):
         self.cfg = CONFIGS[variant]
         self.variant = variant
         self.head_name = "seq.4"
-        assert num_classes <= 64, "SegformerMod's NC-channel tail is built for at most 64 classes"
-        self.CP = 16 if num_classes <= 16 else (32 if num_classes <= 32 else 64)     # channel count of the NC-channel maps
+        assert num_classes <= 32, "SegformerMod's NC-channel tail is built for at most 32 classes (the head kernels' limit)"
+        self.CP = 32          # channel count of the NC-channel maps (the 1x1 GEMM kernels write multiples of 32 output channels)
         # train-mode DropPath / Dropout (the library's defaults, active under net.train() at S/train.py:113); off = deterministic parity runs
         self.stochastic = bool(stochastic)
         self.drop_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.dev)

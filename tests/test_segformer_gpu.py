@@ -29,7 +29,7 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("NC,S,B", [(5, 64, 2), (16, 128, 2), (21, 96, 1)])
 def test_fp32_eval_logits_and_labels_match_the_oracle(NC, S, B):
-    """eval mode (BatchNorm folded, no DropPath / Dropout): NC = 5 / 16 pad to 16 channels, 21 to 32; S = 64 ... 128 gives 4 ... 16 keys"""
+    """eval mode (BatchNorm folded, no DropPath / Dropout): NC = 5 / 16 / 21 padded to 32 channels; S = 64 ... 128 gives 4 ... 16 keys"""
     net = _net(NC, "fp32")
     img, _ = _tiles(B, S, NC)
     net.eval()
