@@ -109,6 +109,8 @@ SIGNATURES = {
     "cvcs_sr_attention_fwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
     "cvcs_sr_attention_bwd_workspace": (_i64, [_i, _i, _i, _i]),
     "cvcs_sr_attention_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_planes_from_nhwc": (_i, [_vp, _i64, _i, _i64, _i, _i, _vp, _i, _vp]),
+    "cvcs_nhwc_from_planes": (_i, [_vp, _i, _i64, _i, _vp, _i64, _i, _i, _vp]),
     "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
     "cvcs_scatter_weight_grads": (_i, [_vp, _i, _vp]),
     "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),

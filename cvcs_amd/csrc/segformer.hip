@@ -11,6 +11,8 @@
 //     saved; backward recomputes the probabilities: a query-major kernel for dQ, a key-major kernel for dK / dV partials, fixed-order sum);
 //   * DropPath as a per-sample scale (counter-based, replayable on the host) fused into the residual add;
 //   * table-driven weight gather: f32 master tensors in the reference's layouts -> the GEMM operands of the patch-matrix layers.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cvcs {
@@ -191,14 +193,32 @@ __global__ __launch_bounds__(256) void phase_shuffle_kernel(const char* ph, int6
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3 (Mix-FFN)
 // nn.Conv2d(C, C, 3, 1, 1, groups=C): w [C][9] f32 as stored ([C,1,3,3]); flip = 1 runs the data gradient (taps reversed, no bias).
-// A thread owns one 16-byte channel chunk (its 9 x V weights stay in registers) and walks pixels.
-constexpr int kDwChunks = 32;
+// A workgroup = (<= 32 channel chunks) x (256 / chunks consecutive columns) walks a band of kDwRows rows of one image top to bottom with a
+// sliding 3x3 window in registers: three new loads per output pixel, the neighbouring columns' loads are L1 hits, the band's halo rows the
+// only re-read.  Work items (image, band, column strip) are handed out in XCD-aware order so that adjacent strips share an L2.
+constexpr int kDwChunks = 32, kDwRows = 16;
 struct DwArgs {
   const char* x; const char* dy; char* out;
   const float* w; const float* bias; float* part;
   int64_t x_ld, dy_ld, out_ld;
   int B, H, W, C, flip;
 };
+
+template <int NB>
+__device__ __forceinline__ void dw_load_row(const char* base, int64_t ld_bytes, int yy, int x, int H, int W, bool col_ok, uint4 (&r)[3]) {
+  // the three horizontally adjacent chunks of row yy around column x (zeros outside the map); NB = bytes per chunk (16 | 8)
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int xx = x + d - 1;
+    r[d] = make_uint4(0u, 0u, 0u, 0u);
+    if (col_ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+      const char* src = base + ((int64_t)yy * W + xx) * ld_bytes;
+      if constexpr (NB == 16) r[d] = *reinterpret_cast<const uint4*>(src);
+      else { const uint2 t = *reinterpret_cast<const uint2*>(src); r[d].x = t.x; r[d].y = t.y; }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
   constexpr int ES = sizeof(T), V = 16 / ES;
@@ -216,40 +236,45 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     for (int t = 0; t < 9; ++t) wv[t][k] = p.w[c * 9 + (p.flip ? 8 - t : t)];
     bv[k] = p.bias ? p.bias[c] : 0.f;
   }
-  const int64_t M = (int64_t)p.B * p.H * p.W;
-  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
-    const int x = (int)(pix % p.W);
-    const int64_t t = pix / p.W;
-    const int y = (int)(t % p.H);
-    uint4 raw[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-      raw[tap] = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-        raw[tap] = *reinterpret_cast<const uint4*>(p.x + ((pix + (int64_t)(tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.x_ld) * ES + cc * 16);
-    }
+  const int xs = (p.W + PL - 1) / PL, ys = (p.H + kDwRows - 1) / kDwRows;
+  const int item = (int)xcd_order(blockIdx.x, gridDim.x);
+  const int xb = item % xs, yb = (item / xs) % ys, b = item / (xs * ys);
+  const int x = xb * PL + pl;
+  const bool col_ok = x < p.W;
+  const int y0 = yb * kDwRows, y1 = y0 + kDwRows < p.H ? y0 + kDwRows : p.H;
+  const char* base = p.x + ((int64_t)b * p.H * p.W * p.x_ld) * ES + cc * 16;
+  char* obase = p.out + ((int64_t)b * p.H * p.W * p.out_ld) * ES + cc * 16;
+  uint4 r0[3], r1[3], r2[3];
+  dw_load_row<16>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, r0);
+  dw_load_row<16>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, r1);
+  for (int y = y0; y < y1; ++y) {
+    dw_load_row<16>(base, p.x_ld * ES, y + 1, x, p.H, p.W, col_ok, r2);
     float acc[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[k] = bv[k];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      float f[V];
-      Elem<T>::unpack(raw[tap], f);
+    for (int d = 0; d < 3; ++d) {
+      float f0[V], f1[V], f2[V];
+      Elem<T>::unpack(r0[d], f0);
+      Elem<T>::unpack(r1[d], f1);
+      Elem<T>::unpack(r2[d], f2);
 #pragma unroll
-      for (int k = 0; k < V; ++k) acc[k] += f[k] * wv[tap][k];
+      for (int k = 0; k < V; ++k) acc[k] += f0[k] * wv[d][k] + f1[k] * wv[3 + d][k] + f2[k] * wv[6 + d][k];
     }
-    *reinterpret_cast<uint4*>(p.out + (pix * p.out_ld) * ES + cc * 16) = Elem<T>::pack(acc);
+    if (col_ok) *reinterpret_cast<uint4*>(obase + ((int64_t)y * p.W + x) * p.out_ld * ES) = Elem<T>::pack(acc);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { r0[d] = r1[d]; r1[d] = r2[d]; }
   }
 }
 
-// partial sums of dW[c][tap] = sum dy[p] * x[p + off(tap)] and db[c] = sum dy[p]: part[blockIdx.x][c*9 + tap | 9C + c]
+// partial sums of dW[c][tap] = sum dy[p] * x[p + off(tap)] and db[c] = sum dy[p]: part[blockIdx.x][c*9 + tap | 9C + c].  Four channels per
+// thread (40 accumulators), the same sliding window; workgroup w takes the contiguous range of work items [w * n / rows, (w + 1) * n / rows)
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
-  constexpr int ES = sizeof(T), V = 16 / ES;
+  constexpr int ES = sizeof(T), V = 4, NB = V * ES;
   __shared__ float red[256][V + 1];
   const int CC = p.C / V;
-  const int ccw = CC < kDwChunks ? CC : kDwChunks;
+  const int ccw = CC < 64 ? CC : 64;
   const int PL = 256 / ccw;
   const int cl = threadIdx.x % ccw, pl = threadIdx.x / ccw;
   const int cc = blockIdx.y * ccw + cl;
@@ -259,29 +284,53 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
   for (int t = 0; t < 10; ++t)
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[t][k] = 0.f;
-  const int64_t M = (int64_t)p.B * p.H * p.W;
+  const int xs = (p.W + PL - 1) / PL, ys = (p.H + kDwRows - 1) / kDwRows;
+  const int nitems = p.B * xs * ys;
+  const int i0 = (int)((int64_t)blockIdx.x * nitems / gridDim.x), i1 = (int)((int64_t)(blockIdx.x + 1) * nitems / gridDim.x);
   if (live) {
-    for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
-      const int x = (int)(pix % p.W);
-      const int64_t t = pix / p.W;
-      const int y = (int)(t % p.H);
-      float g[V];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.dy + (pix * p.dy_ld) * ES + cc * 16), g);
-#pragma unroll
-      for (int k = 0; k < V; ++k) acc[9][k] += g[k];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-          float f[V];
-          Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.x + ((pix + (int64_t)(tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.x_ld) * ES + cc * 16), f);
-#pragma unroll
-          for (int k = 0; k < V; ++k) acc[tap][k] += g[k] * f[k];
+    for (int item = i0; item < i1; ++item) {
+      const int xb = item % xs, yb = (item / xs) % ys, b = item / (xs * ys);
+      const int x = xb * PL + pl;
+      const bool col_ok = x < p.W;
+      const int y0 = yb * kDwRows, y1 = y0 + kDwRows < p.H ? y0 + kDwRows : p.H;
+      const char* base = p.x + ((int64_t)b * p.H * p.W * p.x_ld) * ES + cc * NB;
+      const char* gbase = p.dy + ((int64_t)b * p.H * p.W * p.dy_ld) * ES + cc * NB;
+      uint4 r0[3], r1[3], r2[3];
+      dw_load_row<NB>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, r0);
+      dw_load_row<NB>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, r1);
+      for (int y = y0; y < y1; ++y) {
+        dw_load_row<NB>(base, p.x_ld * ES, y + 1, x, p.H, p.W, col_ok, r2);
+        float g[V];
+        {
+          uint4 gr = make_uint4(0u, 0u, 0u, 0u);
+          if (col_ok) {
+            const char* src = gbase + ((int64_t)y * p.W + x) * p.dy_ld * ES;
+            if constexpr (NB == 16) gr = *reinterpret_cast<const uint4*>(src);
+            else { const uint2 t = *reinterpret_cast<const uint2*>(src); gr.x = t.x; gr.y = t.y; }
+          }
+          if constexpr (ES == 4) { Elem<float>::unpack(gr, g); }
+          else { g[0] = __uint_as_float(gr.x << 16); g[1] = __uint_as_float(gr.x & 0xffff0000u); g[2] = __uint_as_float(gr.y << 16); g[3] = __uint_as_float(gr.y & 0xffff0000u); }
         }
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[9][k] += g[k];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+            const uint4& raw = rr == 0 ? r0[d] : (rr == 1 ? r1[d] : r2[d]);
+            float f[V];
+            if constexpr (ES == 4) { Elem<float>::unpack(raw, f); }
+            else { f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u); f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u); }
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[rr * 3 + d][k] += g[k] * f[k];
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { r0[d] = r1[d]; r1[d] = r2[d]; }
       }
     }
   }
-  // combine the PL pixel lanes, one tap at a time, in lane order
+  // combine the PL column lanes, one tap at a time, in lane order
   float* row = p.part + (int64_t)blockIdx.x * 10 * p.C;
   for (int t = 0; t < 10; ++t) {
     __syncthreads();
@@ -291,10 +340,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
     if (live && pl == 0) {
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        float s = 0.f;
-        for (int q = 0; q < PL; ++q) s += red[q * ccw + cl][k];
+        float s_ = 0.f;
+        for (int q = 0; q < PL; ++q) s_ += red[q * ccw + cl][k];
         const int c = cc * V + k;
-        if (t < 9) row[c * 9 + t] = s; else row[9 * p.C + c] = s;
+        if (t < 9) row[c * 9 + t] = s_; else row[9 * p.C + c] = s_;
       }
     }
   }
@@ -591,6 +640,365 @@ __global__ __launch_bounds__(256) void sr_attn_dkv_reduce_kernel(const float* __
   }
 }
 
+// ---- the same attention on the matrix cores (bf16, Nk a multiple of 32).  Head dimension 32 = ONE K-step of v_mfma_f32_16x16x32_bf16.
+// Scores are computed TRANSPOSED, S^T = K Q^T (A = 16 key rows from LDS, B = the wave's 16 queries, read once): the accumulator layout
+// (lane = query l % 16, registers = keys (l / 16) * 4 + r) is then exactly a B operand of the second MFMA, O^T = V^T P^T, if its 32 K slots
+// are fed as [block 2j keys g*4..g*4+3 | block 2j+1 keys g*4..g*4+3] - the probabilities go from accumulators to operands without leaving
+// the registers; V^T ([32 d][keys], row pitch + 8 bytes: conflict-free 8-byte reads) supplies the matching slots.  Softmax statistics:
+// per lane over its own keys, combined across the four lane groups by two shuffles; 256 keys at a time with the usual online rescale.
+constexpr int kSrVtPitch = kSrKC * 2 + 8;     // bytes per V^T (or K^T) row in LDS
+
+// rows [j0, j0 + n) of the key (which = 0) / value (which = 1) projection of (b, h): row-major [n][32] bf16 at `rows` and / or transposed
+// [32][n] (pitch kSrVtPitch) at `tr`
+__device__ __forceinline__ void sr_stage_bf16(const SrArgs& p, int b, int h, int which, int j0, int n, char* rows, char* tr) {
+  const int C = p.heads * kSrD;
+  for (int id = threadIdx.x; id < n * 4; id += blockDim.x) {
+    const int j = id >> 2, c = id & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + j0 + j) * p.kv_ld + which * C + h * kSrD + c * 8) * 2);
+    if (rows) *reinterpret_cast<uint4*>(rows + j * 64 + c * 16) = v;
+    if (tr) {
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<uint16_t*>(tr + (c * 8 + k) * kSrVtPitch + j * 2) = (uint16_t)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 sr_pack8(const f32x4& a, const f32x4& b) {
+  uint4 u;
+  u.x = pack2_bf16(a[0], a[1]); u.y = pack2_bf16(a[2], a[3]); u.z = pack2_bf16(b[0], b[1]); u.w = pack2_bf16(b[2], b[3]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+// A operand of the transposed product: row d = db*16 + fr of a [32][keys] LDS image, K slots = keys {2j*16 + g*4 .., (2j+1)*16 + g*4 ..}
+__device__ __forceinline__ bf16x8 sr_tr_operand(const char* tr, int db, int fr, int g, int jp) {
+  const char* row = tr + (db * 16 + fr) * kSrVtPitch;
+  const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * jp) * 16 + g * 4) * 2);
+  const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * jp + 1) * 16 + g * 4) * 2);
+  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+__global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char sr_lds[];
+  char* skr = sr_lds;                              // K rows [kSrKC][64 B]
+  char* svt = sr_lds + kSrKC * 64;                 // V^T [32][kSrVtPitch]
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int nbase = blockIdx.x * 256 + wave * 64;
+  bf16x8 bq[4];
+  f32x4 o[4][2];
+  float m[4], l[4];
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int n = nbase + qb * 16 + fr;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (n < p.N) v = *reinterpret_cast<const uint4*>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD + g * 8) * 2);
+    bq[qb] = __builtin_bit_cast(bf16x8, v);
+    o[qb][0] = o[qb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m[qb] = -INFINITY; l[qb] = 0.f;
+  }
+  for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
+    const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;       // a multiple of 32
+    __syncthreads();
+    sr_stage_bf16(p, b, h, 0, j0, nk, skr, nullptr);
+    sr_stage_bf16(p, b, h, 1, j0, nk, nullptr, svt);
+    __syncthreads();
+    const int nblk = nk >> 4;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      f32x4 s[kSrKC / 16];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int jb = 0; jb < kSrKC / 16; ++jb) {
+        if (jb < nblk) {
+          const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(skr + (jb * 16 + fr) * 64 + g * 16));
+          s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[jb][r] *= p.scale; cm = fmaxf(cm, s[jb][r]); }
+        }
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      const float mn = fmaxf(m[qb], cm);
+      const float corr = __expf(m[qb] - mn);
+      m[qb] = mn;
+      l[qb] *= corr;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qb][db][r] *= corr;
+#pragma unroll
+      for (int jb = 0; jb < kSrKC / 16; ++jb) {
+        if (jb < nblk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[jb][r] = __expf(s[jb][r] - mn); l[qb] += s[jb][r]; }
+        }
+      }
+#pragma unroll
+      for (int jp = 0; jp < kSrKC / 32; ++jp) {
+        if (2 * jp < nblk) {
+          const bf16x8 pb = sr_pack8(s[2 * jp], s[2 * jp + 1]);
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+            o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sr_tr_operand(svt, db, fr, g, jp), pb, o[qb][db], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    float lt = l[qb];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const int n = nbase + qb * 16 + fr;
+    if (n < p.N) {
+      const float inv = 1.f / lt;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        uint2 u;
+        u.x = pack2_bf16(o[qb][db][0] * inv, o[qb][db][1] * inv);
+        u.y = pack2_bf16(o[qb][db][2] * inv, o[qb][db][3] * inv);
+        *reinterpret_cast<uint2*>(p.out + (((int64_t)b * p.N + n) * p.out_ld + h * kSrD + db * 16 + g * 4) * 2) = u;
+      }
+      if (p.lse && g == 0) p.lse[(int64_t)bh * p.N + n] = m[qb] + __logf(lt);
+    }
+  }
+}
+
+// dQ on the matrix cores: the forward's structure.  S^T and dP^T = V dO^T per 16-key block, dS^T = P^T (dP^T - delta) scale in the accumulator
+// layout, dQ^T += K^T dS^T with K^T read from a transposed LDS image.  delta = rowsum(dO o O) is formed here (8 channels per lane, two
+// shuffles) and saved for the key-major kernel.
+__global__ __launch_bounds__(256) void sr_attn_bwd_dq_mfma_kernel(SrArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char sr_lds[];
+  char* skr = sr_lds;                              // K rows
+  char* svr = sr_lds + kSrKC * 64;                 // V rows
+  char* skt = sr_lds + 2 * kSrKC * 64;             // K^T
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int nbase = blockIdx.x * 256 + wave * 64;
+  bf16x8 bq[4], bgo[4];
+  f32x4 dq[4][2];
+  float lse[4], delta[4];
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int n = nbase + qb * 16 + fr;
+    uint4 vq = make_uint4(0u, 0u, 0u, 0u), vg = vq, vo = vq;
+    if (n < p.N) {
+      const int64_t tok = (int64_t)b * p.N + n;
+      vq = *reinterpret_cast<const uint4*>(p.q + (tok * p.q_ld + h * kSrD + g * 8) * 2);
+      vg = *reinterpret_cast<const uint4*>(p.go + (tok * p.go_ld + h * kSrD + g * 8) * 2);
+      vo = *reinterpret_cast<const uint4*>(p.o + (tok * p.o_ld + h * kSrD + g * 8) * 2);
+    }
+    bq[qb] = __builtin_bit_cast(bf16x8, vq);
+    bgo[qb] = __builtin_bit_cast(bf16x8, vg);
+    float fg_[8], fo[8];
+    Elem<bf16_t>::unpack(vg, fg_);
+    Elem<bf16_t>::unpack(vo, fo);
+    float d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d += fg_[k] * fo[k];
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    delta[qb] = d;
+    lse[qb] = n < p.N ? p.lse[(int64_t)bh * p.N + n] : INFINITY;
+    if (n < p.N && g == 0) p.delta[(int64_t)bh * p.N + n] = d;
+    dq[qb][0] = dq[qb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
+    const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;
+    __syncthreads();
+    sr_stage_bf16(p, b, h, 0, j0, nk, skr, skt);
+    sr_stage_bf16(p, b, h, 1, j0, nk, svr, nullptr);
+    __syncthreads();
+    const int npair = nk >> 5;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      for (int jp = 0; jp < npair; ++jp) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int jb = 2 * jp + e;
+          const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(skr + (jb * 16 + fr) * 64 + g * 16));
+          const bf16x8 va = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(svr + (jb * 16 + fr) * 64 + g * 16));
+          const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, bgo[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[e][r] = __expf(st[r] * p.scale - lse[qb]) * (dp[r] - delta[qb]) * p.scale;
+        }
+        const bf16x8 pb = sr_pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sr_tr_operand(skt, db, fr, g, jp), pb, dq[qb][db], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int n = nbase + qb * 16 + fr;
+    if (n < p.N) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        uint2 u;
+        u.x = pack2_bf16(dq[qb][db][0], dq[qb][db][1]);
+        u.y = pack2_bf16(dq[qb][db][2], dq[qb][db][3]);
+        *reinterpret_cast<uint2*>(p.gq + (((int64_t)b * p.N + n) * p.gq_ld + h * kSrD + db * 16 + g * 4) * 2) = u;
+      }
+    }
+  }
+}
+
+// dK / dV on the matrix cores (key-major): wave w owns the key blocks {i*4 + w} of this workgroup's 256 keys (their K / V rows stay in
+// registers as B operands), the workgroup walks its query chunk 32 queries at a time.  S = Q K^T and dP = dO V^T come out with lane = key,
+// registers = queries - exactly the A operand (rows = keys, K slots = the 32 queries) of dV += P^T dO and dK += dS^T Q, whose B operands are
+// the step's dO^T / Q^T tiles from a transposed LDS image.  Partials as the VALU kernel's: part[(bh, chunk)][key][dk 32 | dv 32].
+constexpr int kSrQtPitch = 32 * 2 + 8;
+__global__ __launch_bounds__(256) void sr_attn_bwd_dkv_mfma_kernel(SrArgs p) {
+  __shared__ __attribute__((aligned(16))) char sqt[32 * kSrQtPitch];      // Q^T  [32 d][32 queries]
+  __shared__ __attribute__((aligned(16))) char sgt[32 * kSrQtPitch];      // dO^T
+  __shared__ __attribute__((aligned(16))) float sl[32];
+  __shared__ __attribute__((aligned(16))) float sd[32];
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int chunk = blockIdx.x, chunks = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int C = p.heads * kSrD;
+  bf16x8 kop[4], vop[4];
+  f32x4 dk[4][2], dv[4][2];
+  bool live[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int key = blockIdx.z * 256 + (i * 4 + wave) * 16 + fr;
+    live[i] = blockIdx.z * 256 + (i * 4 + wave) * 16 < p.Nk;
+    uint4 vk = make_uint4(0u, 0u, 0u, 0u), vv = vk;
+    if (live[i]) {
+      vk = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + key) * p.kv_ld + h * kSrD + g * 8) * 2);
+      vv = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + key) * p.kv_ld + C + h * kSrD + g * 8) * 2);
+    }
+    kop[i] = __builtin_bit_cast(bf16x8, vk);
+    vop[i] = __builtin_bit_cast(bf16x8, vv);
+    dk[i][0] = dk[i][1] = dv[i][0] = dv[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int n0 = chunk * p.QC;
+  const int n1 = n0 + p.QC < p.N ? n0 + p.QC : p.N;
+  for (int nb = n0; nb < n1; nb += 32) {
+    // this step's Q / dO rows as A operands (lane = query fr of block a, channels g*8 ..)
+    bf16x8 qa[2], ga[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int n = nb + a * 16 + fr;
+      uint4 vq = make_uint4(0u, 0u, 0u, 0u), vg = vq;
+      if (n < n1) {
+        const int64_t tok = (int64_t)b * p.N + n;
+        vq = *reinterpret_cast<const uint4*>(p.q + (tok * p.q_ld + h * kSrD + g * 8) * 2);
+        vg = *reinterpret_cast<const uint4*>(p.go + (tok * p.go_ld + h * kSrD + g * 8) * 2);
+      }
+      qa[a] = __builtin_bit_cast(bf16x8, vq);
+      ga[a] = __builtin_bit_cast(bf16x8, vg);
+    }
+    __syncthreads();
+    {   // the transposed tiles: thread = (tensor, query, 8-channel chunk)
+      const int t = threadIdx.x >> 7, r = (threadIdx.x >> 2) & 31, c = threadIdx.x & 3;
+      const int n = nb + r;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (n < n1) {
+        const int64_t tok = (int64_t)b * p.N + n;
+        v = t ? *reinterpret_cast<const uint4*>(p.go + (tok * p.go_ld + h * kSrD + c * 8) * 2)
+              : *reinterpret_cast<const uint4*>(p.q + (tok * p.q_ld + h * kSrD + c * 8) * 2);
+      }
+      char* tr = t ? sgt : sqt;
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<uint16_t*>(tr + (c * 8 + k) * kSrQtPitch + r * 2) = (uint16_t)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
+      if (threadIdx.x < 32) {
+        const int nn = nb + threadIdx.x;
+        sl[threadIdx.x] = nn < n1 ? p.lse[(int64_t)bh * p.N + nn] : INFINITY;
+        sd[threadIdx.x] = nn < n1 ? p.delta[(int64_t)bh * p.N + nn] : 0.f;
+      }
+    }
+    __syncthreads();
+    bf16x8 qT[2], gT[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const char* rq_ = sqt + (db * 16 + fr) * kSrQtPitch;
+      const char* rg_ = sgt + (db * 16 + fr) * kSrQtPitch;
+      const uint2 a0 = *reinterpret_cast<const uint2*>(rq_ + (g * 4) * 2), a1 = *reinterpret_cast<const uint2*>(rq_ + (16 + g * 4) * 2);
+      const uint2 b0 = *reinterpret_cast<const uint2*>(rg_ + (g * 4) * 2), b1 = *reinterpret_cast<const uint2*>(rg_ + (16 + g * 4) * 2);
+      qT[db] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+      gT[db] = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+    }
+    f32x4 ls[2], dl[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      ls[a] = *reinterpret_cast<const f32x4*>(sl + a * 16 + g * 4);
+      dl[a] = *reinterpret_cast<const f32x4*>(sd + a * 16 + g * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!live[i]) continue;
+      f32x4 pr[2], ds[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a], kop[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a], vop[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[a][r] = __expf(s[r] * p.scale - ls[a][r]);
+          ds[a][r] = pr[a][r] * (dp[r] - dl[a][r]) * p.scale;
+        }
+      }
+      const bf16x8 pa = sr_pack8(pr[0], pr[1]), da = sr_pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dv[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, gT[db], dv[i][db], 0, 0, 0);
+        dk[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, qT[db], dk[i][db], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!live[i]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = blockIdx.z * 256 + (i * 4 + wave) * 16 + g * 4 + r;
+      float* dst = p.part + (((int64_t)bh * chunks + chunk) * p.Nk + key) * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dst[db * 16 + fr] = dk[i][db][r];
+        dst[32 + db * 16 + fr] = dv[i][db][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ NHWC <-> NCHW f32 logits
+// the NC-channel tail ends in an NHWC map with padded channels; the nn.Module contract (S/nets.py:346-349) returns NCHW f32 logits.
+// One thread = one pixel: plane-wise accesses are coalesced across the wave, the pixel's own row is one or two 16-byte chunks per lane.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void planes_kernel(char* x, int64_t x_ld, int64_t M, int64_t HW, int C, int NC, float* planes) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < M; pix += (int64_t)gridDim.x * 256) {
+    const int64_t b = pix / HW, hw = pix - b * HW;
+    float* pl = planes + b * NC * HW + hw;
+    for (int c0 = 0; c0 < C; c0 += V) {
+      float f[V];
+      if constexpr (!BWD) {
+        if (c0 >= NC) break;
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (pix * x_ld + c0) * ES), f);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if (c0 + k < NC) pl[(int64_t)(c0 + k) * HW] = f[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = c0 + k < NC ? pl[(int64_t)(c0 + k) * HW] : 0.f;
+        *reinterpret_cast<uint4*>(x + (pix * x_ld + c0) * ES) = Elem<T>::pack(f);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gather
 // dst[r][c] (row pitch Cp) = r < Rv && c < Cv ? src[base + idx3(r; rd1, rd2, rs*) + idx3(c; cd1, cd2, cs*)] : 0,
 // idx3(x; d1, d2, s0, s1, s2) = (x / (d1*d2)) * s0 + ((x / d2) % d1) * s1 + (x % d2) * s2
@@ -736,10 +1144,9 @@ extern "C" int cvcs_dwconv3x3(const void* x, int64_t x_ld, int B, int H, int W, 
   if ((rc = sf_view(fn, out, out_ld, C, es))) return rc;
   DwArgs a{(const char*)x, nullptr, (char*)out, w, bias, nullptr, x_ld, 0, out_ld, B, H, W, C, flip};
   const int CC = C / V, ccw = CC < kDwChunks ? CC : kDwChunks, PL = 256 / ccw;
-  const int64_t M = (int64_t)B * H * W;
-  int64_t gx = cdiv(M, (int64_t)PL * 4);
-  if (gx > 4096) gx = 4096;
-  const dim3 grid((unsigned)gx, (unsigned)cdiv(CC, ccw));
+  const int64_t items = (int64_t)B * cdiv(H, kDwRows) * cdiv(W, PL);
+  CVCS_CHECK_ARG(items < (1ll << 31), "%s: too many work items", fn);
+  const dim3 grid((unsigned)items, (unsigned)cdiv(CC, ccw));
   if (dtype == CVCS_F32) hipLaunchKernelGGL((dwconv3x3_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
   CVCS_CHECK_LAUNCH(fn);
@@ -760,7 +1167,9 @@ extern "C" int cvcs_dwconv3x3_wgrad(const void* x, int64_t x_ld, const void* dy,
   if ((rc = sf_view(fn, dy, dy_ld, C, es))) return rc;
   CVCS_CHECK_ARG(part != nullptr, "%s: null partial buffer", fn);
   DwArgs a{(const char*)x, (const char*)dy, nullptr, nullptr, nullptr, part, x_ld, dy_ld, 0, B, H, W, C, 0};
-  const int CC = C / V, ccw = CC < kDwChunks ? CC : kDwChunks;
+  (void)V;
+  const int CC = C / 4, ccw = CC < 64 ? CC : 64;        // four channels per thread (the wgrad kernel's own chunking)
+  CVCS_CHECK_ARG(C % 4 == 0, "%s: C %% 4 != 0", fn);
   const dim3 grid((unsigned)cvcs_dwconv3x3_wgrad_rows((int64_t)B * H * W), (unsigned)cdiv(CC, ccw));
   if (dtype == CVCS_F32) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -815,6 +1224,12 @@ extern "C" int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv
   const dim3 grid((unsigned)cdiv(N, 256), (unsigned)(B * heads));
   const size_t lds = 2 * (size_t)kSrKC * kSrD * 4;
   hipStream_t st = (hipStream_t)stream;
+  static const int use_mfma = getenv("CVCS_SR_ATTN_MFMA") ? atoi(getenv("CVCS_SR_ATTN_MFMA")) : 1;      // tuning / A-B knob
+  if (dtype == CVCS_BF16 && use_mfma && Nk % 32 == 0) {
+    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel, grid, dim3(256), kSrKC * 64 + 32 * kSrVtPitch, st, a);
+    CVCS_CHECK_LAUNCH(fn);
+    return CVCS_OK;
+  }
   if (dtype == CVCS_F32) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
@@ -859,6 +1274,14 @@ extern "C" int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv
   const dim3 gk_grid((unsigned)chunks, (unsigned)(B * heads), (unsigned)cdiv(Nk, 256));
   const size_t lds = 2 * (size_t)kSrKC * kSrD * 4;
   const dim3 gr_grid(sf_grid((int64_t)B * heads * Nk * 64));
+  static const int use_mfma = getenv("CVCS_SR_ATTN_MFMA") ? atoi(getenv("CVCS_SR_ATTN_MFMA")) : 1;
+  if (dtype == CVCS_BF16 && use_mfma && Nk % 32 == 0) {
+    hipLaunchKernelGGL(sr_attn_bwd_dq_mfma_kernel, gq_grid, dim3(256), 2 * kSrKC * 64 + 32 * kSrVtPitch, st, a);
+    hipLaunchKernelGGL(sr_attn_bwd_dkv_mfma_kernel, gk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<bf16_t>), gr_grid, dim3(256), 0, st, a.part, chunks, B, Nk, heads, (char*)gkv, gkv_ld);
+    CVCS_CHECK_LAUNCH(fn);
+    return CVCS_OK;
+  }
   if (dtype == CVCS_F32) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_bwd_dq_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
@@ -891,4 +1314,29 @@ extern "C" int cvcs_scatter_weight_grads(const cvcs_gather_item* items_device, i
   hipLaunchKernelGGL(scatter_weight_grads_kernel, dim3(64, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_device);
   CVCS_CHECK_LAUNCH("cvcs_scatter_weight_grads");
   return CVCS_OK;
+}
+
+static int planes_impl(const char* fn, bool bwd, void* x, int64_t x_ld, int B, int64_t HW, int C, int NC, float* planes, int dtype, void* stream) {
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % V == 0 && NC >= 1 && NC <= C && planes, "%s: bad argument", fn);
+  int rc;
+  if ((rc = sf_view(fn, x, x_ld, C, es))) return rc;
+  const int64_t M = (int64_t)B * HW;
+  const dim3 grid(sf_grid(M));
+  hipStream_t st = (hipStream_t)stream;
+#define PL_L(TT, BW) hipLaunchKernelGGL((planes_kernel<TT, BW>), grid, dim3(256), 0, st, (char*)x, x_ld, M, HW, C, NC, planes)
+  if (dtype == CVCS_F32) { if (bwd) PL_L(float, true); else PL_L(float, false); }
+  else { if (bwd) PL_L(bf16_t, true); else PL_L(bf16_t, false); }
+#undef PL_L
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_planes_from_nhwc(const void* x, int64_t x_ld, int B, int64_t HW, int C, int NC, float* planes, int dtype, void* stream) {
+  return planes_impl("cvcs_planes_from_nhwc", false, const_cast<void*>(x), x_ld, B, HW, C, NC, planes, dtype, stream);
+}
+
+extern "C" int cvcs_nhwc_from_planes(const float* planes, int B, int64_t HW, int NC, void* x, int64_t x_ld, int C, int dtype, void* stream) {
+  return planes_impl("cvcs_nhwc_from_planes", true, x, x_ld, B, HW, C, NC, const_cast<float*>(planes), dtype, stream);
 }

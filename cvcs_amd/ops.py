@@ -1105,3 +1105,18 @@ def gather_weights(table, n, dtype, first=0):
 def scatter_weight_grads(table, n, first=0):
     """items [first, first + n) of a table whose `src` fields point at master GRADIENT tensors and `dst` at f32 gathered-layout gradients"""
     check(_lib.lib().cvcs_scatter_weight_grads(table.data_ptr() + first * GATHER_ITEM_BYTES, n, _stream()), "cvcs_scatter_weight_grads")
+
+
+def planes_from_nhwc(x: View, NC: int, planes: torch.Tensor):
+    """NHWC (padded channels) -> NCHW f32 [B, NC, H, W]"""
+    assert planes.dtype == torch.float32 and planes.is_contiguous() and planes.numel() == x.B * NC * x.H * x.W
+    _tag_hbm("layout", _bytes(x) + planes.numel() * 4)
+    check(_lib.lib().cvcs_planes_from_nhwc(x.ptr, x.ld, x.B, x.H * x.W, x.C, NC, planes.data_ptr(), x.code, _stream()), "cvcs_planes_from_nhwc")
+
+
+def nhwc_from_planes(planes: torch.Tensor, NC: int, x: View):
+    """NCHW f32 [B, NC, H, W] -> NHWC with zero padding channels"""
+    assert planes.dtype == torch.float32 and planes.is_contiguous() and planes.numel() == x.B * NC * x.H * x.W
+    _tag_hbm("layout", _bytes(x) + planes.numel() * 4)
+    check(_lib.lib().cvcs_nhwc_from_planes(planes.data_ptr(), x.B, x.H * x.W, NC, x.ptr, x.ld, x.C, x.code, _stream()), "cvcs_nhwc_from_planes")
+

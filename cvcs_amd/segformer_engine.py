@@ -13,8 +13,8 @@ MI355X-first choices:
   * attention never materialises the N x Nk probabilities: the forward keeps the log-sum-exp, the backward recomputes;
   * DropPath is a per-sample factor drawn by a counter-based generator (replayable on the host) and fused into the residual adds; the
     head's Dropout is `cvcs_dropout`;
-  * the NC-channel tail runs NHWC with channels padded to 32; the NCHW f32 logits leave through the 1x1 head kernel with an
-    identity matrix (an exact transposition), the gradient comes back the same way;
+  * the NC-channel tail runs NHWC with channels padded to 32; the NCHW f32 logits leave through a
+    transposition kernel (`cvcs_planes_from_nhwc`), the gradient comes back the same way;
   * recorded launch plans as in resnet_engine.py.
 """
 from __future__ import annotations
@@ -511,7 +511,7 @@ class SegformerEngine(SwinUPerNetEngine):
         if self.shape != (x.shape[0], x.shape[2]):
             self._last_act = {}
         h = self._forward_backbone(x, train)
-        ops.head_fwd(h.v, self.eye, self.zero[:self.NC], self.logits)           # NHWC (padded channels) -> NCHW f32: an exact transposition
+        ops.planes_from_nhwc(h.v, self.NC, self.logits)
         return self.logits
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
@@ -528,10 +528,8 @@ class SegformerEngine(SwinUPerNetEngine):
         B, S = self.shape
         NC, CP = self.NC, self.CP
         h = self._last_act["fwd_train"]
-        rows = ops.head_bwd_rows(B * S * S)
-        part = self._scratch("head_part", rows * (NC * CP + NC))
         gh = ops.view(self._act("head.gx", B, S, S, CP))
-        ops.head_bwd(h.v, dlogits.contiguous(), self.eye, gh, part)             # the transposed move (the identity's own "gradient" is not used)
+        ops.nhwc_from_planes(dlogits.contiguous(), NC, gh)
 
         def run_tape():
             h.grads = [(gh, False)]

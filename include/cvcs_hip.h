@@ -557,6 +557,10 @@ typedef struct {
 } cvcs_gather_item;
 int cvcs_gather_weights(const cvcs_gather_item* items_device, int n_items, int dtype, void* stream);
 int cvcs_scatter_weight_grads(const cvcs_gather_item* items_device, int n_items, void* stream);
+/* NHWC map [B*HW][C] (`dtype`, channels >= NC are padding) <-> the NCHW f32 logits / logit gradients [B][NC][HW] of the nn.Module contract
+ * (S/nets.py:346-349 returns `self.seq(out)`, NCHW).  cvcs_nhwc_from_planes zero-fills the padding channels.                                */
+int cvcs_planes_from_nhwc(const void* x, int64_t x_ld, int B, int64_t HW, int C, int NC, float* planes, int dtype, void* stream);
+int cvcs_nhwc_from_planes(const float* planes, int B, int64_t HW, int NC, void* x, int64_t x_ld, int C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

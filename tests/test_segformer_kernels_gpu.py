@@ -150,10 +150,11 @@ def test_depthwise_3x3_forward_data_and_weight_gradients(dt, B, H, W, C):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,Hq,Hk,heads", [(2, 16, 2, 1), (2, 8, 2, 2), (1, 20, 10, 5), (2, 4, 4, 8), (1, 32, 18, 1)])
+@pytest.mark.parametrize("B,Hq,Hk,heads", [(2, 16, 2, 1), (2, 8, 2, 2), (1, 20, 10, 5), (2, 4, 4, 8), (1, 32, 18, 1), (2, 32, 8, 2), (1, 40, 16, 5), (1, 24, 24, 1)])
 def test_spatial_reduction_attention_forward_and_backward(dt, B, Hq, Hk, heads):
-    """softmax(q k^T / sqrt(32)) v with N = Hq^2 queries and Nk = Hk^2 keys per image and head (Nk = 4 ... 324: below one 8-key block,
-    across the 256-key LDS chunk), gradients against autograd"""
+    """softmax(q k^T / sqrt(32)) v with N = Hq^2 queries and Nk = Hk^2 keys per image and head (Nk = 4 ... 576: below one 8-key block,
+    across the 256-key LDS chunk; Nk = 64 / 256 / 576 in bf16 run the matrix-core kernels, ragged query counts included), gradients
+    against autograd"""
     ops = _ops()
     C = heads * 32
     N, Nk = Hq * Hq, Hk * Hk
