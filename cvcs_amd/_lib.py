@@ -111,6 +111,8 @@ SIGNATURES = {
     "cvcs_sr_attention_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i, _vp]),
     "cvcs_planes_from_nhwc": (_i, [_vp, _i64, _i, _i64, _i, _i, _vp, _i, _vp]),
     "cvcs_nhwc_from_planes": (_i, [_vp, _i, _i64, _i, _vp, _i64, _i, _i, _vp]),
+    "cvcs_deconv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "cvcs_deconv_unpack_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
     "cvcs_scatter_weight_grads": (_i, [_vp, _i, _vp]),
     "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),

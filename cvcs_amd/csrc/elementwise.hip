@@ -31,9 +31,34 @@ __device__ __forceinline__ void merge(Moments& a, double nb, double mean_b, doub
 
 constexpr int kDirectRows = 2048;
 
-// merge partial rows r0, r0+rstep, .. < r1 (row r covers scnt[r] pixels) for channel c
+// merge partial rows r0, r0+rstep, .. < r1 (row r covers scnt[r] pixels) for channel c.
+// Rows of EQUAL pixel count (every full tile; the common case) need no per-row division: with S = sum of the row sums, Q = sum of their
+// squares and M = sum of the row M2s, the merged moments are mean = S / (k n), M2 = M + Q / n - S^2 / (k n) - three f64 FMAs per row instead of
+// two f64 divisions (the serial Chan merge took 15 us per BatchNorm: 63 of them per ResNet50-UNet step).  In f64 the cancellation costs
+// ~1e-16 (mean / sigma)^2 of relative accuracy.  A lane that meets rows of different counts (ragged tiles) merges them pairwise as before.
 __device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, const float* __restrict__ sm2,
                                               const float* __restrict__ scnt, int r0, int r1, int rstep, int C, int c) {
+  double S = 0.0, Q = 0.0, Mm = 0.0, n0 = -1.0;
+  int k = 0;
+  bool uniform = true;
+  for (int r = r0; r < r1; r += rstep) {
+    const double n = (double)scnt[r];
+    if (n <= 0.0) continue;
+    if (n0 < 0.0) n0 = n;
+    uniform = uniform && n == n0;
+    const double s_ = (double)ssum[(int64_t)r * C + c];
+    S += s_;
+    Q += s_ * s_;
+    Mm += (double)sm2[(int64_t)r * C + c];
+    ++k;
+  }
+  if (k == 0) return Moments{0.0, 0.0, 0.0};
+  if (uniform) {
+    const double N = n0 * (double)k;
+    double m2 = Mm + (Q / n0 - S * S / N);
+    if (m2 < 0.0) m2 = 0.0;
+    return Moments{N, S / N, m2};
+  }
   Moments a{0.0, 0.0, 0.0};
   for (int r = r0; r < r1; r += rstep) {
     const double n = (double)scnt[r];

@@ -973,6 +973,72 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_mfma_kernel(SrArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ ConvTranspose2d(k, stride 2, p) as ONE convolution
+// out[2i + a, 2j + b, co] = sum_{jy, jx, ci} in[i + da - jy, j + db - jx, ci] w[ci][co][ay + 2 jy][ax + 2 jx],  da = (a + p) >> 1, ay = (a + p) & 1.
+// Over the four phases the input offsets span a T x T window, T = k/2 + 1 (k = 4: 3x3, k = 8: 5x5, padding T/2): the layer is an ordinary
+// stride-1 convolution from C to 4C channels (channel = phase * CP + co; taps a phase does not touch are zero) followed by the pixel
+// shuffle - no zero-stuffed input, no per-phase patch matrices.  This kernel writes that convolution's operands from the master tensor:
+//   layout 0 (conv kernels):  wf [T*T][4CP][CPk],  wd [T*T flipped][CP][4CP]           (forward / data-gradient images of cvcs_conv2d)
+//   layout 1 (patch GEMM):    wf [4CP][Kp], K = (ty*T + tx)*CP + ci,  wd [Kp][4CP]      (1x1 images over the cvcs_im2col matrix)
+// and bias4[phase*CP + co] = bias[co].  deconv_unpack_grad_kernel is the transposed move for the gradients.
+struct DeconvArgs {
+  const float* w; const float* bias; void* wf; void* wd; float* bias4;
+  const float* dw; const float* db4; float* gw; float* gb;
+  int NC, k, p, CP, CPk, Kp, layout;
+};
+__device__ __forceinline__ bool deconv_tap(int k, int p, int T, int a, int t, int& kk) {   // union tap t of phase bit a -> filter index kk
+  const int da = (a + p) >> 1, ay = (a + p) & 1;
+  const int j = da + T / 2 - t;
+  kk = ay + 2 * j;
+  return j >= 0 && j < k / 2;
+}
+template <typename T_>
+__global__ __launch_bounds__(256) void deconv_pack_kernel(DeconvArgs p) {
+  const int T = p.k / 2 + 1, C4 = 4 * p.CP;
+  const int64_t total = (int64_t)T * T * C4 * p.CP;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(id % p.CP);
+    int64_t r = id / p.CP;
+    const int oc = (int)(r % C4);
+    const int t = (int)(r / C4);
+    const int ph = oc / p.CP, co = oc - ph * p.CP, ty = t / T, tx = t - ty * T;
+    int ky, kx;
+    const bool oky = deconv_tap(p.k, p.p, T, ph >> 1, ty, ky), okx = deconv_tap(p.k, p.p, T, ph & 1, tx, kx);
+    const bool ok = oky && okx;
+    const float v = (ok && ci < p.NC && co < p.NC) ? p.w[(((int64_t)ci * p.NC + co) * p.k + ky) * p.k + kx] : 0.f;
+    if (p.layout == 0) {
+      Elem<T_>::st(reinterpret_cast<T_*>(p.wf) + ((int64_t)t * C4 + oc) * p.CPk + ci, v);
+      Elem<T_>::st(reinterpret_cast<T_*>(p.wd) + ((int64_t)(T * T - 1 - t) * p.CP + ci) * C4 + oc, v);
+    } else {
+      Elem<T_>::st(reinterpret_cast<T_*>(p.wf) + (int64_t)oc * p.Kp + t * p.CP + ci, v);
+      Elem<T_>::st(reinterpret_cast<T_*>(p.wd) + ((int64_t)t * p.CP + ci) * C4 + oc, v);
+    }
+    if (id < C4) p.bias4[id] = (id % p.CP) < p.NC ? p.bias[id % p.CP] : 0.f;
+  }
+}
+// gw[ci][co][ky][kx] = dW element of the (phase, tap) that uses filter tap (ky, kx) - exactly one; gb[co] = sum over the phases of db4
+__global__ __launch_bounds__(256) void deconv_unpack_grad_kernel(DeconvArgs p) {
+  const int T = p.k / 2 + 1;
+  const int64_t total = (int64_t)p.NC * p.NC * p.k * p.k;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total + p.NC; id += (int64_t)gridDim.x * 256) {
+    if (id >= total) {
+      const int co = (int)(id - total);
+      p.gb[co] = ((p.db4[co] + p.db4[p.CP + co]) + p.db4[2 * p.CP + co]) + p.db4[3 * p.CP + co];
+      continue;
+    }
+    const int kx = (int)(id % p.k);
+    int64_t r = id / p.k;
+    const int ky = (int)(r % p.k);
+    r /= p.k;
+    const int co = (int)(r % p.NC), ci = (int)(r / p.NC);
+    // the phase whose parity matches: ay = (a + p) & 1 = ky & 1
+    const int a = ((ky & 1) - p.p) & 1, b = ((kx & 1) - p.p) & 1;
+    const int ty = ((a + p.p) >> 1) + T / 2 - (ky >> 1), tx = ((b + p.p) >> 1) + T / 2 - (kx >> 1);
+    const int oc = (a * 2 + b) * p.CP + co, t = ty * T + tx;
+    p.gw[id] = p.layout == 0 ? p.dw[(((int64_t)oc * p.CP + ci) * T + ty) * T + tx] : p.dw[(int64_t)oc * p.Kp + t * p.CP + ci];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ NHWC <-> NCHW f32 logits
 // the NC-channel tail ends in an NHWC map with padded channels; the nn.Module contract (S/nets.py:346-349) returns NCHW f32 logits.
 // One thread = one pixel: plane-wise accesses are coalesced across the wave, the pixel's own row is one or two 16-byte chunks per lane.
@@ -1103,7 +1169,9 @@ static int phase_shuffle_impl(const char* fn, bool bwd, const void* ph, int64_t 
                               int64_t full_ld, const void* mask, int64_t mask_ld, int relu, int dtype, void* stream) {
   CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
-  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0 && phase_elems >= (int64_t)B * H * W * ph_ld && (phase_elems * es) % 16 == 0, "%s: bad shape", fn);
+  // phase slabs (phase_elems >= B*H*W*ph_ld) or phases interleaved in the channels of one map (ph_ld >= 4 * phase_elems, phase_elems >= C)
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0 && (phase_elems * es) % 16 == 0 &&
+                 (phase_elems >= (int64_t)B * H * W * ph_ld || (phase_elems >= C && ph_ld >= 4 * phase_elems)), "%s: bad shape", fn);
   int rc;
   if ((rc = sf_view(fn, ph, ph_ld, C, es)) || (rc = sf_view(fn, full, full_ld, C, es))) return rc;
   if (mask && (rc = sf_view(fn, mask, mask_ld, C, es))) return rc;
@@ -1340,3 +1408,39 @@ extern "C" int cvcs_planes_from_nhwc(const void* x, int64_t x_ld, int B, int64_t
 extern "C" int cvcs_nhwc_from_planes(const float* planes, int B, int64_t HW, int NC, void* x, int64_t x_ld, int C, int dtype, void* stream) {
   return planes_impl("cvcs_nhwc_from_planes", true, x, x_ld, B, HW, C, NC, const_cast<float*>(planes), dtype, stream);
 }
+
+static int deconv_args_ok(const char* fn, int NC, int k, int p, int CP, int layout) {
+  CVCS_CHECK_ARG(NC >= 1 && CP >= NC && CP % 16 == 0 && (k == 4 || k == 8) && p >= 0 && p < k / 2 && (layout == 0 || layout == 1), "%s: bad argument", fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_deconv_pack(const float* w, const float* bias, int NC, int k, int p, int CP, int layout, int CPk, int Kp, void* wf, void* wd,
+                                float* bias4, int dtype, void* stream) {
+  const char* fn = "cvcs_deconv_pack";
+  CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
+  int rc;
+  if ((rc = deconv_args_ok(fn, NC, k, p, CP, layout))) return rc;
+  const int T = k / 2 + 1;
+  CVCS_CHECK_ARG(w && bias && wf && wd && bias4 && CPk >= CP && (layout == 0 || Kp >= T * T * CP), "%s: null tensor / pitches", fn);
+  DeconvArgs a{};
+  a.w = w; a.bias = bias; a.wf = wf; a.wd = wd; a.bias4 = bias4; a.NC = NC; a.k = k; a.p = p; a.CP = CP; a.CPk = CPk; a.Kp = Kp; a.layout = layout;
+  const dim3 grid(sf_grid((int64_t)T * T * 4 * CP * CP, 1024));
+  if (dtype == CVCS_F32) hipLaunchKernelGGL((deconv_pack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((deconv_pack_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_deconv_unpack_grad(const float* dw, const float* db4, int NC, int k, int p, int CP, int layout, int Kp, float* gw, float* gb,
+                                       void* stream) {
+  const char* fn = "cvcs_deconv_unpack_grad";
+  int rc;
+  if ((rc = deconv_args_ok(fn, NC, k, p, CP, layout))) return rc;
+  CVCS_CHECK_ARG(dw && db4 && gw && gb, "%s: null tensor", fn);
+  DeconvArgs a{};
+  a.dw = dw; a.db4 = db4; a.gw = gw; a.gb = gb; a.NC = NC; a.k = k; a.p = p; a.CP = CP; a.Kp = Kp; a.layout = layout;
+  hipLaunchKernelGGL(deconv_unpack_grad_kernel, dim3(sf_grid((int64_t)NC * NC * k * k + NC, 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+

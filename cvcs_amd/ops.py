@@ -995,16 +995,17 @@ def col2im(col: View, dx: View, KH, KW, stride, oy0, ox0, direction=1, phases=1,
 
 
 def phase_shuffle(ph: View, phase_elems: int, out: View, relu: bool):
-    """four phase maps [4][B,H,W,C] (ph = phase 0) -> out [B,2H,2W,C] (+ReLU)"""
+    """four phase maps -> out [B,2H,2W,C] (+ReLU): slabs [4][B,H,W,C] (ph = phase 0, phase_elems = a slab) or the phases interleaved in the
+    channels of one map [B,H,W,4C] (ph = that map, phase_elems = C)"""
     _tag_hbm("patches", _bytes(out) * 2)
-    check(_lib.lib().cvcs_phase_shuffle(ph.ptr, ph.ld, phase_elems, ph.B, ph.H, ph.W, ph.C, out.ptr, out.ld, int(relu), ph.code, _stream()),
+    check(_lib.lib().cvcs_phase_shuffle(ph.ptr, ph.ld, phase_elems, ph.B, ph.H, ph.W, out.C, out.ptr, out.ld, int(relu), ph.code, _stream()),
           "cvcs_phase_shuffle")
 
 
 def phase_unshuffle(g: View, relu_out: View | None, gph: View, phase_elems: int):
     _tag_hbm("patches", _bytes(g) * (3 if relu_out is not None else 2))
     check(_lib.lib().cvcs_phase_unshuffle(g.ptr, g.ld, 0 if relu_out is None else relu_out.ptr, 0 if relu_out is None else relu_out.ld, gph.B, gph.H,
-                                          gph.W, gph.C, gph.ptr, gph.ld, phase_elems, g.code, _stream()), "cvcs_phase_unshuffle")
+                                          gph.W, g.C, gph.ptr, gph.ld, phase_elems, g.code, _stream()), "cvcs_phase_unshuffle")
 
 
 def dwconv3x3(x: View, w, bias, out: View, flip=False):
@@ -1119,4 +1120,21 @@ def nhwc_from_planes(planes: torch.Tensor, NC: int, x: View):
     assert planes.dtype == torch.float32 and planes.is_contiguous() and planes.numel() == x.B * NC * x.H * x.W
     _tag_hbm("layout", _bytes(x) + planes.numel() * 4)
     check(_lib.lib().cvcs_nhwc_from_planes(planes.data_ptr(), x.B, x.H * x.W, NC, x.ptr, x.ld, x.C, x.code, _stream()), "cvcs_nhwc_from_planes")
+
+
+def deconv_pack(w, bias, k, p, CP, layout, wf, wd, bias4):
+    """ConvTranspose2d(NC, NC, k, 2, p) master weight [NC,NC,k,k] (IOHW) -> the operands of its one-convolution form (cvcs_deconv_pack)"""
+    NC = w.shape[0]
+    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (NC, NC, k, k) and bias4.numel() == 4 * CP
+    CPk = wf.shape[2] if layout == 0 else CP
+    Kp = 0 if layout == 0 else wf.shape[-1]
+    check(_lib.lib().cvcs_deconv_pack(w.data_ptr(), bias.data_ptr(), NC, k, p, CP, layout, CPk, Kp, wf.data_ptr(), wd.data_ptr(), bias4.data_ptr(),
+                                      dtype_code(wf.dtype), _stream()), "cvcs_deconv_pack")
+
+
+def deconv_unpack_grad(dw, db4, k, p, CP, layout, gw, gb):
+    NC = gw.shape[0]
+    Kp = 0 if layout == 0 else dw.shape[-1] if dw.dim() == 2 else dw.shape[1]
+    check(_lib.lib().cvcs_deconv_unpack_grad(dw.data_ptr(), db4.data_ptr(), NC, k, p, CP, layout, Kp, gw.data_ptr(), gb.data_ptr(), _stream()),
+          "cvcs_deconv_unpack_grad")
 

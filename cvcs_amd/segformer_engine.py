@@ -6,8 +6,9 @@ MI355X-first choices:
   * tokens ARE NHWC pixels (as in swin_engine.py): every nn.Linear is a 1x1 convolution on the GEMM kernels, key and value projections are
     ONE GEMM (their weights are adjacent in the flat parameter buffer);
   * every convolution that is neither 1x1 nor 3x3 / stride 1 - the overlapping patch embeddings (7/4/3, 3/2/1), the sequence-reduction
-    convolutions (k = s = 8 | 4 | 2), the two ConvTranspose2d taken phase by phase - is ONE patch gather (`cvcs_im2col`) + the same GEMM
-    kernels (forward, data gradient, weight gradient); the reference's input normalisation is folded into the first gather;
+    convolutions (k = s = 8 | 4 | 2) - is ONE patch gather (`cvcs_im2col`) + the same GEMM kernels (forward, data gradient, weight
+    gradient); each ConvTranspose2d(k, 2, p) of the tail is ONE stride-1 convolution to 4 x the channels over a (k/2 + 1)^2 window + a pixel
+    shuffle (`cvcs_deconv_pack`): k = 4 on the 3x3 conv kernels, k = 8 as a 5x5 patch GEMM; the reference's input normalisation is folded into the first gather;
   * the master parameters keep the reference's shapes (Conv2d OIHW, ConvTranspose2d IOHW, NC channels): the GEMM operands (K-major patch
     order, channels padded to 32) are re-gathered from them each step by one table-driven launch, their gradients scattered back;
   * attention never materialises the N x Nk probabilities: the forward keeps the log-sum-exp, the backward recomputes;
@@ -139,14 +140,25 @@ class SegformerEngine(SwinUPerNetEngine):
         plain(HEAD + ".linear_fuse", params[HEAD + ".linear_fuse.weight"], grads[HEAD + ".linear_fuse.weight"])
         # ---- the NC-channel layers: channels padded to CP, pad rows / columns zero
         gathered(HEAD + ".classifier", HEAD + ".classifier.weight", CP, NC, D, row=(1, BIG, 0, 0, D), col=(1, BIG, 0, 0, 1), bias=HEAD + ".classifier.bias")
-        for name, k, pd in (("seq.0", 8, 3), ("seq.2", 4, 1)):
-            k2 = k // 2
-            for ph in range(4):
-                a, b_ = ph >> 1, ph & 1
-                ay, ax = (a + pd) & 1, (b_ + pd) & 1
-                # ConvTranspose2d weight [ci, co, ky, kx]: rows co, columns (jy, jx, ci padded to CP) -> w[ci][co][ay + 2 jy][ax + 2 jx]
-                gathered(f"{name}.ph{ph}", name + ".weight", CP, NC, k2 * k2 * CP, row=(1, BIG, 0, 0, k * k), col=(k2, CP, 2 * k, 2, NC * k * k),
-                         base=ay * k + ax, cv2=NC, bias=name + ".bias", bias_key=name)
+        # the two ConvTranspose2d of the tail, each as ONE stride-1 convolution CP -> 4 CP (cvcs_deconv_pack): seq.2 (k = 4) on the 3x3 conv
+        # kernels, seq.0 (k = 8, a 5x5 window) as a patch GEMM
+        self.deconv = {}
+        for name, k, pd, layout in (("seq.0", 8, 3, 1), ("seq.2", 4, 1, 0)):
+            T = k // 2 + 1
+            if layout == 0:
+                wf = torch.zeros(T * T, 4 * CP, max(CP, kg), dtype=dt, device=dev)
+                wd = torch.zeros(T * T, CP, 4 * CP, dtype=dt, device=dev)
+                gw = torch.zeros(4 * CP, CP, T, T, dtype=torch.float32, device=dev)
+            else:
+                Kp = -(-T * T * CP // 128) * 128          # (a multiple of 128: the data-gradient GEMM writes Kp columns on the taps kernel)
+                wf = torch.zeros(1, 4 * CP, Kp, dtype=dt, device=dev)
+                wd = torch.zeros(1, Kp, 4 * CP, dtype=dt, device=dev)
+                gw = torch.zeros(4 * CP, Kp, 1, 1, dtype=torch.float32, device=dev)
+            self.deconv[name] = dict(k=k, p=pd, T=T, layout=layout, wf=wf, wd=wd, gw=gw, bias4=torch.zeros(4 * CP, dtype=torch.float32, device=dev),
+                                     gb4=torch.zeros(4 * CP, dtype=torch.float32, device=dev))
+            self.packed[name] = dict(wf=wf, wd=wd)
+            self.W4[name + ".bias"], self.GW4[name] = self.deconv[name]["bias4"], gw
+            self.GW4[name + ".bias"] = self.deconv[name]["gb4"]
         # the last 3x3 (NC -> NC) stays on the conv kernels: [tap][CP][CPk] forward, flipped [tap][CP][CPk] data gradient, OIHW-padded gradient
         cpk = max(CP, kg)
         w3, g3 = params["seq.4.weight"], grads["seq.4.weight"]
@@ -179,6 +191,8 @@ class SegformerEngine(SwinUPerNetEngine):
     def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
         ops.gather_weights(self._gather[0], self._gather[1], self.dtype)
+        for name, d in self.deconv.items():
+            ops.deconv_pack(self.P[name + ".weight"], self.P[name + ".bias"], d["k"], d["p"], self.CP, d["layout"], d["wf"], d["wd"], d["bias4"])
 
     def _scatter_grad(self, key):
         ops.scatter_weight_grads(self._scatter[0], 1, first=self._scat_index[key])
@@ -441,42 +455,45 @@ class SegformerEngine(SwinUPerNetEngine):
         self._scatter_grad(key + ".bias")
 
     def _deconv(self, x: Act, name, k, pd, train, tape) -> Act:
-        """nn.ConvTranspose2d(NC, NC, k, stride 2, padding pd) + ReLU on a CP-channel map: four phase GEMMs over gathered patches"""
+        """nn.ConvTranspose2d(NC, NC, k, stride 2, padding pd) + ReLU on a CP-channel map as ONE stride-1 convolution to 4 CP channels (phase-major)
+        + the pixel shuffle: k = 4 on the 3x3 conv kernels, k = 8 (5x5 window) as a patch GEMM"""
+        d = self.deconv[name]
         v = x.v
         B, H, W, CP = v.B, v.H, v.W, v.C
-        k2 = k // 2
-        K = k2 * k2 * CP
-        Kp = self.packed[name + ".ph0"]["wf"].shape[2]
-        cols = self._buf(name + ".cols", (4, B, H, W, Kp))
-        outs = self._buf(name + ".phases", (4, B, H, W, CP))
-        oy0 = [((ph >> 1) + pd) >> 1 for ph in range(4)]
-        ox0 = [((ph & 1) + pd) >> 1 for ph in range(4)]
+        T, layout = d["T"], d["layout"]
+        y4 = self._tokens(name + ".y4", B, H, W, 4 * CP)
         ops.SCOPE = "dec"
-        for ph in range(4):
-            ops.im2col(v, ops.view(cols[ph]), k2, k2, 1, oy0[ph], ox0[ph], -1)
-            self._lin(ops.view(cols[ph]), f"{name}.ph{ph}", ops.view(outs[ph]))
+        if layout == 0:
+            col = None
+            ops.conv2d(v, d["wf"], d["bias4"], y4, T, T, 1, T // 2)
+        else:
+            col = ops.view(self._act(name + ".col", B, H, W, d["wf"].shape[2]))
+            ops.im2col(v, col, T, T, 1, -(T // 2), -(T // 2))
+            ops.conv2d(col, d["wf"], d["bias4"], y4, 1, 1)
         o = Act(self._tokens(name + ".out", B, 2 * H, 2 * W, CP))
-        ops.SCOPE = "dec"
-        ops.phase_shuffle(ops.view(outs[0]), outs[0].numel(), o.v, relu=True)
+        ops.phase_shuffle(y4, CP, o.v, relu=True)
         if train:
             def bwd():
                 g = self._sum_grads(o, name + ".out.g")
-                gph = self._buf(name + ".gphases", (4, B, H, W, CP))
+                g4 = self._tokens(name + ".g4", B, H, W, 4 * CP)
                 ops.SCOPE = "dec"
-                ops.phase_unshuffle(g, o.v, ops.view(gph[0]), gph[0].numel())
-                self._bias_grad(View(gph.view(1, 4 * B * H * W, 1, CP), 0, CP), name)
-                gcols = self._buf(name + ".gcols", (4, B, H, W, Kp))
-                for ph in range(4):
-                    key = f"{name}.ph{ph}"
-                    ops.SCOPE = "dec"
-                    gw = self.GW4[key]
-                    need = ops.wgrad_workspace_floats_for(ops.view(cols[ph]), ops.view(gph[ph]), 1, 1, 1, 0)
-                    ops.conv2d_wgrad(ops.view(cols[ph]), ops.view(gph[ph]), gw, 1, 1, 1, 0, self._scratch("wg_ws", need))
-                    self._scatter_grad(key)
-                    ops.conv2d(ops.view(gph[ph]), self.packed[key]["wd"], None, ops.view(gcols[ph]), 1, 1)
+                ops.phase_unshuffle(g, o.v, g4, CP)
+                rows = ops.bn_bwd_rows(B * H * W)
+                part = self._scratch("bias_part", rows * 4 * CP)
+                ops.colsum_partial(g4, part)
+                ops.colsum_finalize(part, rows, 4 * CP, d["gb4"])
                 gx = self._tokens(name + ".gx", B, H, W, CP)
-                ops.SCOPE = "dec"
-                ops.col2im(ops.view(gcols[0]), gx, k2, k2, 1, oy0, ox0, -1, phases=4, phase_elems=gcols[0].numel())
+                if layout == 0:
+                    need = ops.wgrad_workspace_floats_for(v, g4, T, T, 1, T // 2)
+                    ops.conv2d_wgrad(v, g4, d["gw"], T, T, 1, T // 2, self._scratch("wg_ws", need))
+                    ops.conv2d(g4, d["wd"], None, gx, T, T, 1, T // 2)
+                else:
+                    need = ops.wgrad_workspace_floats_for(col, g4, 1, 1, 1, 0)
+                    ops.conv2d_wgrad(col, g4, d["gw"], 1, 1, 1, 0, self._scratch("wg_ws", need))
+                    gcol = ops.view(self._act(name + ".gcol", B, H, W, col.C))
+                    ops.conv2d(g4, d["wd"], None, gcol, 1, 1)
+                    ops.col2im(gcol, gx, T, T, 1, -(T // 2), -(T // 2))
+                ops.deconv_unpack_grad(d["gw"], d["gb4"], k, pd, CP, layout, self.G[name + ".weight"], self.G[name + ".bias"])
                 x.grads.append((gx, False))
             tape.append(bwd)
         return o

@@ -561,6 +561,16 @@ int cvcs_scatter_weight_grads(const cvcs_gather_item* items_device, int n_items,
  * (S/nets.py:346-349 returns `self.seq(out)`, NCHW).  cvcs_nhwc_from_planes zero-fills the padding channels.                                */
 int cvcs_planes_from_nhwc(const void* x, int64_t x_ld, int B, int64_t HW, int C, int NC, float* planes, int dtype, void* stream);
 int cvcs_nhwc_from_planes(const float* planes, int B, int64_t HW, int NC, void* x, int64_t x_ld, int C, int dtype, void* stream);
+/* nn.ConvTranspose2d(NC, NC, k, stride 2, padding p) (k = 4 | 8; the reference's tail, S/nets.py:331-334) as ONE stride-1 convolution from CP to
+ * 4*CP channels (channel = phase*CP + co, phase = (oy & 1)*2 + (ox & 1)) over a T x T window, T = k/2 + 1, padding T/2, followed by
+ * cvcs_phase_shuffle with the phases interleaved in the channels (ph_ld = 4*CP, phase_elems = CP).  cvcs_deconv_pack writes the operands from
+ * the master weight w [NC][NC][k][k] (IOHW) and bias: layout 0 = cvcs_conv2d images wf [T*T][4CP][CPk], wd [T*T][CP][4CP] (flipped taps);
+ * layout 1 = 1x1 images over the cvcs_im2col patch matrix, wf [4CP][Kp] with K = (ty*T + tx)*CP + ci, wd [Kp][4CP]; bias4 [4CP].
+ * cvcs_deconv_unpack_grad: the master gradients gw [NC][NC][k][k], gb [NC] from that convolution's dW (layout 0: OIHW [4CP][CP][T][T] f32,
+ * layout 1: [4CP][Kp] f32) and db4 [4CP].                                                                                                   */
+int cvcs_deconv_pack(const float* w, const float* bias, int NC, int k, int p, int CP, int layout, int CPk, int Kp, void* wf, void* wd, float* bias4,
+                     int dtype, void* stream);
+int cvcs_deconv_unpack_grad(const float* dw, const float* db4, int NC, int k, int p, int CP, int layout, int Kp, float* gw, float* gb, void* stream);
 
 #ifdef __cplusplus
 }

@@ -256,3 +256,75 @@ def test_weight_gather_table_and_its_transpose():
     back = gmaster[:, :, ay::2, ax::2].permute(1, 2, 3, 0).reshape(C, k2 * k2 * C)
     assert torch.equal(back, ggath)
     assert (gmaster[:, :, 1 - ay::2, :] == 0).all()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,p,layout", [(4, 1, 0), (8, 3, 1)])
+def test_conv_transpose_as_one_convolution_and_its_gradient_unpack(dt, k, p, layout):
+    """cvcs_deconv_pack: ConvTranspose2d(NC, NC, k, 2, p) == conv (k/2+1)^2 / stride 1 to 4 CP phase-major channels + pixel shuffle, for the
+    conv-kernel layout (k = 4) and the patch-GEMM layout (k = 8); cvcs_deconv_unpack_grad returns autograd's weight / bias gradients"""
+    ops = _ops()
+    NC, CP, B, H, W = 5, 32, 2, 8, 8
+    T = k // 2 + 1
+    g = torch.Generator().manual_seed(6)
+    w = (torch.randn(NC, NC, k, k, generator=g) * 0.3)
+    bias = torch.randn(NC, generator=g) * 0.1
+    x = torch.randn(B, NC, H, W, generator=g).to(dt)
+    xp = torch.zeros(B, H, W, CP, dtype=dt)
+    xp[..., :NC] = _nhwc(x)
+    kg = 32 if dt == torch.bfloat16 else 16
+    if layout == 0:
+        wf = torch.zeros(T * T, 4 * CP, max(CP, kg), dtype=dt, device=DEV)
+        wd = torch.zeros(T * T, CP, 4 * CP, dtype=dt, device=DEV)
+    else:
+        Kp = -(-T * T * CP // 128) * 128
+        wf = torch.zeros(1, 4 * CP, Kp, dtype=dt, device=DEV)
+        wd = torch.zeros(1, Kp, 4 * CP, dtype=dt, device=DEV)
+    bias4 = torch.zeros(4 * CP, device=DEV)
+    ops.deconv_pack(w.to(DEV), bias.to(DEV), k, p, CP, layout, wf, wd, bias4)
+    xv = ops.view(xp.to(DEV))
+    y4 = torch.empty(B, H, W, 4 * CP, dtype=dt, device=DEV)
+    if layout == 0:
+        ops.conv2d(xv, wf, bias4, ops.view(y4), T, T, 1, T // 2)
+    else:
+        col = torch.empty(B, H, W, wf.shape[2], dtype=dt, device=DEV)
+        ops.im2col(xv, ops.view(col), T, T, 1, -(T // 2), -(T // 2))
+        ops.conv2d(ops.view(col), wf, bias4, ops.view(y4), 1, 1)
+    full = torch.empty(B, 2 * H, 2 * W, CP, dtype=dt, device=DEV)
+    ops.phase_shuffle(ops.view(y4), CP, ops.view(full), relu=False)
+    wr = w.to(dt).float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    xr = x.float().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, stride=2, padding=p)
+    tol = dict(atol=2e-5, rtol=1e-4) if dt == torch.float32 else dict(atol=5e-2, rtol=3e-2)
+    assert torch.allclose(full[..., :NC].float().cpu(), _nhwc(ref.detach()), **tol)
+    assert (full[..., NC:] == 0).all()
+    # backward through the same operands: dgrad with wd, weight gradient + unpack
+    go = torch.randn(B, NC, 2 * H, 2 * W, generator=g).to(dt)
+    ref.backward(go.float())
+    gp = torch.zeros(B, 2 * H, 2 * W, CP, dtype=dt)
+    gp[..., :NC] = _nhwc(go)
+    g4 = torch.empty(B, H, W, 4 * CP, dtype=dt, device=DEV)
+    ops.phase_unshuffle(ops.view(gp.to(DEV)), None, ops.view(g4), CP)
+    gx = torch.empty(B, H, W, CP, dtype=dt, device=DEV)
+    if layout == 0:
+        gw = torch.zeros(4 * CP, CP, T, T, device=DEV)
+        ws = torch.empty(ops.wgrad_workspace_floats_for(xv, ops.view(g4), T, T, 1, T // 2), device=DEV)
+        ops.conv2d_wgrad(xv, ops.view(g4), gw, T, T, 1, T // 2, ws)
+        ops.conv2d(ops.view(g4), wd, None, ops.view(gx), T, T, 1, T // 2)
+    else:
+        gw = torch.zeros(4 * CP, wf.shape[2], 1, 1, device=DEV)
+        ws = torch.empty(ops.wgrad_workspace_floats_for(ops.view(col), ops.view(g4), 1, 1, 1, 0), device=DEV)
+        ops.conv2d_wgrad(ops.view(col), ops.view(g4), gw, 1, 1, 1, 0, ws)
+        gcol = torch.empty_like(col)
+        ops.conv2d(ops.view(g4), wd, None, ops.view(gcol), 1, 1)
+        ops.col2im(ops.view(gcol), ops.view(gx), T, T, 1, -(T // 2), -(T // 2))
+    gtol = dict(atol=1e-4, rtol=1e-3) if dt == torch.float32 else dict(atol=1e-1, rtol=5e-2)
+    assert torch.allclose(gx[..., :NC].float().cpu(), _nhwc(xr.grad), **gtol)
+    db4 = g4.float().sum(dim=(0, 1, 2))
+    gwm, gbm = torch.zeros(NC, NC, k, k, device=DEV), torch.zeros(NC, device=DEV)
+    ops.deconv_unpack_grad(gw, db4, k, p, CP, layout, gwm, gbm)
+    sc = wr.grad.abs().max().item()
+    assert (gwm.cpu() - wr.grad).abs().max().item() <= (1e-4 if dt == torch.float32 else 3e-2) * sc
+    assert torch.allclose(gbm.cpu(), br.grad, atol=(1e-3 if dt == torch.float32 else 2e-1), rtol=1e-3)
+
