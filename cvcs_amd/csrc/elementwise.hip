@@ -41,17 +41,30 @@ __device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, co
   double S = 0.0, Q = 0.0, Mm = 0.0, n0 = -1.0;
   int k = 0;
   bool uniform = true;
-  for (int r = r0; r < r1; r += rstep) {
-    const double n = (double)scnt[r];
-    if (n <= 0.0) continue;
+  auto take = [&](float cn, float sv, float mv) {
+    const double n = (double)cn;
+    if (n <= 0.0) return;
     if (n0 < 0.0) n0 = n;
     uniform = uniform && n == n0;
-    const double s_ = (double)ssum[(int64_t)r * C + c];
+    const double s_ = (double)sv;
     S += s_;
     Q += s_ * s_;
-    Mm += (double)sm2[(int64_t)r * C + c];
+    Mm += (double)mv;
     ++k;
+  };
+  int r = r0;
+  for (; r + 3 * rstep < r1; r += 4 * rstep) {       // four rows' loads in flight (these kernels are latency-bound)
+    float cn[4], sv[4], mv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cn[u] = scnt[r + u * rstep];
+      sv[u] = ssum[(int64_t)(r + u * rstep) * C + c];
+      mv[u] = sm2[(int64_t)(r + u * rstep) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(cn[u], sv[u], mv[u]);
   }
+  for (; r < r1; r += rstep) take(scnt[r], ssum[(int64_t)r * C + c], sm2[(int64_t)r * C + c]);
   if (k == 0) return Moments{0.0, 0.0, 0.0};
   if (uniform) {
     const double N = n0 * (double)k;
@@ -454,12 +467,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const char* x, int64_t ld, 
 __device__ __forceinline__ double colsum16(const float* __restrict__ part, int rows, int C, int c, int rl, int cl, int slot) {
   __shared__ double sh[2][kRL][17];
   double a = 0.0;
-  for (int r = rl; r < rows; r += kRL) a += (double)part[(int64_t)r * C + c];
+  int r = rl;
+  for (; r + 3 * kRL < rows; r += 4 * kRL) {          // four loads in flight per lane
+    const float v0 = part[(int64_t)r * C + c], v1 = part[(int64_t)(r + kRL) * C + c];
+    const float v2 = part[(int64_t)(r + 2 * kRL) * C + c], v3 = part[(int64_t)(r + 3 * kRL) * C + c];
+    a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+  }
+  for (; r < rows; r += kRL) a += (double)part[(int64_t)r * C + c];
   sh[slot][rl][cl] = a;
   __syncthreads();
+  if (rl < 8) {                                       // two levels, fixed order: lane rl sums entries rl, rl + 8, ...
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < kRL / 8; ++q) t += sh[slot][rl + 8 * q][cl];
+    sh[slot][rl][cl] = t;
+  }
+  __syncthreads();
   double t = 0.0;
-  if (rl == 0)
-    for (int q = 0; q < kRL; ++q) t += sh[slot][q][cl];
+  if (rl == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sh[slot][q][cl];
+  }
   return t;
 }
 

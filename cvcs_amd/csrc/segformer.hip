@@ -244,26 +244,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
   const int y0 = yb * kDwRows, y1 = y0 + kDwRows < p.H ? y0 + kDwRows : p.H;
   const char* base = p.x + ((int64_t)b * p.H * p.W * p.x_ld) * ES + cc * 16;
   char* obase = p.out + ((int64_t)b * p.H * p.W * p.out_ld) * ES + cc * 16;
-  uint4 r0[3], r1[3], r2[3];
-  dw_load_row<16>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, r0);
-  dw_load_row<16>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, r1);
-  for (int y = y0; y < y1; ++y) {
-    dw_load_row<16>(base, p.x_ld * ES, y + 1, x, p.H, p.W, col_ok, r2);
+  // a ring of four window rows, the loop fully unrolled: the loads of row y + 2 are in flight while row y is computed
+  uint4 R[4][3];
+  dw_load_row<16>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, R[0]);
+  dw_load_row<16>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, R[1]);
+  dw_load_row<16>(base, p.x_ld * ES, y0 + 1, x, p.H, p.W, col_ok, R[2]);
+#pragma unroll
+  for (int i = 0; i < kDwRows; ++i) {
+    const int y = y0 + i;
+    if (y >= y1) break;
+    dw_load_row<16>(base, p.x_ld * ES, y + 2, x, p.H, p.W, col_ok && y + 1 < y1, R[(i + 3) & 3]);
     float acc[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[k] = bv[k];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       float f0[V], f1[V], f2[V];
-      Elem<T>::unpack(r0[d], f0);
-      Elem<T>::unpack(r1[d], f1);
-      Elem<T>::unpack(r2[d], f2);
+      Elem<T>::unpack(R[i & 3][d], f0);
+      Elem<T>::unpack(R[(i + 1) & 3][d], f1);
+      Elem<T>::unpack(R[(i + 2) & 3][d], f2);
 #pragma unroll
       for (int k = 0; k < V; ++k) acc[k] += f0[k] * wv[d][k] + f1[k] * wv[3 + d][k] + f2[k] * wv[6 + d][k];
     }
     if (col_ok) *reinterpret_cast<uint4*>(obase + ((int64_t)y * p.W + x) * p.out_ld * ES) = Elem<T>::pack(acc);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { r0[d] = r1[d]; r1[d] = r2[d]; }
   }
 }
 
@@ -295,38 +298,43 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
       const int y0 = yb * kDwRows, y1 = y0 + kDwRows < p.H ? y0 + kDwRows : p.H;
       const char* base = p.x + ((int64_t)b * p.H * p.W * p.x_ld) * ES + cc * NB;
       const char* gbase = p.dy + ((int64_t)b * p.H * p.W * p.dy_ld) * ES + cc * NB;
-      uint4 r0[3], r1[3], r2[3];
-      dw_load_row<NB>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, r0);
-      dw_load_row<NB>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, r1);
-      for (int y = y0; y < y1; ++y) {
-        dw_load_row<NB>(base, p.x_ld * ES, y + 1, x, p.H, p.W, col_ok, r2);
-        float g[V];
-        {
-          uint4 gr = make_uint4(0u, 0u, 0u, 0u);
-          if (col_ok) {
-            const char* src = gbase + ((int64_t)y * p.W + x) * p.dy_ld * ES;
-            if constexpr (NB == 16) gr = *reinterpret_cast<const uint4*>(src);
-            else { const uint2 t = *reinterpret_cast<const uint2*>(src); gr.x = t.x; gr.y = t.y; }
-          }
-          if constexpr (ES == 4) { Elem<float>::unpack(gr, g); }
-          else { g[0] = __uint_as_float(gr.x << 16); g[1] = __uint_as_float(gr.x & 0xffff0000u); g[2] = __uint_as_float(gr.y << 16); g[3] = __uint_as_float(gr.y & 0xffff0000u); }
+      uint4 R[4][3], G[2];
+      auto load_g = [&](int yy, uint4& gr) {
+        gr = make_uint4(0u, 0u, 0u, 0u);
+        if (col_ok && yy < y1) {
+          const char* src = gbase + ((int64_t)yy * p.W + x) * p.dy_ld * ES;
+          if constexpr (NB == 16) gr = *reinterpret_cast<const uint4*>(src);
+          else { const uint2 t = *reinterpret_cast<const uint2*>(src); gr.x = t.x; gr.y = t.y; }
         }
+      };
+      auto unpack4 = [](const uint4& raw, float* f) {
+        if constexpr (ES == 4) { Elem<float>::unpack(raw, f); }
+        else { f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u); f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u); }
+      };
+      dw_load_row<NB>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, R[0]);
+      dw_load_row<NB>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, R[1]);
+      dw_load_row<NB>(base, p.x_ld * ES, y0 + 1, x, p.H, p.W, col_ok, R[2]);
+      load_g(y0, G[0]);
+#pragma unroll
+      for (int i = 0; i < kDwRows; ++i) {
+        const int y = y0 + i;
+        if (y >= y1) break;
+        dw_load_row<NB>(base, p.x_ld * ES, y + 2, x, p.H, p.W, col_ok && y + 1 < y1, R[(i + 3) & 3]);
+        load_g(y + 1, G[(i + 1) & 1]);
+        float g[V];
+        unpack4(G[i & 1], g);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[9][k] += g[k];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr) {
-            const uint4& raw = rr == 0 ? r0[d] : (rr == 1 ? r1[d] : r2[d]);
             float f[V];
-            if constexpr (ES == 4) { Elem<float>::unpack(raw, f); }
-            else { f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u); f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u); }
+            unpack4(R[(i + rr) & 3][d], f);
 #pragma unroll
             for (int k = 0; k < V; ++k) acc[rr * 3 + d][k] += g[k] * f[k];
           }
         }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { r0[d] = r1[d]; r1[d] = r2[d]; }
       }
     }
   }

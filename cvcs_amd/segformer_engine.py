@@ -51,6 +51,9 @@ class SegformerEngine(SwinUPerNetEngine):
         super().__init__(num_classes, dtype, device)
         self.cfg = CONFIGS[variant]
         self.variant = variant
+        if any(c // h != 32 for c, h in zip(self.cfg["hidden"], self.cfg["heads"])):
+            raise NotImplementedError(f"SegformerMod variant '{variant}': the attention kernels are built for head dimension 32 (MiT-b0 = SegformerConfig(), the "
+                                      "reference's pretrained=False branch); MiT-b1..b5 use 64")
         self.head_name = "seq.4"
         assert num_classes <= 32, "SegformerMod's NC-channel tail is built for at most 32 classes (the head kernels' limit)"
         self.CP = 32          # channel count of the NC-channel maps (the 1x1 GEMM kernels write multiples of 32 output channels)
