@@ -69,6 +69,16 @@ class GatherItem(C.Structure):
                 ("cd1", C.c_int32), ("cd2", C.c_int32), ("f32_out", C.c_int32), ("rv2", C.c_int32), ("cv2", C.c_int32), ("pad_", C.c_int32)]
 
 
+class TailBwdDesc(C.Structure):
+    """cvcs_tail_bwd_desc (include/cvcs_hip.h)"""
+    _fields_ = [("out", C.c_void_p), ("out_ld", C.c_int64),
+                ("g", C.c_void_p * 3), ("g_ld", C.c_int64 * 3), ("g_half", C.c_int32 * 3), ("dtype", C.c_int32),
+                ("dz", C.c_void_p), ("dz_ld", C.c_int64),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("y", C.c_void_p * 2), ("y_ld", C.c_int64 * 2), ("mean", C.c_void_p * 2), ("invstd", C.c_void_p * 2),
+                ("part_dz", C.c_void_p), ("part_dzx", C.c_void_p * 2)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
@@ -113,6 +123,7 @@ SIGNATURES = {
     "cvcs_nhwc_from_planes": (_i, [_vp, _i, _i64, _i, _vp, _i64, _i, _i, _vp]),
     "cvcs_deconv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "cvcs_deconv_unpack_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "cvcs_relu_bwd_sum_bn": (_i, [C.POINTER(TailBwdDesc), _vp]),
     "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
     "cvcs_scatter_weight_grads": (_i, [_vp, _i, _vp]),
     "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),

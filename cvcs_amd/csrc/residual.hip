@@ -101,6 +101,115 @@ __global__ __launch_bounds__(256) void relu_bwd_sum_kernel(SumArgs p) {
   }
 }
 
+// The same pass with the FIRST pass of the BatchNorm backward(s) that consume dz riding on it: the block's last BatchNorm (no ReLU between
+// it and the sum: mode 2) and, in a block with a projection shortcut, the downsample BatchNorm see the same gradient dz, so
+//   part_dz[row][c] = sum dz,  part_dzx[j][row][c] = sum dz * (y_j - mean_j) * invstd_j        (row = workgroup, j = 0 | 1)
+// come from the values this kernel has in registers; the separate reduce launches (read dz, read y) become one extra read of y here.
+// Work distribution of bn_bwd_kernel: <= 32 channel chunks x pixel lanes per workgroup, blockIdx.y over wider layers.
+struct TailBwdArgs {
+  SumArgs s;
+  const char* y[2]; int64_t y_ld[2];
+  const float* mean[2]; const float* invstd[2];
+  float* part_dz; float* part_dzx[2];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_sum_bn_kernel(TailBwdArgs q) {
+  constexpr int ES = sizeof(T), V = 16 / ES;
+  __shared__ float red[3][256 * V];
+  const SumArgs& p = q.s;
+  const int CC = p.C / V;
+  const int ccw = CC < 32 ? CC : 32;
+  const int PL = 256 / ccw;
+  const int tid = threadIdx.x, cl = tid % ccw, pl = tid / ccw;
+  const int cc = blockIdx.y * ccw + cl;
+  float mu[2][V], is[2][V], s0[V], s1[2][V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    s0[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      mu[j][k] = q.y[j] ? q.mean[j][cc * V + k] : 0.f;
+      is[j][k] = q.y[j] ? q.invstd[j][cc * V + k] : 0.f;
+      s1[j][k] = 0.f;
+    }
+  }
+  const bool any_half = p.half[0] | p.half[1] | p.half[2];
+  const int64_t M = (int64_t)p.B * p.H * p.W;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
+    int x = 0, y = 0;
+    int64_t b = 0;
+    if (any_half) {
+      x = (int)(pix % p.W);
+      const int64_t t = pix / p.W;
+      y = (int)(t % p.H);
+      b = t / p.H;
+    }
+    // every load of this pixel first
+    uint4 gr[3], yr[2], orw = make_uint4(0u, 0u, 0u, 0u);
+    bool gok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      gok[j] = p.g[j] != nullptr;
+      int64_t gp = pix;
+      if (gok[j] && p.half[j]) {
+        gok[j] = !((x | y) & 1);
+        gp = (b * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+      }
+      gr[j] = gok[j] ? *reinterpret_cast<const uint4*>(p.g[j] + gp * p.g_ld[j] * ES + cc * 16) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (p.out) orw = *reinterpret_cast<const uint4*>(p.out + pix * p.out_ld * ES + cc * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      yr[j] = q.y[j] ? *reinterpret_cast<const uint4*>(q.y[j] + pix * q.y_ld[j] * ES + cc * 16) : make_uint4(0u, 0u, 0u, 0u);
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (!gok[j]) continue;
+      float f[V];
+      Elem<T>::unpack(gr[j], f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] += f[k];
+    }
+    if (p.out) {
+      float o[V];
+      Elem<T>::unpack(orw, o);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] = o[k] > 0.f ? s[k] : 0.f;
+    }
+    const uint4 pk = Elem<T>::pack(s);
+    *reinterpret_cast<uint4*>(p.dz + pix * p.dz_ld * ES + cc * 16) = pk;
+    // the sums are those of the STORED gradient (what the apply pass will read back)
+    float d[V];
+    Elem<T>::unpack(pk, d);
+#pragma unroll
+    for (int k = 0; k < V; ++k) s0[k] += d[k];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (!q.y[j]) continue;
+      float yv[V];
+      Elem<T>::unpack(yr[j], yv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s1[j][k] += d[k] * ((yv[k] - mu[j][k]) * is[j][k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) { red[0][tid * V + k] = s0[k]; red[1][tid * V + k] = s1[0][k]; red[2][tid * V + k] = s1[1][k]; }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float a = 0.f, b0 = 0.f, b1 = 0.f;
+      for (int w = 0; w < PL; ++w) { a += red[0][(w * ccw + cl) * V + k]; b0 += red[1][(w * ccw + cl) * V + k]; b1 += red[2][(w * ccw + cl) * V + k]; }
+      const int64_t o = (int64_t)blockIdx.x * p.C + cc * V + k;
+      q.part_dz[o] = a;
+      if (q.y[0]) q.part_dzx[0][o] = b0;
+      if (q.y[1]) q.part_dzx[1][o] = b1;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ MaxPool2d(3, 2, 1)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const char* x, int64_t x_ld, int B, int H, int W, int C, char* out,
@@ -474,3 +583,44 @@ extern "C" int cvcs_unpack_stem_wgrad(const float* tmp, int Cout, float* dw, voi
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
+
+extern "C" int cvcs_bn_bwd_rows(int64_t M);
+
+extern "C" int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream) {
+  const char* fn = "cvcs_relu_bwd_sum_bn";
+  CVCS_CHECK_ARG(d != nullptr, "%s: null descriptor", fn);
+  CVCS_CHECK_ARG(RES_DT_OK(d->dtype), "%s: bad dtype", fn);
+  const int es = d->dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % V == 0, "%s: bad shape", fn);
+  const int CC = d->C / V;
+  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % 32 == 0, "%s: C/%d must be a power of two or a multiple of 32", fn, V);
+  CVCS_CHECK_ARG(d->g[0] != nullptr && d->dz && d->y[0] && d->part_dz && d->part_dzx[0], "%s: g[0], dz, y[0] and the partial buffers are required", fn);
+  CVCS_CHECK_ARG(!(d->g_half[0] || (d->g[1] && d->g_half[1]) || (d->g[2] && d->g_half[2])) || (d->H % 2 == 0 && d->W % 2 == 0),
+                 "%s: a half-resolution gradient needs even H, W", fn);
+  int rc;
+  if (d->out && (rc = res_check_view(fn, d->out, d->out_ld, d->C, es))) return rc;
+  if ((rc = res_check_view(fn, d->dz, d->dz_ld, d->C, es))) return rc;
+  TailBwdArgs a{};
+  for (int j = 0; j < 3; ++j) {
+    if (d->g[j] && (rc = res_check_view(fn, d->g[j], d->g_ld[j], d->C, es))) return rc;
+    a.s.g[j] = (const char*)d->g[j]; a.s.g_ld[j] = d->g_ld[j]; a.s.half[j] = d->g[j] ? d->g_half[j] : 0;
+  }
+  for (int j = 0; j < 2; ++j) {
+    if (d->y[j]) {
+      if ((rc = res_check_view(fn, d->y[j], d->y_ld[j], d->C, es))) return rc;
+      CVCS_CHECK_ARG(d->mean[j] && d->invstd[j] && d->part_dzx[j], "%s: BatchNorm %d needs mean, invstd and its partial buffer", fn, j);
+    }
+    a.y[j] = (const char*)d->y[j]; a.y_ld[j] = d->y_ld[j]; a.mean[j] = d->mean[j]; a.invstd[j] = d->invstd[j]; a.part_dzx[j] = d->part_dzx[j];
+  }
+  a.s.out = (const char*)d->out; a.s.out_ld = d->out_ld; a.s.dz = (char*)d->dz; a.s.dz_ld = d->dz_ld;
+  a.s.B = d->B; a.s.H = d->H; a.s.W = d->W; a.s.C = d->C;
+  a.part_dz = d->part_dz;
+  const int ccw = CC < 32 ? CC : 32;
+  const dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)d->B * d->H * d->W), (unsigned)(CC / ccw));
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CVCS_F32) hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<float>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
+}
+

@@ -483,6 +483,32 @@ def bn_add_act(y1: View, s1, b1, y2: View, s2, b2, out: View, q8=None):
                                      out.ptr, out.ld, y1.code, _stream()), "cvcs_bn_add_act")
 
 
+def relu_bwd_sum_bn(out: View | None, grads, dz: View, bns, part_dz, part_dzx):
+    """relu_bwd_sum + the reduce pass of up to two BatchNorm backwards that consume dz: bns = [(y view, mean, invstd)], part_dzx = one buffer
+    per BatchNorm; partial rows = bn_bwd_rows(B*H*W)"""
+    assert 1 <= len(grads) <= 3 and 1 <= len(bns) <= 2 and len(part_dzx) == len(bns)
+    d = _lib.TailBwdDesc()
+    if out is not None:
+        d.out, d.out_ld = out.ptr, out.ld
+    nbytes = dz.B * dz.H * dz.W * dz.C * dz.t.element_size()
+    units = 1.0 + (out is not None) + len(bns)
+    for j, (v, half) in enumerate(grads):
+        want = (dz.B, dz.H // 2, dz.W // 2, dz.C) if half else (dz.B, dz.H, dz.W, dz.C)
+        assert (v.B, v.H, v.W, v.C) == want and v.t.dtype == dz.t.dtype, "gradient view mismatch"
+        d.g[j], d.g_ld[j], d.g_half[j] = v.ptr, v.ld, int(half)
+        units += 0.25 if half else 1.0
+    d.dz, d.dz_ld, d.B, d.H, d.W, d.C, d.dtype = dz.ptr, dz.ld, dz.B, dz.H, dz.W, dz.C, dz.code
+    rows = bn_bwd_rows(dz.B * dz.H * dz.W)
+    assert part_dz.numel() >= rows * dz.C and all(p.numel() >= rows * dz.C for p in part_dzx)
+    d.part_dz = part_dz.data_ptr()
+    for j, ((yv, mean, invstd), pz) in enumerate(zip(bns, part_dzx)):
+        assert (yv.B, yv.H, yv.W, yv.C) == (dz.B, dz.H, dz.W, dz.C) and yv.t.dtype == dz.t.dtype
+        d.y[j], d.y_ld[j], d.mean[j], d.invstd[j], d.part_dzx[j] = yv.ptr, yv.ld, mean.data_ptr(), invstd.data_ptr(), pz.data_ptr()
+    _tag_hbm("residual", nbytes * units)
+    check(_lib.lib().cvcs_relu_bwd_sum_bn(C.byref(d), _stream()), "cvcs_relu_bwd_sum_bn")
+    return rows
+
+
 def relu_bwd_sum(out: View | None, grads, dz: View):
     """dz = (sum of up to three gradients) * (out > 0); grads = [(view, half_resolution: bool)]"""
     assert 1 <= len(grads) <= 3

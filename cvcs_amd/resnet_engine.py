@@ -123,6 +123,7 @@ class ResNetUNetEngine:
         self._saved_train = False
         self._last_act = {}
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
+        self.fuse_tail_bn = os.environ.get("CVCS_FUSE_TAIL_BN", "1") == "1"  # the residual tails' BatchNorm reduce passes on relu_bwd_sum (_block)
         # Weight gradients are off the critical chain of backward (dy -> data gradient -> BatchNorm backward of the layer below): they
         # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
         # beside the HBM-bound BatchNorm / residual passes (CVCS_OVERLAP_WGRAD=0: one stream, in program order)
@@ -384,8 +385,21 @@ class ResNetUNetEngine:
         if train:
             def bwd():
                 dz = ops.view(self._act(p + ".dz", out.B, out.H, out.W, out.C))
-                ops.relu_bwd_sum(o.v, o.grads, dz)
-                dy = self._unit_bwd(ut, dz, 2)
+                red_t = red_d = None
+                if self.fuse_tail_bn and not getattr(ut, "gn", False):
+                    # the reduce passes of the block's last BatchNorm and of the downsample BatchNorm ride on the tail's backward pass
+                    st_t = self.bn[ut.bn]
+                    bns = [(ut.y, st_t.mean, st_t.invstd)]
+                    if ud is not None:
+                        bns.append((ud.y, self.bn[ud.bn].mean, self.bn[ud.bn].invstd))
+                    n_ = ops.bn_bwd_rows(out.B * out.H * out.W) * out.C
+                    pz = [self._scratch(f"tz{i}", n_) for i in range(3)]
+                    rows_t = ops.relu_bwd_sum_bn(o.v, o.grads, dz, bns, pz[0], pz[1:1 + len(bns)])
+                    red_t = (pz[0], pz[1], rows_t)
+                    red_d = (pz[0], pz[2], rows_t) if ud is not None else None
+                else:
+                    ops.relu_bwd_sum(o.v, o.grads, dz)
+                dy = self._unit_bwd(ut, dz, 2, reduced=red_t)
                 fz = None
                 if self.kind == "basic" and self._fusable(ut, chain[-1][0]):
                     gx, half, fz = self._dgrad(ut, dy, p + ".g_t", fuse_into=chain[-1][0])
@@ -402,7 +416,7 @@ class ResNetUNetEngine:
                     else:
                         xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
                 if ud is not None:
-                    dyd = self._unit_bwd(ud, dz, 2)
+                    dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
                     h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
                 else:
                     h.grads.append((dz, False))
@@ -421,7 +435,7 @@ class ResNetUNetEngine:
         return (self.fuse_bn_bwd and not getattr(consumer, "gn", False) and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
                 producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128 and y.C % 64 == 0)
 
-    def _unit_bwd(self, u: Unit, g: View, mode, fused=None) -> View:
+    def _unit_bwd(self, u: Unit, g: View, mode, fused=None, reduced=None) -> View:
         """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
         output) in a scratch buffer that lives until the next _unit_bwd.  fused = (part_dz, part_dzx, rows): the reduce pass
         was taken by the launch that produced g (one partial row per 16x16 tile)"""
@@ -441,7 +455,12 @@ class ResNetUNetEngine:
         st = self.bn[u.bn]
         rows = ops.bn_bwd_rows(M)
         p0, p1, p2 = (self._scratch(f"bnb{i}", rows * C_) for i in range(3))
-        if fused is not None:
+        if reduced is not None:
+            # reduced = (part_dz, part_dzx, rows): the reduce pass rode on the block-tail backward (ops.relu_bwd_sum_bn), rows as bn_bwd_rows
+            r0, r1, rrows = reduced
+            ops.bn_bwd_finalize(r0, r1, rrows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
+                                st.ca, st.cb)
+        elif fused is not None:
             f0, f1, trows = fused
             rows1 = ops.bn_bwd_rows(trows)
             for src, dst in ((f0, p0), (f1, p1)):

@@ -571,6 +571,20 @@ int cvcs_nhwc_from_planes(const float* planes, int B, int64_t HW, int NC, void* 
 int cvcs_deconv_pack(const float* w, const float* bias, int NC, int k, int p, int CP, int layout, int CPk, int Kp, void* wf, void* wd, float* bias4,
                      int dtype, void* stream);
 int cvcs_deconv_unpack_grad(const float* dw, const float* db4, int NC, int k, int p, int CP, int layout, int Kp, float* gw, float* gb, void* stream);
+/* cvcs_relu_bwd_sum with the first pass of the BatchNorm backward(s) that consume dz (S/blocks.py has no residual blocks; this is the tail of
+ * torchvision's BasicBlock / Bottleneck as BASELINE's ResNet encoders use it): the block's last BatchNorm y[0] and, with a projection shortcut, the
+ * downsample BatchNorm y[1] (NULL: none) both receive dz, so part_dz[row][c] = sum dz and part_dzx[j][row][c] = sum dz * (y_j - mean_j) * invstd_j
+ * (rows = cvcs_bn_bwd_rows(B*H*W), the layout cvcs_bn_bwd_finalize reads) come out of the same launch.                                        */
+typedef struct {
+  const void* out; int64_t out_ld;
+  const void* g[3]; int64_t g_ld[3]; int32_t g_half[3]; int32_t dtype;
+  void* dz; int64_t dz_ld;
+  int32_t B, H, W, C;
+  const void* y[2]; int64_t y_ld[2];
+  const float* mean[2]; const float* invstd[2];
+  float* part_dz; float* part_dzx[2];
+} cvcs_tail_bwd_desc;
+int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

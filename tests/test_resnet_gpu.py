@@ -239,6 +239,39 @@ def test_block_tail_forward_and_backward_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C_,H,two", [(2, 256, 16, True), (3, 64, 8, False), (2, 2048, 4, True)])
+def test_block_tail_backward_carries_the_batchnorm_reduce_passes(dtype, B, C_, H, two):
+    """cvcs_relu_bwd_sum_bn == cvcs_relu_bwd_sum followed by cvcs_bn_bwd_reduce (mode 2) on its output, for the block's last BatchNorm and
+    the downsample BatchNorm: the same dz bit for bit, the same column sums after the finalize's f64 merge"""
+    g = torch.Generator().manual_seed(C_ + H)
+    o = to_nhwc(F.relu(torch.randn(B, C_, H, H, generator=g)), dtype)
+    ga = to_nhwc(torch.randn(B, C_, H, H, generator=g), dtype)
+    gh = to_nhwc(torch.randn(B, C_, H // 2, H // 2, generator=g), dtype)
+    ys = [to_nhwc(torch.randn(B, C_, H, H, generator=g) * 2 + 0.5, dtype) for _ in range(2 if two else 1)]
+    mean = [torch.randn(C_, generator=g).to(DEV) * 0.3 for _ in ys]
+    invstd = [(torch.rand(C_, generator=g) + 0.5).to(DEV) for _ in ys]
+    grads = [(ops.view(ga), False), (ops.view(gh), True)]
+    M = B * H * H
+    rows = ops.bn_bwd_rows(M)
+    dz_ref, dz = torch.empty_like(o), torch.empty_like(o)
+    ops.relu_bwd_sum(ops.view(o), grads, ops.view(dz_ref))
+    one, zero = torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV)
+    want = []
+    for y, m, i in zip(ys, mean, invstd):
+        p0, p1 = torch.empty(rows * C_, device=DEV), torch.empty(rows * C_, device=DEV)
+        ops.bn_bwd_reduce(ops.view(y), ops.view(dz_ref), None, one, zero, m, i, 2, p0, p1)
+        want.append((p0.view(rows, C_).double().sum(0), p1.view(rows, C_).double().sum(0)))
+    pz = [torch.full((rows * C_,), 7.0, device=DEV) for _ in range(3)]
+    r = ops.relu_bwd_sum_bn(ops.view(o), grads, ops.view(dz), [(ops.view(y), m, i) for y, m, i in zip(ys, mean, invstd)], pz[0], pz[1:1 + len(ys)])
+    torch.cuda.synchronize()
+    assert r == rows and torch.equal(dz, dz_ref)
+    got0 = pz[0].view(rows, C_).double().sum(0)
+    for j, (w0, w1) in enumerate(want):
+        close(got0.cpu(), w0.cpu(), 1e-5, "sum dz")
+        close(pz[1 + j].view(rows, C_).double().sum(0).cpu(), w1.cpu(), 1e-5, f"sum dz xhat {j}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm_backward_without_relu(dtype):
     """mode 2 of cvcs_bn_bwd_*: the last BatchNorm of a residual block (its ReLU comes after the add)"""
     g = torch.Generator().manual_seed(11)
