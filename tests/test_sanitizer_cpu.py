@@ -18,7 +18,7 @@ from cvcs_amd import _lib
 h = C.CDLL(%(lib)r)
 for name, (res, args) in _lib.SIGNATURES.items():
     fn = getattr(h, name); fn.restype = res; fn.argtypes = args
-assert h.cvcs_abi_version() == 10
+assert h.cvcs_abi_version() == _lib.ABI_VERSION
 assert h.cvcs_sizeof_conv_desc() == C.sizeof(_lib.ConvDesc) and h.cvcs_sizeof_wgrad_desc() == C.sizeof(_lib.WgradDesc)
 n = 0
 # planners / sizing queries over a sweep of shapes (pure host code)
