@@ -123,6 +123,7 @@ class ResNetUNetEngine:
         self._saved_train = False
         self._last_act = {}
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
+        self.gather_shortcut = os.environ.get("CVCS_GATHER_SHORTCUT", "1") == "1"   # stride-2 projection shortcuts on compact even-pixel maps (_block)
         self.fuse_tail_bn = os.environ.get("CVCS_FUSE_TAIL_BN", "1") == "1"  # the residual tails' BatchNorm reduce passes on relu_bwd_sum (_block)
         # Weight gradients are off the critical chain of backward (dy -> data gradient -> BatchNorm backward of the layer below): they
         # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
@@ -378,7 +379,16 @@ class ResNetUNetEngine:
             ut = self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
             chain = [(u1, h, a1), (u2, a1, a2)]
             last_in = a2
-        ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
+        if has_ds and stride == 2 and self.gather_shortcut:
+            # the projection shortcut of a down-sampling block reads the even pixels only: gather them once (a quarter of h) and the 1x1 /
+            # stride-2 conv becomes a plain GEMM - forward on the taps kernel, weight gradient on the GEMM kernel instead of the generic ones
+            hs = ops.view(self._act(p + ".hs", B, Ho, Wo, h.v.C))
+            ops.SCOPE = "enc"
+            ops.im2col(h.v, hs, 1, 1, 2, 0, 0)
+            ud = self._unit(hs, p + ".downsample.0", p + ".downsample.1", 1, 1, 0, train, None)
+            ud.half_out = True            # its data gradient lives at half the resolution of h (scattered by the consumer)
+        else:
+            ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
         self._tail(ut, ud, h, out, train)
         self.relu_order.append(out if self._grid == 1 else GridView(out, self._grid))
         o = Act(out)
@@ -534,7 +544,7 @@ class ResNetUNetEngine:
             ops.conv2d(dy, wd, None, gx, 1, 1)
             if self.keep_all:
                 self.bwd_units[u.conv]["gx"] = gx
-            return gx, u.stride == 2
+            return gx, (u.stride == 2 or getattr(u, "half_out", False))
         gx = ops.view(self._act(name, B, x.H, x.W, cin))
         if getattr(u, "fp8", False):
             # e5m2 gradient (range over precision) x e4m3 flipped weights on the same kernel
