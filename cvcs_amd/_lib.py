@@ -116,9 +116,9 @@ SIGNATURES = {
     "cvcs_dwconv3x3_wgrad": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
     "cvcs_drop_path_scales": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "cvcs_scale_rows_add": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i64, _i, _vp, _i64, _i, _vp]),
-    "cvcs_sr_attention_fwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
-    "cvcs_sr_attention_bwd_workspace": (_i64, [_i, _i, _i, _i]),
-    "cvcs_sr_attention_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_sr_attention_fwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i, _vp]),
+    "cvcs_sr_attention_bwd_workspace": (_i64, [_i, _i, _i, _i, _i]),
+    "cvcs_sr_attention_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i, _vp]),
     "cvcs_planes_from_nhwc": (_i, [_vp, _i64, _i, _i64, _i, _i, _vp, _i, _vp]),
     "cvcs_nhwc_from_planes": (_i, [_vp, _i, _i64, _i, _vp, _i64, _i, _i, _vp]),
     "cvcs_deconv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),

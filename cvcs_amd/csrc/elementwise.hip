@@ -884,7 +884,7 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   const int V = 16 / es;
   CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0, "%s: bad shape", fn);
   const int CC = C / V;
-  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % 256 == 0, "%s: C/%d must be a power of two (or a multiple of 256)", fn, V);
+  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % kBnBwdChunks == 0, "%s: C/%d must be a power of two (or a multiple of %d)", fn, V, kBnBwdChunks);
   CVCS_CHECK_ARG(mode >= 0 && mode <= 2, "%s: bad mode", fn);
   CVCS_CHECK_ARG(!(g2 && mode == 1), "%s: pooled gradient only in encoder mode", fn);
   int rc;

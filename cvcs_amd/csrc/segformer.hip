@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void scale_rows_add_kernel(const char* x, int6
 // softmax(q k^T / sqrt(32)) v per image and head.  One thread = one query (its 32 q values and 32 accumulators in registers); the keys and
 // values of the (image, head) are staged in LDS as f32, 256 at a time, and read as broadcasts; the softmax runs online over blocks of
 // 8 keys.  (The matrix-core version is the next step: at Nk = 256 this VALU form costs ~70 instructions per query-key pair.)
-constexpr int kSrD = 32, kSrKC = 256;
+constexpr int kSrKC = 256;
 struct SrArgs {
   const char* q; const char* kv; const char* o; const char* go; char* out; char* gq;
   float* lse; float* delta; float* part;
@@ -416,34 +416,34 @@ struct SrArgs {
   float scale;
 };
 
-template <typename T>
-__device__ __forceinline__ void sr_load_row(const char* base, float* f) {   // 32 consecutive channels of one token -> f32
+template <typename T, int kSrD>
+__device__ __forceinline__ void sr_load_row(const char* base, float* f) {   // the D consecutive channels of one head of one token -> f32
   constexpr int ES = sizeof(T), V = 16 / ES;
 #pragma unroll
   for (int i = 0; i < kSrD / V; ++i) Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + i * 16), f + i * V);
 }
-template <typename T>
+template <typename T, int kSrD>
 __device__ __forceinline__ void sr_store_row(char* base, const float* f) {
   constexpr int ES = sizeof(T), V = 16 / ES;
 #pragma unroll
   for (int i = 0; i < kSrD / V; ++i) *reinterpret_cast<uint4*>(base + i * 16) = Elem<T>::pack(f + i * V);
 }
 // stage keys [j0, j0 + n) of (b, h): sk[j][32], sv[j][32] as f32
-template <typename T>
+template <typename T, int kSrD>
 __device__ __forceinline__ void sr_stage_kv(const SrArgs& p, int b, int h, int j0, int n, float* sk, float* sv) {
   constexpr int ES = sizeof(T);
   const int C = p.heads * kSrD;
   for (int id = threadIdx.x; id < n * 2; id += blockDim.x) {
     const int j = id >> 1, which = id & 1;
     float f[kSrD];
-    sr_load_row<T>(p.kv + (((int64_t)b * p.Nk + j0 + j) * p.kv_ld + which * C + h * kSrD) * ES, f);
+    sr_load_row<T, kSrD>(p.kv + (((int64_t)b * p.Nk + j0 + j) * p.kv_ld + which * C + h * kSrD) * ES, f);
     float* dst = (which ? sv : sk) + j * kSrD;
 #pragma unroll
     for (int d = 0; d < kSrD; d += 4) *reinterpret_cast<f32x4*>(dst + d) = (f32x4){f[d], f[d + 1], f[d + 2], f[d + 3]};
   }
 }
 
-template <typename T>
+template <typename T, int kSrD>
 __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(SrArgs p) {
   constexpr int ES = sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sr_smem[];
@@ -453,14 +453,14 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(SrArgs p) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const bool live = n < p.N;
   float q[kSrD], acc[kSrD];
-  if (live) sr_load_row<T>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD) * ES, q);
+  if (live) sr_load_row<T, kSrD>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD) * ES, q);
 #pragma unroll
   for (int d = 0; d < kSrD; ++d) { q[d] = live ? q[d] : 0.f; acc[d] = 0.f; }
   float m = -INFINITY, l = 0.f;
   for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
     const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;
     __syncthreads();
-    sr_stage_kv<T>(p, b, h, j0, nk, sk, sv);
+    sr_stage_kv<T, kSrD>(p, b, h, j0, nk, sk, sv);
     __syncthreads();
     for (int jb = 0; jb < nk; jb += 8) {
       float s[8];
@@ -505,13 +505,13 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(SrArgs p) {
     const float inv = 1.f / l;
 #pragma unroll
     for (int d = 0; d < kSrD; ++d) acc[d] *= inv;
-    sr_store_row<T>(p.out + (((int64_t)b * p.N + n) * p.out_ld + h * kSrD) * ES, acc);
+    sr_store_row<T, kSrD>(p.out + (((int64_t)b * p.N + n) * p.out_ld + h * kSrD) * ES, acc);
     if (p.lse) p.lse[(int64_t)bh * p.N + n] = m + __logf(l);
   }
 }
 
 // dQ (query-major, the forward's structure): p = exp(s - lse), dp = go . v, ds = p (dp - delta) scale, dq += ds k;  delta = go . o saved
-template <typename T>
+template <typename T, int kSrD>
 __global__ __launch_bounds__(256) void sr_attn_bwd_dq_kernel(SrArgs p) {
   constexpr int ES = sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sr_smem[];
@@ -523,10 +523,10 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dq_kernel(SrArgs p) {
   float q[kSrD], go[kSrD], dq[kSrD];
   float delta = 0.f, lse = 0.f;
   if (live) {
-    sr_load_row<T>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD) * ES, q);
-    sr_load_row<T>(p.go + (((int64_t)b * p.N + n) * p.go_ld + h * kSrD) * ES, go);
+    sr_load_row<T, kSrD>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD) * ES, q);
+    sr_load_row<T, kSrD>(p.go + (((int64_t)b * p.N + n) * p.go_ld + h * kSrD) * ES, go);
     float o[kSrD];
-    sr_load_row<T>(p.o + (((int64_t)b * p.N + n) * p.o_ld + h * kSrD) * ES, o);
+    sr_load_row<T, kSrD>(p.o + (((int64_t)b * p.N + n) * p.o_ld + h * kSrD) * ES, o);
 #pragma unroll
     for (int d = 0; d < kSrD; ++d) delta += go[d] * o[d];
     lse = p.lse[(int64_t)bh * p.N + n];
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dq_kernel(SrArgs p) {
   for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
     const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;
     __syncthreads();
-    sr_stage_kv<T>(p, b, h, j0, nk, sk, sv);
+    sr_stage_kv<T, kSrD>(p, b, h, j0, nk, sk, sv);
     __syncthreads();
     for (int j = 0; j < nk; ++j) {
       float s = 0.f, dp = 0.f;
@@ -557,12 +557,12 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dq_kernel(SrArgs p) {
       }
     }
   }
-  if (live) sr_store_row<T>(p.gq + (((int64_t)b * p.N + n) * p.gq_ld + h * kSrD) * ES, dq);
+  if (live) sr_store_row<T, kSrD>(p.gq + (((int64_t)b * p.N + n) * p.gq_ld + h * kSrD) * ES, dq);
 }
 
 // dK / dV (key-major): one thread = one key (k, v, dk, dv in registers), the workgroup walks the queries [chunk*QC, (chunk+1)*QC) staged
 // 64 at a time; part[(bh * chunks + chunk)][key][dk 32 | dv 32]
-template <typename T>
+template <typename T, int kSrD>
 __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_kernel(SrArgs p) {
   constexpr int ES = sizeof(T);
   __shared__ __attribute__((aligned(16))) float sq[64 * kSrD];
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_kernel(SrArgs p) {
   const int C = p.heads * kSrD;
   float k[kSrD], v[kSrD], dk[kSrD], dv[kSrD];
   if (live) {
-    sr_load_row<T>(p.kv + (((int64_t)b * p.Nk + j) * p.kv_ld + h * kSrD) * ES, k);
-    sr_load_row<T>(p.kv + (((int64_t)b * p.Nk + j) * p.kv_ld + C + h * kSrD) * ES, v);
+    sr_load_row<T, kSrD>(p.kv + (((int64_t)b * p.Nk + j) * p.kv_ld + h * kSrD) * ES, k);
+    sr_load_row<T, kSrD>(p.kv + (((int64_t)b * p.Nk + j) * p.kv_ld + C + h * kSrD) * ES, v);
   }
 #pragma unroll
   for (int d = 0; d < kSrD; ++d) { if (!live) { k[d] = 0.f; v[d] = 0.f; } dk[d] = 0.f; dv[d] = 0.f; }
@@ -589,8 +589,8 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_kernel(SrArgs p) {
       const int r = id >> 1, which = id & 1;
       float f[kSrD];
       const int64_t tok = (int64_t)b * p.N + nb + r;
-      if (which) sr_load_row<T>(p.go + (tok * p.go_ld + h * kSrD) * ES, f);
-      else sr_load_row<T>(p.q + (tok * p.q_ld + h * kSrD) * ES, f);
+      if (which) sr_load_row<T, kSrD>(p.go + (tok * p.go_ld + h * kSrD) * ES, f);
+      else sr_load_row<T, kSrD>(p.q + (tok * p.q_ld + h * kSrD) * ES, f);
       float* dst = (which ? sg : sq) + r * kSrD;
 #pragma unroll
       for (int d = 0; d < kSrD; d += 4) *reinterpret_cast<f32x4*>(dst + d) = (f32x4){f[d], f[d + 1], f[d + 2], f[d + 3]};
@@ -622,48 +622,52 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_kernel(SrArgs p) {
     }
   }
   if (live) {
-    float* dst = p.part + (((int64_t)bh * chunks + chunk) * p.Nk + j) * 64;
+    float* dst = p.part + (((int64_t)bh * chunks + chunk) * p.Nk + j) * (2 * kSrD);
 #pragma unroll
     for (int d = 0; d < kSrD; d += 4) {
       *reinterpret_cast<f32x4*>(dst + d) = (f32x4){dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
-      *reinterpret_cast<f32x4*>(dst + 32 + d) = (f32x4){dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
+      *reinterpret_cast<f32x4*>(dst + kSrD + d) = (f32x4){dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
     }
   }
 }
 
-// gkv[b, j, which*C + h*32 + d] = sum over chunks (in chunk order) of part[(bh, chunk)][j][which*32 + d]
-template <typename T>
+// gkv[b, j, which*C + h*D + d] = sum over chunks (in chunk order) of part[(bh, chunk)][j][which*D + d]
+template <typename T, int kSrD>
 __global__ __launch_bounds__(256) void sr_attn_dkv_reduce_kernel(const float* __restrict__ part, int chunks, int B, int Nk, int heads, char* gkv, int64_t gkv_ld) {
-  const int64_t total = (int64_t)B * heads * Nk * 64;
+  constexpr int E = 2 * kSrD;
+  const int64_t total = (int64_t)B * heads * Nk * E;
   const int C = heads * kSrD;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    const int e = (int)(id & 63);
-    const int64_t t = id >> 6;
+    const int e = (int)(id % E);
+    const int64_t t = id / E;
     const int j = (int)(t % Nk);
     const int bh = (int)(t / Nk);
     const int b = bh / heads, h = bh - b * heads;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(((int64_t)bh * chunks + c) * Nk + j) * 64 + e];
-    Elem<T>::st(reinterpret_cast<T*>(gkv) + ((int64_t)b * Nk + j) * gkv_ld + (e >> 5) * C + h * kSrD + (e & 31), s);
+    for (int c = 0; c < chunks; ++c) s += part[(((int64_t)bh * chunks + c) * Nk + j) * E + e];
+    Elem<T>::st(reinterpret_cast<T*>(gkv) + ((int64_t)b * Nk + j) * gkv_ld + (e / kSrD) * C + h * kSrD + (e % kSrD), s);
   }
 }
 
-// ---- the same attention on the matrix cores (bf16, Nk a multiple of 32).  Head dimension 32 = ONE K-step of v_mfma_f32_16x16x32_bf16.
-// Scores are computed TRANSPOSED, S^T = K Q^T (A = 16 key rows from LDS, B = the wave's 16 queries, read once): the accumulator layout
-// (lane = query l % 16, registers = keys (l / 16) * 4 + r) is then exactly a B operand of the second MFMA, O^T = V^T P^T, if its 32 K slots
-// are fed as [block 2j keys g*4..g*4+3 | block 2j+1 keys g*4..g*4+3] - the probabilities go from accumulators to operands without leaving
-// the registers; V^T ([32 d][keys], row pitch + 8 bytes: conflict-free 8-byte reads) supplies the matching slots.  Softmax statistics:
-// per lane over its own keys, combined across the four lane groups by two shuffles; 256 keys at a time with the usual online rescale.
+// ---- the same attention on the matrix cores (bf16, Nk a multiple of 32, head dimension D = 32 | 64 = one | two K-steps of
+// v_mfma_f32_16x16x32_bf16).  Scores are computed TRANSPOSED, S^T = K Q^T (A = 16 key rows from LDS, B = the wave's 16 queries, read once):
+// the accumulator layout (lane = query l % 16, registers = keys (l / 16) * 4 + r) is then exactly a B operand of the second MFMA,
+// O^T = V^T P^T, if its 32 K slots are fed as [block 2j keys g*4..g*4+3 | block 2j+1 keys g*4..g*4+3] - the probabilities go from accumulators
+// to operands without leaving the registers; V^T ([D][keys], row pitch + 8 bytes: conflict-free 8-byte reads) supplies the matching slots.
+// Softmax statistics: per lane over its own keys, combined across the four lane groups by two shuffles; 256 keys at a time with the usual
+// online rescale.
 constexpr int kSrVtPitch = kSrKC * 2 + 8;     // bytes per V^T (or K^T) row in LDS
 
-// rows [j0, j0 + n) of the key (which = 0) / value (which = 1) projection of (b, h): row-major [n][32] bf16 at `rows` and / or transposed
-// [32][n] (pitch kSrVtPitch) at `tr`
+// rows [j0, j0 + n) of the key (which = 0) / value (which = 1) projection of (b, h): row-major [n][D] bf16 at `rows` and / or transposed
+// [D][n] (pitch kSrVtPitch) at `tr`
+template <int D>
 __device__ __forceinline__ void sr_stage_bf16(const SrArgs& p, int b, int h, int which, int j0, int n, char* rows, char* tr) {
-  const int C = p.heads * kSrD;
-  for (int id = threadIdx.x; id < n * 4; id += blockDim.x) {
-    const int j = id >> 2, c = id & 3;
-    const uint4 v = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + j0 + j) * p.kv_ld + which * C + h * kSrD + c * 8) * 2);
-    if (rows) *reinterpret_cast<uint4*>(rows + j * 64 + c * 16) = v;
+  const int C = p.heads * D;
+  constexpr int CH = D / 8;
+  for (int id = threadIdx.x; id < n * CH; id += blockDim.x) {
+    const int j = id / CH, c = id % CH;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + j0 + j) * p.kv_ld + which * C + h * D + c * 8) * 2);
+    if (rows) *reinterpret_cast<uint4*>(rows + j * (D * 2) + c * 16) = v;
     if (tr) {
       const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -678,39 +682,48 @@ __device__ __forceinline__ bf16x8 sr_pack8(const f32x4& a, const f32x4& b) {
   u.x = pack2_bf16(a[0], a[1]); u.y = pack2_bf16(a[2], a[3]); u.z = pack2_bf16(b[0], b[1]); u.w = pack2_bf16(b[2], b[3]);
   return __builtin_bit_cast(bf16x8, u);
 }
-// A operand of the transposed product: row d = db*16 + fr of a [32][keys] LDS image, K slots = keys {2j*16 + g*4 .., (2j+1)*16 + g*4 ..}
-__device__ __forceinline__ bf16x8 sr_tr_operand(const char* tr, int db, int fr, int g, int jp) {
-  const char* row = tr + (db * 16 + fr) * kSrVtPitch;
+// A operand of the transposed product: row d = db*16 + fr of a [D][keys] LDS image, K slots = keys {2j*16 + g*4 .., (2j+1)*16 + g*4 ..}
+__device__ __forceinline__ bf16x8 sr_tr_operand(const char* tr, int pitch, int db, int fr, int g, int jp) {
+  const char* row = tr + (db * 16 + fr) * pitch;
   const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * jp) * 16 + g * 4) * 2);
   const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * jp + 1) * 16 + g * 4) * 2);
   return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
+// the 16-byte operand chunk (channels ks*32 + g*8 ..) of token `tok` of a [tokens][ld] bf16 tensor, head offset included in `base`
+__device__ __forceinline__ bf16x8 sr_tok_operand(const char* base, int64_t tok, int64_t ld, int ks, int g, bool ok) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (ok) v = *reinterpret_cast<const uint4*>(base + (tok * ld + ks * 32 + g * 8) * 2);
+  return __builtin_bit_cast(bf16x8, v);
+}
 
+template <int D>
 __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
+  constexpr int KS = D / 32, DB = D / 16;
   extern __shared__ __attribute__((aligned(16))) char sr_lds[];
-  char* skr = sr_lds;                              // K rows [kSrKC][64 B]
-  char* svt = sr_lds + kSrKC * 64;                 // V^T [32][kSrVtPitch]
+  char* skr = sr_lds;                              // K rows [kSrKC][D bf16]
+  char* svt = sr_lds + kSrKC * D * 2;              // V^T [D][kSrVtPitch]
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int nbase = blockIdx.x * 256 + wave * 64;
-  bf16x8 bq[4];
-  f32x4 o[4][2];
+  const char* qbase = p.q + (int64_t)h * D * 2;
+  bf16x8 bq[4][KS];
+  f32x4 o[4][DB];
   float m[4], l[4];
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
     const int n = nbase + qb * 16 + fr;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (n < p.N) v = *reinterpret_cast<const uint4*>(p.q + (((int64_t)b * p.N + n) * p.q_ld + h * kSrD + g * 8) * 2);
-    bq[qb] = __builtin_bit_cast(bf16x8, v);
-    o[qb][0] = o[qb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bq[qb][ks] = sr_tok_operand(qbase, (int64_t)b * p.N + n, p.q_ld, ks, g, n < p.N);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
     m[qb] = -INFINITY; l[qb] = 0.f;
   }
   for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
     const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;       // a multiple of 32
     __syncthreads();
-    sr_stage_bf16(p, b, h, 0, j0, nk, skr, nullptr);
-    sr_stage_bf16(p, b, h, 1, j0, nk, nullptr, svt);
+    sr_stage_bf16<D>(p, b, h, 0, j0, nk, skr, nullptr);
+    sr_stage_bf16<D>(p, b, h, 1, j0, nk, nullptr, svt);
     __syncthreads();
     const int nblk = nk >> 4;
 #pragma unroll
@@ -720,8 +733,13 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
 #pragma unroll
       for (int jb = 0; jb < kSrKC / 16; ++jb) {
         if (jb < nblk) {
-          const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(skr + (jb * 16 + fr) * 64 + g * 16));
-          s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(skr + (jb * 16 + fr) * (D * 2) + ks * 64 + g * 16));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[qb][ks], acc, 0, 0, 0);
+          }
+          s[jb] = acc;
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s[jb][r] *= p.scale; cm = fmaxf(cm, s[jb][r]); }
         }
@@ -733,7 +751,7 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
       m[qb] = mn;
       l[qb] *= corr;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+      for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[qb][db][r] *= corr;
 #pragma unroll
@@ -748,8 +766,8 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
         if (2 * jp < nblk) {
           const bf16x8 pb = sr_pack8(s[2 * jp], s[2 * jp + 1]);
 #pragma unroll
-          for (int db = 0; db < 2; ++db)
-            o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sr_tr_operand(svt, db, fr, g, jp), pb, o[qb][db], 0, 0, 0);
+          for (int db = 0; db < DB; ++db)
+            o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sr_tr_operand(svt, kSrVtPitch, db, fr, g, jp), pb, o[qb][db], 0, 0, 0);
         }
       }
     }
@@ -763,11 +781,11 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
     if (n < p.N) {
       const float inv = 1.f / lt;
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+      for (int db = 0; db < DB; ++db) {
         uint2 u;
         u.x = pack2_bf16(o[qb][db][0] * inv, o[qb][db][1] * inv);
         u.y = pack2_bf16(o[qb][db][2] * inv, o[qb][db][3] * inv);
-        *reinterpret_cast<uint2*>(p.out + (((int64_t)b * p.N + n) * p.out_ld + h * kSrD + db * 16 + g * 4) * 2) = u;
+        *reinterpret_cast<uint2*>(p.out + (((int64_t)b * p.N + n) * p.out_ld + h * D + db * 16 + g * 4) * 2) = u;
       }
       if (p.lse && g == 0) p.lse[(int64_t)bh * p.N + n] = m[qb] + __logf(lt);
     }
@@ -775,50 +793,52 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_mfma_kernel(SrArgs p) {
 }
 
 // dQ on the matrix cores: the forward's structure.  S^T and dP^T = V dO^T per 16-key block, dS^T = P^T (dP^T - delta) scale in the accumulator
-// layout, dQ^T += K^T dS^T with K^T read from a transposed LDS image.  delta = rowsum(dO o O) is formed here (8 channels per lane, two
-// shuffles) and saved for the key-major kernel.
+// layout, dQ^T += K^T dS^T with K^T read from a transposed LDS image.  delta = rowsum(dO o O) is formed here (8 channels per lane and K-step,
+// two shuffles) and saved for the key-major kernel.
+template <int D>
 __global__ __launch_bounds__(256) void sr_attn_bwd_dq_mfma_kernel(SrArgs p) {
+  constexpr int KS = D / 32, DB = D / 16;
   extern __shared__ __attribute__((aligned(16))) char sr_lds[];
   char* skr = sr_lds;                              // K rows
-  char* svr = sr_lds + kSrKC * 64;                 // V rows
-  char* skt = sr_lds + 2 * kSrKC * 64;             // K^T
+  char* svr = sr_lds + kSrKC * D * 2;              // V rows
+  char* skt = sr_lds + 2 * kSrKC * D * 2;          // K^T
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int nbase = blockIdx.x * 256 + wave * 64;
-  bf16x8 bq[4], bgo[4];
-  f32x4 dq[4][2];
+  const int64_t hoff = (int64_t)h * D * 2;
+  bf16x8 bq[4][KS], bgo[4][KS];
+  f32x4 dq[4][DB];
   float lse[4], delta[4];
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
     const int n = nbase + qb * 16 + fr;
-    uint4 vq = make_uint4(0u, 0u, 0u, 0u), vg = vq, vo = vq;
-    if (n < p.N) {
-      const int64_t tok = (int64_t)b * p.N + n;
-      vq = *reinterpret_cast<const uint4*>(p.q + (tok * p.q_ld + h * kSrD + g * 8) * 2);
-      vg = *reinterpret_cast<const uint4*>(p.go + (tok * p.go_ld + h * kSrD + g * 8) * 2);
-      vo = *reinterpret_cast<const uint4*>(p.o + (tok * p.o_ld + h * kSrD + g * 8) * 2);
-    }
-    bq[qb] = __builtin_bit_cast(bf16x8, vq);
-    bgo[qb] = __builtin_bit_cast(bf16x8, vg);
-    float fg_[8], fo[8];
-    Elem<bf16_t>::unpack(vg, fg_);
-    Elem<bf16_t>::unpack(vo, fo);
+    const int64_t tok = (int64_t)b * p.N + n;
     float d = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) d += fg_[k] * fo[k];
+    for (int ks = 0; ks < KS; ++ks) {
+      bq[qb][ks] = sr_tok_operand(p.q + hoff, tok, p.q_ld, ks, g, n < p.N);
+      bgo[qb][ks] = sr_tok_operand(p.go + hoff, tok, p.go_ld, ks, g, n < p.N);
+      const bf16x8 bo = sr_tok_operand(p.o + hoff, tok, p.o_ld, ks, g, n < p.N);
+      float fg_[8], fo[8];
+      Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, bgo[qb][ks]), fg_);
+      Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, bo), fo);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d += fg_[k] * fo[k];
+    }
     d += __shfl_xor(d, 16, 64);
     d += __shfl_xor(d, 32, 64);
     delta[qb] = d;
     lse[qb] = n < p.N ? p.lse[(int64_t)bh * p.N + n] : INFINITY;
     if (n < p.N && g == 0) p.delta[(int64_t)bh * p.N + n] = d;
-    dq[qb][0] = dq[qb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dq[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   for (int j0 = 0; j0 < p.Nk; j0 += kSrKC) {
     const int nk = p.Nk - j0 < kSrKC ? p.Nk - j0 : kSrKC;
     __syncthreads();
-    sr_stage_bf16(p, b, h, 0, j0, nk, skr, skt);
-    sr_stage_bf16(p, b, h, 1, j0, nk, svr, nullptr);
+    sr_stage_bf16<D>(p, b, h, 0, j0, nk, skr, skt);
+    sr_stage_bf16<D>(p, b, h, 1, j0, nk, svr, nullptr);
     __syncthreads();
     const int npair = nk >> 5;
 #pragma unroll
@@ -828,17 +848,21 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dq_mfma_kernel(SrArgs p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int jb = 2 * jp + e;
-          const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(skr + (jb * 16 + fr) * 64 + g * 16));
-          const bf16x8 va = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(svr + (jb * 16 + fr) * 64 + g * 16));
-          const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, bgo[qb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = st;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(skr + (jb * 16 + fr) * (D * 2) + ks * 64 + g * 16));
+            const bf16x8 va = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(svr + (jb * 16 + fr) * (D * 2) + ks * 64 + g * 16));
+            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[qb][ks], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, bgo[qb][ks], dp, 0, 0, 0);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) ds[e][r] = __expf(st[r] * p.scale - lse[qb]) * (dp[r] - delta[qb]) * p.scale;
         }
         const bf16x8 pb = sr_pack8(ds[0], ds[1]);
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-          dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sr_tr_operand(skt, db, fr, g, jp), pb, dq[qb][db], 0, 0, 0);
+        for (int db = 0; db < DB; ++db)
+          dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sr_tr_operand(skt, kSrVtPitch, db, fr, g, jp), pb, dq[qb][db], 0, 0, 0);
       }
     }
   }
@@ -847,11 +871,11 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dq_mfma_kernel(SrArgs p) {
     const int n = nbase + qb * 16 + fr;
     if (n < p.N) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+      for (int db = 0; db < DB; ++db) {
         uint2 u;
         u.x = pack2_bf16(dq[qb][db][0], dq[qb][db][1]);
         u.y = pack2_bf16(dq[qb][db][2], dq[qb][db][3]);
-        *reinterpret_cast<uint2*>(p.gq + (((int64_t)b * p.N + n) * p.gq_ld + h * kSrD + db * 16 + g * 4) * 2) = u;
+        *reinterpret_cast<uint2*>(p.gq + (((int64_t)b * p.N + n) * p.gq_ld + h * D + db * 16 + g * 4) * 2) = u;
       }
     }
   }
@@ -860,82 +884,78 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dq_mfma_kernel(SrArgs p) {
 // dK / dV on the matrix cores (key-major): wave w owns the key blocks {i*4 + w} of this workgroup's 256 keys (their K / V rows stay in
 // registers as B operands), the workgroup walks its query chunk 32 queries at a time.  S = Q K^T and dP = dO V^T come out with lane = key,
 // registers = queries - exactly the A operand (rows = keys, K slots = the 32 queries) of dV += P^T dO and dK += dS^T Q, whose B operands are
-// the step's dO^T / Q^T tiles from a transposed LDS image.  Partials as the VALU kernel's: part[(bh, chunk)][key][dk 32 | dv 32].
+// the step's dO^T / Q^T tiles from a transposed LDS image.  Partials as the VALU kernel's: part[(bh, chunk)][key][dk D | dv D].
 constexpr int kSrQtPitch = 32 * 2 + 8;
+template <int D>
 __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_mfma_kernel(SrArgs p) {
-  __shared__ __attribute__((aligned(16))) char sqt[32 * kSrQtPitch];      // Q^T  [32 d][32 queries]
-  __shared__ __attribute__((aligned(16))) char sgt[32 * kSrQtPitch];      // dO^T
+  constexpr int KS = D / 32, DB = D / 16, CH = D / 8;
+  __shared__ __attribute__((aligned(16))) char sqt[D * kSrQtPitch];      // Q^T  [D][32 queries]
+  __shared__ __attribute__((aligned(16))) char sgt[D * kSrQtPitch];      // dO^T
   __shared__ __attribute__((aligned(16))) float sl[32];
   __shared__ __attribute__((aligned(16))) float sd[32];
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
   const int chunk = blockIdx.x, chunks = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int C = p.heads * kSrD;
-  bf16x8 kop[4], vop[4];
-  f32x4 dk[4][2], dv[4][2];
+  const int C = p.heads * D;
+  const int64_t hoff = (int64_t)h * D * 2;
+  bf16x8 kop[4][KS], vop[4][KS];
+  f32x4 dk[4][DB], dv[4][DB];
   bool live[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int key = blockIdx.z * 256 + (i * 4 + wave) * 16 + fr;
     live[i] = blockIdx.z * 256 + (i * 4 + wave) * 16 < p.Nk;
-    uint4 vk = make_uint4(0u, 0u, 0u, 0u), vv = vk;
-    if (live[i]) {
-      vk = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + key) * p.kv_ld + h * kSrD + g * 8) * 2);
-      vv = *reinterpret_cast<const uint4*>(p.kv + (((int64_t)b * p.Nk + key) * p.kv_ld + C + h * kSrD + g * 8) * 2);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kop[i][ks] = sr_tok_operand(p.kv + hoff, (int64_t)b * p.Nk + key, p.kv_ld, ks, g, live[i]);
+      vop[i][ks] = sr_tok_operand(p.kv + hoff + (int64_t)C * 2, (int64_t)b * p.Nk + key, p.kv_ld, ks, g, live[i]);
     }
-    kop[i] = __builtin_bit_cast(bf16x8, vk);
-    vop[i] = __builtin_bit_cast(bf16x8, vv);
-    dk[i][0] = dk[i][1] = dv[i][0] = dv[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dk[i][db] = dv[i][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int n0 = chunk * p.QC;
   const int n1 = n0 + p.QC < p.N ? n0 + p.QC : p.N;
   for (int nb = n0; nb < n1; nb += 32) {
-    // this step's Q / dO rows as A operands (lane = query fr of block a, channels g*8 ..)
-    bf16x8 qa[2], ga[2];
+    // this step's Q / dO rows as A operands (lane = query fr of block a, channels ks*32 + g*8 ..)
+    bf16x8 qa[2][KS], ga[2][KS];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int n = nb + a * 16 + fr;
-      uint4 vq = make_uint4(0u, 0u, 0u, 0u), vg = vq;
-      if (n < n1) {
-        const int64_t tok = (int64_t)b * p.N + n;
-        vq = *reinterpret_cast<const uint4*>(p.q + (tok * p.q_ld + h * kSrD + g * 8) * 2);
-        vg = *reinterpret_cast<const uint4*>(p.go + (tok * p.go_ld + h * kSrD + g * 8) * 2);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qa[a][ks] = sr_tok_operand(p.q + hoff, (int64_t)b * p.N + n, p.q_ld, ks, g, n < n1);
+        ga[a][ks] = sr_tok_operand(p.go + hoff, (int64_t)b * p.N + n, p.go_ld, ks, g, n < n1);
       }
-      qa[a] = __builtin_bit_cast(bf16x8, vq);
-      ga[a] = __builtin_bit_cast(bf16x8, vg);
     }
     __syncthreads();
-    {   // the transposed tiles: thread = (tensor, query, 8-channel chunk)
-      const int t = threadIdx.x >> 7, r = (threadIdx.x >> 2) & 31, c = threadIdx.x & 3;
+    // the transposed tiles: work item = (tensor, query, 8-channel chunk)
+    for (int id = threadIdx.x; id < 2 * 32 * CH; id += 256) {
+      const int t = id / (32 * CH), r = (id / CH) & 31, c = id % CH;
       const int n = nb + r;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (n < n1) {
         const int64_t tok = (int64_t)b * p.N + n;
-        v = t ? *reinterpret_cast<const uint4*>(p.go + (tok * p.go_ld + h * kSrD + c * 8) * 2)
-              : *reinterpret_cast<const uint4*>(p.q + (tok * p.q_ld + h * kSrD + c * 8) * 2);
+        v = t ? *reinterpret_cast<const uint4*>(p.go + hoff + (tok * p.go_ld + c * 8) * 2)
+              : *reinterpret_cast<const uint4*>(p.q + hoff + (tok * p.q_ld + c * 8) * 2);
       }
       char* tr = t ? sgt : sqt;
       const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         *reinterpret_cast<uint16_t*>(tr + (c * 8 + k) * kSrQtPitch + r * 2) = (uint16_t)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
-      if (threadIdx.x < 32) {
-        const int nn = nb + threadIdx.x;
-        sl[threadIdx.x] = nn < n1 ? p.lse[(int64_t)bh * p.N + nn] : INFINITY;
-        sd[threadIdx.x] = nn < n1 ? p.delta[(int64_t)bh * p.N + nn] : 0.f;
-      }
+    }
+    if (threadIdx.x < 32) {
+      const int nn = nb + threadIdx.x;
+      sl[threadIdx.x] = nn < n1 ? p.lse[(int64_t)bh * p.N + nn] : INFINITY;
+      sd[threadIdx.x] = nn < n1 ? p.delta[(int64_t)bh * p.N + nn] : 0.f;
     }
     __syncthreads();
-    bf16x8 qT[2], gT[2];
+    bf16x8 qT[DB], gT[DB];
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const char* rq_ = sqt + (db * 16 + fr) * kSrQtPitch;
-      const char* rg_ = sgt + (db * 16 + fr) * kSrQtPitch;
-      const uint2 a0 = *reinterpret_cast<const uint2*>(rq_ + (g * 4) * 2), a1 = *reinterpret_cast<const uint2*>(rq_ + (16 + g * 4) * 2);
-      const uint2 b0 = *reinterpret_cast<const uint2*>(rg_ + (g * 4) * 2), b1 = *reinterpret_cast<const uint2*>(rg_ + (16 + g * 4) * 2);
-      qT[db] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-      gT[db] = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+    for (int db = 0; db < DB; ++db) {
+      qT[db] = sr_tr_operand(sqt, kSrQtPitch, db, fr, g, 0);
+      gT[db] = sr_tr_operand(sgt, kSrQtPitch, db, fr, g, 0);
     }
     f32x4 ls[2], dl[2];
 #pragma unroll
@@ -949,8 +969,12 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_mfma_kernel(SrArgs p) {
       f32x4 pr[2], ds[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a], kop[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a], vop[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[a][ks], kop[i][ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a][ks], vop[i][ks], dp, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pr[a][r] = __expf(s[r] * p.scale - ls[a][r]);
@@ -959,7 +983,7 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_mfma_kernel(SrArgs p) {
       }
       const bf16x8 pa = sr_pack8(pr[0], pr[1]), da = sr_pack8(ds[0], ds[1]);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+      for (int db = 0; db < DB; ++db) {
         dv[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, gT[db], dv[i][db], 0, 0, 0);
         dk[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, qT[db], dk[i][db], 0, 0, 0);
       }
@@ -971,11 +995,11 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_dkv_mfma_kernel(SrArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = blockIdx.z * 256 + (i * 4 + wave) * 16 + g * 4 + r;
-      float* dst = p.part + (((int64_t)bh * chunks + chunk) * p.Nk + key) * 64;
+      float* dst = p.part + (((int64_t)bh * chunks + chunk) * p.Nk + key) * (2 * D);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+      for (int db = 0; db < DB; ++db) {
         dst[db * 16 + fr] = dk[i][db][r];
-        dst[32 + db * 16 + fr] = dv[i][db][r];
+        dst[D + db * 16 + fr] = dv[i][db][r];
       }
     }
   }
@@ -1277,63 +1301,98 @@ extern "C" int cvcs_scale_rows_add(const void* x, int64_t x_ld, const float* sca
   return CVCS_OK;
 }
 
-static int sr_check(const char* fn, int B, int N, int Nk, int heads, int dtype) {
+static int sr_check(const char* fn, int B, int N, int Nk, int heads, int head_dim, int dtype) {
   CVCS_CHECK_ARG(SF_DT(dtype), "%s: bad dtype", fn);
   CVCS_CHECK_ARG(B > 0 && N > 0 && Nk > 0 && heads > 0 && heads <= 64 && (int64_t)B * heads <= 65535, "%s: bad shape", fn);
+  CVCS_CHECK_ARG(head_dim == 32 || head_dim == 64, "%s: head_dim=%d (built: 32 = MiT-b0, 64 = MiT-b1 ... b5)", fn, head_dim);
   return CVCS_OK;
 }
 static int sr_chunk(int N) {     // queries per key-major workgroup
   int qc = N / 16;
   return qc < 256 ? 256 : qc;
 }
+static int sr_use_mfma() {
+  static const int on = getenv("CVCS_SR_ATTN_MFMA") ? atoi(getenv("CVCS_SR_ATTN_MFMA")) : 1;      // tuning / A-B knob
+  return on;
+}
+template <typename K>
+static void sr_lds_attr(K kernel, size_t lds) {
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 
-extern "C" int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, int B, int N, int Nk, int heads, void* out,
-                                     int64_t out_ld, float* lse, int dtype, void* stream) {
-  const char* fn = "cvcs_sr_attention_fwd";
-  int rc;
-  if ((rc = sr_check(fn, B, N, Nk, heads, dtype))) return rc;
-  const int es = dtype == CVCS_F32 ? 4 : 2, C = heads * kSrD;
-  if ((rc = sf_view(fn, q, q_ld, C, es)) || (rc = sf_view(fn, kv, kv_ld, 2 * C, es)) || (rc = sf_view(fn, out, out_ld, C, es))) return rc;
-  SrArgs a{};
-  a.q = (const char*)q; a.kv = (const char*)kv; a.out = (char*)out; a.lse = lse; a.q_ld = q_ld; a.kv_ld = kv_ld; a.out_ld = out_ld;
-  a.B = B; a.N = N; a.Nk = Nk; a.heads = heads; a.scale = 0.17677669529663687f;   // 32^-0.5
-  const dim3 grid((unsigned)cdiv(N, 256), (unsigned)(B * heads));
-  const size_t lds = 2 * (size_t)kSrKC * kSrD * 4;
-  hipStream_t st = (hipStream_t)stream;
-  static const int use_mfma = getenv("CVCS_SR_ATTN_MFMA") ? atoi(getenv("CVCS_SR_ATTN_MFMA")) : 1;      // tuning / A-B knob
-  if (dtype == CVCS_BF16 && use_mfma && Nk % 32 == 0) {
-    hipLaunchKernelGGL(sr_attn_fwd_mfma_kernel, grid, dim3(256), kSrKC * 64 + 32 * kSrVtPitch, st, a);
-    CVCS_CHECK_LAUNCH(fn);
-    return CVCS_OK;
-  }
-  if (dtype == CVCS_F32) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-    hipLaunchKernelGGL((sr_attn_fwd_kernel<float>), grid, dim3(256), lds, st, a);
+template <int D>
+static int sr_fwd_launch(const SrArgs& a, const char* fn, int dtype, hipStream_t st) {
+  const dim3 grid((unsigned)cdiv(a.N, 256), (unsigned)(a.B * a.heads));
+  if (dtype == CVCS_BF16 && sr_use_mfma() && a.Nk % 32 == 0) {
+    const size_t lds = (size_t)kSrKC * D * 2 + (size_t)D * kSrVtPitch;
+    sr_lds_attr(&sr_attn_fwd_mfma_kernel<D>, lds);
+    hipLaunchKernelGGL((sr_attn_fwd_mfma_kernel<D>), grid, dim3(256), lds, st, a);
   } else {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-    hipLaunchKernelGGL((sr_attn_fwd_kernel<bf16_t>), grid, dim3(256), lds, st, a);
+    const size_t lds = 2 * (size_t)kSrKC * D * 4;
+    if (dtype == CVCS_F32) { sr_lds_attr(&sr_attn_fwd_kernel<float, D>, lds); hipLaunchKernelGGL((sr_attn_fwd_kernel<float, D>), grid, dim3(256), lds, st, a); }
+    else { sr_lds_attr(&sr_attn_fwd_kernel<bf16_t, D>, lds); hipLaunchKernelGGL((sr_attn_fwd_kernel<bf16_t, D>), grid, dim3(256), lds, st, a); }
   }
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
 
-// floats: delta [B*heads*N] then the key-major partials [B*heads][chunks][Nk][64]
-extern "C" int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads) {
-  if (B <= 0 || N <= 0 || Nk <= 0 || heads <= 0) return CVCS_EINVAL;
+extern "C" int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, int B, int N, int Nk, int heads, int head_dim,
+                                     void* out, int64_t out_ld, float* lse, int dtype, void* stream) {
+  const char* fn = "cvcs_sr_attention_fwd";
+  int rc;
+  if ((rc = sr_check(fn, B, N, Nk, heads, head_dim, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2, C = heads * head_dim;
+  if ((rc = sf_view(fn, q, q_ld, C, es)) || (rc = sf_view(fn, kv, kv_ld, 2 * C, es)) || (rc = sf_view(fn, out, out_ld, C, es))) return rc;
+  SrArgs a{};
+  a.q = (const char*)q; a.kv = (const char*)kv; a.out = (char*)out; a.lse = lse; a.q_ld = q_ld; a.kv_ld = kv_ld; a.out_ld = out_ld;
+  a.B = B; a.N = N; a.Nk = Nk; a.heads = heads; a.scale = 1.0f / sqrtf((float)head_dim);
+  return head_dim == 32 ? sr_fwd_launch<32>(a, fn, dtype, (hipStream_t)stream) : sr_fwd_launch<64>(a, fn, dtype, (hipStream_t)stream);
+}
+
+// floats: delta [B*heads*N] then the key-major partials [B*heads][chunks][Nk][2*head_dim]
+extern "C" int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads, int head_dim) {
+  if (B <= 0 || N <= 0 || Nk <= 0 || heads <= 0 || (head_dim != 32 && head_dim != 64)) return CVCS_EINVAL;
   const int64_t chunks = cdiv(N, sr_chunk(N));
   const int64_t delta = ((int64_t)B * heads * N + 3) / 4 * 4;
-  return delta + (int64_t)B * heads * chunks * Nk * 64;
+  return delta + (int64_t)B * heads * chunks * Nk * 2 * head_dim;
+}
+
+template <int D>
+static int sr_bwd_launch(const SrArgs& a, const char* fn, int dtype, void* gkv, int64_t gkv_ld, hipStream_t st) {
+  const int chunks = (int)cdiv(a.N, a.QC);
+  const dim3 gq_grid((unsigned)cdiv(a.N, 256), (unsigned)(a.B * a.heads));
+  const dim3 gk_grid((unsigned)chunks, (unsigned)(a.B * a.heads), (unsigned)cdiv(a.Nk, 256));
+  const dim3 gr_grid(sf_grid((int64_t)a.B * a.heads * a.Nk * 2 * D));
+  if (dtype == CVCS_BF16 && sr_use_mfma() && a.Nk % 32 == 0) {
+    const size_t lds = 2 * (size_t)kSrKC * D * 2 + (size_t)D * kSrVtPitch;
+    sr_lds_attr(&sr_attn_bwd_dq_mfma_kernel<D>, lds);
+    hipLaunchKernelGGL((sr_attn_bwd_dq_mfma_kernel<D>), gq_grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sr_attn_bwd_dkv_mfma_kernel<D>), gk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<bf16_t, D>), gr_grid, dim3(256), 0, st, a.part, chunks, a.B, a.Nk, a.heads, (char*)gkv, gkv_ld);
+  } else if (dtype == CVCS_F32) {
+    const size_t lds = 2 * (size_t)kSrKC * D * 4;
+    sr_lds_attr(&sr_attn_bwd_dq_kernel<float, D>, lds);
+    hipLaunchKernelGGL((sr_attn_bwd_dq_kernel<float, D>), gq_grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sr_attn_bwd_dkv_kernel<float, D>), gk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<float, D>), gr_grid, dim3(256), 0, st, a.part, chunks, a.B, a.Nk, a.heads, (char*)gkv, gkv_ld);
+  } else {
+    const size_t lds = 2 * (size_t)kSrKC * D * 4;
+    sr_lds_attr(&sr_attn_bwd_dq_kernel<bf16_t, D>, lds);
+    hipLaunchKernelGGL((sr_attn_bwd_dq_kernel<bf16_t, D>), gq_grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sr_attn_bwd_dkv_kernel<bf16_t, D>), gk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<bf16_t, D>), gr_grid, dim3(256), 0, st, a.part, chunks, a.B, a.Nk, a.heads, (char*)gkv, gkv_ld);
+  }
+  CVCS_CHECK_LAUNCH(fn);
+  return CVCS_OK;
 }
 
 extern "C" int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, const void* o, int64_t o_ld, const void* go, int64_t go_ld,
-                                     const float* lse, int B, int N, int Nk, int heads, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld,
-                                     float* workspace, int dtype, void* stream) {
+                                     const float* lse, int B, int N, int Nk, int heads, int head_dim, void* gq, int64_t gq_ld, void* gkv,
+                                     int64_t gkv_ld, float* workspace, int dtype, void* stream) {
   const char* fn = "cvcs_sr_attention_bwd";
   int rc;
-  if ((rc = sr_check(fn, B, N, Nk, heads, dtype))) return rc;
-  const int es = dtype == CVCS_F32 ? 4 : 2, C = heads * kSrD;
+  if ((rc = sr_check(fn, B, N, Nk, heads, head_dim, dtype))) return rc;
+  const int es = dtype == CVCS_F32 ? 4 : 2, C = heads * head_dim;
   CVCS_CHECK_ARG(lse && workspace, "%s: null argument", fn);
   if ((rc = sf_view(fn, q, q_ld, C, es)) || (rc = sf_view(fn, kv, kv_ld, 2 * C, es)) || (rc = sf_view(fn, o, o_ld, C, es)) ||
       (rc = sf_view(fn, go, go_ld, C, es)) || (rc = sf_view(fn, gq, gq_ld, C, es)) || (rc = sf_view(fn, gkv, gkv_ld, 2 * C, es))) return rc;
@@ -1343,36 +1402,8 @@ extern "C" int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv
   a.delta = workspace;
   a.part = workspace + ((int64_t)B * heads * N + 3) / 4 * 4;
   a.q_ld = q_ld; a.kv_ld = kv_ld; a.o_ld = o_ld; a.go_ld = go_ld; a.gq_ld = gq_ld;
-  a.B = B; a.N = N; a.Nk = Nk; a.heads = heads; a.QC = sr_chunk(N); a.scale = 0.17677669529663687f;
-  const int chunks = (int)cdiv(N, a.QC);
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 gq_grid((unsigned)cdiv(N, 256), (unsigned)(B * heads));
-  const dim3 gk_grid((unsigned)chunks, (unsigned)(B * heads), (unsigned)cdiv(Nk, 256));
-  const size_t lds = 2 * (size_t)kSrKC * kSrD * 4;
-  const dim3 gr_grid(sf_grid((int64_t)B * heads * Nk * 64));
-  static const int use_mfma = getenv("CVCS_SR_ATTN_MFMA") ? atoi(getenv("CVCS_SR_ATTN_MFMA")) : 1;
-  if (dtype == CVCS_BF16 && use_mfma && Nk % 32 == 0) {
-    hipLaunchKernelGGL(sr_attn_bwd_dq_mfma_kernel, gq_grid, dim3(256), 2 * kSrKC * 64 + 32 * kSrVtPitch, st, a);
-    hipLaunchKernelGGL(sr_attn_bwd_dkv_mfma_kernel, gk_grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<bf16_t>), gr_grid, dim3(256), 0, st, a.part, chunks, B, Nk, heads, (char*)gkv, gkv_ld);
-    CVCS_CHECK_LAUNCH(fn);
-    return CVCS_OK;
-  }
-  if (dtype == CVCS_F32) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_bwd_dq_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-    hipLaunchKernelGGL((sr_attn_bwd_dq_kernel<float>), gq_grid, dim3(256), lds, st, a);
-    hipLaunchKernelGGL((sr_attn_bwd_dkv_kernel<float>), gk_grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<float>), gr_grid, dim3(256), 0, st, a.part, chunks, B, Nk, heads, (char*)gkv, gkv_ld);
-  } else {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_attn_bwd_dq_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-    hipLaunchKernelGGL((sr_attn_bwd_dq_kernel<bf16_t>), gq_grid, dim3(256), lds, st, a);
-    hipLaunchKernelGGL((sr_attn_bwd_dkv_kernel<bf16_t>), gk_grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((sr_attn_dkv_reduce_kernel<bf16_t>), gr_grid, dim3(256), 0, st, a.part, chunks, B, Nk, heads, (char*)gkv, gkv_ld);
-  }
-  CVCS_CHECK_LAUNCH(fn);
-  return CVCS_OK;
+  a.B = B; a.N = N; a.Nk = Nk; a.heads = heads; a.QC = sr_chunk(N); a.scale = 1.0f / sqrtf((float)head_dim);
+  return head_dim == 32 ? sr_bwd_launch<32>(a, fn, dtype, gkv, gkv_ld, (hipStream_t)stream) : sr_bwd_launch<64>(a, fn, dtype, gkv, gkv_ld, (hipStream_t)stream);
 }
 
 extern "C" int cvcs_gather_weights(const cvcs_gather_item* items_device, int n_items, int dtype, void* stream) {

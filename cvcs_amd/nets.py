@@ -657,8 +657,8 @@ class SegformerMod(_HipUNet):
     Transformer encoder, all-MLP decode head) with an NC-class classifier, followed by the reference's ConvTranspose2d(NC,NC,8,2,3) - ReLU -
     ConvTranspose2d(NC,NC,4,2,1) - ReLU - Conv2d(NC,NC,3,padding=1) tail; the input is normalised with the ImageNet constants on the RAW
     0..255 scale, as the reference's preprocessor does.  `pretrained=False` there means `SegformerConfig()` = MiT-b0, which is what this class
-    builds (`variant="b3"`, the architecture of the checkpoint the reference fetches with pretrained=True, registers the right parameters but the
-    attention kernels are built for MiT-b0's 32-wide heads: the engine refuses it).  Train mode applies the library's DropPath (0 ... 0.1 over the blocks) and the head's
+    builds (`variant="b3"`: the architecture of the checkpoint the reference fetches with pretrained=True - hidden 64 / 128 / 320 / 512, depths
+    3 / 4 / 18 / 3, 64-wide heads, decoder 768; there is no network here to fetch it, a state_dict with its tensors loads by name).  Train mode applies the library's DropPath (0 ... 0.1 over the blocks) and the head's
     Dropout(0.1) from a counter-based generator (`stochastic=False`: off).  State-dict keys follow transformers 5.x; checkpoints written
     under the 4.x module layout (`segformer.segformer.encoder.block.N.M.attention.self.query...`) are mapped on load.  The tile side must be
     a multiple of 32, NC at most 32."""

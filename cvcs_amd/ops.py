@@ -1085,25 +1085,27 @@ def scale_rows_add(x: View, scale, res: View | None, out: View):
 
 
 def sr_attention_fwd(q: View, kv: View, heads: int, out: View, lse):
-    """q [B,H,W,heads*32], kv [B,Hk,Wk,2*heads*32] (keys | values) -> out like q; lse f32 [B*heads*N]"""
+    """q [B,H,W,heads*D], kv [B,Hk,Wk,2*heads*D] (keys | values), D = 32 | 64 -> out like q; lse f32 [B*heads*N]"""
     N, Nk = q.H * q.W, kv.H * kv.W
-    assert q.C == heads * 32 and kv.C == 2 * q.C and kv.B == q.B and lse.numel() >= q.B * heads * N
+    D = q.C // heads
+    assert q.C == heads * D and kv.C == 2 * q.C and kv.B == q.B and lse.numel() >= q.B * heads * N
     if _lib._recording is not None:
         _lib.pending_tag = ("sr_attention" + (f":{SCOPE}" if SCOPE else ""), 4.0 * q.B * N * Nk * q.C)
-    check(_lib.lib().cvcs_sr_attention_fwd(q.ptr, q.ld, kv.ptr, kv.ld, q.B, N, Nk, heads, out.ptr, out.ld, lse.data_ptr(), q.code, _stream()),
+    check(_lib.lib().cvcs_sr_attention_fwd(q.ptr, q.ld, kv.ptr, kv.ld, q.B, N, Nk, heads, D, out.ptr, out.ld, lse.data_ptr(), q.code, _stream()),
           "cvcs_sr_attention_fwd")
 
 
-def sr_attention_bwd_workspace(B, N, Nk, heads) -> int:
-    return _lib.lib().cvcs_sr_attention_bwd_workspace(B, N, Nk, heads)
+def sr_attention_bwd_workspace(B, N, Nk, heads, head_dim=32) -> int:
+    return _lib.lib().cvcs_sr_attention_bwd_workspace(B, N, Nk, heads, head_dim)
 
 
 def sr_attention_bwd(q: View, kv: View, o: View, go: View, lse, heads: int, gq: View, gkv: View, workspace):
     N, Nk = q.H * q.W, kv.H * kv.W
-    assert workspace.numel() >= sr_attention_bwd_workspace(q.B, N, Nk, heads)
+    D = q.C // heads
+    assert workspace.numel() >= sr_attention_bwd_workspace(q.B, N, Nk, heads, D)
     if _lib._recording is not None:
         _lib.pending_tag = ("sr_attention" + (f":{SCOPE}" if SCOPE else ""), 10.0 * q.B * N * Nk * q.C)
-    check(_lib.lib().cvcs_sr_attention_bwd(q.ptr, q.ld, kv.ptr, kv.ld, o.ptr, o.ld, go.ptr, go.ld, lse.data_ptr(), q.B, N, Nk, heads, gq.ptr, gq.ld,
+    check(_lib.lib().cvcs_sr_attention_bwd(q.ptr, q.ld, kv.ptr, kv.ld, o.ptr, o.ld, go.ptr, go.ld, lse.data_ptr(), q.B, N, Nk, heads, D, gq.ptr, gq.ld,
                                            gkv.ptr, gkv.ld, workspace.data_ptr(), q.code, _stream()), "cvcs_sr_attention_bwd")
 
 

@@ -51,9 +51,7 @@ class SegformerEngine(SwinUPerNetEngine):
         super().__init__(num_classes, dtype, device)
         self.cfg = CONFIGS[variant]
         self.variant = variant
-        if any(c // h != 32 for c, h in zip(self.cfg["hidden"], self.cfg["heads"])):
-            raise NotImplementedError(f"SegformerMod variant '{variant}': the attention kernels are built for head dimension 32 (MiT-b0 = SegformerConfig(), the "
-                                      "reference's pretrained=False branch); MiT-b1..b5 use 64")
+        assert all(c // h in (32, 64) for c, h in zip(self.cfg["hidden"], self.cfg["heads"])), "the attention kernels are built for head dimensions 32 and 64"
         self.head_name = "seq.4"
         assert num_classes <= 32, "SegformerMod's NC-channel tail is built for at most 32 classes (the head kernels' limit)"
         self.CP = 32          # channel count of the NC-channel maps (the 1x1 GEMM kernels write multiples of 32 output channels)
@@ -306,7 +304,7 @@ class SegformerEngine(SwinUPerNetEngine):
                 g_ao = self._lin_bwd(ao.v, g, att + ".o_proj", p + ".g_ao")
                 gq = self._tokens(p + ".gq", B, H, W, C_)
                 gkv = self._tokens(p + ".gkv", B, Hk, Wk, 2 * C_)
-                ws = self._scratch("sr_attn_ws", ops.sr_attention_bwd_workspace(B, H * W, Hk * Wk, heads))
+                ws = self._scratch("sr_attn_ws", ops.sr_attention_bwd_workspace(B, H * W, Hk * Wk, heads, C_ // heads))
                 ops.SCOPE = "enc"
                 ops.sr_attention_bwd(q.v, kv.v, ao.v, g_ao, lse, heads, gq, gkv, ws)
                 g_kvin = self._lin_bwd(kvin.v, gkv, att + ".kv", p + ".g_kvin")

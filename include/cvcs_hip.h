@@ -533,16 +533,17 @@ int cvcs_dwconv3x3_wgrad(const void* x, int64_t x_ld, const void* dy, int64_t dy
 int cvcs_drop_path_scales(const uint64_t* state, const float* rates, int n, int B, float* out, void* stream);
 int cvcs_scale_rows_add(const void* x, int64_t x_ld, const float* scale, const void* res, int64_t res_ld, int B, int64_t HW, int C, void* out,
                         int64_t out_ld, int dtype, void* stream);
-/* Spatial-reduction attention (transformers SegformerAttention + eager_attention_forward): q [B, N, heads*32], kv [B, Nk, 2*heads*32] (key
- * projection in channels [0, C), value projection in [C, 2C): the two nn.Linear run as one GEMM), out = softmax(q k^T / sqrt(32)) v per image and
- * head; lse f32 [B*heads][N] (log-sum-exp of the scaled scores) is what the backward recomputes the probabilities from.
+/* Spatial-reduction attention (transformers SegformerAttention + eager_attention_forward): q [B, N, heads*D], kv [B, Nk, 2*heads*D] (key
+ * projection in channels [0, C), value projection in [C, 2C): the two nn.Linear run as one GEMM), head_dim D = 32 (MiT-b0) | 64 (MiT-b1 ... b5),
+ * out = softmax(q k^T / sqrt(D)) v per image and head; lse f32 [B*heads][N] (log-sum-exp of the scaled scores) is what the backward recomputes the
+ * probabilities from.
  * cvcs_sr_attention_bwd: gq, gkv from go (gradient of out); workspace of cvcs_sr_attention_bwd_workspace floats.                              */
-int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, int B, int N, int Nk, int heads, void* out, int64_t out_ld,
-                          float* lse, int dtype, void* stream);
-int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads);
+int cvcs_sr_attention_fwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, int B, int N, int Nk, int heads, int head_dim, void* out,
+                          int64_t out_ld, float* lse, int dtype, void* stream);
+int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads, int head_dim);
 int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, const void* o, int64_t o_ld, const void* go, int64_t go_ld,
-                          const float* lse, int B, int N, int Nk, int heads, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld, float* workspace,
-                          int dtype, void* stream);
+                          const float* lse, int B, int N, int Nk, int heads, int head_dim, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld,
+                          float* workspace, int dtype, void* stream);
 /* Table-driven weight gather: the f32 master tensors keep the reference's layouts (Conv2d OIHW, ConvTranspose2d IOHW); the GEMM operands of the
  * patch-matrix layers are re-gathered from them every step in ONE launch:
  *   dst[r][c] (R rows of pitch Cp; `dtype`, or f32 when f32_out) = valid(r, c) ? src[base + idx3(r; rd1, rd2, rs0..2) + idx3(c; cd1, cd2, cs0..2)] : 0

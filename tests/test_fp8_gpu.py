@@ -250,8 +250,9 @@ def test_fp8_network_against_the_emulating_oracle_and_the_bf16_path():
         floor_rms = max((z8 - z32).pow(2).mean().sqrt().item(), (z16 - z32).pow(2).mean().sqrt().item()) / scale
         print(f"step {step}: loss fp8 HIP {runs['fp8'][step][0]:.5f} | fp8 oracle {l8:.5f} | bf16 HIP {runs['bf16'][step][0]:.5f} | bf16 oracle {l16:.5f} | f32 oracle {l32:.5f}; "
               f"logits / max|logit|: {e_emul:.2e} from the fp8 oracle (rms {rms:.2e}), {e_f32:.2e} from f32; emulation floor {floor:.2e} (rms {floor_rms:.2e})")
-        assert e_emul <= 1.5 * floor and e_f32 <= 1.5 * floor, (step, e_emul, e_f32, floor)
-        # two realisations of the same rounding noise are sqrt(2) floors apart; against the noiseless f32 run the path shows ONE floor
+        # two realisations of the same rounding noise are sqrt(2) floors apart (and the max norm is one pixel's luck on top: 2 x); against the
+        # noiseless f32 run the path shows ONE floor
+        assert e_emul <= 2.0 * floor and e_f32 <= 1.5 * floor, (step, e_emul, e_f32, floor)
         assert rms32 <= 1.5 * floor_rms and rms <= 2.0 * floor_rms, (step, rms, rms32, floor_rms)
         assert abs(runs["fp8"][step][0] - l8) <= 1e-2 * max(1.0, abs(l8))
         assert abs(runs["fp8"][step][0] - runs["bf16"][step][0]) <= 2e-2 * max(1.0, abs(l8))

@@ -171,3 +171,52 @@ def test_checkpoints_in_the_4x_module_layout_and_through_custom_load(tmp_path):
     with torch.no_grad():
         out = other(img.to(DEV), None)
     assert out.shape == (2, NC, 64, 64) and torch.isfinite(out).all()
+
+
+def test_mit_b3_the_architecture_of_the_reference_default_checkpoint():
+    """`SegformerMod(classes)` with the reference's default pretrained=True fetches nvidia/segformer-b3 (S/nets.py:322-324): hidden 64 / 128 / 320 / 512,
+    depths 3 / 4 / 18 / 3, 64-wide heads, decoder 768.  Same code, `variant="b3"`: f32 eval logits and one train step against the oracle; a bf16 step
+    (the matrix-core attention kernels with two K-steps) inside the emulation floor"""
+    NC, S, B = 6, 64, 2
+    p0 = SO.init_params(NC, seed=4, variant="b3")
+    net = nets.SegformerMod(NC, "fp32", stochastic=False, variant="b3")
+    missing, unexpected = net.load_state_dict(p0, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    net = net.to(DEV)
+    img, lab = _tiles(B, S, NC)
+    net.eval()
+    with torch.no_grad():
+        got = net(img.to(DEV), None).cpu()
+        want = SO.forward({k: v.clone() for k, v in p0.items()}, img.float(), train=False, variant="b3")
+    assert _rel(got, want) <= 3e-4
+    crit = utils.CrossEntropyLoss()
+    net.train()
+    logits = net(img.to(DEV), None)
+    loss = crit(logits, lab.to(DEV).long())
+    loss.backward()
+    p = {k: v.clone() for k, v in p0.items()}
+    names = [k for k in p if not SO.is_buffer(k)]
+    for k in names:
+        p[k].requires_grad_(True)
+    z = SO.forward(p, img.float(), train=True, variant="b3")
+    lo = U.cross_entropy(z, lab.long(), None, -100)
+    grads = dict(zip(names, torch.autograd.grad(lo, [p[k] for k in names])))
+    assert _rel(logits.detach().cpu(), z.detach()) <= 3e-4 and abs(loss.item() - lo.item()) <= 1e-5 * max(1.0, abs(lo.item()))
+    gmax = max(g.abs().max().item() for g in grads.values())
+    worst = max(((v.grad.detach().cpu() - grads[k]).abs().max().item() / max(grads[k].abs().max().item(), 1e-4 * gmax), k) for k, v in net.named_parameters())
+    assert worst[0] <= 3e-3, worst
+    # bf16 at a size whose key counts (S = 256: 64 keys) run the matrix-core kernels
+    nb = nets.SegformerMod(NC, "bf16", stochastic=False, variant="b3")
+    nb.load_state_dict(p0, strict=False)
+    nb = nb.to(DEV)
+    img2, lab2 = _tiles(2, 256, NC, seed=9)
+    nb.train()
+    lg = nb(img2.to(DEV), None)
+    crit(lg, lab2.to(DEV).long()).backward()
+    with torch.no_grad():
+        z2 = SO.forward({k: v.clone() for k, v in p0.items()}, img2.float(), train=True, variant="b3")
+        ze = SO.forward({k: v.clone() for k, v in p0.items()}, img2.float(), train=True, variant="b3", emulate_bf16=True)
+    floor = _rel(ze, z2)
+    assert _rel(lg.detach().cpu(), z2) <= 2.0 * floor + 1e-3, (_rel(lg.detach().cpu(), z2), floor)
+    assert all(torch.isfinite(q.grad).all() for q in nb.parameters())
+

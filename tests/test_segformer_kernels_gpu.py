@@ -150,23 +150,24 @@ def test_depthwise_3x3_forward_data_and_weight_gradients(dt, B, H, W, C):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,Hq,Hk,heads", [(2, 16, 2, 1), (2, 8, 2, 2), (1, 20, 10, 5), (2, 4, 4, 8), (1, 32, 18, 1), (2, 32, 8, 2), (1, 40, 16, 5), (1, 24, 24, 1)])
-def test_spatial_reduction_attention_forward_and_backward(dt, B, Hq, Hk, heads):
-    """softmax(q k^T / sqrt(32)) v with N = Hq^2 queries and Nk = Hk^2 keys per image and head (Nk = 4 ... 576: below one 8-key block,
+@pytest.mark.parametrize("B,Hq,Hk,heads,D", [(2, 16, 2, 1, 32), (2, 8, 2, 2, 32), (1, 20, 10, 5, 32), (2, 4, 4, 8, 32), (1, 32, 18, 1, 32), (2, 32, 8, 2, 32),
+                                              (1, 40, 16, 5, 32), (1, 24, 24, 1, 32), (2, 16, 2, 1, 64), (1, 24, 8, 2, 64), (1, 20, 16, 5, 64), (1, 8, 18, 8, 64)])
+def test_spatial_reduction_attention_forward_and_backward(dt, B, Hq, Hk, heads, D):
+    """softmax(q k^T / sqrt(D)) v (D = 32: MiT-b0, 64: MiT-b1 ... b5) with N = Hq^2 queries and Nk = Hk^2 keys per image and head (Nk = 4 ... 576: below one 8-key block,
     across the 256-key LDS chunk; Nk = 64 / 256 / 576 in bf16 run the matrix-core kernels, ragged query counts included), gradients
     against autograd"""
     ops = _ops()
-    C = heads * 32
+    C = heads * D
     N, Nk = Hq * Hq, Hk * Hk
     g = torch.Generator().manual_seed(4)
     q = torch.randn(B, N, C, generator=g).to(dt)
     kv = torch.randn(B, Nk, 2 * C, generator=g).to(dt)
     go = torch.randn(B, N, C, generator=g).to(dt)
     qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
-    qh = qr.view(B, N, heads, 32).transpose(1, 2)
-    kh = kvr[..., :C].reshape(B, Nk, heads, 32).transpose(1, 2)
-    vh = kvr[..., C:].reshape(B, Nk, heads, 32).transpose(1, 2)
-    att = torch.softmax(qh @ kh.transpose(2, 3) / math.sqrt(32), dim=-1)
+    qh = qr.view(B, N, heads, D).transpose(1, 2)
+    kh = kvr[..., :C].reshape(B, Nk, heads, D).transpose(1, 2)
+    vh = kvr[..., C:].reshape(B, Nk, heads, D).transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(2, 3) / math.sqrt(D), dim=-1)
     ref = (att @ vh).transpose(1, 2).reshape(B, N, C)
     ref.backward(go.float())
     qv = ops.view(q.view(B, Hq, Hq, C).to(DEV))
@@ -176,11 +177,11 @@ def test_spatial_reduction_attention_forward_and_backward(dt, B, Hq, Hk, heads):
     ops.sr_attention_fwd(qv, kvv, heads, ops.view(out), lse)
     tol = dict(atol=2e-5, rtol=1e-4) if dt == torch.float32 else dict(atol=2e-2, rtol=2e-2)
     assert torch.allclose(out.float().cpu().view(B, N, C), ref.detach(), **tol)
-    want_lse = torch.logsumexp(qh @ kh.transpose(2, 3) / math.sqrt(32), dim=-1).detach().reshape(-1)
+    want_lse = torch.logsumexp(qh @ kh.transpose(2, 3) / math.sqrt(D), dim=-1).detach().reshape(-1)
     assert torch.allclose(lse.cpu(), want_lse, atol=1e-4, rtol=1e-4)
     gq = torch.empty_like(out)
     gkv = torch.empty(B, Hk, Hk, 2 * C, dtype=dt, device=DEV)
-    ws = torch.empty(ops.sr_attention_bwd_workspace(B, N, Nk, heads), dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.sr_attention_bwd_workspace(B, N, Nk, heads, D), dtype=torch.float32, device=DEV)
     # the backward sees the forward's stored output (bf16-rounded on that path)
     ops.sr_attention_bwd(qv, kvv, ops.view(out), ops.view(go.view(B, Hq, Hq, C).to(DEV)), lse, heads, ops.view(gq), ops.view(gkv), ws)
     gtol = dict(atol=5e-5, rtol=1e-3) if dt == torch.float32 else dict(atol=6e-2, rtol=3e-2)
