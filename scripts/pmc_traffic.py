@@ -17,9 +17,13 @@ def family(name):
         return "conv3x3_halo_kernel"
     if n.startswith("conv_igemm_kernel"):
         return "conv_igemm_kernel"
-    if n.startswith(("wgrad_kernel", "wgrad_fast_kernel")):
-        return "wgrad"
+    if n.startswith("wgrad") or n.startswith("void wgrad"):
+        return "wgrad"          # every weight-gradient kernel, split-K / bias reduces included (bench.py's `wgrad` family = one entry per layer)
     return re.sub(r"<.*", "", n)
+
+
+def is_reduce(name):
+    return "reduce" in name
 
 
 def load(path, counter):
@@ -28,7 +32,7 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         f = family(r["Kernel_Name"])
-        agg[f][0] += 1
+        agg[f][0] += 0 if (f == "wgrad" and is_reduce(r["Kernel_Name"])) else 1      # a layer's reduce launches ride on its main launch
         agg[f][1] += float(r["Counter_Value"])
     return agg
 
