@@ -100,7 +100,8 @@ def parity_at_dtype(net, name, nc, tile, dev):
     The north star's "1e-3 on logits, bit-exact argmax" is met by the f32 path only (that test); bf16 / fp8 storage cannot reach it."""
     import torch
     from oracle import unet_oracle as O
-    p = {k: v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu() for k, v in net.state_dict().items()}
+    back = getattr(net, "_from_reference", lambda k: k)      # (the torchvision-keyed wrappers export `model.backbone.*`; the oracle speaks the engine's names)
+    p = {back(k): v.detach().cpu().float() if v.is_floating_point() else v.detach().cpu() for k, v in net.state_dict().items()}
     if name in ("Resnet50Unet", "Resnet18Unet", "Resnet34Unet"):
         from oracle import resnet_unet_oracle as R
         arch = {"Resnet50Unet": "resnet50", "Resnet18Unet": "resnet18", "Resnet34Unet": "resnet34"}[name]

@@ -364,6 +364,10 @@ class SegformerEngine(SwinUPerNetEngine):
         li = 0
         for s, (C_, depth, heads, sr, k, stride) in enumerate(zip(cfg["hidden"], cfg["depths"], cfg["heads"], cfg["sr"], cfg["patch"], cfg["strides"])):
             pre = f"{ENC}.{s}"
+            if train:
+                # (first closure of the stage = the last one its backward runs: every gradient at a flat offset >= this stage's first parameter
+                # is final then - the signal the data-parallel reducer buckets on)
+                tape.append(lambda pre=pre: self._ready(pre + ".patch_embeddings.proj.weight"))
             e = self._patch_conv(None if s == 0 else x.v, pre + ".patch_embeddings.proj", k, stride, k // 2, pre + ".pe", train, tape, x)
             x = self._ln_act(e, pre + ".patch_embeddings.layer_norm", pre + ".pe_ln", train, tape)
             for b in range(depth):
@@ -378,8 +382,6 @@ class SegformerEngine(SwinUPerNetEngine):
                 li += 1
             x = self._ln_act(x, pre + ".layer_norm", pre + ".feat", train, tape)
             feats.append(x)
-            if train:
-                tape.append(lambda pre=pre: self._ready(pre + ".patch_embeddings.proj.weight"))
         # ---- all-MLP decode head
         D = cfg["decoder"]
         h1 = S // 4

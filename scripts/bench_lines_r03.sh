@@ -2,7 +2,7 @@
 # gpurun_out/r03_lines/, copied to profiles/r03_bench_<tag>.json afterwards.   scripts/bench_lines_r03.sh [tags...]
 set -e
 mkdir -p gpurun_out/r03_lines
-run() { tag=$1; shift; echo "== $tag"; timeout -k 10 420 python3 bench.py "$@" > gpurun_out/r03_lines/$tag.log 2> gpurun_out/r03_lines/$tag.err; tail -1 gpurun_out/r03_lines/$tag.log > gpurun_out/r03_lines/$tag.json; python3 scripts/show_bench.py gpurun_out/r03_lines/$tag.json | head -3; }
+run() { tag=$1; shift; echo "== $tag"; timeout -k 10 420 python3 bench.py "$@" > gpurun_out/r03_lines/$tag.log 2> gpurun_out/r03_lines/$tag.err; tail -1 gpurun_out/r03_lines/$tag.log > gpurun_out/r03_lines/$tag.json; python3 scripts/show_bench.py gpurun_out/r03_lines/$tag.json > gpurun_out/r03_lines/$tag.txt 2>&1 || true; sed -n 1,3p gpurun_out/r03_lines/$tag.txt; }
 for t in "$@"; do
   case $t in
     deeplabv3plus) run deeplabv3plus_b32_s512_bf16 --net DeepLabV3Plus ;;
