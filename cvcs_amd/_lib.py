@@ -124,6 +124,7 @@ SIGNATURES = {
     "cvcs_deconv_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "cvcs_deconv_unpack_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cvcs_relu_bwd_sum_bn": (_i, [C.POINTER(TailBwdDesc), _vp]),
+    "cvcs_scale_unless_one": (_i, [_vp, _i64, _vp, _vp]),
     "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
     "cvcs_scatter_weight_grads": (_i, [_vp, _i, _vp]),
     "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),

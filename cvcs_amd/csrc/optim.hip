@@ -53,7 +53,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace cvcs
 
+namespace cvcs {
+// x *= *scalar unless *scalar == 1 (decided on the device: no host round trip, capturable) - the incoming gradient of the fused loss
+__global__ __launch_bounds__(256) void scale_unless_one_kernel(float* x, int64_t n, const float* __restrict__ scalar) {
+  const float v = *scalar;
+  if (v == 1.0f) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= v;
+}
+}  // namespace cvcs
+
 using namespace cvcs;
+
+extern "C" int cvcs_scale_unless_one(float* x, int64_t n, const float* scalar_device, void* stream) {
+  CVCS_CHECK_ARG(x && scalar_device && n > 0, "cvcs_scale_unless_one: bad argument");
+  int64_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(scale_unless_one_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, scalar_device);
+  CVCS_CHECK_LAUNCH("cvcs_scale_unless_one");
+  return CVCS_OK;
+}
 
 extern "C" int cvcs_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
                              float weight_decay, float grad_scale, int first_step, void* stream) {

@@ -1025,7 +1025,8 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWgArgs p) {
 // consecutive slab elements (a wave reads 256 contiguous bytes of one slab); slice lane l sums slabs l, l + 16, ... eight loads in
 // flight, then the 16 lanes are added in order.  (The generic reduce kernel above walks the slices with 16 lanes per OUTPUT PAIR: with
 // thousands of slabs of a few thousand elements it took 0.3 ms - 3 x the thin kernel itself.)
-__global__ __launch_bounds__(1024) void wgrad_thin_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int CO, int CI) {
+__global__ __launch_bounds__(1024) void wgrad_thin_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int CO, int CI, int CI_total = 0,
+                                                                 int ci0 = 0) {
   __shared__ float sh[16][64];
   const int n = 9 * CO * CI;
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(1024) void wgrad_thin_reduce_kernel(const float* __
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
     const int ci = e % CI, r = e / CI, co = r % CO, tap = r / CO;
-    dw[((int64_t)co * CI + ci) * 9 + tap] = t;
+    dw[((int64_t)co * (CI_total ? CI_total : CI) + ci0 + ci) * 9 + tap] = t;
   }
 }
 
@@ -1056,8 +1057,8 @@ static bool thin_wgrad_shape(const cvcs_wgrad_desc* d) {
   static const int on = getenv("CVCS_WGRAD_THIN") ? atoi(getenv("CVCS_WGRAD_THIN")) : 1;   // tuning knob
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   return on && d->dtype == CVCS_BF16 && !special && d->dil <= 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
-         (d->Cout == 16 || d->Cout == 32) && (d->Cin == 16 || d->Cin == 32) && d->Cin_real == d->Cin && d->H == d->Ho && d->W == d->Wo &&
-         d->H >= 4 && d->W >= 32;
+         (d->Cout == 16 || d->Cout == 32) && (d->Cin == 16 || d->Cin == 32 || (d->Cin % 32 == 0 && d->Cin <= 256)) && d->Cin_real == d->Cin &&
+         d->H == d->Ho && d->W == d->Wo && d->H >= 4 && d->W >= 32;
 }
 static int thin_wgrad_groups(const cvcs_wgrad_desc* d) {
   const int64_t ntiles = (int64_t)d->B * cdiv(d->H, kThinTH) * cdiv(d->W, kThinTW);
@@ -1250,7 +1251,7 @@ extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
 static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d) {
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   int n;
-  if (thin_wgrad_shape(d)) return (int64_t)thin_wgrad_groups(d) * 4 * 9 * d->Cout * d->Cin;
+  if (thin_wgrad_shape(d)) return (int64_t)thin_wgrad_groups(d) * 4 * 9 * d->Cout * (d->Cin > 32 ? 32 : d->Cin);     // (one 32-channel group at a time)
   if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
     const int a = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 1, 0).nslice;
     const int g = gemm_shape(1, 1, 1, d->Cout, d->Cin) ? gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice : 0;
@@ -1300,15 +1301,22 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     const int lds = kThinTH * kThinTW * (CO_) * 2 + (kThinHR * kThinHC * (CI_) * 2 + 1023) / 1024 * 1024;                  \
     hipLaunchKernelGGL((wgrad_thin_kernel<CO_, CI_>), dim3((unsigned)groups), dim3(256), lds, tst, ta);                    \
   } while (0)
-    if (d->Cout == 16 && d->Cin == 16) LAUNCH_THIN(16, 16);
-    else if (d->Cout == 16) LAUNCH_THIN(16, 32);
-    else if (d->Cin == 16) LAUNCH_THIN(32, 16);
-    else LAUNCH_THIN(32, 32);
+    // a wide input (Cin = 64 ... 256 under a thin Cout: the 128 -> 32 decoder layer) runs as 32-channel groups of the same kernel: the
+    // generic kernel took 552 us there, four group launches take a third less and re-read only the thin dy
+    const int cgrp = d->Cin > 32 ? 32 : d->Cin;
+    for (int ci0 = 0; ci0 < d->Cin; ci0 += cgrp) {
+      ta.x = (const char*)d->x + (int64_t)ci0 * 2;
+      ta.Cin = cgrp;
+      if (d->Cout == 16 && cgrp == 16) LAUNCH_THIN(16, 16);
+      else if (d->Cout == 16) LAUNCH_THIN(16, 32);
+      else if (cgrp == 16) LAUNCH_THIN(32, 16);
+      else LAUNCH_THIN(32, 32);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin)");
+      hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)cdiv(9 * d->Cout * cgrp, 64)), dim3(1024), 0, tst, d->workspace, d->dw, groups * 4,
+                         d->Cout, cgrp, d->Cin, ci0);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin reduce)");
+    }
 #undef LAUNCH_THIN
-    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin)");
-    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)cdiv(9 * d->Cout * d->Cin, 64)), dim3(1024), 0, tst, d->workspace, d->dw, groups * 4,
-                       d->Cout, d->Cin);
-    CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin reduce)");
     return CVCS_OK;
   }
   const int fastp = (aniso || pitched) ? 0 : fast_path(d);

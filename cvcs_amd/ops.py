@@ -1166,3 +1166,9 @@ def deconv_unpack_grad(dw, db4, k, p, CP, layout, gw, gb):
     check(_lib.lib().cvcs_deconv_unpack_grad(dw.data_ptr(), db4.data_ptr(), NC, k, p, CP, layout, Kp, gw.data_ptr(), gb.data_ptr(), _stream()),
           "cvcs_deconv_unpack_grad")
 
+
+def scale_unless_one(x: torch.Tensor, scalar: torch.Tensor):
+    """x *= scalar (a one-element f32 tensor ON THE DEVICE) unless it is exactly 1 - decided by the kernel, no host round trip"""
+    assert x.dtype == torch.float32 and x.is_contiguous() and scalar.dtype == torch.float32 and scalar.numel() == 1 and scalar.device == x.device
+    check(_lib.lib().cvcs_scale_unless_one(x.data_ptr(), x.numel(), scalar.data_ptr(), _stream()), "cvcs_scale_unless_one")
+

@@ -119,8 +119,9 @@ class _CEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         dl = ctx.crit._dl   # d(loss)/d(logits) was produced by the forward launch
-        if not ctx.crit.unit_grad and float(gout) != 1.0:
-            dl.mul_(gout)   # chained through further autograd ops: scale by the incoming gradient
+        if not ctx.crit.unit_grad:
+            # chained through further autograd ops: scale by the incoming gradient - compared with 1 ON THE DEVICE (no host round trip)
+            ops.scale_unless_one(dl, gout.detach().to(device=dl.device, dtype=torch.float32).reshape(1).contiguous())
         return dl, None, None
 
 

@@ -586,6 +586,9 @@ typedef struct {
   float* part_dz; float* part_dzx[2];
 } cvcs_tail_bwd_desc;
 int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream);
+/* x[0..n) *= *scalar_device unless it is exactly 1 (decided on the device: no host synchronisation).  Used for the incoming gradient of the fused
+ * cross-entropy (`loss.backward()` hands a 1; `(loss / k).backward()` a 1 / k) - replaces a float(tensor) comparison on the host.              */
+int cvcs_scale_unless_one(float* x, int64_t n, const float* scalar_device, void* stream);
 
 #ifdef __cplusplus
 }

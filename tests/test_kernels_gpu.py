@@ -305,6 +305,8 @@ WGRAD_CASES = [
     (1, 12, 40, 16, 16, 32, 3, 1, 1),    # thin 16 -> 32
     (2, 8, 24, 128, 128, 32, 3, 1, 1),   # Cout = 32 on the generic kernel (masked row tile, skipped zero blocks), narrow map
     (1, 16, 16, 64, 64, 16, 3, 1, 1),    # Cout = 16 on the generic kernel
+    (2, 20, 72, 128, 128, 32, 3, 1, 1),  # thin Cout under a wide input (the 128 -> 32 decoder layer): four 32-channel groups of the thin kernel
+    (1, 9, 40, 96, 96, 16, 3, 1, 1),     # thin 96 -> 16: three groups, ragged tiles
 ]
 
 
