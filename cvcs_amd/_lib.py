@@ -79,6 +79,14 @@ class TailBwdDesc(C.Structure):
                 ("part_dz", C.c_void_p), ("part_dzx", C.c_void_p * 2)]
 
 
+CALL_MAX_INT, CALL_MAX_FLT = 28, 8
+
+
+class Call(C.Structure):
+    """cvcs_call (include/cvcs_hip.h): one launch of a plan replayed from C"""
+    _fields_ = [("fn", C.c_void_p), ("nint", C.c_int32), ("nflt", C.c_int32), ("i", C.c_int64 * CALL_MAX_INT), ("f", C.c_float * CALL_MAX_FLT)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
@@ -125,6 +133,8 @@ SIGNATURES = {
     "cvcs_deconv_unpack_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cvcs_relu_bwd_sum_bn": (_i, [C.POINTER(TailBwdDesc), _vp]),
     "cvcs_scale_unless_one": (_i, [_vp, _i64, _vp, _vp]),
+    "cvcs_sizeof_call": (_i, []),
+    "cvcs_replay": (_i, [_vp, _i, _vp, C.POINTER(C.c_int)]),
     "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
     "cvcs_scatter_weight_grads": (_i, [_vp, _i, _vp]),
     "cvcs_dropout": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _vp, _f, _i, _vp]),
@@ -223,7 +233,8 @@ _recording = None          # the Recording that is capturing launches right now 
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_sizeof_conv8_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
-            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_sr_attention_bwd_workspace"}
+            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay"}
+C_REPLAY = os.environ.get("CVCS_C_REPLAY", "1") == "1"     # single-stream replays without timers run from C (cvcs_replay)
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 
 
@@ -245,6 +256,7 @@ class Recording:
     def __init__(self):
         self.items = []     # (fn, args, tag, lane) | (None, callable, None, 0) | ("wait", index | None, None, 0)
         self._ev = None     # per-item events of the two-lane replay (created once)
+        self._c = None      # the plan as cvcs_call arrays between host callbacks (built on the first C replay)
 
     def __enter__(self):
         global _recording
@@ -270,8 +282,74 @@ class Recording:
         """the main chain must not pass this point before side launch `index` (None: every side launch so far) is done"""
         self.items.append(("wait", index, None, 0))
 
+    def _compile(self):
+        """segments of the single-stream plan: ("c", cvcs_call array, n, first item index) | ("host", callable)"""
+        segs, cur, first = [], [], 0
+
+        def flush():
+            if cur:
+                arr = (Call * len(cur))()
+                for c, (fn, args) in zip(arr, cur):
+                    types = fn.argtypes[:-1]
+                    assert len(types) == len(args), fn.__name__
+                    c.fn = C.cast(fn, C.c_void_p).value
+                    ni = nf = 0
+                    for a, t in zip(args, types):
+                        if t is C.c_float:
+                            c.f[nf] = float(a)
+                            nf += 1
+                            continue
+                        if a is None:
+                            v = 0
+                        elif isinstance(a, int):
+                            v = a
+                        elif hasattr(a, "_obj"):                      # byref(descriptor)
+                            v = C.addressof(a._obj)
+                        elif isinstance(a, (C.Array, C.Structure)):
+                            v = C.addressof(a)
+                        elif isinstance(a, C._SimpleCData):
+                            v = a.value or 0
+                        else:
+                            v = C.cast(a, C.c_void_p).value or 0
+                        c.i[ni] = v if v < (1 << 63) else v - (1 << 64)
+                        ni += 1
+                    assert ni < CALL_MAX_INT and nf <= CALL_MAX_FLT, fn.__name__
+                    c.nint, c.nflt = ni, nf
+                segs.append(("c", arr, len(cur), first))
+                cur.clear()
+
+        for idx, (fn, args, tag, _) in enumerate(self.items):
+            if fn == "wait":
+                continue
+            if fn is None:
+                flush()
+                segs.append(("host", args, 0, idx))
+                continue
+            if not cur:
+                first = idx
+            cur.append((fn, args))
+        flush()
+        self._c = segs
+
+    def _replay_c(self, stream: int):
+        h = _load()
+        if self._c is None:
+            self._compile()
+        failed = C.c_int(-1)
+        for kind, obj, n, first in self._c:
+            if kind == "host":
+                obj()
+                continue
+            rc = h.cvcs_replay(obj, n, stream, C.byref(failed))
+            if rc != 0:
+                launches = [it for it in self.items[first:] if it[0] is not None and it[0] != "wait"]
+                name = launches[failed.value][0].__name__ if 0 <= failed.value < len(launches) else "cvcs_replay"
+                check(rc, name)
+
     def replay(self, stream: int, timers=None, side=None):
         """stream: raw handle of the main stream.  side: a torch.cuda.Stream for the side lane (None: one stream, in order)"""
+        if side is None and timers is None and C_REPLAY:
+            return self._replay_c(stream)
         if side is None:
             for fn, args, tag, _ in self.items:
                 if fn is None:

@@ -589,6 +589,21 @@ int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream);
 /* x[0..n) *= *scalar_device unless it is exactly 1 (decided on the device: no host synchronisation).  Used for the incoming gradient of the fused
  * cross-entropy (`loss.backward()` hands a 1; `(loss / k).backward()` a 1 / k) - replaces a float(tensor) comparison on the host.              */
 int cvcs_scale_unless_one(float* x, int64_t n, const float* scalar_device, void* stream);
+/* A recorded launch plan driven from C (host time per step < 0.5 ms).  A plan is the list of launch entry points of
+ * THIS header that one pass of a network issues for one input shape, with their arguments (every pointer a persistent buffer).  cvcs_call holds one
+ * launch: the function, its integer-class arguments in declaration order WITHOUT the trailing stream (pointers, int, int64_t), and its float
+ * arguments in declaration order.  cvcs_replay issues calls[0..n) on `stream`; on the first non-zero return it stops, stores the index and
+ * returns that code.  (x86-64 System V only: one 28 + 8 slot prototype calls every entry point; no struct is passed by value anywhere.)        */
+#define CVCS_CALL_MAX_INT 28
+#define CVCS_CALL_MAX_FLT 8
+typedef struct {
+  void* fn;
+  int32_t nint, nflt;
+  int64_t i[CVCS_CALL_MAX_INT];
+  float f[CVCS_CALL_MAX_FLT];
+} cvcs_call;
+int cvcs_sizeof_call(void);
+int cvcs_replay(const cvcs_call* calls, int n, void* stream, int* failed_index);
 
 #ifdef __cplusplus
 }

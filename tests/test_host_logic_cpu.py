@@ -164,3 +164,43 @@ def test_host_only_c_abi_sizing_functions():
         assert lib.cvcs_bn_bwd_rows(M) == min(1024, max(1, -(-M // 64)))
         assert lib.cvcs_head_bwd_rows(M) == min(1024, max(1, -(-M // 64)))
         assert lib.cvcs_ce_workspace_floats(M) == 2 + 2 * min(4096, max(1, -(-M // 1024)))
+
+
+def test_c_replay_trampoline_passes_register_stack_and_float_arguments_in_place():
+    """cvcs_replay calls every launch entry point through ONE 28-integer + 8-float prototype (x86-64 System V): arguments 1-6 travel in general
+    registers, the rest in stack slots, floats in xmm registers.  Host-side argument checks that echo a value prove each class lands where the
+    callee reads it (no GPU needed: the calls are refused before any launch)."""
+    import ctypes as C
+    from cvcs_amd import _lib
+    h = _lib._load()
+    assert h.cvcs_sizeof_call() == C.sizeof(_lib.Call)
+
+    def one(fn, ints, flts=()):
+        arr = (_lib.Call * 1)()
+        arr[0].fn = C.cast(fn, C.c_void_p).value
+        arr[0].nint, arr[0].nflt = len(ints), len(flts)
+        for k, v in enumerate(ints):
+            arr[0].i[k] = v
+        for k, v in enumerate(flts):
+            arr[0].f[k] = v
+        failed = C.c_int(-1)
+        rc = h.cvcs_replay(arr, 1, None, C.byref(failed))
+        return rc, failed.value, h.cvcs_last_error().decode()
+
+    # 4th integer argument (a register): cvcs_layernorm_fwd(x, x_ld, M, C, gamma, beta, eps, out, out_ld, mean, invstd, dtype)
+    rc, idx, msg = one(h.cvcs_layernorm_fwd, [4096, 16, 7, 13, 4096, 4096, 4096, 16, 4096, 4096, 1], [1e-5])
+    assert rc == -1 and idx == 0 and "C=13" in msg, msg
+    # 9th integer argument (a stack slot): cvcs_sr_attention_fwd(q, q_ld, kv, kv_ld, B, N, Nk, heads, head_dim, ...)
+    rc, idx, msg = one(h.cvcs_sr_attention_fwd, [4096, 64, 4096, 128, 2, 16, 4, 2, 48, 4096, 64, 4096, 1])
+    assert rc == -1 and "head_dim=48" in msg, msg
+    # a float argument: cvcs_dropout(x, x_ld, M, C, out, out_ld, state, p, dtype) refuses p >= 1 but accepts p = 0.5 up to the next check
+    rc, _, msg = one(h.cvcs_dropout, [4096, 8, 4, 8, 4096, 8, 4096, 1], [1.5])
+    assert rc == -1 and "bad argument" in msg
+    import torch
+    if not torch.cuda.is_available():     # (with a device the accepted call would really launch on these dummy pointers)
+        rc, _, msg = one(h.cvcs_dropout, [4096, 8, 4, 8, 4096, 8, 4096, 1], [0.5])
+        assert rc != 0 and "bad argument" not in msg, msg        # past the p check: refused at the launch itself (no device here)
+    # a bad record is refused by cvcs_replay itself
+    arr = (_lib.Call * 1)()
+    assert h.cvcs_replay(arr, 1, None, None) == -1 and "bad record" in h.cvcs_last_error().decode()
+

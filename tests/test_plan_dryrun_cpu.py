@@ -25,6 +25,7 @@ def no_device(monkeypatch):
             failed[0] += 1
             return
         raise _lib.CvcsError(f"{what} failed ({rc}): {msg}")
+    monkeypatch.setattr(_lib, "C_REPLAY", False)        # (the C replay stops at the first refused launch; here every launch is refused: no device)
     monkeypatch.setattr(ops, "_stream", lambda: 0)
     monkeypatch.setattr(ops, "check", check)
     monkeypatch.setattr(_lib, "check", check)
