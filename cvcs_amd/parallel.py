@@ -58,6 +58,7 @@ class GradientAllReducer:
         self.works = []
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self._events = [torch.cuda.Event() for _ in self.buckets] if self.cuda else []      # one per bucket, re-recorded every step
 
     def begin(self):
         self.next = 0
@@ -68,10 +69,10 @@ class GradientAllReducer:
         extra_events: events of other streams that produced part of those gradients (the weight-gradient stream)."""
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= lo_floats:
             lo, hi = self.buckets[self.next]
+            ev = self._events[self.next] if self.cuda else None
             self.next += 1
             chunk = self.g[lo:hi]
             if self.cuda:
-                ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 self.comm_stream.wait_event(ev)
                 for e in extra_events:
