@@ -53,7 +53,19 @@ __device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, co
     ++k;
   };
   int r = r0;
-  for (; r + 3 * rstep < r1; r += 4 * rstep) {       // four rows' loads in flight (these kernels are latency-bound)
+  // sixteen, then four rows' loads in flight: these kernels are chains of dependent memory round trips (~1.5 us each), not arithmetic
+  for (; r + 15 * rstep < r1; r += 16 * rstep) {
+    float cn[16], sv[16], mv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      cn[u] = scnt[r + u * rstep];
+      sv[u] = ssum[(int64_t)(r + u * rstep) * C + c];
+      mv[u] = sm2[(int64_t)(r + u * rstep) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) take(cn[u], sv[u], mv[u]);
+  }
+  for (; r + 3 * rstep < r1; r += 4 * rstep) {
     float cn[4], sv[4], mv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -468,7 +480,14 @@ __device__ __forceinline__ double colsum16(const float* __restrict__ part, int r
   __shared__ double sh[2][kRL][17];
   double a = 0.0;
   int r = rl;
-  for (; r + 3 * kRL < rows; r += 4 * kRL) {          // four loads in flight per lane
+  for (; r + 15 * kRL < rows; r += 16 * kRL) {        // sixteen, then four loads in flight per lane
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(int64_t)(r + u * kRL) * C + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a += (double)v[u];
+  }
+  for (; r + 3 * kRL < rows; r += 4 * kRL) {
     const float v0 = part[(int64_t)r * C + c], v1 = part[(int64_t)(r + kRL) * C + c];
     const float v2 = part[(int64_t)(r + 2 * kRL) * C + c], v3 = part[(int64_t)(r + 3 * kRL) * C + c];
     a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
