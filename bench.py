@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
     ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "SwinBUperNet", "SegformerMod", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
-                    help="fp8 = mixed bf16 / fp8 convolutions (BASELINE configs[4]; ResNet-UNets)")
+                    help="fp8 = mixed bf16 / fp8 convolutions (BASELINE configs[4]; ResNet-UNets and the UPerNet head of Swin + UPerNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     a = ap.parse_args()

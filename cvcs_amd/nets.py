@@ -101,7 +101,8 @@ class _HipUNet(nn.Module):
     def __init__(self, num_classes: int, precision: str = "bf16"):
         super().__init__()
         assert precision in PRECISIONS, f"precision must be one of {list(PRECISIONS)}"
-        assert precision != "fp8" or self.variant == "ResnetUnet", "precision 'fp8' (mixed bf16 / fp8 convolutions) is built for the ResNet-UNets"
+        assert precision != "fp8" or self.variant in ("ResnetUnet", "SwinTUperNet", "SwinBUperNet"), \
+            "precision 'fp8' (mixed bf16 / fp8 convolutions) is built for the ResNet-UNets and the UPerNet head of Swin + UPerNet"
         self.requires_context = False   # S/nets.py:37,120
         self.wrapper = False
         self.returns_logits = True
@@ -545,7 +546,7 @@ class SwinTUperNet(_HipUNet):
         return swin_upernet_param_spec(self.num_classes, self.swin)
 
     def _build_engine(self, dev):
-        return SwinUPerNetEngine(self.num_classes, PRECISIONS[self.precision], dev, self.swin)
+        return SwinUPerNetEngine(self.num_classes, PRECISIONS[self.precision], dev, self.swin, fp8=self.precision == "fp8")
 
     def _flat_order(self, params):
         # (1) q | k | v weights, then their biases, adjacent: the engine runs the three projections as one [3C, C] GEMM;

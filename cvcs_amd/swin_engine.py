@@ -35,8 +35,11 @@ PE = "backbone.swin.embeddings.patch_embeddings.projection"
 
 
 class SwinUPerNetEngine(ResNetUNetEngine):
-    def __init__(self, num_classes: int, dtype: torch.dtype, device, variant="tiny"):
-        super().__init__("resnet18", num_classes, dtype, device)   # (arch only sizes helper vectors; no ResNet stage is built)
+    def __init__(self, num_classes: int, dtype: torch.dtype, device, variant="tiny", fp8=False):
+        # fp8: the UPerNet head's 3x3 convolutions (bottleneck 2816 -> 512, three FPN 512 -> 512, the 2048 -> 512 fusion conv: every channel
+        # count a multiple of 128) run forward and data gradient on the fp8 kernel (resnet_engine._unit / _unit_bwd / _dgrad); everything
+        # else - the transformer, the 1x1 laterals, all weight gradients - stays bf16
+        super().__init__("resnet18", num_classes, dtype, device, fp8=fp8)   # (arch only sizes helper vectors; no ResNet stage is built)
         self.head_name = "decode_head.classifier"
         self.embed, self.swin_depths, self.swin_heads = VARIANTS[variant]
         self.dims = tuple(self.embed * 2 ** i for i in range(4))
@@ -82,14 +85,28 @@ class SwinUPerNetEngine(ResNetUNetEngine):
             elif w.dim() == 4:
                 add(key, w, grads[name])
         self._pack_table = ops.pack_table(entries, dev)
+        if self.fp8:
+            self.f8 = ops.Fp8Slots(dev)
+            for name, pk in self.packed.items():
+                t_, cout, cin = pk["wf"].shape
+                if t_ == 9 and cout % 128 == 0 and cin % 128 == 0 and pk["wd"] is not None:
+                    pk["wf8"], pk["wd8"] = (torch.empty(t.shape, dtype=torch.uint8, device=dev) for t in (pk["wf"], pk["wd"]))
         from .engine import _BN
         self.bn = {n[:-len(".weight")]: _BN(p.numel(), dev) for n, p in params.items() if n.endswith("batch_norm.weight")}
         self.one = torch.ones(4096, dtype=torch.float32, device=dev)
         self.zero = torch.zeros(4096, dtype=torch.float32, device=dev)
         self._rec, self._bufs, self.shape, self.gn = {}, {}, None, {}
 
-    def refresh_weights(self):
+    def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
+        if self.fp8:
+            for name, pk in self.packed.items():
+                if "wf8" in pk:
+                    i = self.f8.slot("w:" + name, _lib.E4M3)
+                    for src, dst in ((pk["wf"], pk["wf8"]), (pk["wd"], pk["wd8"])):
+                        rows, k = src.shape[0] * src.shape[1], src.shape[2]
+                        ops.quantize_fp8(View(src.view(1, rows, 1, k), 0, k), View(dst.view(1, rows, 1, k), 0, k), _lib.E4M3, self.f8, i,
+                                         take_amax=train and src is pk["wf"])
 
     # ------------------------------------------------------------------------------------------------ small pieces
     def _tokens(self, name, B, H, W, C_):
@@ -223,7 +240,8 @@ class SwinUPerNetEngine(ResNetUNetEngine):
     def _backbone(self, B, S, train):
         tape = []
         self.units, self.relu_order = {}, []
-        self.refresh_weights()
+        self._q8, self._train_pass = {}, train
+        self.refresh_weights(train)
         H = S // 4
         h4, h1 = S // 32, S // 4
         # ---- patch embedding (the packed patches come from the eager cvcs_pack_patches launch in _forward_backbone)
@@ -427,4 +445,6 @@ class SwinUPerNetEngine(ResNetUNetEngine):
             h.grads = [(gh, False)]
             for fn in reversed(self._tape):
                 fn()
+            if self.fp8:
+                self.f8.update()      # delayed scaling: this step's amax of every quantised tensor becomes the next step's scale
         self._run("bwd", run_tape)
