@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import View
 
 WIDTHS = (64, 128, 256, 512, 1024)
@@ -37,9 +37,17 @@ class _BN:
 
 
 class UNetEngine:
-    def __init__(self, variant: str, num_classes: int, dtype: torch.dtype, device):
+    def __init__(self, variant: str, num_classes: int, dtype: torch.dtype, device, fp8: bool = False):
         assert variant in ("Unet", "Unetv2")
+        assert not fp8 or dtype == torch.bfloat16, "the fp8 convolutions live beside bf16 storage (precision 'fp8' = mixed bf16 / fp8)"
         self.variant, self.NC, self.dtype, self.dev = variant, num_classes, dtype, torch.device(device)
+        # precision "fp8" (BASELINE configs[4]'s "mixed bf16/fp8 convs" on the reference's own U-Nets): the 3x3 convolutions whose channel counts
+        # are multiples of 128 (levels 2-5 and their decoder stages) run forward AND data gradient on the block-scaled fp8 MFMA
+        # (csrc/conv_fp8.hip) in train mode; weight gradients, the 64-channel level and every evaluation pass stay bf16
+        self.fp8 = bool(fp8)
+        self.f8 = None
+        self._q8buf = {}
+        self._produced = set()     # bf16 tensors whose fp8 image was written by their producer pass in this step
         self.code = ops.dtype_code(dtype)
         self.KG = ops.KGROUP[self.code]
         self.shape = None
@@ -94,8 +102,13 @@ class UNetEngine:
                 first = cin == 3
                 self.packed[key] = dict(kind="conv", wf=torch.empty(kh * kw, cout, cpad, dtype=dt, device=dev),
                                         wd=None if first else torch.empty(kh * kw, cin, cout, dtype=dt, device=dev))
+                if self.fp8 and kh * kw == 9 and cout % 128 == 0 and cin % 128 == 0:
+                    pk = self.packed[key]
+                    pk["wf8"], pk["wd8"] = (torch.empty(t.shape, dtype=torch.uint8, device=dev) for t in (pk["wf"], pk["wd"]))
+        if self.fp8:
+            self.f8 = ops.Fp8Slots(dev)
 
-    def refresh_weights(self):
+    def refresh_weights(self, train=True):
         """re-pack the f32 master weights into the MFMA operand layouts (after every optimiser step): every 3x3 conv in one
         launch driven by a device-resident table, the four ConvTranspose layers by their own small kernels."""
         if self._pack_table is None:
@@ -105,6 +118,48 @@ class UNetEngine:
         for key, pk in self.packed.items():
             if pk["kind"] == "convT":
                 ops.pack_convT_weight_into(self.P[key + ".weight"], self.P[key + ".bias"], pk["wf"], pk["b4"], pk["wd"])
+        if self.fp8 and train:
+            # e4m3 images of the packed bf16 weights, one scale per layer (forward and data-gradient image hold the same values)
+            for key, pk in self.packed.items():
+                if "wf8" in pk:
+                    i = self.f8.slot("w:" + key, _lib.E4M3)
+                    for src, dst in ((pk["wf"], pk["wf8"]), (pk["wd"], pk["wd8"])):
+                        rows, k = src.shape[0] * src.shape[1], src.shape[2]
+                        ops.quantize_fp8(View(src.view(1, rows, 1, k), 0, k), View(dst.view(1, rows, 1, k), 0, k), _lib.E4M3, self.f8, i,
+                                         take_amax=src is pk["wf"])
+
+    def _fp8_ok(self, conv, x: View, cout):
+        pk = self.packed.get(conv)
+        return self.fp8 and pk is not None and "wf8" in pk and x.H >= 8 and x.W >= 8 and x.C % 128 == 0 and cout % 128 == 0
+
+    def _fp8_dgrad(self, conv, dyv: View):
+        """will the data gradient of `conv` (input dy) run on the fp8 kernel?"""
+        pk = self.packed.get(conv)
+        return (self.fp8 and pk is not None and "wd8" in pk and pk["wd"] is not None and dyv.H >= 8 and dyv.W >= 8 and dyv.C % 128 == 0 and
+                pk["wd"].shape[1] % 128 == 0)
+
+    def _q8_view(self, x: View, tag, fmt):
+        key = (x.t.data_ptr(), tuple(x.t.shape))
+        q = self._q8buf.get(key)
+        if q is None:
+            q = self._q8buf[key] = torch.empty(x.t.shape, dtype=torch.uint8, device=self.dev)
+        return View(q, x.off, x.C), self.f8.slot(tag, fmt)
+
+    def _quantised(self, x: View, tag, fmt):
+        """the fp8 image of the bf16 view x and its slot: written by x's producer pass where that pass could (self._produced), else by a
+        quantisation sweep here.  A slot WITHOUT history was fed its amax by the producer but scaled with a placeholder: it is calibrated
+        now and the image taken again once (later steps run on the delayed scale alone)"""
+        qv, i = self._q8_view(x, tag, fmt)
+        if x.t.data_ptr() in self._produced and i not in self.f8.fresh:
+            self._produced.discard(x.t.data_ptr())
+            return qv, i
+        self._produced.discard(x.t.data_ptr())
+        if i in self.f8.fresh and self.f8.amax_now(i) > 0:
+            h, st = _lib._load(), torch.cuda.current_stream().cuda_stream
+            _lib.check(h.cvcs_fp8_update_scales(self.f8.ptr(i), 1, ops.FP8_MARGIN, st), "cvcs_fp8_update_scales")
+            self.f8.fresh.discard(i)
+        ops.quantize_fp8(x, qv, fmt, self.f8, i, take_amax=True)
+        return qv, i
 
     # ------------------------------------------------------------------------------------------------ planning
     def plan(self, B, S):
@@ -114,6 +169,7 @@ class UNetEngine:
         dev, dt = self.dev, self.dtype
         A = lambda s, c: torch.empty((B, s, s, c), dtype=dt, device=dev)  # noqa: E731
         self.shape = (B, S)
+        self._q8buf = {}
         self.sizes = [S >> l for l in range(5)]
         s_ = self.sizes
         # the 3-channel tile as NHWC rows of 16 bytes (8 bf16 / 4 f32 channels, zero padded); the first conv contracts over
@@ -212,7 +268,7 @@ class UNetEngine:
         self._sync_sums = torch.empty(2 * 1024, dtype=torch.float32, device=self.dev)
 
     def _conv_bn(self, x: View, conv, bnname, y, out: View, relu_after_bn: bool, train: bool, pool: View | None = None,
-                 apply: bool = True):
+                 apply: bool = True, q8_for: str | None = None):
         """conv3x3(+bias) [-> ReLU] with fused statistics, BN finalize, BN apply [-> ReLU] [-> pool]."""
         pk = self.packed[conv]
         ops.SCOPE = "enc" if conv.startswith("encode") else "dec"
@@ -234,10 +290,17 @@ class UNetEngine:
             if pool is not None and not fuse_pool:
                 ops.bn_act(out, self.one[:C_], self.zero[:C_], False, None, pool)
             return
-        rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1)
         stats = (self.stat_sum, self.stat_m2, self.stat_cnt)
-        ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats,
-                   cin_real=3 if conv == "encode1.0.layer.0" else None)
+        if self._fp8_ok(conv, x, C_):
+            rows = ops.fp8_stat_rows(x)
+            x8, ix = self._quantised(x, "a:" + conv, _lib.E4M3)
+            # (the conv bias rides in the epilogue's per-channel affine: v = acc * s_x * s_w * 1 + bias)
+            ops.conv3x3_fp8(x8, _lib.E4M3, pk["wf8"], ops.view(y), self.f8, ix, self.f8.slot("w:" + conv, _lib.E4M3), stats=stats,
+                            relu=not relu_after_bn, pre_affine=(self.one[:C_], self.P[conv + ".bias"]))
+        else:
+            rows = ops.conv_stat_rows(x, C_, 3, 3, 1, 1)
+            ops.conv2d(x, pk["wf"], self.P[conv + ".bias"], ops.view(y), 3, 3, 1, 1, relu=not relu_after_bn, stats=stats,
+                       cin_real=3 if conv == "encode1.0.layer.0" else None)
         if self.sync_bn is None:
             ops.bn_finalize(stats, rows, M, C_, self.P[bnname + ".weight"], self.P[bnname + ".bias"],
                             self.Bf[bnname + ".running_mean"], self.Bf[bnname + ".running_var"], True, st.scale, st.shift,
@@ -245,7 +308,14 @@ class UNetEngine:
         else:
             self._sync_bn_finalize(stats, rows, C_, bnname, st)
         if apply:   # apply=False: the consumer folds scale/shift into its weights (the 1x1 head)
-            ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool)
+            # fp8: an activation that the next conv reads as e4m3 leaves this pass with its fp8 image (no quantisation sweep of its own);
+            # pooled layers (the pass writes two tensors) keep the separate sweep
+            q8 = None
+            if self.fp8 and pool is None and q8_for is not None and out.C % 128 == 0 and out.H >= 8 and out.W >= 8 and out.off == 0 and out.C == out.ld:
+                qv, i = self._q8_view(out, "a:" + q8_for, _lib.E4M3)
+                q8 = (qv, _lib.E4M3, self.f8, i, True)
+                self._produced.add(out.t.data_ptr())
+            ops.bn_act(ops.view(y), st.scale, st.shift, relu_after_bn, out, pool, q8=q8)
 
     def _sync_bn_finalize(self, stats, rows, C_, bnname, st):
         # batch statistics over the tiles of ALL ranks (the reference's batch is not sharded): one [3][C] f64 sum
@@ -262,13 +332,14 @@ class UNetEngine:
         B, C_, S, S2 = x.shape
         assert C_ == 3 and S == S2
         self.plan(B, S)
-        self.refresh_weights()
+        self._produced.clear()
+        self.refresh_weights(train)
         ops.pack_input(x.contiguous(), self.in0)
         cur = ops.view(self.in0)
         for L in range(1, 6):
             base = 0 if L == 1 else 1
             ca, cb = f"encode{L}.{base}.layer.0", f"encode{L}.{base + 1}.layer.0"
-            self._conv_bn(cur, ca, f"encode{L}.{base}.layer.1", self.ya[L], ops.view(self.aa[L]), True, train)
+            self._conv_bn(cur, ca, f"encode{L}.{base}.layer.1", self.ya[L], ops.view(self.aa[L]), True, train, q8_for=cb)
             if L < 5:
                 d = 5 - L
                 skip_v = self._skip_up(d)[0]
@@ -290,7 +361,7 @@ class UNetEngine:
                 key = f"upscale{d}.0.layer.1"
                 ops.conv2d(ops.view(self.up_in[d]), self.packed[key]["wf"], self.P[key + ".bias"], up_v, 3, 3, 1, 1)
             pre = f"decode_forward{d}.0.layer"
-            self._conv_bn(ops.view(self.cat[L]), pre + ".0", pre + ".2", self.ra[d], ops.view(self.za[d]), False, train)
+            self._conv_bn(ops.view(self.cat[L]), pre + ".0", pre + ".2", self.ra[d], ops.view(self.za[d]), False, train, q8_for=pre + ".3")
             # train mode: the very last BatchNorm is followed only by the 1x1 head -> its apply pass (over the largest
             # activation) is skipped, forward() folds the affine into the head weights
             fold_head = train and d == 4
@@ -320,12 +391,14 @@ class UNetEngine:
         return labels
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _fused_reduce(self, bnname, y, mode):
+    def _fused_reduce(self, bnname, y, mode, dgrad_conv=None, dy=None):
         """argument of ops.conv2d(bn_bwd=...) for the data-gradient launch whose output is the gradient this BatchNorm
         consumes - or None where the reduce pass stays its own launch (f32, maps under 8 pixels, CVCS_FUSE_BN_BWD=0)"""
         yv = ops.view(y)
         if not self.fuse_bn_bwd or self.dtype != torch.bfloat16 or yv.H < 8 or yv.W < 8:
             return None
+        if self.fp8 and dgrad_conv is not None and self._fp8_dgrad(dgrad_conv, ops.view(dy)):
+            return None        # (the fp8 kernel has no fused reduce epilogue)
         if not (self.fuse_bn_bwd_c[0] <= yv.C <= self.fuse_bn_bwd_c[1]):
             return None
         st = self.bn[bnname]
@@ -360,7 +433,13 @@ class UNetEngine:
             sums[C_:].copy_(self.G[bnname + ".weight"])
             self.sync_bn.all_reduce(sums)
             ops.bn_bwd_coeffs(sums, M * self.sync_bn.world, C_, st.ca, st.cb)
-        ops.bn_bwd_apply(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, ops.view(dy), p2)
+        q8 = None
+        dyv = ops.view(dy)
+        if self.fp8 and g2 is None and self._fp8_dgrad(conv, dyv):
+            qv, i = self._q8_view(dyv, "g:" + conv, _lib.E5M2)
+            q8 = (qv, _lib.E5M2, self.f8, i, True)
+            self._produced.add(dy.data_ptr())
+        ops.bn_bwd_apply(yv, g1, g2, st.scale, st.shift, st.mean, st.invstd, st.ca, st.cb, mode, dyv, p2, q8=q8)
         ops.colsum_finalize(p2, rows, C_, self.G[conv + ".bias"])
 
     def _wgrad(self, x: View, dy: View, dw, KH, KW, stride, pad, cin_real=None):
@@ -389,13 +468,25 @@ class UNetEngine:
         self._wgrad(x, dyv, self.G[conv + ".weight"], 3, 3, 1, 1, cin_real=cin_real)
         if gin is None:
             return
+        f8 = self._fp8_ok(conv, dyv, gin.C)
+        if f8:    # e5m2 gradient (range over precision) x e4m3 flipped weights
+            dy8, ig = self._quantised(dyv, "g:" + conv, _lib.E5M2)
+            iw = self.f8.slot("w:" + conv, _lib.E4M3)
         if colsum_of is None:
-            ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, bn_bwd=bn_bwd)
+            if f8:
+                assert bn_bwd is None
+                ops.conv3x3_fp8(dy8, _lib.E5M2, self.packed[conv]["wd8"], gin, self.f8, ig, iw)
+            else:
+                ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, bn_bwd=bn_bwd)
             return
         assert bn_bwd is None
         C2 = gin.C
-        rows = ops.conv_stat_rows(dyv, C2, 3, 3, 1, 1)
-        ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, stats=(self.stat_sum, self.stat_m2, self.stat_cnt))
+        if f8:
+            rows = ops.fp8_stat_rows(dyv)
+            ops.conv3x3_fp8(dy8, _lib.E5M2, self.packed[conv]["wd8"], gin, self.f8, ig, iw, stats=(self.stat_sum, self.stat_m2, self.stat_cnt))
+        else:
+            rows = ops.conv_stat_rows(dyv, C2, 3, 3, 1, 1)
+            ops.conv2d(dyv, self.packed[conv]["wd"], None, gin, 3, 3, 1, 1, stats=(self.stat_sum, self.stat_m2, self.stat_cnt))
         if rows > 2048:   # many partial rows: a parallel first stage (the one-launch finalize has only C/16 workgroups)
             prow = ops.bn_bwd_rows(rows)
             ops.colsum_partial(View(self.stat_sum[:rows * C2].view(1, rows, 1, C2), 0, C2), self.part[0][:prow * C2])
@@ -434,7 +525,7 @@ class UNetEngine:
             pre = f"decode_forward{d}.0.layer"
             _, up_v, gskip_v, gup_v = self._skip_up(d)
             self._bn_backward(pre + ".5", pre + ".3", self.rb[d], g, None, 1, self.ddy_b[d])
-            fz = self._fused_reduce(pre + ".2", self.ra[d], 1)
+            fz = self._fused_reduce(pre + ".2", self.ra[d], 1, pre + ".3", self.ddy_b[d])
             self._conv_backward(pre + ".3", ops.view(self.za[d]), self.ddy_b[d], ops.view(self.g_za[d]), bn_bwd=fz)
             self._bn_backward(pre + ".2", pre + ".0", self.ra[d], ops.view(self.g_za[d]), None, 1, self.ddy_a[d], fused=fz is not None)
             key = f"upscale{d}.0" if self.variant == "Unetv2" else f"upscale{d}.0.layer.1"
@@ -462,7 +553,7 @@ class UNetEngine:
             else:
                 g1, g2 = self._skip_up(5 - L)[2], ops.view(self.g_pool[L])
             self._bn_backward(f"encode{L}.{base + 1}.layer.1", cb, self.yb[L], g1, g2, 0, self.dy_b[L])
-            fz = self._fused_reduce(f"encode{L}.{base}.layer.1", self.ya[L], 0)
+            fz = self._fused_reduce(f"encode{L}.{base}.layer.1", self.ya[L], 0, cb, self.dy_b[L])
             self._conv_backward(cb, ops.view(self.aa[L]), self.dy_b[L], ops.view(self.g_aa[L]), bn_bwd=fz)
             ready(cb + ".weight")
             self._bn_backward(f"encode{L}.{base}.layer.1", ca, self.ya[L], ops.view(self.g_aa[L]), None, 0, self.dy_a[L],
@@ -474,3 +565,5 @@ class UNetEngine:
             ready(ca + ".weight")
         if self._side is not None:   # the optimiser and the next forward run after every weight gradient has landed
             torch.cuda.current_stream().wait_stream(self._side)
+        if self.fp8:
+            self.f8.update()      # delayed scaling: this step's amax of every quantised tensor becomes the next step's scale

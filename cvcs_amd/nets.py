@@ -101,8 +101,8 @@ class _HipUNet(nn.Module):
     def __init__(self, num_classes: int, precision: str = "bf16"):
         super().__init__()
         assert precision in PRECISIONS, f"precision must be one of {list(PRECISIONS)}"
-        assert precision != "fp8" or self.variant in ("ResnetUnet", "SwinTUperNet", "SwinBUperNet"), \
-            "precision 'fp8' (mixed bf16 / fp8 convolutions) is built for the ResNet-UNets and the UPerNet head of Swin + UPerNet"
+        assert precision != "fp8" or self.variant in ("ResnetUnet", "SwinTUperNet", "SwinBUperNet", "Unet", "Unetv2"), \
+            "precision 'fp8' (mixed bf16 / fp8 convolutions) is built for the U-Nets, the ResNet-UNets and the UPerNet head of Swin + UPerNet"
         self.requires_context = False   # S/nets.py:37,120
         self.wrapper = False
         self.returns_logits = True
@@ -143,7 +143,7 @@ class _HipUNet(nn.Module):
         return unet_param_spec(self.variant, self.num_classes)
 
     def _build_engine(self, dev):
-        return UNetEngine(self.variant, self.num_classes, PRECISIONS[self.precision], dev)
+        return UNetEngine(self.variant, self.num_classes, PRECISIONS[self.precision], dev, fp8=self.precision == "fp8")
 
     # ------------------------------------------------------------------------------------------------ flat storage
     def _flat_order(self, params):
