@@ -61,7 +61,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(net, nc, tile, tiles, steps):
+def cpu_baseline(net, nc, tile, tiles, steps, variant="b0"):
     """the CPU oracle (torch fp32 restatement of the same train step) on a bounded sample of the same workload"""
     import torch
     from oracle import resnet_unet_oracle as R
@@ -76,7 +76,7 @@ def cpu_baseline(net, nc, tile, tiles, steps):
         tr, what = W.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0, variant=v), f"oracle.swin_upernet_oracle (torch-CPU fp32 Swin-{v[0].upper()} + UPerNet"
     elif net == "SegformerMod":
         from oracle import segformer_oracle as SO
-        tr, what = SO.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0), "oracle.segformer_oracle (torch-CPU fp32 SegformerMod = MiT-b0 + the reference's tail, stochastic layers off"
+        tr, what = SO.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0, variant=variant), f"oracle.segformer_oracle (torch-CPU fp32 SegformerMod = MiT-{variant} + the reference's tail, stochastic layers off"
     elif net in ("DeepLabV3Plus", "Resnet101"):
         from oracle import deeplab_oracle as D
         plus = net == "DeepLabV3Plus"
@@ -94,7 +94,7 @@ def cpu_baseline(net, nc, tile, tiles, steps):
             "sample": f"{what} NC={nc}, CE ignore_index=0, SGD2): {steps} train steps of {tiles} tiles {tile}x{tile} after 1 warm-up step"}
 
 
-def parity_at_dtype(net, name, nc, tile, dev):
+def parity_at_dtype(net, name, nc, tile, dev, variant="b0"):
     """eval-mode logits and labels of the benchmarked network AT THE BENCHMARKED PRECISION against the f32 CPU oracle evaluated at the same
     (current) parameters, on one structured synthetic tile of the benchmarked size - the figures tests/test_named_configs_gpu.py asserts.
     The north star's "1e-3 on logits, bit-exact argmax" is met by the f32 path only (that test); bf16 / fp8 storage cannot reach it."""
@@ -115,7 +115,7 @@ def parity_at_dtype(net, name, nc, tile, dev):
         fwd = lambda x: W.forward(p, x, train=False)   # noqa: E731
     elif name == "SegformerMod":
         from oracle import segformer_oracle as SO
-        fwd = lambda x: SO.forward(p, x, train=False)   # noqa: E731
+        fwd = lambda x: SO.forward(p, x, train=False, variant=variant)   # noqa: E731
     else:
         fwd = lambda x: O.unet_forward(p, x, name, train=False)   # noqa: E731
     img, _ = O.synthetic_tiles(1, tile, nc, seed=11, structured=True)
@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "SwinBUperNet", "SegformerMod", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="fp8 = mixed bf16 / fp8 convolutions (BASELINE configs[4]; ResNet-UNets and the UPerNet head of Swin + UPerNet)")
+    ap.add_argument("--segformer-variant", default="b0", choices=["b0", "b3"], help="SegformerMod: b0 = SegformerConfig() (the reference's pretrained=False branch), "
+                    "b3 = the architecture of the checkpoint its default pretrained=True fetches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     a = ap.parse_args()
@@ -186,7 +188,7 @@ def main():
 
     from cvcs_amd import ops, utils
     cfg = {"net": a.net, "num_classes": a.classes, "precision": a.precision, "loss": "CEL", "ignore_background": True,
-           "opt": "SGD2", "epochs": 20, "device": "gpu"}
+           "opt": "SGD2", "epochs": 20, "device": "gpu", "segformer_variant": a.segformer_variant}
     NC = a.classes + 1
     torch.manual_seed(0)
     net = utils.load_network(cfg, dev)
@@ -257,7 +259,7 @@ def main():
                  "Resnet101": "DeepLabV3-ResNet101 (the reference's factory name Resnet101, S/nets.py:234-257; output stride 8, ASPP 12/24/36)",
                  "SwinTUperNet": "Swin-T + UPerNet (BASELINE configs[3]: embed 96, depths 2/2/6/2, window 7; UPerNet hidden 512, pool scales 1/2/3/6)",
                  "SwinBUperNet": "Swin-B + UPerNet (the reference's documented `BSwin` name: embed 128, depths 2/2/18/2, window 7; UPerNet hidden 512)",
-                 "SegformerMod": "SegformerMod (the reference's factory name, S/nets.py:313-349: transformers' Segformer MiT-b0 = SegformerConfig(), NC-class head, ConvTranspose 8/2/3 + 4/2/1 + Conv3x3 tail; DropPath 0-0.1 and Dropout 0.1 active)",
+                 "SegformerMod": "SegformerMod (the reference's factory name, S/nets.py:313-349: transformers' Segformer " + ("MiT-b0 = SegformerConfig()" if a.segformer_variant == "b0" else "MiT-b3 (the checkpoint architecture its default fetches)") + ", NC-class head, ConvTranspose 8/2/3 + 4/2/1 + Conv3x3 tail; DropPath 0-0.1 and Dropout 0.1 active)",
                  "Unetv2": "Unetv2 (the reference's own U-Net, source/scripts/nets.py:117-199)", "Unet": "Unet (reference)"}[a.net]
         out = {
             "metric": "512x512 tiles/sec (train fwd+bwd)" if a.tile == 512 else f"{a.tile}x{a.tile} tiles/sec (train fwd+bwd)",
@@ -332,8 +334,8 @@ def main():
             out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in mf.values()) / psteps / 1e9, 1)
             out["step_tflops"] = round(sum(f["flops"] for f in mf.values()) / psteps * a.steps / dt / 1e12, 1)
         if world == 1 and not a.no_cpu_baseline:
-            out["parity_at_dtype"] = parity_at_dtype(net, a.net, NC, a.tile, dev)
-            out["cpu_baseline"] = cpu_baseline(a.net, NC, a.tile, 2, 2)
+            out["parity_at_dtype"] = parity_at_dtype(net, a.net, NC, a.tile, dev, a.segformer_variant)
+            out["cpu_baseline"] = cpu_baseline(a.net, NC, a.tile, 2, 2, a.segformer_variant)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

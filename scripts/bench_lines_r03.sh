@@ -15,6 +15,7 @@ for t in "$@"; do
     cfg5bf16)      run cfg5_resnet50unet_b8_s1024_nc21_bf16 --net Resnet50Unet --batch 8 --tile 1024 --classes 20 ;;
     fp8)           run resnet50unet_b32_s512_fp8 --precision fp8 ;;
     swinfp8)       run swintupernet_b32_s512_fp8 --net SwinTUperNet --precision fp8 ;;
+    segb3)         run segformermod_b3_b32_s512_bf16 --net SegformerMod --segformer-variant b3 --steps 20 ;;
     unetfp8)       run unetv2_b32_s512_fp8 --net Unetv2 --precision fp8 ;;
   esac
 done

@@ -106,7 +106,8 @@ def test_factories_keep_the_reference_error_behaviour(capsys):
     with pytest.raises(Exception):
         utils.load_loss({"loss": "Dice", "num_classes": 4}, "cpu")
     with pytest.raises(AssertionError):
-        nets.Urnetv2(5, precision="fp8")
+        nets.DeepLabV3Plus(5, precision="fp8")                                      # fp8 is built for the U-Nets, ResNet-UNets, Swin + UPerNet
+    assert nets.Urnetv2(5, precision="fp8").precision == "fp8"
     with pytest.raises(RuntimeError, match="GPU only"):                             # no CPU fallback
         net(torch.zeros(1, 3, 32, 32))
     assert utils.load_device({"device": "cpu"}) == torch.device("cpu")
