@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcvcs_hip.so")
 
 F32, BF16 = 0, 1
 E4M3, E5M2 = 0, 1          # fp8 formats (CVCS_E4M3 / CVCS_E5M2)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class CvcsError(RuntimeError):
@@ -121,6 +121,15 @@ SIGNATURES = {
     "cvcs_phase_unshuffle": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _i64, _i, _vp]),
     "cvcs_dwconv3x3": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _i, _vp]),
     "cvcs_dwconv3x3_wgrad_rows": (_i, [_i64]),
+    "cvcs_dwconv_rows": (_i, [_i64, _i, _i]),
+    "cvcs_dwconv": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "cvcs_dwconv_dgrad": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
+    "cvcs_dwconv_wgrad_rows": (_i, [_i64, _i]),
+    "cvcs_dwconv_wgrad": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cvcs_se_scale": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _f, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_image_dot": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "cvcs_bn_add": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp]),
+    "cvcs_hardsigmoid": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp]),
     "cvcs_dwconv3x3_wgrad": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp]),
     "cvcs_drop_path_scales": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "cvcs_scale_rows_add": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i64, _i, _vp, _i64, _i, _vp]),
@@ -233,7 +242,7 @@ _recording = None          # the Recording that is capturing launches right now 
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_sizeof_conv8_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
-            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay"}
+            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_dwconv_rows", "cvcs_dwconv_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay"}
 C_REPLAY = os.environ.get("CVCS_C_REPLAY", "1") == "1"     # single-stream replays without timers run from C (cvcs_replay)
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 

@@ -583,8 +583,11 @@ extern "C" int cvcs_image_sum(const void* x, int64_t x_ld, int B, int HW, int C,
   CVCS_CHECK_ARG(DL_DT_OK(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2;
   CVCS_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % (16 / es) == 0, "%s: bad shape", fn);
-  const int CC = C / (16 / es), ccw = CC % 32 == 0 ? 32 : (CC < 256 ? CC : 256);
-  CVCS_CHECK_ARG(256 % ccw == 0 && CC % ccw == 0, "%s: C/%d must divide 256 or be a multiple of 32", fn, 16 / es);
+  const int CC = C / (16 / es);
+  int ccw = CC % 32 == 0 ? 32 : (CC < 256 && 256 % CC == 0 ? CC : 1);
+  if (ccw == 1)      // widths like 96 / 160 / 960 (MobileNetV3): the largest divisor up to 32; the 256 - ccw * PL threads beyond the pixel lanes idle
+    for (int d = 1; d <= 32 && d <= CC; ++d)
+      if (CC % d == 0) ccw = d;
   int rc;
   if ((rc = dl_check_view(fn, x, x_ld, C, es)) || (rc = dl_check_view(fn, out, out_ld, C, es))) return rc;
   const dim3 grid((unsigned)B, (unsigned)(CC / ccw));

@@ -205,6 +205,11 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply fwd
+// nn.Hardswish (the activation of MobileNetV3's "HS" blocks, reached through S/nets.py:277-311): x * relu6(x + 3) / 6 and its derivative
+// (0 below -3, x / 3 + 1/2 up to 3, 1 above - torch's hardswish_backward)
+__device__ __forceinline__ float hardswish(float z) { return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+__device__ __forceinline__ float hardswish_grad(float z) { return z < -3.f ? 0.f : (z <= 3.f ? z * (1.f / 3.f) + 0.5f : 1.f); }
+
 struct BnActArgs {
   const char* y; char* out; char* pool;
   int64_t y_ld, out_ld, pool_ld;
@@ -233,7 +238,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         f[k] = f[k] * sc[k] + sh[k];
-        if (p.relu) f[k] = fmaxf(f[k], 0.f);
+        if (p.relu == 1) f[k] = fmaxf(f[k], 0.f);
+        else if (p.relu == 2) f[k] = hardswish(f[k]);
       }
       const uint4 pk = Elem<T>::pack(f);
       *reinterpret_cast<uint4*>(p.out + (it * p.out_ld) * ES + cc * 16) = pk;
@@ -277,7 +283,7 @@ struct BnBwdArgs {
   const float* scale; const float* shift; const float* mean; const float* invstd;
   const float* ca; const float* cb;
   float* part0; float* part1;   // reduce: (dz, dz*xhat); apply: (db, unused)
-  int B, H, W, C, mode;
+  int B, H, W, C, mode, ccw;    // ccw: channel-chunk lanes per workgroup (bn_bwd_chunk_lanes)
   Q8Out q8;                     // apply: fp8 image of dy (the data gradient of an fp8 convolution reads it)
 };
 
@@ -289,14 +295,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   constexpr int ES = sizeof(T), V = 16 / ES;
   constexpr int NPIX = POOL ? 4 : 1;
   __shared__ float red[2][256 * V];
-  const int CC = p.C / V;
-  const int ccw = CC < kBnBwdChunks ? CC : kBnBwdChunks;   // chunk lanes per workgroup (a 512-byte slab of a pixel at most: wide layers
-                                                           // spread over blockIdx.y, so that small maps still fill the chip)
-  const int PL = 256 / ccw;                 // pixel lanes per workgroup
+  const int ccw = p.ccw;                    // chunk lanes per workgroup (a 512-byte slab of a pixel at most: wide layers spread over
+                                            // blockIdx.y, so that small maps still fill the chip)
+  const int PL = 256 / ccw;                 // pixel lanes per workgroup; widths like 96 / 160 / 960 leave 256 - ccw * PL threads idle
   const int tid = threadIdx.x;
   const int cl = tid % ccw, pl = tid / ccw;
   const int cc = blockIdx.y * ccw + cl;
-  const int64_t items = POOL ? (int64_t)p.B * (p.H / 2) * (p.W / 2) : (int64_t)p.B * p.H * p.W;
+  const int64_t items = pl < PL ? (POOL ? (int64_t)p.B * (p.H / 2) * (p.W / 2) : (int64_t)p.B * p.H * p.W) : 0;
   float sc[V], sh[V], mu[V], is[V], ca[V], cb[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) {
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
           const float xh = (yv[k] - mu[k]) * is[k];
           float dz = gv[k];
           if (p.mode == 0) dz = (yv[k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;
+          else if (p.mode == 3) dz *= hardswish_grad(yv[k] * sc[k] + sh[k]);
           if constexpr (!APPLY) {
             s0[k] += dz;
             s1[k] += dz * xh;
@@ -400,6 +406,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
         const float xh = (yv[w][k] - mu[k]) * is[k];
         float dz = gv[w][k];
         if (p.mode == 0) dz = (yv[w][k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;  // encoder: ReLU after BN
+        else if (p.mode == 3) dz *= hardswish_grad(yv[w][k] * sc[k] + sh[k]);  // hardswish after BN
         if constexpr (!APPLY) {
           s0[k] += dz;
           s1[k] += dz * xh;
@@ -903,8 +910,7 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   const int V = 16 / es;
   CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % V == 0, "%s: bad shape", fn);
   const int CC = C / V;
-  CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % kBnBwdChunks == 0, "%s: C/%d must be a power of two (or a multiple of %d)", fn, V, kBnBwdChunks);
-  CVCS_CHECK_ARG(mode >= 0 && mode <= 2, "%s: bad mode", fn);
+  CVCS_CHECK_ARG(mode >= 0 && mode <= 3, "%s: bad mode", fn);
   CVCS_CHECK_ARG(!(g2 && mode == 1), "%s: pooled gradient only in encoder mode", fn);
   int rc;
   if ((rc = check_view(fn, y, y_ld, C, es))) return rc;
@@ -916,8 +922,11 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   if (apply && (rc = check_view(fn, dy, dy_ld, C, es))) return rc;
   CVCS_CHECK_ARG(scale && shift && mean && invstd && part0 && (apply ? (ca && cb) : part1 != nullptr), "%s: null argument", fn);
   BnBwdArgs a{(const char*)y, (const char*)g1, (const char*)g2, (char*)dy, y_ld, g1_ld, g2_ld, dy_ld, scale, shift, mean,
-              invstd, ca, cb, part0, part1, B, H, W, C, mode, q8};
-  const int ccw = CC < kBnBwdChunks ? CC : kBnBwdChunks;
+              invstd, ca, cb, part0, part1, B, H, W, C, mode, 0, q8};
+  int ccw = 1;      // the largest divisor of CC up to kBnBwdChunks (powers of two and multiples of 32 use every thread)
+  for (int d = 1; d <= kBnBwdChunks && d <= CC; ++d)
+    if (CC % d == 0) ccw = d;
+  a.ccw = ccw;
   dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)B * H * W), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BNB(TT)                                                                                      \

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void phase_shuffle_kernel(const char* ph, int6
 // A workgroup = (<= 32 channel chunks) x (256 / chunks consecutive columns) walks a band of kDwRows rows of one image top to bottom with a
 // sliding 3x3 window in registers: three new loads per output pixel, the neighbouring columns' loads are L1 hits, the band's halo rows the
 // only re-read.  Work items (image, band, column strip) are handed out in XCD-aware order so that adjacent strips share an L2.
-constexpr int kDwChunks = 32, kDwRows = 16;
+constexpr int kDwChunks = 32, kDwRows = 16, kDwRing = 6;
 struct DwArgs {
   const char* x; const char* dy; char* out;
   const float* w; const float* bias; float* part;
@@ -244,25 +244,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
   const int y0 = yb * kDwRows, y1 = y0 + kDwRows < p.H ? y0 + kDwRows : p.H;
   const char* base = p.x + ((int64_t)b * p.H * p.W * p.x_ld) * ES + cc * 16;
   char* obase = p.out + ((int64_t)b * p.H * p.W * p.out_ld) * ES + cc * 16;
-  // a ring of four window rows, the loop fully unrolled: the loads of row y + 2 are in flight while row y is computed
-  uint4 R[4][3];
-  dw_load_row<16>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, R[0]);
-  dw_load_row<16>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, R[1]);
-  dw_load_row<16>(base, p.x_ld * ES, y0 + 1, x, p.H, p.W, col_ok, R[2]);
+  // a ring of kDwRing window rows, the loop fully unrolled: the loads of rows y + 2 ... y + kDwRing - 2 are in flight while row y is computed
+  // (at ~200 VGPRs two waves share a SIMD: with one row ahead the kernel held 24 KB per CU in flight - 2.1 TB/s; three rows ahead triple it)
+  uint4 R[kDwRing][3];
+#pragma unroll
+  for (int r = 0; r < kDwRing - 1; ++r)
+    dw_load_row<16>(base, p.x_ld * ES, y0 - 1 + r, x, p.H, p.W, col_ok && y0 - 1 + r <= y1, R[r]);
 #pragma unroll
   for (int i = 0; i < kDwRows; ++i) {
     const int y = y0 + i;
     if (y >= y1) break;
-    dw_load_row<16>(base, p.x_ld * ES, y + 2, x, p.H, p.W, col_ok && y + 1 < y1, R[(i + 3) & 3]);
+    dw_load_row<16>(base, p.x_ld * ES, y + kDwRing - 2, x, p.H, p.W, col_ok && y + kDwRing - 2 <= y1, R[(i + kDwRing - 1) % kDwRing]);
     float acc[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[k] = bv[k];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       float f0[V], f1[V], f2[V];
-      Elem<T>::unpack(R[i & 3][d], f0);
-      Elem<T>::unpack(R[(i + 1) & 3][d], f1);
-      Elem<T>::unpack(R[(i + 2) & 3][d], f2);
+      Elem<T>::unpack(R[i % kDwRing][d], f0);
+      Elem<T>::unpack(R[(i + 1) % kDwRing][d], f1);
+      Elem<T>::unpack(R[(i + 2) % kDwRing][d], f2);
 #pragma unroll
       for (int k = 0; k < V; ++k) acc[k] += f0[k] * wv[d][k] + f1[k] * wv[3 + d][k] + f2[k] * wv[6 + d][k];
     }
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
       const int y0 = yb * kDwRows, y1 = y0 + kDwRows < p.H ? y0 + kDwRows : p.H;
       const char* base = p.x + ((int64_t)b * p.H * p.W * p.x_ld) * ES + cc * NB;
       const char* gbase = p.dy + ((int64_t)b * p.H * p.W * p.dy_ld) * ES + cc * NB;
-      uint4 R[4][3], G[2];
+      uint4 R[kDwRing][3], G[kDwRing - 2];
       auto load_g = [&](int yy, uint4& gr) {
         gr = make_uint4(0u, 0u, 0u, 0u);
         if (col_ok && yy < y1) {
@@ -311,18 +312,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
         if constexpr (ES == 4) { Elem<float>::unpack(raw, f); }
         else { f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u); f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u); }
       };
-      dw_load_row<NB>(base, p.x_ld * ES, y0 - 1, x, p.H, p.W, col_ok, R[0]);
-      dw_load_row<NB>(base, p.x_ld * ES, y0, x, p.H, p.W, col_ok, R[1]);
-      dw_load_row<NB>(base, p.x_ld * ES, y0 + 1, x, p.H, p.W, col_ok, R[2]);
-      load_g(y0, G[0]);
+#pragma unroll
+      for (int r = 0; r < kDwRing - 1; ++r)
+        dw_load_row<NB>(base, p.x_ld * ES, y0 - 1 + r, x, p.H, p.W, col_ok && y0 - 1 + r <= y1, R[r]);
+#pragma unroll
+      for (int r = 0; r < kDwRing - 3; ++r) load_g(y0 + r, G[r]);
 #pragma unroll
       for (int i = 0; i < kDwRows; ++i) {
         const int y = y0 + i;
         if (y >= y1) break;
-        dw_load_row<NB>(base, p.x_ld * ES, y + 2, x, p.H, p.W, col_ok && y + 1 < y1, R[(i + 3) & 3]);
-        load_g(y + 1, G[(i + 1) & 1]);
+        dw_load_row<NB>(base, p.x_ld * ES, y + kDwRing - 2, x, p.H, p.W, col_ok && y + kDwRing - 2 <= y1, R[(i + kDwRing - 1) % kDwRing]);
+        load_g(y + kDwRing - 3, G[(i + kDwRing - 3) % (kDwRing - 2)]);
         float g[V];
-        unpack4(G[i & 1], g);
+        unpack4(G[i % (kDwRing - 2)], g);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[9][k] += g[k];
 #pragma unroll
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwArgs p) {
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr) {
             float f[V];
-            unpack4(R[(i + rr) & 3][d], f);
+            unpack4(R[(i + rr) % kDwRing][d], f);
 #pragma unroll
             for (int k = 0; k < V; ++k) acc[rr * 3 + d][k] += g[k] * f[k];
           }

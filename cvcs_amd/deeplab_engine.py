@@ -41,11 +41,10 @@ class DeepLabEngine(ResNetUNetEngine):
         tape = []
         self.units, self.relu_order = {}, []
         self.refresh_weights()
-        OS, C5 = self.os, self.widths[3]
+        OS = self.os
         h5 = S // OS
-        f1, p0 = self._stem(B, S, train, tape)
-        feats = self._stages(p0, train, tape, lambda s: None, output_stride=OS)
-        f2, f5 = feats[1], feats[4]
+        f2, f5 = self._encoder(B, S, train, tape)
+        C5 = f5.v.C
         # ---- ASPP: five branches into one buffer
         cat = self._act("aspp.cat", B, h5, h5, 5 * 256)
         br = [Act(View(cat, 256 * i, 256)) for i in range(5)]
@@ -127,6 +126,12 @@ class DeepLabEngine(ResNetUNetEngine):
             self._tape = tape
         self._last = last
         return last
+
+    def _encoder(self, B, S, train, tape):
+        """-> (stride-4 feature, output-stride feature): the dilated ResNet (the MobileNetV3 engine overrides this)"""
+        f1, p0 = self._stem(B, S, train, tape)
+        feats = self._stages(p0, train, tape, lambda s: None, output_stride=self.os)
+        return feats[1], feats[4]
 
     def _plan(self, B, S):
         if self.shape != (B, S):

@@ -475,6 +475,70 @@ class DeepLabv3Resnet50(_TorchvisionDeepLabKeys, DeepLabV3Plus):
         self.wrapper = True
 
 
+def mobilenet_param_spec(num_classes: int):
+    """(name, shape, kind) of torchvision's deeplabv3_mobilenet_v3_large as the reference wraps it (S/nets.py:277-311): the
+    `mobilenet_v3_large(dilated=True).features` backbone under `encoder.N...` (torchvision: `backbone.N...`; block layers as
+    `encoder.N.block.M.{0,1}` / `.fc1` / `.fc2`), then the DeepLabHead names of deeplab_param_spec (`aspp.*`, `head.*`, `classifier`)."""
+    from .mobilenet_engine import BLOCKS, LAST_CHANNELS, block_layers, make_divisible
+    spec = []
+
+    def conv(p, cin, cout, k, bias=False, groups=1):
+        spec.append((p + ".weight", (cout, cin // groups, k, k), "conv_w"))
+        if bias:
+            spec.append((p + ".bias", (cout,), "conv_b"))
+
+    def bn(p, c):
+        spec.extend([(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b"), (p + ".running_mean", (c,), "rm"),
+                     (p + ".running_var", (c,), "rv"), (p + ".num_batches_tracked", (), "nbt")])
+
+    conv("encoder.0.0", 3, 16, 3); bn("encoder.0.1", 16)
+    for i, (cin, k, exp, cout, se, act, stride, dil) in enumerate(BLOCKS):
+        p = f"encoder.{i + 1}.block"
+        e, d, s, pr = block_layers(i)
+        if e is not None:
+            conv(f"{p}.{e}.0", cin, exp, 1); bn(f"{p}.{e}.1", exp)
+        conv(f"{p}.{d}.0", exp, exp, k, groups=exp); bn(f"{p}.{d}.1", exp)
+        if s is not None:
+            sq = make_divisible(exp // 4, 8)
+            conv(f"{p}.{s}.fc1", exp, sq, 1, bias=True)
+            conv(f"{p}.{s}.fc2", sq, exp, 1, bias=True)
+        conv(f"{p}.{pr}.0", exp, cout, 1); bn(f"{p}.{pr}.1", cout)
+    last = f"encoder.{len(BLOCKS) + 1}"
+    conv(last + ".0", BLOCKS[-1][3], LAST_CHANNELS, 1); bn(last + ".1", LAST_CHANNELS)
+    cin = LAST_CHANNELS
+    conv("aspp.convs.0.0", cin, 256, 1); bn("aspp.convs.0.1", 256)
+    for i in (1, 2, 3):
+        conv(f"aspp.convs.{i}.0", cin, 256, 3); bn(f"aspp.convs.{i}.1", 256)
+    conv("aspp.convs.4.1", cin, 256, 1); bn("aspp.convs.4.2", 256)
+    conv("aspp.project.0", 5 * 256, 256, 1); bn("aspp.project.1", 256)
+    conv("head.0", 256, 256, 3); bn("head.1", 256)
+    conv("classifier", 256, num_classes, 1, bias=True)
+    return spec
+
+
+class DeepLabV3MobileNet(_TorchvisionDeepLabKeys, DeepLabV3Plus):
+    """the network behind the reference's factory name `MobileNet` (S/nets.py:277-311, S/utils.py:183-184: torchvision
+    deeplabv3_mobilenet_v3_large with `classifier[4]` -> Conv2d(256, num_classes, 1); forward casts to float and returns d['out']) on the
+    HIP kernels (mobilenet_engine.py), with the reference module's `wrapper` / `custom_load` contract (:306-311) and state_dict key names
+    (`model.backbone.N...`, `model.classifier...`; `model.aux_classifier.*` tensors of a reference checkpoint are kept as loaded).  The
+    reference starts from COCO weights through a network fetch; here the weights are randomly initialised unless a checkpoint is loaded.
+    Its `_googlenet_backbone` / `_resnet18_backbone` switches (never set by the factory) are not built.  The tile side must be a multiple of
+    32; train mode needs at least 2 tiles (the image-pooling BatchNorm).  The input is fed raw, as the reference does."""
+    arch, output_stride, plus = "mobilenet_v3_large", 16, False
+    variant = "MobileNet"
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.wrapper = True
+
+    def _build_spec(self):
+        return mobilenet_param_spec(self.num_classes)
+
+    def _build_engine(self, dev):
+        from .mobilenet_engine import MobileNetEngine
+        return MobileNetEngine(self.num_classes, PRECISIONS[self.precision], dev, aspp_dropout=self.aspp_dropout, dropout_seed=self.dropout_seed)
+
+
 # ---------------------------------------------------------------------------------------------------- Swin-T + UPerNet
 def swin_upernet_param_spec(num_classes: int, variant: str = "tiny"):
     """(name, shape, kind): the parameter names of transformers' UperNetForSemanticSegmentation over a SwinBackbone (embed 96, depths

@@ -433,6 +433,7 @@ def bn_bwd_rows(M: int) -> int:
 
 
 def bn_bwd_reduce(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, mode, part_dz, part_dzx):
+    assert (g1.B, g1.H, g1.W, g1.C) == (y.B, y.H, y.W, y.C), "gradient / activation shape mismatch"
     _tag_hbm("bn_bwd", y.B * y.H * y.W * y.C * y.t.element_size() * 2)
     check(_lib.lib().cvcs_bn_bwd_reduce(y.ptr, y.ld, g1.ptr, g1.ld, 0 if g2 is None else g2.ptr, 0 if g2 is None else g2.ld,
                                         y.B, y.H, y.W, y.C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
@@ -447,6 +448,7 @@ def bn_bwd_finalize(part_dz, part_dzx, rows, M, C_, gamma, invstd, dgamma, dbeta
 
 
 def bn_bwd_apply(y: View, g1: View, g2: View | None, scale, shift, mean, invstd, ca, cb, mode, dy: View, part_db, q8=None):
+    assert (g1.B, g1.H, g1.W, g1.C) == (y.B, y.H, y.W, y.C) == (dy.B, dy.H, dy.W, dy.C), "gradient / activation shape mismatch"
     _tag_hbm("bn_bwd", y.B * y.H * y.W * y.C * (y.t.element_size() * 3 + (1 if q8 is not None else 0)))
     if q8 is not None:      # also the fp8 image of dy (cvcs_bn_bwd_apply_q8)
         assert g2 is None
@@ -1172,3 +1174,74 @@ def scale_unless_one(x: torch.Tensor, scalar: torch.Tensor):
     assert x.dtype == torch.float32 and x.is_contiguous() and scalar.dtype == torch.float32 and scalar.numel() == 1 and scalar.device == x.device
     check(_lib.lib().cvcs_scale_unless_one(x.data_ptr(), x.numel(), scalar.data_ptr(), _stream()), "cvcs_scale_unless_one")
 
+
+
+# ------------------------------------------------------------------------------------------------ MobileNetV3 pieces (csrc/mobilenet.hip)
+HARDSWISH = 2          # activation code of bn_act (relu=...); its BatchNorm-backward mode is BN_MODE_HARDSWISH
+BN_MODE_HARDSWISH = 3
+
+
+def dwconv_rows(M: int, C_: int, dtype) -> int:
+    return _lib.lib().cvcs_dwconv_rows(M, C_, dtype_code(dtype))
+
+
+def dwconv(x: View, w: torch.Tensor, K, stride, pad, dil, y: View, stats=None):
+    """depthwise K x K convolution, w f32 [K*K][C] tap-major; stats = (sum, m2, cnt) partial BatchNorm statistics of dwconv_rows(M, C, dtype) rows"""
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == K * K * x.C and (y.B, y.C) == (x.B, x.C)
+    assert (y.H, y.W) == conv_out_hw(x.H, x.W, K, K, stride, pad, dil)
+    if stats is not None:
+        rows = dwconv_rows(y.B * y.H * y.W, y.C, y.t.dtype)
+        assert stats[0].numel() >= rows * y.C and stats[1].numel() >= rows * y.C and stats[2].numel() >= rows
+    _tag_hbm("dwconv", _bytes(x, y))
+    s = [0, 0, 0] if stats is None else [t.data_ptr() for t in stats]
+    check(_lib.lib().cvcs_dwconv(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), K, stride, pad, dil, y.ptr, y.ld, y.H, y.W, *s, x.code, _stream()),
+          "cvcs_dwconv")
+
+
+def dwconv_dgrad(dy: View, w: torch.Tensor, K, stride, pad, dil, dx: View):
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == K * K * dy.C and (dx.B, dx.C) == (dy.B, dy.C)
+    _tag_hbm("dwconv", _bytes(dy, dx))
+    check(_lib.lib().cvcs_dwconv_dgrad(dy.ptr, dy.ld, dy.B, dy.H, dy.W, dy.C, w.data_ptr(), K, stride, pad, dil, dx.ptr, dx.ld, dx.H, dx.W, dy.code,
+                                       _stream()), "cvcs_dwconv_dgrad")
+
+
+def dwconv_wgrad_rows(M: int, C_: int) -> int:
+    return _lib.lib().cvcs_dwconv_wgrad_rows(M, C_)
+
+
+def dwconv_wgrad(x: View, dy: View, K, stride, pad, dil, part: torch.Tensor):
+    """partial rows part[dwconv_wgrad_rows(M, C)][K*K][C] of the depthwise weight gradient (colsum_finalize sums them)"""
+    rows = dwconv_wgrad_rows(dy.B * dy.H * dy.W, dy.C)
+    assert part.dtype == torch.float32 and part.numel() >= rows * K * K * dy.C and (x.B, x.C) == (dy.B, dy.C)
+    _tag_hbm("dwconv", _bytes(x, dy))
+    check(_lib.lib().cvcs_dwconv_wgrad(x.ptr, x.ld, dy.ptr, dy.ld, x.B, x.H, x.W, x.C, K, stride, pad, dil, dy.H, dy.W, part.data_ptr(), x.code, _stream()),
+          "cvcs_dwconv_wgrad")
+    return rows
+
+
+def se_scale(x: View, s: View, out: View, add: View | None = None, add_scale: float = 0.0):
+    """out[b,p,c] = x[b,p,c] * s[b,c] (+ add[b,c] * add_scale)"""
+    assert (s.B, s.H, s.W, s.C) == (x.B, 1, 1, x.C) and (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+    _tag_hbm("se", _bytes(x, out))
+    check(_lib.lib().cvcs_se_scale(x.ptr, x.ld, s.ptr, s.ld, 0 if add is None else add.ptr, 0 if add is None else add.ld, add_scale, x.B, x.H * x.W, x.C,
+                                   out.ptr, out.ld, x.code, _stream()), "cvcs_se_scale")
+
+
+def image_dot(a: View, x: View, out: View):
+    """out [B,1,1,C] = per-image sum over the pixels of a * x"""
+    assert (out.B, out.H, out.W, out.C) == (x.B, 1, 1, x.C) and (a.B, a.H, a.W, a.C) == (x.B, x.H, x.W, x.C)
+    _tag_hbm("se", _bytes(a, x))
+    check(_lib.lib().cvcs_image_dot(a.ptr, a.ld, x.ptr, x.ld, x.B, x.H * x.W, x.C, out.ptr, out.ld, x.code, _stream()), "cvcs_image_dot")
+
+
+def hardsigmoid(t: View, out: View, g: View | None = None):
+    """out = hardsigmoid(t), or with g its backward g * hardsigmoid'(t)"""
+    check(_lib.lib().cvcs_hardsigmoid(t.ptr, t.ld, 0 if g is None else g.ptr, 0 if g is None else g.ld, t.B * t.H * t.W, t.C, out.ptr, out.ld, t.code,
+                                      _stream()), "cvcs_hardsigmoid")
+
+
+def bn_add(y: View, scale, shift, res: View | None, out: View):
+    """out = scale*y + shift (+ res): BatchNorm apply of a linear bottleneck projection with the residual add, no activation"""
+    _tag_hbm("residual", _bytes(y, out) + (0 if res is None else _bytes(res)))
+    check(_lib.lib().cvcs_bn_add(y.ptr, y.ld, scale.data_ptr(), shift.data_ptr(), 0 if res is None else res.ptr, 0 if res is None else res.ld,
+                                 y.B * y.H * y.W, y.C, out.ptr, out.ld, y.code, _stream()), "cvcs_bn_add")

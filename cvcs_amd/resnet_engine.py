@@ -510,16 +510,20 @@ class ResNetUNetEngine:
         side = self.overlap_wgrad and rec is not None
         ws_name = "wg_ws_side" if side else "wg_ws"      # (the side lane's launches share one workspace: their stream serialises them)
         with (_lib.side_lane() if side else contextlib.nullcontext()):
-            if u.virt:
-                need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
-                ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch(ws_name, need), cin_real=32, virt=True)
-                ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
-            else:
-                need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
-                ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)
+            self._wgrad(u, dy, ws_name)
         if side:
             self._dy_reader[dyname] = rec.last_index()
         return dy
+
+    def _wgrad(self, u: Unit, dy: View, ws_name):
+        """weight gradient of a unit's convolution into self.G (an engine with other convolution kinds overrides this)"""
+        if u.virt:
+            need = ops.wgrad_workspace_floats_for(u.x, dy, 7, 1, 2, 3, virt=True)
+            ops.conv2d_wgrad(u.x, dy, self.stem_dw_tmp, 7, 1, 2, 3, self._scratch(ws_name, need), cin_real=32, virt=True)
+            ops.unpack_stem_wgrad(self.stem_dw_tmp, self.G[u.conv + ".weight"])
+        else:
+            need = ops.wgrad_workspace_floats_for(u.x, dy, u.k, u.k, u.stride, u.pad, dil=u.dil)
+            ops.conv2d_wgrad(u.x, dy, self.G[u.conv + ".weight"], u.k, u.k, u.stride, u.pad, self._scratch(ws_name, need), dil=u.dil)
 
     def _dgrad(self, u: Unit, dy: View, name, fuse_into: Unit | None = None):
         """data gradient of a unit's conv -> (view, half_resolution).  fuse_into: the unit whose activation this gradient

@@ -42,8 +42,7 @@ def load_network(config, device):
     ResNet-101, torchvision key names), `Ensemble` (votes over HIP member networks), BASELINE.json's `Resnet18Unet` / `Resnet34Unet` /
     `Resnet50Unet`, `DeepLabV3Plus` and `TSwin` (Swin-T + UPerNet), and the reference's `SegformerMod` (S/utils.py:191-192: transformers'
     Segformer + the reference's ConvTranspose tail; config keys `segformer_variant` "b0" | "b3", `stochastic` false = DropPath / Dropout off,
-    `seed`).  `MobileNet` (torchvision's DeepLabV3 on MobileNetV3-large: depthwise 5x5, squeeze-excite, 8-channel-granular widths) is
-    not built and raises."""
+    `seed`) and `MobileNet` (S/utils.py:183-184: torchvision's DeepLabV3 on a dilated MobileNetV3-large, torchvision key names)."""
     netname = config["net"]
     classes = config["num_classes"] + 1
     precision = config.get("precision", "bf16")
@@ -76,7 +75,9 @@ def load_network(config, device):
         # S/utils.py:191-192 -> nets.SegformerMod (random-init MiT-b0 = the reference's pretrained=False branch; its default fetches b3 weights)
         return nets.SegformerMod(classes, precision, config.get("stochastic", True), config.get("seed", 0), config.get("segformer_variant")).to(device)
     elif netname == "MobileNet":
-        raise NotImplementedError("network 'MobileNet' (S/nets.py:277-311: torchvision's deeplabv3_mobilenet_v3_large) is not built on the HIP kernels yet")
+        # S/utils.py:183-184 -> nets.DeepLabV3MobileNet: torchvision's deeplabv3_mobilenet_v3_large on the HIP kernels (random-init: the
+        # reference's COCO weights come from a network fetch)
+        return nets.DeepLabV3MobileNet(classes, precision, config.get("aspp_dropout"), config.get("seed", 0)).to(device)
     else:
         print("Invalid network name.")
         raise Exception

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 11
+#define CVCS_ABI_VERSION 12
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_E4M3 = 0, CVCS_E5M2 = 1 };   /* OCP fp8 formats of the fp8 convolution path (gfx950: e4m3fn / e5m2, not the MI300 fnuz forms) */
@@ -544,6 +544,35 @@ int64_t cvcs_sr_attention_bwd_workspace(int B, int N, int Nk, int heads, int hea
 int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t kv_ld, const void* o, int64_t o_ld, const void* go, int64_t go_ld,
                           const float* lse, int B, int N, int Nk, int heads, int head_dim, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld,
                           float* workspace, int dtype, void* stream);
+/* ---- MobileNetV3 pieces (factory name `MobileNet`: S/nets.py:277-311, S/utils.py:183-184 = torchvision deeplabv3_mobilenet_v3_large) ------------
+ * Depthwise K x K convolution (nn.Conv2d(C, C, K, stride, pad, dil, groups=C), K*K <= 25; no bias - a BatchNorm follows), NHWC:
+ *   w f32 [K*K][C] tap-major (the engine gathers it from the module's [C][1][K][K]).
+ * cvcs_dwconv: forward; stat_* (NULL = none): the BatchNorm partial statistics of the values written, cvcs_dwconv_rows(B*Ho*Wo, C, dtype)
+ *   rows in the format cvcs_bn_finalize reads (sum, second moment about the row's own mean, count).
+ * cvcs_dwconv_dgrad: dx [B,H,W,C] from dy [B,Ho,Wo,C].  cvcs_dwconv_wgrad (K = 3 | 5): partial rows
+ *   part[cvcs_dwconv_wgrad_rows(B*Ho*Wo, C)][K*K][C]; cvcs_colsum_finalize(part, rows, K*K*C) sums them into the tap-major gradient.
+ * hardswish is an activation code of the BatchNorm passes: cvcs_bn_act(relu = 2), cvcs_bn_bwd_reduce / _apply(mode = 3).            */
+int cvcs_dwconv_rows(int64_t M, int C, int dtype);
+int cvcs_dwconv(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, int K, int stride, int pad, int dil, void* y, int64_t y_ld,
+                int Ho, int Wo, float* stat_sum, float* stat_m2, float* stat_cnt, int dtype, void* stream);
+int cvcs_dwconv_dgrad(const void* dy, int64_t dy_ld, int B, int Ho, int Wo, int C, const float* w, int K, int stride, int pad, int dil, void* dx,
+                      int64_t dx_ld, int H, int W, int dtype, void* stream);
+int cvcs_dwconv_wgrad_rows(int64_t M, int C);
+int cvcs_dwconv_wgrad(const void* x, int64_t x_ld, const void* dy, int64_t dy_ld, int B, int H, int W, int C, int K, int stride, int pad, int dil,
+                      int Ho, int Wo, float* part, int dtype, void* stream);
+/* Squeeze-excite (torchvision SqueezeExcitation: x * hardsigmoid(fc2(relu(fc1(avgpool(x)))))); the pooled mean is cvcs_image_sum, the two fully
+ * connected layers are 1x1 convolutions on [B,1,1,C] maps.
+ * cvcs_se_scale: out[b,p,c] = x[b,p,c] * s[b,c] (+ add[b,c] * add_scale; add NULL = none) - the forward, and the backward w.r.t. x with the
+ *   gradient of the mean riding along (x = g, add = gradient of the pooled vector, add_scale = 1/HW);
+ * cvcs_image_dot: out[b,c] = sum_p a[b,p,c] * x[b,p,c] (the gradient of s);
+ * cvcs_hardsigmoid: out = clamp(t/6 + 1/2, 0, 1) (g NULL) or the backward g * (|t| < 3 ? 1/6 : 0).                                     */
+int cvcs_se_scale(const void* x, int64_t x_ld, const void* s, int64_t s_ld, const void* add, int64_t add_ld, float add_scale, int B, int HW, int C,
+                  void* out, int64_t out_ld, int dtype, void* stream);
+int cvcs_image_dot(const void* a, int64_t a_ld, const void* x, int64_t x_ld, int B, int HW, int C, void* out, int64_t out_ld, int dtype, void* stream);
+/* cvcs_bn_add: out = scale[c] * y + shift[c] (+ res): the BatchNorm apply of a linear bottleneck's projection with the residual add, no activation */
+int cvcs_bn_add(const void* y, int64_t y_ld, const float* scale, const float* shift, const void* res, int64_t res_ld, int64_t M, int C, void* out,
+                int64_t out_ld, int dtype, void* stream);
+int cvcs_hardsigmoid(const void* t, int64_t t_ld, const void* g, int64_t g_ld, int64_t M, int C, void* out, int64_t out_ld, int dtype, void* stream);
 /* Table-driven weight gather: the f32 master tensors keep the reference's layouts (Conv2d OIHW, ConvTranspose2d IOHW); the GEMM operands of the
  * patch-matrix layers are re-gathered from them every step in ONE launch:
  *   dst[r][c] (R rows of pitch Cp; `dtype`, or f32 when f32_out) = valid(r, c) ? src[base + idx3(r; rd1, rd2, rs0..2) + idx3(c; cd1, cd2, cs0..2)] : 0

@@ -48,7 +48,8 @@ def _bind_on_cpu(net, dtype):
 
 CASES = [("SwinTUperNet", {}, 4, 64), ("SwinTUperNet", {}, 2, 224), ("SwinBUperNet", {}, 2, 96), ("Resnet18Unet", {}, 2, 64), ("Resnet50Unet", {}, 2, 96),
          ("Resnet50Unet", {"decoder_norm": "gn_silu"}, 2, 64), ("DeepLabV3Plus", {}, 2, 64), ("DeepLabv3Resnet101", {}, 2, 64),
-         ("SegformerMod", {}, 2, 64), ("SegformerMod", {"stochastic": False}, 2, 256), ("SegformerMod", {"variant": "b3"}, 2, 96)]
+         ("SegformerMod", {}, 2, 64), ("SegformerMod", {"stochastic": False}, 2, 256), ("SegformerMod", {"variant": "b3"}, 2, 96),
+         ("DeepLabV3MobileNet", {}, 2, 64), ("DeepLabV3MobileNet", {}, 3, 224)]
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
