@@ -44,7 +44,8 @@ FAMILY_KERNEL = {
     "hbm_residual": "bn_add_act_kernel / relu_bwd_sum_kernel (residual block tail forward and backward)",
     "hbm_resize": "upsample2x_fwd / upsample2x_bwd (bilinear x2 of the decoder)",
     "hbm_patches": "im2col / col2im / phase shuffle (patch matrices of the strided, sequence-reduction and transposed convolutions of SegformerMod)",
-    "hbm_dwconv": "dwconv3x3 kernels (depthwise 3x3 of the Mix-FFN: forward, data gradient, weight-gradient partials)",
+    "hbm_dwconv": "depthwise kernels (dwconv3x3 of SegformerMod's Mix-FFN / dwconv k x k of MobileNetV3: forward, data gradient, weight-gradient partials)",
+    "hbm_se": "squeeze-excite passes of MobileNetV3 (se_scale forward / backward, image_dot)",
     "sr_attention": "sr_attn_* kernels (spatial-reduction attention forward / backward, VALU; FLOPs = 4 N Nk C forward, 10 N Nk C backward)",
     "hbm_quantize_fp8": "quantize_fp8_kernel (bf16 -> fp8 image + amax of the tensors the fp8 convolutions read)",
 }
@@ -77,6 +78,9 @@ def cpu_baseline(net, nc, tile, tiles, steps, variant="b0"):
     elif net == "SegformerMod":
         from oracle import segformer_oracle as SO
         tr, what = SO.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0, variant=variant), f"oracle.segformer_oracle (torch-CPU fp32 SegformerMod = MiT-{variant} + the reference's tail, stochastic layers off"
+    elif net == "MobileNet":
+        from oracle import mobilenet_oracle as MO
+        tr, what = MO.OracleTrainer(nc, opt="SGD2", ignore_index=0, seed=0), "oracle.mobilenet_oracle (torch-CPU fp32 DeepLabV3 on MobileNetV3-large"
     elif net in ("DeepLabV3Plus", "Resnet101"):
         from oracle import deeplab_oracle as D
         plus = net == "DeepLabV3Plus"
@@ -116,6 +120,9 @@ def parity_at_dtype(net, name, nc, tile, dev, variant="b0"):
     elif name == "SegformerMod":
         from oracle import segformer_oracle as SO
         fwd = lambda x: SO.forward(p, x, train=False, variant=variant)   # noqa: E731
+    elif name == "MobileNet":
+        from oracle import mobilenet_oracle as MO
+        fwd = lambda x: MO.forward(p, x, train=False)   # noqa: E731
     else:
         fwd = lambda x: O.unet_forward(p, x, name, train=False)   # noqa: E731
     img, _ = O.synthetic_tiles(1, tile, nc, seed=11, structured=True)
@@ -155,7 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--classes", type=int, default=15, help="config num_classes (NC = classes + 1)")
-    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "SwinBUperNet", "SegformerMod", "Unetv2", "Unet"])
+    ap.add_argument("--net", default="Resnet50Unet", choices=["Resnet50Unet", "Resnet18Unet", "Resnet34Unet", "DeepLabV3Plus", "Resnet101", "SwinTUperNet", "SwinBUperNet", "SegformerMod", "MobileNet", "Unetv2", "Unet"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="fp8 = mixed bf16 / fp8 convolutions (BASELINE configs[4]; ResNet-UNets and the UPerNet head of Swin + UPerNet)")
     ap.add_argument("--segformer-variant", default="b0", choices=["b0", "b3"], help="SegformerMod: b0 = SegformerConfig() (the reference's pretrained=False branch), "
@@ -260,6 +267,7 @@ def main():
                  "SwinTUperNet": "Swin-T + UPerNet (BASELINE configs[3]: embed 96, depths 2/2/6/2, window 7; UPerNet hidden 512, pool scales 1/2/3/6)",
                  "SwinBUperNet": "Swin-B + UPerNet (the reference's documented `BSwin` name: embed 128, depths 2/2/18/2, window 7; UPerNet hidden 512)",
                  "SegformerMod": "SegformerMod (the reference's factory name, S/nets.py:313-349: transformers' Segformer " + ("MiT-b0 = SegformerConfig()" if a.segformer_variant == "b0" else "MiT-b3 (the checkpoint architecture its default fetches)") + ", NC-class head, ConvTranspose 8/2/3 + 4/2/1 + Conv3x3 tail; DropPath 0-0.1 and Dropout 0.1 active)",
+                 "MobileNet": "MobileNet (the reference's factory name, S/nets.py:277-311: torchvision deeplabv3_mobilenet_v3_large = dilated MobileNetV3-large at output stride 16 + DeepLabHead, ASPP 12/24/36, Dropout 0.5 active)",
                  "Unetv2": "Unetv2 (the reference's own U-Net, source/scripts/nets.py:117-199)", "Unet": "Unet (reference)"}[a.net]
         out = {
             "metric": "512x512 tiles/sec (train fwd+bwd)" if a.tile == 512 else f"{a.tile}x{a.tile} tiles/sec (train fwd+bwd)",
