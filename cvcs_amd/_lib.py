@@ -124,7 +124,7 @@ SIGNATURES = {
     "cvcs_dwconv_rows": (_i, [_i64, _i, _i]),
     "cvcs_dwconv": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "cvcs_dwconv_dgrad": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp]),
-    "cvcs_dwconv_wgrad_rows": (_i, [_i64, _i]),
+    "cvcs_dwconv_wgrad_rows": (_i, [_i64, _i, _i, _i]),
     "cvcs_dwconv_wgrad": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "cvcs_se_scale": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _f, _i, _i, _i, _vp, _i64, _i, _vp]),
     "cvcs_image_dot": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _vp]),

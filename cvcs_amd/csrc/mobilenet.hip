@@ -27,7 +27,7 @@ static inline int chunk_lanes(int CC, int cap) {
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise forward / data gradient
-constexpr int kDwMaxTaps = 25, kDwPixPerLane = 8, kDwMaxRows = 1024;
+constexpr int kDwPixPerLane = 4, kDwMaxWgs = 8192, kDwWgradWgs = 4096;
 struct DwgArgs {
   const char* in; char* out; const float* w;        // w f32 [K*K][C] (tap-major)
   int64_t in_ld, out_ld;
@@ -37,13 +37,15 @@ struct DwgArgs {
 
 // FWD:  out[b, oy, ox, c] = sum_t in[b, oy*s - pad + ky*d, ox*s - pad + kx*d, c] * w[t][c]                 (in = x, out = y)
 // DGRAD: out[b, iy, ix, c] = sum_t in[b, (iy + pad - ky*d) / s, (ix + pad - kx*d) / s, c] * w[t][c]       (in = dy, out = dx; exact divisions only)
-template <typename T, bool DGRAD>
+// K is a template parameter: the K*K taps are fully unrolled - every 16-byte load of a window row is issued before the first multiply (the
+// rolled loop with one load in flight per thread ran at 0.7 TB/s); the filter sits in LDS (K = 5: 200 values per thread would not fit registers)
+template <typename T, int K, bool DGRAD>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
-  constexpr int ES = sizeof(T), V = 16 / ES;
-  __shared__ float wl[kDwMaxTaps * 32 * V];
+  constexpr int ES = sizeof(T), V = 16 / ES, KK = K * K, kDwRowUnroll = K == 3 ? 3 : 1;
+  __shared__ float wl[KK * 32 * V];
   __shared__ float red[2][256 * V];
   __shared__ int cntl[256];
-  const int ccw = p.ccw, PL = 256 / ccw, KK = p.K * p.K;
+  const int ccw = p.ccw, PL = 256 / ccw;
   const int tid = threadIdx.x, cl = tid % ccw, pl = tid / ccw;
   const bool active = pl < PL;
   const int cc = blockIdx.y * ccw + cl;
@@ -52,7 +54,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
     wl[i] = p.w[(int64_t)t * p.C + blockIdx.y * ccw * V + c];
   }
   __syncthreads();
+  const char* __restrict__ in = p.in + cc * 16;
+  char* __restrict__ out = p.out + cc * 16;
   const int64_t items = (int64_t)p.B * p.Ho * p.Wo;
+  const int64_t in_row = (int64_t)p.Wi * p.in_ld * ES, in_pix = p.in_ld * ES;
   float s1[V], s2[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
@@ -63,38 +68,54 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
       const int64_t t0 = it / p.Wo;
       const int oy = (int)(t0 % p.Ho);
       const int64_t b = t0 / p.Ho;
+      int ix[K];
+      bool vx[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if constexpr (!DGRAD) {
+          ix[k] = ox * p.s - p.pad + k * p.d;
+          vx[k] = (unsigned)ix[k] < (unsigned)p.Wi;
+        } else {
+          const int tx = ox + p.pad - k * p.d;
+          ix[k] = tx / p.s;
+          vx[k] = tx >= 0 && ix[k] * p.s == tx && ix[k] < p.Wi;
+        }
+      }
+      const char* img = in + b * p.Hi * in_row;
       float acc[V];
 #pragma unroll
       for (int k = 0; k < V; ++k) acc[k] = 0.f;
-      for (int ky = 0; ky < p.K; ++ky) {
+      // K = 3: all nine loads in flight; K = 5: one window row (five loads) per trip of a rolled loop - unrolled, the 25 loads of a pixel
+      // (100 VGPRs) leave one wave per SIMD
+#pragma unroll kDwRowUnroll
+      for (int ky = 0; ky < K; ++ky) {
         int iy;
+        bool vy;
         if constexpr (!DGRAD) {
           iy = oy * p.s - p.pad + ky * p.d;
+          vy = (unsigned)iy < (unsigned)p.Hi;
         } else {
           const int ty = oy + p.pad - ky * p.d;
-          if (ty < 0 || ty % p.s) continue;
           iy = ty / p.s;
+          vy = ty >= 0 && iy * p.s == ty && iy < p.Hi;
         }
-        if ((unsigned)iy >= (unsigned)p.Hi) continue;
-        for (int kx = 0; kx < p.K; ++kx) {
-          int ix;
-          if constexpr (!DGRAD) {
-            ix = ox * p.s - p.pad + kx * p.d;
-          } else {
-            const int tx = ox + p.pad - kx * p.d;
-            if (tx < 0 || tx % p.s) continue;
-            ix = tx / p.s;
-          }
-          if ((unsigned)ix >= (unsigned)p.Wi) continue;
+        uint4 raw[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          raw[kx] = make_uint4(0u, 0u, 0u, 0u);
+          if (vy && vx[kx]) raw[kx] = *reinterpret_cast<const uint4*>(img + iy * in_row + ix[kx] * in_pix);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
           float f[V];
-          Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.in + (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld) * ES + cc * 16), f);
-          const float* wt = wl + ((ky * p.K + kx) * ccw + cl) * V;
+          Elem<T>::unpack(raw[kx], f);
+          const float* wt = wl + ((ky * K + kx) * ccw + cl) * V;
 #pragma unroll
           for (int k = 0; k < V; ++k) acc[k] += f[k] * wt[k];
         }
       }
       const uint4 pk = Elem<T>::pack(acc);
-      *reinterpret_cast<uint4*>(p.out + (it * p.out_ld) * ES + cc * 16) = pk;
+      *reinterpret_cast<uint4*>(out + (it * p.out_ld) * ES) = pk;
       if constexpr (!DGRAD) {
         float r[V];
         Elem<T>::unpack(pk, r);      // the statistics of the values as stored
@@ -128,22 +149,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise weight gradient
-// part[blockIdx.x][t][c] = sum over this workgroup's output pixels of dy[b, oy, ox, c] * x[b, oy*s - pad + ky*d, ox*s - pad + kx*d, c];
-// four channels per thread (K*K*4 accumulators), the pixel lanes combined through LDS one tap at a time, in lane order
-template <typename T> struct Quad;
-template <> struct Quad<float> {
-  __device__ static __forceinline__ void ld(const char* p, float* f) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
-  }
-};
-template <> struct Quad<bf16_t> {
-  __device__ static __forceinline__ void ld(const char* p, float* f) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-  }
-};
+// part[blockIdx.x][t][c] = sum over this workgroup's output pixels of dy[b, oy, ox, c] * x[b, oy*s - pad + ky*d, ox*s - pad + kx*d, c].
+// One filter ROW per workgroup (ky = blockIdx.z): K x V accumulators per thread instead of K*K x 4 (K = 5: 130 VGPRs, three waves per SIMD,
+// 8-byte loads - 0.3-0.4 ms per launch), 16-byte loads, K + 1 loads in flight per pixel; the pixel lanes are combined through LDS one tap at a
+// time, in lane order
 struct DwgWgArgs {
   const char* x; const char* dy; float* part;
   int64_t x_ld, dy_ld;
@@ -151,17 +160,21 @@ struct DwgWgArgs {
 };
 template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
-  constexpr int ES = sizeof(T), KK = K * K;
-  __shared__ float red[256 * 4];
+  constexpr int ES = sizeof(T), V = 16 / ES, KK = K * K;
+  __shared__ float red[256 * V];
   const int ccw = p.ccw, PL = 256 / ccw;
   const int tid = threadIdx.x, cl = tid % ccw, pl = tid / ccw;
   const bool active = pl < PL;
-  const int c0 = (blockIdx.y * ccw + cl) * 4;
-  float acc[KK][4];
+  const int cc = blockIdx.y * ccw + cl;
+  const int ky = blockIdx.z;
+  const char* __restrict__ xb = p.x + cc * 16;
+  const char* __restrict__ gb = p.dy + cc * 16;
+  const int64_t x_row = (int64_t)p.Wi * p.x_ld * ES, x_pix = p.x_ld * ES;
+  float acc[K][V];
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int t = 0; t < K; ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[t][k] = 0.f;
+    for (int k = 0; k < V; ++k) acc[t][k] = 0.f;
   const int64_t items = (int64_t)p.B * p.Ho * p.Wo;
   if (active)
     for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < items; it += (int64_t)gridDim.x * PL) {
@@ -169,34 +182,38 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
       const int64_t t0 = it / p.Wo;
       const int oy = (int)(t0 % p.Ho);
       const int64_t b = t0 / p.Ho;
-      float g[4];
-      Quad<T>::ld(p.dy + (it * p.dy_ld + c0) * ES, g);
+      const int iy = oy * p.s - p.pad + ky * p.d;
+      if ((unsigned)iy >= (unsigned)p.Hi) continue;
+      const char* rowp = xb + (b * p.Hi + iy) * x_row;
+      const uint4 graw = *reinterpret_cast<const uint4*>(gb + (it * p.dy_ld) * ES);
+      uint4 raw[K];
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * p.s - p.pad + ky * p.d;
-        if ((unsigned)iy >= (unsigned)p.Hi) continue;
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * p.s - p.pad + kx * p.d;
+        raw[kx] = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)ix < (unsigned)p.Wi) raw[kx] = *reinterpret_cast<const uint4*>(rowp + ix * x_pix);
+      }
+      float g[V];
+      Elem<T>::unpack(graw, g);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const int ix = ox * p.s - p.pad + kx * p.d;
-          if ((unsigned)ix >= (unsigned)p.Wi) continue;
-          float f[4];
-          Quad<T>::ld(p.x + ((((b * p.Hi + iy) * p.Wi + ix) * p.x_ld) + c0) * ES, f);
+      for (int kx = 0; kx < K; ++kx) {
+        float f[V];
+        Elem<T>::unpack(raw[kx], f);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) acc[ky * K + kx][k] += g[k] * f[k];
-        }
+        for (int k = 0; k < V; ++k) acc[kx][k] += g[k] * f[k];
       }
     }
 #pragma unroll
-  for (int t = 0; t < KK; ++t) {
+  for (int t = 0; t < K; ++t) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) red[tid * 4 + k] = active ? acc[t][k] : 0.f;
+    for (int k = 0; k < V; ++k) red[tid * V + k] = active ? acc[t][k] : 0.f;
     __syncthreads();
     if (pl == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < V; ++k) {
         float a = 0.f;
-        for (int q = 0; q < PL; ++q) a += red[(q * ccw + cl) * 4 + k];
-        p.part[((int64_t)blockIdx.x * KK + t) * p.C + c0 + k] = a;
+        for (int q = 0; q < PL; ++q) a += red[(q * ccw + cl) * V + k];
+        p.part[((int64_t)blockIdx.x * KK + ky * K + t) * p.C + cc * V + k] = a;
       }
     }
     __syncthreads();
@@ -315,10 +332,13 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const char* y, int64_t y_ld
   }
 }
 
-static int dw_rows(int64_t M, int ccw) {
+// rows (= gridDim.x) of a depthwise launch: ~pix_per_lane pixels per thread, at most max_wgs workgroups over the whole (rows x channel slabs) grid
+static int dw_rows(int64_t M, int ccw, int slabs, int pix_per_lane, int max_wgs) {
   const int PL = 256 / ccw;
-  int64_t r = (M + (int64_t)PL * kDwPixPerLane - 1) / ((int64_t)PL * kDwPixPerLane);
-  return (int)(r < 1 ? 1 : (r > kDwMaxRows ? kDwMaxRows : r));
+  int64_t r = (M + (int64_t)PL * pix_per_lane - 1) / ((int64_t)PL * pix_per_lane);
+  int64_t cap = max_wgs / slabs;
+  if (cap < 64) cap = 64;
+  return (int)(r < 1 ? 1 : (r > cap ? cap : r));
 }
 
 }  // namespace cvcs
@@ -329,7 +349,8 @@ extern "C" int cvcs_dwconv_rows(int64_t M, int C, int dtype) {
   if (M <= 0 || C <= 0 || !MB_DT(dtype)) return 0;
   const int V = dtype == CVCS_F32 ? 4 : 8;
   if (C % V) return 0;
-  return dw_rows(M, chunk_lanes(C / V, 32));
+  const int ccw = chunk_lanes(C / V, 32);
+  return dw_rows(M, ccw, C / V / ccw, kDwPixPerLane, kDwMaxWgs);
 }
 
 static int dwconv_launch(const char* fn, bool dgrad, const void* in, int64_t in_ld, int B, int Hi, int Wi, int C, const float* w, int K, int stride, int pad,
@@ -337,7 +358,7 @@ static int dwconv_launch(const char* fn, bool dgrad, const void* in, int64_t in_
   CVCS_CHECK_ARG(MB_DT(dtype), "%s: bad dtype", fn);
   const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
   CVCS_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0 && w, "%s: bad shape", fn);
-  CVCS_CHECK_ARG(K >= 1 && K * K <= kDwMaxTaps && stride >= 1 && dil >= 1 && pad >= 0, "%s: bad geometry", fn);
+  CVCS_CHECK_ARG((K == 3 || K == 5) && stride >= 1 && dil >= 1 && pad >= 0, "%s: bad geometry (kernel size 3 or 5)", fn);
   // the geometry of the FORWARD convolution: (Hi, Wi) -> (Ho, Wo) forward, (Ho, Wo) <- (Hi, Wi) for the data gradient
   const int Hx = dgrad ? Ho : Hi, Wx = dgrad ? Wo : Wi, Hy = dgrad ? Hi : Ho, Wy = dgrad ? Wi : Wo;
   CVCS_CHECK_ARG(Hy == (Hx + 2 * pad - dil * (K - 1) - 1) / stride + 1 && Wy == (Wx + 2 * pad - dil * (K - 1) - 1) / stride + 1, "%s: output size mismatch", fn);
@@ -349,15 +370,16 @@ static int dwconv_launch(const char* fn, bool dgrad, const void* in, int64_t in_
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.C = C; a.K = K; a.s = stride; a.d = dil; a.pad = pad;
   a.ccw = chunk_lanes(C / V, 32);
   a.stat_sum = stat_sum; a.stat_m2 = stat_m2; a.stat_cnt = stat_cnt;
-  const dim3 grid((unsigned)dw_rows((int64_t)B * Ho * Wo, a.ccw), (unsigned)(C / V / a.ccw));
+  const dim3 grid((unsigned)dw_rows((int64_t)B * Ho * Wo, a.ccw, C / V / a.ccw, kDwPixPerLane, kDwMaxWgs), (unsigned)(C / V / a.ccw));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVCS_F32) {
-    if (dgrad) hipLaunchKernelGGL((dwconv_kernel<float, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((dwconv_kernel<float, false>), grid, dim3(256), 0, st, a);
-  } else {
-    if (dgrad) hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), grid, dim3(256), 0, st, a);
-  }
+#define DW_L(TT, KK_)                                                                                  \
+  do {                                                                                                 \
+    if (dgrad) hipLaunchKernelGGL((dwconv_kernel<TT, KK_, true>), grid, dim3(256), 0, st, a);          \
+    else hipLaunchKernelGGL((dwconv_kernel<TT, KK_, false>), grid, dim3(256), 0, st, a);               \
+  } while (0)
+  if (dtype == CVCS_F32) { if (K == 3) DW_L(float, 3); else DW_L(float, 5); }
+  else { if (K == 3) DW_L(bf16_t, 3); else DW_L(bf16_t, 5); }
+#undef DW_L
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }
@@ -372,17 +394,25 @@ extern "C" int cvcs_dwconv_dgrad(const void* dy, int64_t dy_ld, int B, int Ho, i
   return dwconv_launch("cvcs_dwconv_dgrad", true, dy, dy_ld, B, Ho, Wo, C, w, K, stride, pad, dil, dx, dx_ld, H, W, nullptr, nullptr, nullptr, dtype, stream);
 }
 
-extern "C" int cvcs_dwconv_wgrad_rows(int64_t M, int C) {
-  if (M <= 0 || C <= 0 || C % 4) return 0;
-  return dw_rows(M, chunk_lanes(C / 4, 64));
+static int dw_wgrad_rows(int64_t M, int C, int K, int V, int* ccw_out) {
+  const int ccw = chunk_lanes(C / V, 32);
+  if (ccw_out) *ccw_out = ccw;
+  return dw_rows(M, ccw, (C / V / ccw) * K, 2 * kDwPixPerLane, kDwWgradWgs);
+}
+
+extern "C" int cvcs_dwconv_wgrad_rows(int64_t M, int C, int K, int dtype) {
+  if (M <= 0 || C <= 0 || !MB_DT(dtype) || (K != 3 && K != 5)) return 0;
+  const int V = dtype == CVCS_F32 ? 4 : 8;
+  if (C % V) return 0;
+  return dw_wgrad_rows(M, C, K, V, nullptr);
 }
 
 extern "C" int cvcs_dwconv_wgrad(const void* x, int64_t x_ld, const void* dy, int64_t dy_ld, int B, int H, int W, int C, int K, int stride, int pad, int dil,
                                  int Ho, int Wo, float* part, int dtype, void* stream) {
   const char* fn = "cvcs_dwconv_wgrad";
   CVCS_CHECK_ARG(MB_DT(dtype), "%s: bad dtype", fn);
-  const int es = dtype == CVCS_F32 ? 4 : 2;
-  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % (16 / es) == 0 && part, "%s: bad shape", fn);
+  const int es = dtype == CVCS_F32 ? 4 : 2, V = 16 / es;
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0 && part, "%s: bad shape", fn);
   CVCS_CHECK_ARG((K == 3 || K == 5) && stride >= 1 && dil >= 1 && pad >= 0, "%s: kernel size 3 or 5", fn);
   CVCS_CHECK_ARG(Ho == (H + 2 * pad - dil * (K - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (K - 1) - 1) / stride + 1, "%s: output size mismatch", fn);
   int rc;
@@ -390,8 +420,8 @@ extern "C" int cvcs_dwconv_wgrad(const void* x, int64_t x_ld, const void* dy, in
   DwgWgArgs a;
   a.x = (const char*)x; a.dy = (const char*)dy; a.part = part; a.x_ld = x_ld; a.dy_ld = dy_ld;
   a.B = B; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.s = stride; a.d = dil; a.pad = pad;
-  a.ccw = chunk_lanes(C / 4, 64);
-  const dim3 grid((unsigned)dw_rows((int64_t)B * Ho * Wo, a.ccw), (unsigned)(C / 4 / a.ccw));
+  const int rows = dw_wgrad_rows((int64_t)B * Ho * Wo, C, K, V, &a.ccw);
+  const dim3 grid((unsigned)rows, (unsigned)(C / V / a.ccw), (unsigned)K);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CVCS_F32) {
     if (K == 3) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, 3>), grid, dim3(256), 0, st, a);

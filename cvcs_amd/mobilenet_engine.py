@@ -258,7 +258,7 @@ class MobileNetEngine(DeepLabEngine):
     def _wgrad(self, u: Unit, dy: View, ws_name):
         if getattr(u, "dw", False):
             T = u.k * u.k
-            rows = ops.dwconv_wgrad_rows(dy.B * dy.H * dy.W, dy.C)
+            rows = ops.dwconv_wgrad_rows(dy.B * dy.H * dy.W, dy.C, u.k, self.dtype)
             part = self._scratch("dw_part", rows * T * dy.C)
             ops.dwconv_wgrad(u.x, dy, u.k, u.stride, u.pad, u.dil, part)
             ops.colsum_finalize(part, rows, T * dy.C, self.G[u.conv + ".weight"])

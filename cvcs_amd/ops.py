@@ -1205,13 +1205,13 @@ def dwconv_dgrad(dy: View, w: torch.Tensor, K, stride, pad, dil, dx: View):
                                        _stream()), "cvcs_dwconv_dgrad")
 
 
-def dwconv_wgrad_rows(M: int, C_: int) -> int:
-    return _lib.lib().cvcs_dwconv_wgrad_rows(M, C_)
+def dwconv_wgrad_rows(M: int, C_: int, K: int, dtype) -> int:
+    return _lib.lib().cvcs_dwconv_wgrad_rows(M, C_, K, dtype_code(dtype))
 
 
 def dwconv_wgrad(x: View, dy: View, K, stride, pad, dil, part: torch.Tensor):
     """partial rows part[dwconv_wgrad_rows(M, C)][K*K][C] of the depthwise weight gradient (colsum_finalize sums them)"""
-    rows = dwconv_wgrad_rows(dy.B * dy.H * dy.W, dy.C)
+    rows = dwconv_wgrad_rows(dy.B * dy.H * dy.W, dy.C, K, dy.t.dtype)
     assert part.dtype == torch.float32 and part.numel() >= rows * K * K * dy.C and (x.B, x.C) == (dy.B, dy.C)
     _tag_hbm("dwconv", _bytes(x, dy))
     check(_lib.lib().cvcs_dwconv_wgrad(x.ptr, x.ld, dy.ptr, dy.ld, x.B, x.H, x.W, x.C, K, stride, pad, dil, dy.H, dy.W, part.data_ptr(), x.code, _stream()),

@@ -545,19 +545,19 @@ int cvcs_sr_attention_bwd(const void* q, int64_t q_ld, const void* kv, int64_t k
                           const float* lse, int B, int N, int Nk, int heads, int head_dim, void* gq, int64_t gq_ld, void* gkv, int64_t gkv_ld,
                           float* workspace, int dtype, void* stream);
 /* ---- MobileNetV3 pieces (factory name `MobileNet`: S/nets.py:277-311, S/utils.py:183-184 = torchvision deeplabv3_mobilenet_v3_large) ------------
- * Depthwise K x K convolution (nn.Conv2d(C, C, K, stride, pad, dil, groups=C), K*K <= 25; no bias - a BatchNorm follows), NHWC:
+ * Depthwise K x K convolution (nn.Conv2d(C, C, K, stride, pad, dil, groups=C), K = 3 | 5; no bias - a BatchNorm follows), NHWC:
  *   w f32 [K*K][C] tap-major (the engine gathers it from the module's [C][1][K][K]).
  * cvcs_dwconv: forward; stat_* (NULL = none): the BatchNorm partial statistics of the values written, cvcs_dwconv_rows(B*Ho*Wo, C, dtype)
  *   rows in the format cvcs_bn_finalize reads (sum, second moment about the row's own mean, count).
  * cvcs_dwconv_dgrad: dx [B,H,W,C] from dy [B,Ho,Wo,C].  cvcs_dwconv_wgrad (K = 3 | 5): partial rows
- *   part[cvcs_dwconv_wgrad_rows(B*Ho*Wo, C)][K*K][C]; cvcs_colsum_finalize(part, rows, K*K*C) sums them into the tap-major gradient.
+ *   part[cvcs_dwconv_wgrad_rows(B*Ho*Wo, C, K, dtype)][K*K][C]; cvcs_colsum_finalize(part, rows, K*K*C) sums them into the tap-major gradient.
  * hardswish is an activation code of the BatchNorm passes: cvcs_bn_act(relu = 2), cvcs_bn_bwd_reduce / _apply(mode = 3).            */
 int cvcs_dwconv_rows(int64_t M, int C, int dtype);
 int cvcs_dwconv(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, int K, int stride, int pad, int dil, void* y, int64_t y_ld,
                 int Ho, int Wo, float* stat_sum, float* stat_m2, float* stat_cnt, int dtype, void* stream);
 int cvcs_dwconv_dgrad(const void* dy, int64_t dy_ld, int B, int Ho, int Wo, int C, const float* w, int K, int stride, int pad, int dil, void* dx,
                       int64_t dx_ld, int H, int W, int dtype, void* stream);
-int cvcs_dwconv_wgrad_rows(int64_t M, int C);
+int cvcs_dwconv_wgrad_rows(int64_t M, int C, int K, int dtype);
 int cvcs_dwconv_wgrad(const void* x, int64_t x_ld, const void* dy, int64_t dy_ld, int B, int H, int W, int C, int K, int stride, int pad, int dil,
                       int Ho, int Wo, float* part, int dtype, void* stream);
 /* Squeeze-excite (torchvision SqueezeExcitation: x * hardsigmoid(fc2(relu(fc1(avgpool(x)))))); the pooled mean is cvcs_image_sum, the two fully

@@ -59,7 +59,7 @@ def test_bilinear_resize_nhwc_forward_and_backward(dtype, scale, H, W):
     close(from_nhwc(gin), x.grad, t, "resize backward")
 
 
-@pytest.mark.parametrize("scale", [4, 8, 2, 3])
+@pytest.mark.parametrize("scale", [4, 8, 2, 3, 16])
 def test_bilinear_resize_of_the_logits(scale):
     g = torch.Generator().manual_seed(scale)
     z = torch.randn(2, 5, 9, 6, generator=g).requires_grad_(True)
