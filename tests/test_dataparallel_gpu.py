@@ -142,7 +142,7 @@ def _resnet_worker(rank, world, port, path, name="Resnet18Unet"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["Resnet18Unet", "TSwin", "SegformerMod"])
+@pytest.mark.parametrize("name", ["Resnet18Unet", "TSwin", "SegformerMod", "MobileNet"])
 def test_resnet_unet_two_ranks_average_their_gradients_through_the_replayed_plan(name):
     """(also Swin-T + UPerNet, whose flat parameter order is arranged for exactly this: nets.SwinTUperNet._flat_order)
     the bucket hooks are host callbacks INSIDE the recorded backward launch list (resnet_engine._ready): two ranks must

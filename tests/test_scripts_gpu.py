@@ -30,10 +30,10 @@ def _run(cmd, env=None):
     return r.stdout
 
 
-@pytest.mark.parametrize("netname", ["Unetv2", "Resnet18Unet", "Resnet101", "TSwin", "SegformerMod"])
+@pytest.mark.parametrize("netname", ["Unetv2", "Resnet18Unet", "Resnet101", "TSwin", "SegformerMod", "MobileNet"])
 def test_train_eval_inference_scripts(tmp_path, netname):
     """the three reference entry points end to end for the reference's own U-Net, BASELINE cfg 1's ResNet18-UNet, the reference's
-    `Resnet101` (DeepLabV3, checkpoint in torchvision key names), `TSwin` (Swin-T + UPerNet) and the reference's `SegformerMod`"""
+    `Resnet101` (DeepLabV3, checkpoint in torchvision key names), `TSwin` (Swin-T + UPerNet) and the reference's `SegformerMod` and `MobileNet`"""
     from PIL import Image
     out = _run([sys.executable, "train.py", _cfg(tmp_path, epochs=2, net=netname)])
     assert "Training Done!" in out and "Saved checkpoint 2" in out and "mIoU" in out
