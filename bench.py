@@ -29,7 +29,7 @@ PEAK_FP8_TFLOPS = 5000.0   # dense fp8 peak (block-scaled v_mfma_scale_f32_16x16
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (6.3 TB/s is what a streaming copy reaches on this chip: MI355X_MICROARCH.md, HBM)
 PMC_FILES = {"Resnet50Unet": "r03_pmc_traffic_resnet50unet_b32_s512_bf16.json", "DeepLabV3Plus": "r02_pmc_traffic_deeplabv3plus_b32_s512_bf16.json", "SwinTUperNet": "r02_pmc_traffic_swintupernet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json",
-             "SegformerMod": "r03_pmc_traffic_segformermod_b32_s512_bf16.json"}
+             "SegformerMod": "r03_pmc_traffic_segformermod_b32_s512_bf16.json", "MobileNet": "r03_pmc_traffic_mobilenet_b32_s512_bf16.json"}
 FAMILY_KERNEL = {
     "conv3x3_halo": "conv3x3_halo_kernel (3x3 / stride 1 forward and data-gradient launches; strided 3x3 data gradients run it on the zero-dilated gradient, counted at their algorithmic FLOPs)",
     "conv3x3_halo_bn_bwd": "conv3x3_halo_kernel + fused BatchNorm-backward reduce pass (conv FLOPs only)",
@@ -331,7 +331,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", PMC_FILES.get(a.net, ""))
             if a.batch == 32 and a.tile == 512 and a.precision == "bf16" and os.path.isfile(pmc):
                 kern = {"conv3x3_halo": "conv3x3_halo_kernel", "conv_taps": "conv_taps_kernel", "conv_igemm": "conv_igemm_kernel",
-                        "hbm_bn_bwd": "bn_bwd_kernel", "wgrad": "wgrad", "hbm_residual": "relu_bwd_sum_bn_kernel"}.get(dom)
+                        "hbm_bn_bwd": "bn_bwd_kernel", "wgrad": "wgrad", "hbm_residual": "relu_bwd_sum_bn_kernel", "hbm_dwconv": "dwconv"}.get(dom)
                 pm = json.load(open(pmc)).get(kern)
                 if pm:
                     out["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])

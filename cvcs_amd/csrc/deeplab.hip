@@ -266,7 +266,21 @@ __global__ __launch_bounds__(256) void image_sum_kernel(const char* x, int64_t l
   float s[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) s[k] = 0.f;
-  for (int p = pl; p < HW; p += PL) {
+  // four pixels per trip, their loads issued together (B x slabs workgroups only: one load in flight per thread left a 64 x 64 map at 60 us)
+  int p = pl;
+  for (; p + 3 * PL < HW; p += 4 * PL) {
+    uint4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p + u * PL) * ld * ES + cc * 16);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[V];
+      Elem<T>::unpack(raw[u], f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] += f[k];
+    }
+  }
+  for (; p < HW; p += PL) {
     float f[V];
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p) * ld * ES + cc * 16), f);
 #pragma unroll

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
 struct DwgWgArgs {
   const char* x; const char* dy; float* part;
   int64_t x_ld, dy_ld;
-  int B, Hi, Wi, Ho, Wo, C, s, d, pad, ccw;
+  int B, Hi, Wi, Ho, Wo, C, s, d, pad, ccw, rows;
 };
 template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
   const int tid = threadIdx.x, cl = tid % ccw, pl = tid / ccw;
   const bool active = pl < PL;
   const int cc = blockIdx.y * ccw + cl;
-  const int ky = blockIdx.z;
+  // the K workgroups of one pixel set (one per filter row) read the same x / dy: they get workgroup ids 8 apart - the SAME XCD (ids are dealt
+  // round-robin over the 8 XCDs, each with its own L2), back to back - so the K passes over the operands are L2 hits (with ky on blockIdx.z
+  // they ran a whole grid apart: 441 MB of HBM reads per launch for ~90 MB of operands)
+  const int grp = blockIdx.x / (8 * K), rem = blockIdx.x % (8 * K);
+  const int ky = rem / 8, row = grp * 8 + rem % 8;
+  if (row >= p.rows) return;
   const char* __restrict__ xb = p.x + cc * 16;
   const char* __restrict__ gb = p.dy + cc * 16;
   const int64_t x_row = (int64_t)p.Wi * p.x_ld * ES, x_pix = p.x_ld * ES;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
     for (int k = 0; k < V; ++k) acc[t][k] = 0.f;
   const int64_t items = (int64_t)p.B * p.Ho * p.Wo;
   if (active)
-    for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < items; it += (int64_t)gridDim.x * PL) {
+    for (int64_t it = (int64_t)row * PL + pl; it < items; it += (int64_t)p.rows * PL) {
       const int ox = (int)(it % p.Wo);
       const int64_t t0 = it / p.Wo;
       const int oy = (int)(t0 % p.Ho);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
       for (int k = 0; k < V; ++k) {
         float a = 0.f;
         for (int q = 0; q < PL; ++q) a += red[(q * ccw + cl) * V + k];
-        p.part[((int64_t)blockIdx.x * KK + ky * K + t) * p.C + cc * V + k] = a;
+        p.part[((int64_t)row * KK + ky * K + t) * p.C + cc * V + k] = a;
       }
     }
     __syncthreads();
@@ -261,14 +266,32 @@ __global__ __launch_bounds__(256) void image_dot_kernel(const char* a, int64_t a
   float s[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) s[k] = 0.f;
-  if (pl < PL)
-    for (int p = pl; p < HW; p += PL) {
+  if (pl < PL) {
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {      // four pixels per trip, eight loads in flight
+      uint4 ra[4], rx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ra[u] = *reinterpret_cast<const uint4*>(a + ((int64_t)b * HW + p + u * PL) * a_ld * ES + cc * 16);
+        rx[u] = *reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p + u * PL) * x_ld * ES + cc * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[V], g[V];
+        Elem<T>::unpack(ra[u], g);
+        Elem<T>::unpack(rx[u], f);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += f[k] * g[k];
+      }
+    }
+    for (; p < HW; p += PL) {
       float f[V], g[V];
       Elem<T>::unpack(*reinterpret_cast<const uint4*>(a + ((int64_t)b * HW + p) * a_ld * ES + cc * 16), g);
       Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p) * x_ld * ES + cc * 16), f);
 #pragma unroll
       for (int k = 0; k < V; ++k) s[k] += f[k] * g[k];
     }
+  }
 #pragma unroll
   for (int k = 0; k < V; ++k) red[threadIdx.x * V + k] = s[k];
   __syncthreads();
@@ -420,8 +443,8 @@ extern "C" int cvcs_dwconv_wgrad(const void* x, int64_t x_ld, const void* dy, in
   DwgWgArgs a;
   a.x = (const char*)x; a.dy = (const char*)dy; a.part = part; a.x_ld = x_ld; a.dy_ld = dy_ld;
   a.B = B; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.s = stride; a.d = dil; a.pad = pad;
-  const int rows = dw_wgrad_rows((int64_t)B * Ho * Wo, C, K, V, &a.ccw);
-  const dim3 grid((unsigned)rows, (unsigned)(C / V / a.ccw), (unsigned)K);
+  a.rows = dw_wgrad_rows((int64_t)B * Ho * Wo, C, K, V, &a.ccw);
+  const dim3 grid((unsigned)((a.rows + 7) / 8 * 8 * K), (unsigned)(C / V / a.ccw));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CVCS_F32) {
     if (K == 3) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, 3>), grid, dim3(256), 0, st, a);

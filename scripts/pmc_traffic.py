@@ -19,6 +19,8 @@ def family(name):
         return "conv_igemm_kernel"
     if n.startswith("wgrad") or n.startswith("void wgrad"):
         return "wgrad"          # every weight-gradient kernel, split-K / bias reduces included (bench.py's `wgrad` family = one entry per layer)
+    if n.startswith("dwconv"):
+        return "dwconv"         # depthwise forward / data gradient / weight gradient launches (bench.py's `hbm_dwconv` family)
     return re.sub(r"<.*", "", n)
 
 
