@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
   for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   int cnt = 0;
   if (active)
-    for (int64_t it = (int64_t)blockIdx.x * PL + pl; it < items; it += (int64_t)gridDim.x * PL) {
-      const int ox = (int)(it % p.Wo);
-      const int64_t t0 = it / p.Wo;
-      const int oy = (int)(t0 % p.Ho);
-      const int64_t b = t0 / p.Ho;
+    for (unsigned it = blockIdx.x * PL + pl; it < (unsigned)items; it += gridDim.x * PL) {      // (32-bit index arithmetic: items < 2^31, checked by the host;
+      const unsigned t0 = it / (unsigned)p.Wo;                                                  //  64-bit divisions cost more than the window's loads on thin layers)
+      const int ox = (int)(it - t0 * (unsigned)p.Wo);
+      const int64_t b = t0 / (unsigned)p.Ho;
+      const int oy = (int)(t0 - (unsigned)b * (unsigned)p.Ho);
       int ix[K];
       bool vx[K];
 #pragma unroll
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
         }
       }
       const uint4 pk = Elem<T>::pack(acc);
-      *reinterpret_cast<uint4*>(out + (it * p.out_ld) * ES) = pk;
+      *reinterpret_cast<uint4*>(out + ((int64_t)it * p.out_ld) * ES) = pk;
       if constexpr (!DGRAD) {
         float r[V];
         Elem<T>::unpack(pk, r);      // the statistics of the values as stored
@@ -182,15 +182,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwgWgArgs p) {
     for (int k = 0; k < V; ++k) acc[t][k] = 0.f;
   const int64_t items = (int64_t)p.B * p.Ho * p.Wo;
   if (active)
-    for (int64_t it = (int64_t)row * PL + pl; it < items; it += (int64_t)p.rows * PL) {
-      const int ox = (int)(it % p.Wo);
-      const int64_t t0 = it / p.Wo;
-      const int oy = (int)(t0 % p.Ho);
-      const int64_t b = t0 / p.Ho;
+    for (unsigned it = row * PL + pl; it < (unsigned)items; it += p.rows * PL) {
+      const unsigned t0 = it / (unsigned)p.Wo;
+      const int ox = (int)(it - t0 * (unsigned)p.Wo);
+      const int64_t b = t0 / (unsigned)p.Ho;
+      const int oy = (int)(t0 - (unsigned)b * (unsigned)p.Ho);
       const int iy = oy * p.s - p.pad + ky * p.d;
       if ((unsigned)iy >= (unsigned)p.Hi) continue;
       const char* rowp = xb + (b * p.Hi + iy) * x_row;
-      const uint4 graw = *reinterpret_cast<const uint4*>(gb + (it * p.dy_ld) * ES);
+      const uint4 graw = *reinterpret_cast<const uint4*>(gb + ((int64_t)it * p.dy_ld) * ES);
       uint4 raw[K];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
@@ -386,6 +386,7 @@ static int dwconv_launch(const char* fn, bool dgrad, const void* in, int64_t in_
   const int Hx = dgrad ? Ho : Hi, Wx = dgrad ? Wo : Wi, Hy = dgrad ? Hi : Ho, Wy = dgrad ? Wi : Wo;
   CVCS_CHECK_ARG(Hy == (Hx + 2 * pad - dil * (K - 1) - 1) / stride + 1 && Wy == (Wx + 2 * pad - dil * (K - 1) - 1) / stride + 1, "%s: output size mismatch", fn);
   CVCS_CHECK_ARG(!stat_sum == !stat_m2 && !stat_sum == !stat_cnt && !(dgrad && stat_sum), "%s: statistics pointers", fn);
+  CVCS_CHECK_ARG((int64_t)B * Ho * Wo < (1ll << 31) - (1 << 22), "%s: more than 2^31 output pixels", fn);
   int rc;
   if ((rc = mb_view(fn, in, in_ld, C, es)) || (rc = mb_view(fn, out, out_ld, C, es))) return rc;
   DwgArgs a;
@@ -438,6 +439,7 @@ extern "C" int cvcs_dwconv_wgrad(const void* x, int64_t x_ld, const void* dy, in
   CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % V == 0 && part, "%s: bad shape", fn);
   CVCS_CHECK_ARG((K == 3 || K == 5) && stride >= 1 && dil >= 1 && pad >= 0, "%s: kernel size 3 or 5", fn);
   CVCS_CHECK_ARG(Ho == (H + 2 * pad - dil * (K - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (K - 1) - 1) / stride + 1, "%s: output size mismatch", fn);
+  CVCS_CHECK_ARG((int64_t)B * Ho * Wo < (1ll << 31) - (1 << 22), "%s: more than 2^31 output pixels", fn);
   int rc;
   if ((rc = mb_view(fn, x, x_ld, C, es)) || (rc = mb_view(fn, dy, dy_ld, C, es))) return rc;
   DwgWgArgs a;
