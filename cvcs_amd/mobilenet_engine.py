@@ -247,7 +247,7 @@ class MobileNetEngine(DeepLabEngine):
         if act_out is not None:
             ops.bn_act(y, st.scale, st.shift, act, act_out)
             if act == RE:
-                self.relu_order.append(act_out)      # every ReLU output in execution order (tests evaluate the oracle at these decisions)
+                self.relu_order.append(act_out)      # every ReLU output in execution order (tests evaluate their float64 reference at these decisions)
             elif act == HS:
                 self.hs_order.append(act_out)        # ... and every hardswish output (its derivative jumps at -3 and 3)
         u = Unit(x, y, conv, bn, k, stride, pad, False, dil)

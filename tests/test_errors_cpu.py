@@ -95,8 +95,8 @@ def test_factories_keep_the_reference_error_behaviour(capsys):
     with pytest.raises(Exception):
         utils.load_network({"net": "NoSuchNet", "num_classes": 4}, "cpu")
     assert "Invalid network name." in capsys.readouterr().out                       # S/utils.py:193-195
-    with pytest.raises(NotImplementedError):
-        utils.load_network({"net": "MobileNet", "num_classes": 4}, "cpu")          # third-party wrapper, not built
+    mb = utils.load_network({"net": "MobileNet", "num_classes": 4}, "cpu")           # S/utils.py:183-184: every factory name of the reference is built
+    assert isinstance(mb, nets.DeepLabV3MobileNet) and mb.wrapper and mb.num_classes == 5
     with pytest.raises(Exception):
         utils.load_network({"net": "Ensemble", "num_classes": 4}, "cpu")            # no ensemble_config (S/utils.py:475-478)
     assert "specify a config file" in capsys.readouterr().out
