@@ -91,6 +91,38 @@ def test_other_entry_points_reject_bad_arguments(lib):
     assert lib.cvcs_bn_finalize(None, None, None, 0, 0, 60, a, a, a, a, 0.1, 1e-5, 0, a, a, None, None, None, None) == -1
 
 
+def test_mobilenet_entry_points_reject_bad_arguments(lib):
+    """depthwise / squeeze-excite entry points (csrc/mobilenet.hip): kernel sizes other than 3 / 5, an output size that is not the
+    convolution's, half-given statistics pointers, misaligned views; the row queries the engine sizes its scratch buffers with"""
+    keep, a = _buf(1 << 16)
+    # x [1,8,8,32] bf16, 3x3 / stride 1 / pad 1 -> y [1,8,8,32]
+    ok = (a, 32, 1, 8, 8, 32, a, 3, 1, 1, 1, a, 32, 8, 8, None, None, None, 1, None)
+    bad_k = ok[:7] + (4,) + ok[8:]
+    assert lib.cvcs_dwconv(*bad_k) == -1 and b"kernel size 3 or 5" in lib.cvcs_last_error()
+    bad_out = ok[:13] + (7, 8) + ok[15:]
+    assert lib.cvcs_dwconv(*bad_out) == -1 and b"output size mismatch" in lib.cvcs_last_error()
+    half_stats = ok[:15] + (a, None, None) + ok[18:]
+    assert lib.cvcs_dwconv(*half_stats) == -1 and b"statistics pointers" in lib.cvcs_last_error()
+    misaligned = (a + 2,) + ok[1:]
+    assert lib.cvcs_dwconv(*misaligned) == -1 and b"16-byte aligned" in lib.cvcs_last_error()
+    assert lib.cvcs_dwconv_dgrad(a, 32, 1, 4, 4, 32, a, 3, 2, 1, 1, a, 32, 9, 8, 1, None) == -1 and b"output size mismatch" in lib.cvcs_last_error()
+    assert lib.cvcs_dwconv_wgrad(a, 32, a, 32, 1, 8, 8, 32, 7, 1, 3, 1, 8, 8, a, 1, None) == -1 and b"kernel size 3 or 5" in lib.cvcs_last_error()
+    assert lib.cvcs_dwconv_wgrad(a, 32, a, 32, 1, 8, 8, 36, 3, 1, 1, 1, 8, 8, a, 1, None) == -1 and b"bad shape" in lib.cvcs_last_error()      # C % 8 (bf16)
+    assert lib.cvcs_se_scale(a, 32, None, 32, None, 0, 0.0, 1, 64, 32, a, 32, 1, None) == -1 and b"null tensor" in lib.cvcs_last_error()
+    assert lib.cvcs_image_dot(a, 16, a, 32, 1, 64, 32, a, 32, 1, None) == -1 and b"16-byte aligned" in lib.cvcs_last_error()                 # ld < C
+    assert lib.cvcs_hardsigmoid(a, 32, None, 0, 0, 32, a, 32, 1, None) == -1 and b"bad shape" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_add(a, 32, None, a, None, 0, 64, 32, a, 32, 1, None) == -1 and b"bad shape" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_bwd_reduce(a, 32, a, 32, None, 0, 1, 8, 8, 32, a, a, a, a, 4, a, a, 1, None) == -1 and b"bad mode" in lib.cvcs_last_error()  # modes 0..3
+    # row queries: at least one row, never more workgroups than the caps (8192 forward / 4096 weight gradient over rows x slabs [x K])
+    assert lib.cvcs_dwconv_rows(0, 32, 1) == 0 and lib.cvcs_dwconv_rows(64, 36, 1) == 0 and lib.cvcs_dwconv_wgrad_rows(64, 32, 4, 1) == 0
+    for M, C_, K in ((1, 32, 3), (64, 960, 5), (32 * 256 * 256, 32, 3), (32 * 64 * 64, 96, 5), (32 * 32 * 32, 672, 5)):
+        for dt, V in ((0, 4), (1, 8)):
+            r, rw = lib.cvcs_dwconv_rows(M, C_, dt), lib.cvcs_dwconv_wgrad_rows(M, C_, K, dt)
+            cc = C_ // V
+            lanes = max(d for d in range(1, 33) if cc % d == 0)
+            assert 1 <= r <= max(64, 8192 // (cc // lanes)) and 1 <= rw <= max(64, 4096 // ((cc // lanes) * K)), (M, C_, K, dt, r, rw)
+
+
 def test_factories_keep_the_reference_error_behaviour(capsys):
     with pytest.raises(Exception):
         utils.load_network({"net": "NoSuchNet", "num_classes": 4}, "cpu")
