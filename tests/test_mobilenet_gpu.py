@@ -384,3 +384,60 @@ def test_aspp_dropout_mask_is_the_replayable_counter_hash():
         plain = M.forward({k: v.clone() for k, v in p.items()}, img.float(), train=True)
     close(logits, want, 1e-3, "logits under the replayed mask")
     assert rel_l2(logits, plain) > 0.05
+
+
+def test_bf16_layer_by_layer_from_the_stored_operands():
+    """the benchmarked precision, 4 x 256 x 256: every convolution output (GEMM 1x1 with padded widths, depthwise, atrous, the stem as patch
+    GEMM) recomputed in f32 from the path's OWN stored bf16 input and the master weights (bf16-rounded where the kernel reads bf16 operands;
+    the depthwise filters stay f32) must agree to bf16 storage rounding; the padding channels of every map are exactly zero"""
+    NC, B, S = 16, 4, 256
+    net = _build(NC, "bf16")
+    img, _ = O.synthetic_tiles(B, S, NC, seed=9, structured=True)
+    net.train()
+    net(img.to(DEV), None)
+    torch.cuda.synchronize()
+    eng = net._engine
+    worst, n_dw, n_pad = (0.0, ""), 0, 0
+    for conv, (u, act_out) in eng.units.items():
+        w = eng.MP[conv + ".weight"].detach().cpu()
+        cout, cin_g, k, _ = w.shape
+        dw = getattr(u, "dw", False)
+        got = from_nhwc(u.y.torch())
+        if conv == "encoder.0.0":       # the stem: its stored operand is the patch matrix of the raw tile
+            ref = F.conv2d(img.float(), w.to(torch.bfloat16).float(), None, 2, 1)
+        else:
+            x = from_nhwc(u.x.torch())
+            if dw:
+                ref = F.conv2d(x[:, :cout], w, None, u.stride, u.pad, u.dil, groups=cout)
+                n_dw += 1
+            else:
+                ref = F.conv2d(x[:, :cin_g], w.to(torch.bfloat16).float(), None, u.stride, u.pad, u.dil)
+        if got.shape[1] > cout:
+            assert (got[:, cout:] == 0).all(), f"{conv}: padding channels of the output are not zero"
+            n_pad += 1
+        e = (got[:, :cout] - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, (e, conv))
+        assert e <= 2.0 ** -8, f"{conv}: conv output off by {e:.3e} of its max"
+    assert n_dw == 15 and n_pad >= 20 and len(eng.units) == 1 + 15 * 2 + 14 + 1 + 7
+    print(f"MobileNet {B}x{S}: worst conv output error {worst[0]:.3e} ({worst[1]}) of its max [bf16 ulp = 3.9e-3]; {n_pad} padded maps with exactly-zero padding")
+
+
+def test_mobilenet_trains_reproducibly():
+    """fixed-order reductions everywhere (statistics, weight-gradient partials, the gather / scatter tables): two runs agree bit for bit"""
+    img, lab = O.synthetic_tiles(4, 128, 5, seed=2, structured=True)
+    runs = []
+    for _ in range(2):
+        net = _build(5, "bf16", aspp_dropout=0.5)
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
+        net.train()
+        losses = []
+        for _ in range(8):
+            loss = crit(net(img.to(DEV), None), lab.to(DEV))
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+            losses.append(loss.item())
+        runs.append((losses, net.flat_parameters()[0].clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][-1] < runs[0][0][0], runs[0][0]
