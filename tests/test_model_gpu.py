@@ -372,19 +372,21 @@ def _miou_parity():
     return mod
 
 
-@pytest.mark.parametrize("model,precision,steps,S", [("Resnet18Unet", "bf16", 40, 64), ("DeepLabV3Plus", "bf16", 120, 128)])
+@pytest.mark.parametrize("model,precision,steps,S", [("Resnet18Unet", "bf16", 40, 64), ("DeepLabV3Plus", "bf16", 120, 128), ("TSwin", "bf16", 100, 128)])
 def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, precision, steps, S):
     """the same for BASELINE's model families (measured on the MI355X: ResNet18-UNet bf16 0.012, ResNet50-UNet bf16 0.005, DeepLabV3+ bf16
     0.005, Swin-T + UPerNet f32 0.030 points - the last one takes 70 s of CPU oracle time and is left to `scripts/miou_parity.py fp32 120 128
-    TSwin`).  Swin in bf16 lands 0.15-0.24 points from the f32 oracle after this schedule (its mIoU
-    plateaus at 95 % and the trajectory is chaotic: the oracle trained in its own forward-only bf16 emulation lands 0.08 away) - reported by
-    `scripts/miou_parity.py bf16 120 128 TSwin emu`, not asserted here."""
+    TSwin`).  Swin-T + UPerNet in bf16: this round's build lands -0.02 / -0.08 / -0.01 points from the f32 oracle after 100 / 110 / 120 steps
+    (`scripts/miou_spread.py TSwin bf16 128 100 110 120`, profiles/r03_miou_spread_swint_bf16.txt); the builds of rounds 1-2 measured 0.15-0.24 on
+    the same schedules and the oracle TRAINED in its own forward-only bf16 emulation lands 0.08 away - the end point of a bf16 trajectory moves by
+    +-0.15 points with the build (profiles/r03_miou_spread_unetv2_bf16.txt: two builds of the same kernels on either side of the oracle).
+    Asserted at 0.25 on the 100-step schedule (~80 s, most of it the CPU oracle)."""
     m_o, m_h = _miou_parity().run(precision, steps=steps, S=S, verbose=False, model=model)
     assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
     # DeepLabV3+ after 120 bf16 steps is a chaotic trajectory (tests/test_dataparallel_gpu.py measures it: the SAME f32 step with the tiles in
     # reverse order lands 2 % away in loss): three builds that differ only in the summation order of the BatchNorm-backward partial sums
     # measured 0.005, 0.06 and 0.135 points here.  The north star's 0.1 is asserted for the ResNet-UNet twin and the f32 paths; this one is held to 0.2
-    bound = 0.2 if model == "DeepLabV3Plus" else 0.1
+    bound = {"DeepLabV3Plus": 0.2, "TSwin": 0.25}.get(model, 0.1)
     assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= bound, (m_o["mIoU"], m_h["mIoU"])
 
 
