@@ -24,7 +24,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib, ops
+from . import ops
 from .deeplab_engine import DeepLabEngine
 from .engine import _BN
 from .ops import View
@@ -104,7 +104,7 @@ class MobileNetEngine(DeepLabEngine):
                 dstG[name] = g
             return m
 
-        def gemm(key, K_of_c=None):
+        def gemm(key):
             """Conv2d [co, ci, k, k] as a GEMM over (ky, kx, ci) patches: forward operand [1][R][Kp], data-gradient operand [1][Kp][R], f32
             gradient [R][Kp]; R = co padded to 32, Kp = k*k*ci padded to 32"""
             w, g = params[key + ".weight"], grads[key + ".weight"]

@@ -8,7 +8,6 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from cvcs_amd import nets, ops, utils  # noqa: E402
-from cvcs_amd.ops import View  # noqa: E402
 from oracle import mobilenet_oracle as M  # noqa: E402
 from oracle import unet_oracle as O  # noqa: E402
 
