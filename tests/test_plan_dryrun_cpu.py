@@ -74,3 +74,45 @@ def test_one_tile_batches_are_refused_in_train_mode_like_torch(no_device, cls):
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         eng.forward(torch.zeros(1, 3, 64, 64), True)
     assert tuple(eng.forward(torch.zeros(1, 3, 64, 64), False).shape) == (1, 5, 64, 64)
+
+
+def _idx3(x, d1, d2, s0, s1, s2):
+    return (x // (d1 * d2)) * s0 + ((x // d2) % d1) * s1 + (x % d2) * s2
+
+
+@pytest.mark.parametrize("cls,kw", [("DeepLabV3MobileNet", {}), ("SegformerMod", {})])
+def test_gather_tables_cover_every_master_element_exactly_once(cls, kw):
+    """host logic of the table-driven weight gather / gradient scatter (cvcs_gather_item, include/cvcs_hip.h): for every scatter item the
+    map (row, column) -> master index must be a bijection onto the master tensor (every gradient element written once, none twice), and every
+    gather item must stay inside its source and its padded destination.  Evaluated from the item dictionaries the engines keep."""
+    import numpy as np
+    net = getattr(nets, cls)(5, "bf16", **kw)
+    eng = _bind_on_cpu(net, torch.bfloat16)
+    tables = eng._keep
+    gath, scat = tables[0], tables[1]
+    assert len(gath) > 20 and len(scat) > 10
+    seen = {}
+    for it in scat:
+        rv2, cv2 = it.get("rv2", 0), it.get("cv2", 0)
+        r = np.arange(it["Rv"]); c = np.arange(it["Cv"])
+        r = r[(r % it["row"][1] < rv2)] if rv2 else r
+        c = c[(c % it["col"][1] < cv2)] if cv2 else c
+        idx = (it.get("base", 0) + _idx3(r, *it["row"])[:, None] + _idx3(c, *it["col"])[None, :]).ravel()
+        n = it["src"].numel()
+        assert idx.min() >= 0 and idx.max() < n, "scatter item writes outside its master tensor"
+        assert len(np.unique(idx)) == len(idx), "scatter item writes a master element twice"
+        key = it["src"].data_ptr()
+        seen.setdefault(key, [n, 0])[1] += len(idx)
+        assert it["dst"].numel() >= it["R"] * it["Cp"] and it["Rv"] <= it["R"] and it["Cv"] <= it["Cp"]
+    if cls == "DeepLabV3MobileNet":      # every backbone gradient goes through exactly one item: the items of a tensor cover it completely
+        assert all(n == hit for n, hit in seen.values()), [v for v in seen.values() if v[0] != v[1]][:3]
+    for it in gath:
+        rv2, cv2 = it.get("rv2", 0), it.get("cv2", 0)
+        r = np.arange(it["Rv"]); c = np.arange(it["Cv"])
+        r = r[(r % it["row"][1] < rv2)] if rv2 else r
+        c = c[(c % it["col"][1] < cv2)] if cv2 else c
+        if len(r) == 0 or len(c) == 0:
+            continue
+        idx = it.get("base", 0) + _idx3(r, *it["row"])[:, None] + _idx3(c, *it["col"])[None, :]
+        assert idx.min() >= 0 and idx.max() < it["src"].numel(), "gather item reads outside its master tensor"
+        assert it["dst"].numel() >= it["R"] * it["Cp"]
