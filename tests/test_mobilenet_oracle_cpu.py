@@ -165,3 +165,25 @@ def test_oracle_matches_the_module_tree_forward_and_backward():
         want = net(x)
         got = M.forward({k: v.detach() for k, v in p.items()}, x, train=False)
     assert (got - want).abs().max() <= 1e-4 * want.abs().max()
+
+
+def test_wrapper_state_dict_speaks_the_reference_key_names_on_cpu():
+    """cvcs_amd.nets.DeepLabV3MobileNet without a device: `state_dict()` carries the names the reference's wrapper saves (`self.model =
+    deeplabv3_mobilenet_v3_large(...)`, S/nets.py:288-293 -> `model.backbone.N...`, `model.classifier...`) and loads them back - with the
+    DataParallel `module.` prefix the reference's `custom_load` strips (S/nets.py:306-311) and with the auxiliary head's tensors, which are kept
+    and written out again; the module tree above loads the same dictionary strictly (minus the `model.` prefix)"""
+    from cvcs_amd import nets
+    net = nets.DeepLabV3MobileNet(7, "bf16")
+    assert net.wrapper and net.returns_logits and not net.requires_context
+    sd = net.state_dict()
+    tv = TVDeepLabV3MobileNet(7)
+    want = {"model." + k: tuple(v.shape) for k, v in tv.state_dict().items()}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    tv.load_state_dict({k[len("model."):]: v for k, v in sd.items()}, strict=True)
+    ck = {"module." + k: (torch.full_like(v, 0.5) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    ck["module.model.aux_classifier.4.weight"] = torch.zeros(21, 10, 1, 1)
+    other = nets.DeepLabV3MobileNet(7, "bf16")
+    other.custom_load({"model_state_dict": ck})
+    out = other.state_dict()
+    assert all((v == 0.5).all() for k, v in out.items() if v.dtype == torch.float32 and "aux_classifier" not in k)
+    assert (out["model.aux_classifier.4.weight"] == 0).all() and set(out) == set(sd) | {"model.aux_classifier.4.weight"}
