@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcvcs_hip.so")
 
 F32, BF16 = 0, 1
 E4M3, E5M2 = 0, 1          # fp8 formats (CVCS_E4M3 / CVCS_E5M2)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class CvcsError(RuntimeError):
@@ -38,6 +38,8 @@ class ConvDesc(C.Structure):
         ("bwd_part_dz", C.c_void_p), ("bwd_part_dzx", C.c_void_p),
         ("aniso", C.c_int32), ("stride_w", C.c_int32), ("pad_w", C.c_int32),
         ("in_row_pitch", C.c_int64), ("in_img_pitch", C.c_int64),
+        ("res", C.c_void_p), ("res_ld", C.c_int64), ("res_scale", C.c_void_p), ("res_shift", C.c_void_p),
+        ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32),
     ]
 
 
@@ -233,6 +235,11 @@ SIGNATURES = {
     "cvcs_argmax_stitch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "cvcs_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "cvcs_label_histogram": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "cvcs_gram_workspace_floats": (_i64, [_i64, _i]),
+    "cvcs_gram": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_gram_finalize": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_gram_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_gram_mmat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cvcs_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
     "cvcs_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }
@@ -242,7 +249,8 @@ _recording = None          # the Recording that is capturing launches right now 
 _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvcs_sizeof_wgrad_desc", "cvcs_sizeof_conv8_desc", "cvcs_conv_stat_rows",
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
-            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_dwconv_rows", "cvcs_dwconv_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay"}
+            "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_dwconv_rows", "cvcs_dwconv_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay",
+            "cvcs_gram_workspace_floats"}
 C_REPLAY = os.environ.get("CVCS_C_REPLAY", "1") == "1"     # single-stream replays without timers run from C (cvcs_replay)
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 

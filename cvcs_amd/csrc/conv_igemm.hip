@@ -52,6 +52,9 @@ struct ConvArgs {
   int stride_w, pad_w;
   int64_t in_row_pitch, in_img_pitch;
   int xcd_order;          // taps kernel: XCD-aware workgroup order (CVCS_XCD_ORDER=0 switches it off: a tuning knob)
+  // ABI 13 (1x1 / stride 1): residual tile added between the pre-affine and the ReLU (taps kernel); second contraction source
+  const char* res; int64_t res_ld; const float* res_scale; const float* res_shift;
+  const char* in2; int64_t in2_ld; int Cin2;
 };
 
 template <typename T> struct Mma;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   // ---- per-lane DMA sources: A pieces wave + 4i (rows = output pixels), B pieces wave + 4j (rows = output channels)
   int iy0[APW], ix0[APW], ac[APW];
-  int64_t pbase[APW];
+  int64_t pbase[APW], pix2[APW];
   bool mvalid[APW];
 #pragma unroll
   for (int i = 0; i < APW; ++i) {
@@ -129,18 +132,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     iy0[i] = oy * p.stride - p.pad;
     ix0[i] = ox * p.stride_w - p.pad_w;
     pbase[i] = (int64_t)b * p.in_img_pitch;
+    pix2[i] = (int64_t)mm * p.in2_ld;      // second source (1x1 / stride 1 / pad 0): same pixel of `in2`
   }
   const int taps = p.KH * p.KW;
-  const int nslice = p.Cin / KG;
+  const int nslice1 = p.Cin / KG;               // slices of the first source
+  const int nslice = (p.Cin + p.Cin2) / KG;
+  const int ktot = p.Cin + p.Cin2;              // row length of the weight matrix
   const int nsteps = taps * nslice;
-  const int64_t wt_tap_stride = (int64_t)p.Cout * p.Cin;  // elements
+  const int64_t wt_tap_stride = (int64_t)p.Cout * ktot;  // elements
   const char* bsrc[BPW];
   bool bvalid[BPW];     // output channels beyond Cout (a last column tile that is not full: Swin's 96 / 288 widths) read zero weights
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
     const int row = (wave + 4 * j) * 16 + rr;
     bvalid[j] = n0 + row < p.Cout;
-    bsrc[j] = p.wt + ((int64_t)(n0 + row) * p.Cin) * ES + swz(row, pc) * 16;
+    bsrc[j] = p.wt + ((int64_t)(n0 + row) * ktot) * ES + swz(row, pc) * 16;
   }
   auto dma_step = [&](int tap, int cs, int stage) {
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -151,6 +157,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       const bool ok = mvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cs * 64 + ac[i] * 16 < p.valid_bytes;
       const char* src = ok ? p.in + (pbase[i] + (int64_t)iy * p.in_row_pitch + (int64_t)ix * p.in_ld + (int64_t)cs * KG) * ES + ac[i] * 16
                            : reinterpret_cast<const char*>(&g_gzero16);
+      if (cs >= nslice1)      // (wave-uniform) second source
+        src = mvalid[i] ? p.in2 + (pix2[i] + (int64_t)(cs - nslice1) * KG) * ES + ac[i] * 16 : reinterpret_cast<const char*>(&g_gzero16);
       dma16(src, sa + (wave + 4 * i) * 1024);
     }
     const int64_t soff = ((int64_t)tap * wt_tap_stride + (int64_t)cs * KG) * ES;
@@ -1118,8 +1126,8 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
 // (packed staging of the whole 256 x 128 tile, LDS reads in flight before the stores).
 // Workgroup: 256 output pixels (linear index) x 128 channels, 8 waves (4 x 2, 64 pixels x 64 channels each), K-slice of
 // 32 channels per step through a 3-stage LDS-DMA ring of 24 KiB (two workgroups per CU).
-template <int TAPS>
-__global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
+template <int TAPS, bool EPI = false>      // EPI: the BatchNorm / residual epilogue of cvcs_conv_desc.pre_scale / res (its own instance: +16 registers)
+__global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      // (4 waves per SIMD = two workgroups per CU: at most 128 registers)
   using T = bf16_t;
   constexpr int ES = 2, KG = 32, BN = 128, BM = 256, NW = 8, NT = 512;
   constexpr int A_BYTES = BM * 64, STAGE = A_BYTES + BN * 64;   // 16 KiB of pixel rows + 8 KiB of weight rows per K-slice
@@ -1138,9 +1146,11 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
   const int ncol = p.Cout / BN;
   const int bx = (int)(lid / ncol), by = (int)(lid % ncol);
   const int m0 = bx * BM, n0 = by * BN;
-  const int nslice = p.Cin / KG;
+  const int nslice1 = p.Cin / KG;               // K-slices of the first source; a second source (TAPS == 1) follows
+  const int nslice = (p.Cin + p.Cin2) / KG;
+  const int ktot = p.Cin + p.Cin2;
   const int nsteps = TAPS * nslice;
-  const int64_t wt_tap_bytes = (int64_t)p.Cout * p.Cin * ES;
+  const int64_t wt_tap_bytes = (int64_t)p.Cout * ktot * ES;
 
   f32x4 bias0[4];
 #pragma unroll
@@ -1149,7 +1159,7 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
 
   // ---- DMA sources.  Pixel rows: pieces wave and wave + 8 (16 rows each); a row beyond M re-reads row M-1 (never stored).
   // Byte offsets from p.in fit 32 bits (checked by the host).
-  unsigned asrc[2][TAPS];
+  unsigned asrc[2][TAPS], asrc2[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wave + NW * i) * 16 + rr;
@@ -1161,22 +1171,28 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
       const int iy = oy * p.stride + (tp >> 1), ix = ox * p.stride + (tp & 1);
       asrc[i][tp] = (unsigned)(((((int64_t)b * p.H + iy) * p.W + ix) * p.in_ld) * ES) + swz(row, pc) * 16;
     }
+    asrc2[i] = (unsigned)(((int64_t)m * p.in2_ld) * ES) + swz(row, pc) * 16;   // (1x1: the pixel index is the row index)
   }
-  const char* bsrc = p.wt + ((int64_t)(n0 + wave * 16 + rr) * p.Cin) * ES + swz(wave * 16 + rr, pc) * 16;
+  const char* bsrc = p.wt + ((int64_t)(n0 + wave * 16 + rr) * ktot) * ES + swz(wave * 16 + rr, pc) * 16;
   unsigned acur[2] = {asrc[0][0], asrc[1][0]};
+  const char* ain = p.in;   // source of the slices being issued (wave-uniform)
   const char* bcur = bsrc;
   int cs2 = 0, t2 = 0;   // (slice, tap) of the next DMA step
   auto dma_step = [&](int stage) {
     char* sa = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + acur[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ain + acur[i]),
                                        (__attribute__((address_space(3))) void*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bcur,
                                      (__attribute__((address_space(3))) void*)(sa + A_BYTES + wave * 1024), 16, 0, 0);
     // advance to the next (tap, slice): slices innermost
     acur[0] += 64; acur[1] += 64; bcur += 64;
-    if (++cs2 == nslice) {
+    ++cs2;
+    if constexpr (TAPS == 1) {
+      if (cs2 == nslice1 && p.Cin2) { ain = p.in2; acur[0] = asrc2[0]; acur[1] = asrc2[1]; }   // the second source's slices follow
+    }
+    if (cs2 == nslice) {
       cs2 = 0; ++t2;
       if constexpr (TAPS > 1) {
 #pragma unroll
@@ -1224,6 +1240,50 @@ __global__ __launch_bounds__(512, 2) void conv_taps_kernel(ConvArgs p) {
   }
 
   // ---- epilogue: acc[i][j][r] = pixel row wm*64 + i*16 + fr, channel wn*64 + j*16 + fg*4 + r (bias already inside)
+  // A BatchNorm applied here (cvcs_bn_gram_finalize: statistics known BEFORE the launch) and the block's shortcut added in f32: the
+  // tail of a bottleneck block without a stored conv output.  The residual is read in accumulator layout: 8 bytes per (pixel, 4
+  // channels), the four j of a lane cover one 128-byte line of its pixel row.
+  if constexpr (EPI) {
+    // (register-lean: one 16-channel column group j at a time - its scale / shift vectors, the four residual chunks of the lane's pixel
+    //  rows - and a compiler barrier in front of each group so that the loads are not hoisted above the main loop: hoisted, the kernel
+    //  needed 174 registers and lost its second workgroup per CU)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" ::: "memory");
+      const int ch = n0 + wn * 64 + j * 16 + fg * 4;
+      uint2 rv[4];
+      if (p.res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int m = m0 + wm * 64 + i * 16 + fr; m = m < p.M ? m : p.M - 1;
+          rv[i] = *reinterpret_cast<const uint2*>(p.res + ((int64_t)m * p.res_ld + ch) * ES);
+        }
+      }
+      if (p.pre_scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pre_scale + ch);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pre_shift + ch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * sc[r] + sh[r];
+      }
+      if (p.res) {
+        f32x4 rs = (f32x4){1.f, 1.f, 1.f, 1.f}, rt = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.res_scale) {
+          rs = *reinterpret_cast<const f32x4*>(p.res_scale + ch);
+          rt = *reinterpret_cast<const f32x4*>(p.res_shift + ch);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint2 u = rv[i];
+          acc[i][j][0] += __uint_as_float(u.x << 16) * rs[0] + rt[0];
+          acc[i][j][1] += __uint_as_float(u.x & 0xffff0000u) * rs[1] + rt[1];
+          acc[i][j][2] += __uint_as_float(u.y << 16) * rs[2] + rt[2];
+          acc[i][j][3] += __uint_as_float(u.y & 0xffff0000u) * rs[3] + rt[3];
+        }
+      }
+    }
+  }
   // BatchNorm partial statistics (1x1 convolutions of the residual blocks): one row per 64-pixel wave block, (count, sum,
   // M2 centred on the block's own mean) of the f32 accumulators, as the generic kernel emits them; the 16 lanes that share
   // a channel quadruple (fg) are merged with xor-shuffles.
@@ -1449,16 +1509,16 @@ static bool thin_conv_shape(const cvcs_conv_desc* d) {
          (d->Cout == 16 || d->Cout == 32) && d->H >= 4 && d->W >= 16 && !d->post_scale && !d->pool_out && !d->bwd_y;
 }
 
-template <int TAPS>
+template <int TAPS, bool EPI = false>
 static int launch_taps(const ConvArgs& a, hipStream_t st) {
   const size_t lds = 3 * (size_t)(256 * 64 + 128 * 64);   // the ring; the staged output tile (256 x 272 B) aliases it
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_taps_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_taps_kernel<TAPS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid((unsigned)(cdiv(a.M, 256) * (a.Cout / 128)));
-  hipLaunchKernelGGL((conv_taps_kernel<TAPS>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_taps_kernel<TAPS, EPI>), grid, dim3(512), lds, st, a);
   CVCS_CHECK_LAUNCH("cvcs_conv2d(taps)");
   return CVCS_OK;
 }
@@ -1522,7 +1582,8 @@ static bool use_taps(const cvcs_conv_desc* d) {
   const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1, k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
   const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
   return (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !(d->stat_sum && d->relu) &&
-         !d->pre_scale && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&
+         (!d->pre_scale || (k1 && !d->stat_sum && !d->pixel_shuffle)) && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&
+         (!d->in2 || (int64_t)d->B * d->H * d->W * d->in2_ld * 2 < (1ll << 32)) &&
          (!d->pixel_shuffle || ((d->Cout / 4) % 8 == 0 && !d->stat_sum)) && (int64_t)d->B * d->H * d->W * d->in_ld * 2 < (1ll << 32);
 }
 // partial-statistics rows per 16x16 tile: bf16 = one (MFMA statistics over the staged tile), f32 = one per wave row group
@@ -1611,6 +1672,24 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     CVCS_CHECK_ARG(((uintptr_t)d->bwd_y % 16) == 0 && d->bwd_y_ld >= d->Cout && (d->bwd_y_ld * es) % 16 == 0, "cvcs_conv2d: bwd_y view");
     CVCS_CHECK_ARG(!d->stat_sum && !d->pool_out && !d->pre_scale && !d->post_scale, "cvcs_conv2d: bwd_y excludes statistics, pooling and the folds");
   }
+  a.res = (const char*)d->res; a.res_ld = d->res_ld; a.res_scale = d->res_scale; a.res_shift = d->res_shift;
+  a.in2 = (const char*)d->in2; a.in2_ld = d->in2_ld; a.Cin2 = d->in2 ? d->Cin2 : 0;
+  if (d->res || d->in2) {
+    const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->dil == 1 && !aniso && !pitched && !d->pixel_shuffle;
+    CVCS_CHECK_ARG(k1 && d->dtype == CVCS_BF16 && cin_valid == d->Cin, "cvcs_conv2d: res / in2 are built for bf16 1x1 / stride 1 launches");
+  }
+  if (d->res) {
+    CVCS_CHECK_ARG(use_taps(d) && !d->stat_sum, "cvcs_conv2d: a residual epilogue needs Cout %% 128 == 0 and no statistics");
+    CVCS_CHECK_ARG(((uintptr_t)d->res % 8) == 0 && d->res_ld >= d->Cout && (d->res_ld * es) % 8 == 0, "cvcs_conv2d: res view");
+    CVCS_CHECK_ARG((d->res_scale == nullptr) == (d->res_shift == nullptr), "cvcs_conv2d: res_scale / res_shift go together");
+  } else {
+    CVCS_CHECK_ARG(!d->res_scale && !d->res_shift, "cvcs_conv2d: res_scale without res");
+  }
+  if (d->in2) {
+    CVCS_CHECK_ARG(d->Cin2 > 0 && d->Cin2 % kg == 0 && d->in2_ld >= d->Cin2 && (d->in2_ld * es) % 16 == 0 && ((uintptr_t)d->in2 % 16) == 0,
+                   "cvcs_conv2d: in2 view (Cin2=%d)", d->Cin2);
+    CVCS_CHECK_ARG(!ragged_n, "cvcs_conv2d: in2 needs Cout %% 64 == 0");
+  }
   a.tiles_x = (int)cdiv(d->W, 16); a.tiles_y = (int)cdiv(d->H, 16);
   a.in_ld = d->in_ld; a.out_ld = d->out_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -1655,6 +1734,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
-  if (use_taps(d)) return (d->KH == 1) ? launch_taps<1>(a, st) : launch_taps<4>(a, st);
+  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
+  CVCS_CHECK_ARG(!d->res, "cvcs_conv2d: the residual epilogue runs on the 1x1 taps kernel only");
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

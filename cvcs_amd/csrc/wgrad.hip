@@ -1110,13 +1110,13 @@ static bool gemm_shape(int KH, int KW, int stride, int Cout, int Cin) {
   static const int on = getenv("CVCS_WGRAD_GEMM") ? atoi(getenv("CVCS_WGRAD_GEMM")) : 1;   // tuning knob
   // channel counts: multiples of 8 (a 16-byte chunk); the last tile of a count that is no multiple of the tile is masked
   // (chunks beyond the last channel read zeros, their outputs are not stored) - the 96 * 2^k widths of Swin
-  return on && KH == 1 && KW == 1 && stride == 1 && Cout % 8 == 0 && Cin % 8 == 0 && (Cout > 64 || Cin > 64);
+  return on && KH == 1 && KW == 1 && stride == 1 && Cout % 8 == 0 && Cin % 8 == 0 && (Cout > 64 || Cin > 64 || (Cout == 64 && Cin == 64));
 }
 static GemmPlan gemm_plan(int B, int Ho, int Wo, int Cout, int Cin) {
   GemmPlan g;
   g.BM = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 128);
   g.BN = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 128);
-  if (g.BM == 64 && g.BN == 64) {           // (no 64 x 64 instance)
+  if (g.BM == 64 && g.BN == 64 && !(Cout == 64 && Cin == 64)) {           // (the 64 x 64 instance serves the 64 -> 64 layer only)
     if (Cout >= Cin) g.BM = 128; else g.BN = 128;
   }
   // 8-wave 256 x 128 tiles for LARGE problems only (>= 16 tiles of 128 x 128 and >= 64 K pixels): measured +2 % on the DeepLabV3-ResNet101
@@ -1201,6 +1201,7 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
       else if (g.BM == 256) LAUNCH_GEMM_D(256, 128, 4);
       else if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM_D(128, 128, 2);
       else if (g.BM == 128) LAUNCH_GEMM_D(128, 64, 2);
+      else if (g.BN == 64) LAUNCH_GEMM_D(64, 64, 2);
       else LAUNCH_GEMM_D(64, 128, 2);
 #undef LAUNCH_GEMM_D
     }
@@ -1358,6 +1359,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     else if (g.BM == 256) LAUNCH_GEMM(256, 128, 4);
     else if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM(128, 128, 2);
     else if (g.BM == 128) LAUNCH_GEMM(128, 64, 2);
+    else if (g.BN == 64) LAUNCH_GEMM(64, 64, 2);
     else LAUNCH_GEMM(64, 128, 2);
 #undef LAUNCH_GEMM
     if (d->dbias)
@@ -1426,5 +1428,102 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
 #undef LAUNCH_RED_T
 #undef LAUNCH_RED
   CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(reduce)");
+  return CVCS_OK;
+}
+
+
+// ===================================================================================================================
+// Second-moment ("Gram") matrix of an activation view: G[i][j] = sum_p a[p][i] a[p][j], s[i] = sum_p a[p][i] over the M pixels - the
+// sufficient statistics of EVERY BatchNorm behind a 1x1 convolution of a (cvcs_bn_gram_finalize): mean_c = w_c . s / M,
+// E[y_c^2] = w_c^T G w_c / M.  It is the 1x1 weight-gradient GEMM with dy = x = a (same kernel, same LDS-DMA ring), K-split into slabs
+// that are summed in f64 in slice order (bitwise reproducible) - one pass over a tensor that is 4x narrower than the conv output whose
+// statistics it yields.
+namespace cvcs {
+template <int KS>
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias_ws, int nslice, int C,
+                                                         double* __restrict__ gram, double* __restrict__ colsum) {
+  constexpr int EL = 256 / KS;
+  __shared__ double sh[KS][EL];
+  const int64_t total = (int64_t)C * C + C;       // the matrix, then the column sums
+  const int el = threadIdx.x % EL, kg = threadIdx.x / EL;
+  const int64_t id = (int64_t)blockIdx.x * EL + el;
+  double a = 0.0;
+  if (id < total) {
+    const bool mat = id < (int64_t)C * C;
+    const float* src = mat ? ws + id : bias_ws + (id - (int64_t)C * C);
+    const int64_t stride = mat ? (int64_t)C * C : C;
+    int k = kg;
+    for (; k + 3 * KS < nslice; k += 4 * KS) {
+      const float v0 = src[(int64_t)k * stride], v1 = src[(int64_t)(k + KS) * stride];
+      const float v2 = src[(int64_t)(k + 2 * KS) * stride], v3 = src[(int64_t)(k + 3 * KS) * stride];
+      a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+    }
+    for (; k < nslice; k += KS) a += (double)src[(int64_t)k * stride];
+  }
+  sh[kg][el] = a;
+  __syncthreads();
+  if (kg == 0 && id < total) {
+    double t = sh[0][el];
+#pragma unroll
+    for (int q = 1; q < KS; ++q) t += sh[q][el];
+    if (id < (int64_t)C * C) gram[id] = t; else colsum[id - (int64_t)C * C] = t;
+  }
+}
+struct GramPlan { int BM, tiles, ktiles, per_slice, nslice; };
+static GramPlan gram_plan(int64_t M, int C) {
+  GramPlan g;
+  g.BM = C % 128 == 0 ? 128 : 64;
+  g.tiles = (C / g.BM) * (C / g.BM);
+  g.ktiles = (int)cdiv(M, 32);
+  int want = (int)cdiv(512, g.tiles);
+  // partial slabs are written and read once each: keep them below ~8 MB (at 128 channels 512 slices would be 32 MB for a 34 MB input)
+  const int64_t cap = (8ll << 20) / ((int64_t)C * C * 4);
+  if (want > cap) want = (int)(cap < 1 ? 1 : cap);
+  if (want > g.ktiles) want = g.ktiles;
+  if (want < 1) want = 1;
+  g.per_slice = (int)cdiv(g.ktiles, want);
+  g.nslice = (int)cdiv(g.ktiles, g.per_slice);
+  return g;
+}
+}  // namespace cvcs
+
+extern "C" int64_t cvcs_gram_workspace_floats(int64_t M, int C) {
+  if (M <= 0 || C < 64 || C % 64 != 0 || M >= (1ll << 31)) return CVCS_EINVAL;
+  const GramPlan g = gram_plan(M, C);
+  return (int64_t)g.nslice * ((int64_t)C * C + C);
+}
+
+extern "C" int cvcs_gram(const void* x, int64_t x_ld, int64_t M, int C, double* gram, double* colsum, float* workspace, void* stream) {
+  CVCS_CHECK_ARG(x && gram && colsum && workspace, "cvcs_gram: null argument");
+  CVCS_CHECK_ARG(M > 0 && M < (1ll << 31) && C >= 64 && C % 64 == 0 && C <= 2048, "cvcs_gram: M=%lld C=%d (channels: a multiple of 64)", (long long)M, C);
+  CVCS_CHECK_ARG(x_ld >= C && (x_ld * 2) % 16 == 0 && ((uintptr_t)x % 16) == 0, "cvcs_gram: view");
+  const GramPlan g = gram_plan(M, C);
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const char*)x; a.dy = (const char*)x; a.x_ld = x_ld; a.dy_ld = x_ld;
+  a.B = 1; a.H = 1; a.W = (int)M; a.Ho = 1; a.Wo = (int)M; a.Cin = C; a.Cout = C;
+  a.KW = 1; a.stride = 1; a.stride_w = 1;
+  a.ws = workspace; a.bias_ws = workspace + (int64_t)g.nslice * C * C;
+  a.ktiles = g.ktiles; a.per_slice = g.per_slice; a.ntile_n = C / g.BM; a.tiles_mn = g.tiles; a.xcd_order = wgrad_xcd_order();
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(g.tiles * g.nslice));
+  if (g.BM == 128) {
+    const int lds = 3 * 4 * 4096;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<128, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128, 2>), grid, dim3(256), lds, st, a);
+  } else {
+    const int lds = 3 * 2 * 4096;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<64, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64, 2>), grid, dim3(256), lds, st, a);
+  }
+  CVCS_CHECK_LAUNCH("cvcs_gram");
+  const int64_t total = (int64_t)C * C + C;
+  // lanes per element: enough threads in flight for the small matrices, never more than the slices there are
+  int ks = 1;
+  while (ks < 16 && total * ks < 131072 && ks * 4 <= g.nslice) ks *= 4;
+  if (ks >= 16) hipLaunchKernelGGL((gram_reduce_kernel<16>), dim3((unsigned)cdiv(total, 16)), dim3(256), 0, st, workspace, a.bias_ws, g.nslice, C, gram, colsum);
+  else if (ks >= 4) hipLaunchKernelGGL((gram_reduce_kernel<4>), dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, workspace, a.bias_ws, g.nslice, C, gram, colsum);
+  else hipLaunchKernelGGL((gram_reduce_kernel<1>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, workspace, a.bias_ws, g.nslice, C, gram, colsum);
+  CVCS_CHECK_LAUNCH("cvcs_gram(reduce)");
   return CVCS_OK;
 }

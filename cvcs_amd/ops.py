@@ -155,12 +155,23 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None) -> 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
            pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None,
-           bn_bwd=None, virt=None, flops=None):
+           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...).
     bn_bwd = (y view, scale, shift, mean, invstd, mode, part_dz, part_dzx): the launch also takes the first pass of the
     BatchNorm backward that consumes `out` (bf16 3x3 / stride 1 / pad 1; one partial row per 16x16 tile)."""
     d, Ho, Wo, Cout = _conv_desc(x, wt, bias, out, KH, KW, stride, pad, dil, relu, pixel_shuffle, stats, virt=virt)
+    if res is not None:
+        # residual epilogue (bf16 1x1): out = relu?(pre_scale * acc + pre_shift + (res | res_scale * res + res_shift))
+        assert (res.B, res.H, res.W, res.C) == (x.B, Ho, Wo, Cout) and res.t.dtype == x.t.dtype
+        d.res, d.res_ld = res.ptr, res.ld
+        if res_affine is not None:
+            d.res_scale, d.res_shift = res_affine[0].data_ptr(), res_affine[1].data_ptr()
+    if x2 is not None:
+        # second contraction source of the same pixels (bf16 1x1): wt rows are x.C + x2.C long
+        assert (x2.B, x2.H, x2.W) == (x.B, x.H, x.W) and x2.t.dtype == x.t.dtype and wt.shape[2] == x.C + x2.C
+        d.in2, d.in2_ld, d.Cin2 = x2.ptr, x2.ld, x2.C
+        d.Cin, d.Cin_valid = x.C, 0          # (_conv_desc read the longer weight rows as a zero-padded K-group)
     if bn_bwd is not None:
         yv, bsc, bsh, bmu, bis, bmode, p0, p1 = bn_bwd
         rows = conv_stat_rows(x, Cout, KH, KW, stride, pad)
@@ -179,6 +190,7 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         assert (pool.B, pool.H, pool.W, pool.C) == (x.B, Ho // 2, Wo // 2, Cout) and pool.t.dtype == x.t.dtype
         d.pool_out, d.pool_ld = pool.ptr, pool.ld
     assert wt.shape[0] == KH * KW and (virt is not None or wt.shape[2] >= x.C) and wt.dtype == x.t.dtype and out.t.dtype == x.t.dtype
+
     if pixel_shuffle:
         assert (out.H, out.W, out.C) == (2 * Ho, 2 * Wo, Cout // 4), "pixel-shuffled output view mismatch"
     else:
@@ -187,7 +199,8 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     # same dispatch rule as cvcs_conv2d: 3x3 / stride 1 / pad 1 on maps of at least 8 pixels -> the halo kernel
     halo = KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1 and not pixel_shuffle and x.H >= 8 and x.W >= 8
     taps = (not halo and x.code == BF16 and virt is None and pad == 0 and dil == 1 and Cout % 128 == 0 and
-            not (stats is not None and relu) and pre_affine is None and post_affine is None and
+            not (stats is not None and relu) and post_affine is None and
+            (pre_affine is None or ((KH, KW, stride) == (1, 1, 1) and stats is None and not pixel_shuffle)) and
             ((KH, KW, stride) == (1, 1, 1) or (KH, KW, stride) == (2, 2, 2)))
     # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count; `flops` overrides
     # (a zero-dilated strided data gradient multiplies four times the pixels its convolution has).
@@ -196,7 +209,8 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     fam = ("conv3x3_halo_bn_bwd" if bn_bwd is not None else "conv3x3_halo") if halo else ("conv_taps" if taps else "conv_igemm")
     if SCOPE:
         fam = f"{fam}:{SCOPE}"
-    tag = (fam, float(flops) if flops is not None else 2.0 * x.B * Ho * Wo * Cout * (cin_real or (x.C if virt is None else 21)) * KH * KW)
+    tag = (fam, float(flops) if flops is not None else
+           2.0 * x.B * Ho * Wo * Cout * (cin_real or ((x.C + (x2.C if x2 is not None else 0)) if virt is None else 21)) * KH * KW)
     if _lib._recording is not None:
         _lib.pending_tag = tag
     elif TIMERS is not None:
@@ -469,6 +483,50 @@ def colsum_finalize(part, rows, C_, out):
 def colsum_partial(x: View, part):
     check(_lib.lib().cvcs_colsum_partial(x.ptr, x.ld, x.B * x.H * x.W, x.C, part.data_ptr(), x.code, _stream()),
           "cvcs_colsum_partial")
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm from the Gram matrix
+def gram_workspace_floats(M: int, C_: int) -> int:
+    n = _lib.lib().cvcs_gram_workspace_floats(M, C_)
+    if n < 0:
+        raise _lib.CvcsError("cvcs_gram_workspace_floats: bad shape")
+    return n
+
+
+def gram(a: View, G: torch.Tensor, s: torch.Tensor, workspace: torch.Tensor):
+    """G (f64 [C, C]) = sum_p a_p a_p^T, s (f64 [C]) = sum_p a_p over the pixels of the bf16 view a"""
+    M = a.B * a.H * a.W
+    assert a.code == BF16 and G.dtype == torch.float64 and s.dtype == torch.float64 and G.numel() == a.C * a.C and s.numel() == a.C
+    assert workspace.dtype == torch.float32 and workspace.numel() >= gram_workspace_floats(M, a.C)
+    _tag_hbm("gram", M * a.C * 2)
+    check(_lib.lib().cvcs_gram(a.ptr, a.ld, M, a.C, G.data_ptr(), s.data_ptr(), workspace.data_ptr(), _stream()), "cvcs_gram")
+
+
+def bn_gram_finalize(G, s, w, M, gamma, beta, rmean, rvar, scale, shift, save_mean, save_invstd, q, momentum=0.1, eps=1e-5):
+    """train-mode BatchNorm statistics of y = w a from the Gram matrix of a (w: bf16 [C, m], the conv's packed forward weight); q <- w G"""
+    C_, m = w.shape[-2], w.shape[-1]
+    assert w.dtype == torch.bfloat16 and w.is_contiguous() and q.dtype == torch.float32 and q.numel() == C_ * m and G.numel() == m * m
+    check(_lib.lib().cvcs_bn_gram_finalize(G.data_ptr(), s.data_ptr(), w.data_ptr(), C_, m, M, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
+                                           rvar.data_ptr(), momentum, eps, scale.data_ptr(), shift.data_ptr(), save_mean.data_ptr(),
+                                           save_invstd.data_ptr(), q.data_ptr(), _stream()), "cvcs_bn_gram_finalize")
+
+
+def bn_gram_bwd(r, sum_dz, w, q, s, M, scale, save_mean, save_invstd, dgamma, dbeta, dw, wd2, coef):
+    """BatchNorm backward of y = w a without y: r = dz^T a (f32 [C, m]), sum_dz (f32 [C]) -> dgamma, dbeta, dw (f32 [C, m]), the dz columns of
+    the packed two-source data-gradient weight wd2 (bf16 [m, C + m]), coef (f32 [2, C]: kappa, beta0)"""
+    C_, m = w.shape[-2], w.shape[-1]
+    assert r.dtype == torch.float32 and r.numel() == C_ * m and dw.numel() == C_ * m and dw.is_contiguous() and wd2.dtype == torch.bfloat16
+    assert wd2.numel() == m * (C_ + m) and coef.numel() == 2 * C_ and sum_dz.numel() == C_
+    check(_lib.lib().cvcs_bn_gram_bwd(r.data_ptr(), sum_dz.data_ptr(), w.data_ptr(), q.data_ptr(), s.data_ptr(), C_, m, M, scale.data_ptr(),
+                                      save_mean.data_ptr(), save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dw.data_ptr(),
+                                      wd2.data_ptr(), coef.data_ptr(), _stream()), "cvcs_bn_gram_bwd")
+
+
+def bn_gram_mmat(w, coef, wd2, bias):
+    """the `a` columns of wd2 (w^T diag(kappa) w) and the data gradient's bias w^T beta0 (f32 [m])"""
+    C_, m = w.shape[-2], w.shape[-1]
+    assert bias.dtype == torch.float32 and bias.numel() == m
+    check(_lib.lib().cvcs_bn_gram_mmat(w.data_ptr(), coef.data_ptr(), C_, m, wd2.data_ptr(), bias.data_ptr(), _stream()), "cvcs_bn_gram_mmat")
 
 
 # ------------------------------------------------------------------------------------------------ residual networks

@@ -125,6 +125,10 @@ class ResNetUNetEngine:
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
         self.gather_shortcut = os.environ.get("CVCS_GATHER_SHORTCUT", "1") == "1"   # stride-2 projection shortcuts on compact even-pixel maps (_block)
         self.fuse_tail_bn = os.environ.get("CVCS_FUSE_TAIL_BN", "1") == "1"  # the residual tails' BatchNorm reduce passes on relu_bwd_sum (_block)
+        # bottleneck tails without a stored conv3 output: BatchNorm statistics from the Gram matrix of conv3's input, BatchNorm + shortcut +
+        # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
+        self.gram_bn = os.environ.get("CVCS_GRAM_BN", "1") == "1"
+        self.gram_max_m = int(os.environ.get("CVCS_GRAM_MAX_M", "256"))   # widest conv3 input that takes the path (the finalizes are O(C m^2))
         # Weight gradients are off the critical chain of backward (dy -> data gradient -> BatchNorm backward of the layer below): they
         # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
         # beside the HBM-bound BatchNorm / residual passes (CVCS_OVERLAP_WGRAD=0: one stream, in program order)
@@ -136,6 +140,7 @@ class ResNetUNetEngine:
         self._dy_toggle = 0
         self.keep_all = False            # tests: every backward intermediate in its own buffer (no scratch reuse) + a registry
         self.bwd_units = {}
+        self.bwd_gram = {}               # keep_all: the Gram-path tails (dz, data gradient) by conv name
 
     # ------------------------------------------------------------------------------------------------ binding
     def bind(self, params, grads, buffers):
@@ -376,7 +381,8 @@ class ResNetUNetEngine:
                 self._register_q8(a1.v.t, "a:" + p + ".conv2")
             u1 = self._unit(h.v, p + ".conv1", p + ".bn1", 1, 1, 0, train, a1.v)
             u2 = self._unit(a1.v, p + ".conv2", p + ".bn2", 3, stride, dil, train, a2.v, dil=dil)
-            ut = self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
+            gram = train and self._gram_ok(p, a2.v, out)
+            ut = self._unit_gram(a2.v, p + ".conv3", p + ".bn3") if gram else self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
             chain = [(u1, h, a1), (u2, a1, a2)]
             last_in = a2
         if has_ds and stride == 2 and self.gather_shortcut:
@@ -389,13 +395,46 @@ class ResNetUNetEngine:
             ud.half_out = True            # its data gradient lives at half the resolution of h (scattered by the consumer)
         else:
             ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
-        self._tail(ut, ud, h, out, train)
+        if getattr(ut, "gram", False):
+            # conv3 -> BatchNorm -> + shortcut (its own BatchNorm for a projection) -> ReLU in ONE launch: the conv output is never stored
+            s3 = self.bn[ut.bn]
+            ops.SCOPE = "enc"
+            ut.out, ut.res, ut.res_bn = out, (ud.y if ud is not None else h.v), (ud.bn if ud is not None else None)   # (tests)
+            if ud is not None:
+                sd = self.bn[ud.bn]
+                ops.conv2d(a2.v, self.packed[ut.conv]["wf"], None, out, 1, 1, relu=True, pre_affine=(s3.scale, s3.shift), res=ud.y, res_affine=(sd.scale, sd.shift))
+            else:
+                ops.conv2d(a2.v, self.packed[ut.conv]["wf"], None, out, 1, 1, relu=True, pre_affine=(s3.scale, s3.shift), res=h.v)
+        else:
+            self._tail(ut, ud, h, out, train)
         self.relu_order.append(out if self._grid == 1 else GridView(out, self._grid))
         o = Act(out)
         if train:
             def bwd():
                 dz = ops.view(self._act(p + ".dz", out.B, out.H, out.W, out.C))
                 red_t = red_d = None
+                if getattr(ut, "gram", False):
+                    # no pass over a conv3 output: the tail's backward is the gradient sum under the ReLU mask (+ the reduce pass of the
+                    # projection shortcut's BatchNorm, which still has a stored output)
+                    if ud is not None and self.fuse_tail_bn:
+                        n_ = ops.bn_bwd_rows(out.B * out.H * out.W) * out.C
+                        pz = [self._scratch(f"tz{i}", n_) for i in range(2)]
+                        rows_t = ops.relu_bwd_sum_bn(o.v, o.grads, dz, [(ud.y, self.bn[ud.bn].mean, self.bn[ud.bn].invstd)], pz[0], pz[1:2])
+                        red_d = (pz[0], pz[1], rows_t)
+                    else:
+                        ops.relu_bwd_sum(o.v, o.grads, dz)
+                    last_in.grads.append((self._gram_bwd(ut, dz, p + ".g_t"), False))
+                    for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
+                        assert len(aout.grads) == 1
+                        dy = self._unit_bwd(u, aout.grads[0][0], 0)
+                        xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
+                    if ud is not None:
+                        dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
+                        h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
+                    else:
+                        h.grads.append((dz, False))
+                    self._ready(p + ".conv1.weight")
+                    return
                 if self.fuse_tail_bn and not getattr(ut, "gn", False):
                     # the reduce passes of the block's last BatchNorm and of the downsample BatchNorm ride on the tail's backward pass
                     st_t = self.bn[ut.bn]
@@ -433,6 +472,58 @@ class ResNetUNetEngine:
                 self._ready(p + ".conv1.weight")
             tape.append(bwd)
         return o
+
+    # ------------------------------------------------------------------------------------------------ BatchNorm from the Gram matrix
+    def _gram_ok(self, p, a: View, out: View):
+        """does the block's conv3 -> bn3 -> (+ shortcut) -> ReLU run without a stored conv3 output?  bf16 bottlenecks whose conv3 input is
+        64 ... gram_max_m wide; not in exact data-parallel mode (its exchanges are written against per-layer moments) and not when the block
+        output also leaves as an fp8 image (the tail pass writes that image)"""
+        return (self.gram_bn and self.kind == "bottleneck" and self.dtype == torch.bfloat16 and self.sync_bn is None and
+                (p + ".bn3.running_mean") in self.Bf and a.C % 64 == 0 and 64 <= a.C <= self.gram_max_m and out.C % 128 == 0 and
+                self._q8_of(out) is None)
+
+    def _unit_gram(self, a: View, conv, bn) -> Unit:
+        """statistics of bn(conv1x1(a)) from the Gram matrix of a: scale / shift / saved statistics / running statistics, Q = W G kept for
+        the backward.  The conv itself runs in _block with the BatchNorm in its epilogue."""
+        wf = self.packed[conv]["wf"]
+        C_, m = wf.shape[1], wf.shape[2]
+        M = a.B * a.H * a.W
+        st = self.bn[bn]
+        G = self._buf(conv + ".gram", (m, m), torch.float64)
+        sv = self._buf(conv + ".gram_s", (m,), torch.float64)
+        q = self._buf(conv + ".gram_q", (C_, m), torch.float32)
+        ops.SCOPE = "enc"
+        ops.gram(a, G, sv, self._scratch("gram_ws", ops.gram_workspace_floats(M, m)))
+        ops.bn_gram_finalize(G, sv, wf, M, self.P[bn + ".weight"], self.P[bn + ".bias"], self.Bf[bn + ".running_mean"], self.Bf[bn + ".running_var"],
+                             st.scale, st.shift, st.mean, st.invstd, q)
+        u = Unit(a, None, conv, bn, 1, 1, 0)
+        u.gram, u.gram_s, u.gram_q = True, sv, q
+        self.units[conv] = (u, None)
+        return u
+
+    def _gram_bwd(self, u: Unit, dz: View, name) -> View:
+        """backward of conv1x1 -> BatchNorm given dz (gradient w.r.t. the BatchNorm output): R = dz^T a and sum dz from the weight-gradient
+        GEMM, coefficients + dW + the packed two-source weight from cvcs_bn_gram_bwd / _mmat, the data gradient as ONE GEMM over [dz | a]"""
+        a, st = u.x, self.bn[u.bn]
+        wf = self.packed[u.conv]["wf"]
+        C_, m = wf.shape[1], wf.shape[2]
+        M = a.B * a.H * a.W
+        R = self._scratch("gram_R", C_ * m)
+        sdz = self._scratch("gram_sdz", C_)
+        coef = self._scratch("gram_coef", 2 * C_)
+        wd2 = self._buf(u.conv + ".wd2", (1, m, C_ + m))
+        bias2 = self._buf(u.conv + ".bias2", (m,), torch.float32)
+        need = ops.wgrad_workspace_floats_for(a, dz, 1, 1, 1, 0, with_bias=True)
+        ops.conv2d_wgrad(a, dz, R, 1, 1, 1, 0, self._scratch("wg_ws", need), dbias=sdz)
+        ops.bn_gram_bwd(R, sdz, wf, u.gram_q, u.gram_s, M, st.scale, st.mean, st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
+                        self.G[u.conv + ".weight"], wd2, coef)
+        ops.bn_gram_mmat(wf, coef, wd2, bias2)
+        gx = ops.view(self._act(name, a.B, a.H, a.W, m))
+        ops.SCOPE = "enc"
+        ops.conv2d(dz, wd2, bias2, gx, 1, 1, x2=a)
+        if self.keep_all:
+            self.bwd_gram[u.conv] = dict(unit=u, dz=dz, gx=gx)
+        return gx
 
     # ------------------------------------------------------------------------------------------------ backward pieces
     def _fusable(self, producer: Unit, consumer: Unit):

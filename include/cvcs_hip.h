@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 12
+#define CVCS_ABI_VERSION 13
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_E4M3 = 0, CVCS_E5M2 = 1 };   /* OCP fp8 formats of the fp8 convolution path (gfx950: e4m3fn / e5m2, not the MI300 fnuz forms) */
@@ -97,6 +97,16 @@ typedef struct {
    * stride (2, 1) over 32 virtual channels = (kw, c) pairs - seven K-steps instead of 49.                          */
   int32_t aniso, stride_w, pad_w;
   int64_t in_row_pitch, in_img_pitch;
+  /* ---- ABI 13 (bf16 1x1 / stride 1 launches; all NULL / 0 = none) --------------------------------------------------------
+   * res: a residual tile ADDED between the pre-affine and the ReLU - out = relu?(pre_scale*acc + pre_shift + r), r = res[p, n]
+   * or res_scale[n]*res[p, n] + res_shift[n] (the projection shortcut's own BatchNorm).  With pre_scale / pre_shift from
+   * cvcs_bn_gram_finalize this is the whole tail of a bottleneck block - conv3 -> BatchNorm -> + shortcut -> ReLU - in the conv's
+   * epilogue: the conv output itself is never stored (torchvision Bottleneck.forward as used by S/nets.py:234-311).
+   * in2: a SECOND contraction source of the same pixels - out[p, n] = sum_c in[p, c] wt[n][c] + sum_c in2[p, c] wt[n][Cin + c],
+   * `wt` rows Cin + Cin2 long (the data gradient of such a block, see cvcs_bn_gram_bwd).                                    */
+  const void* res;   int64_t res_ld;
+  const float* res_scale;  const float* res_shift;
+  const void* in2;   int64_t in2_ld;  int32_t Cin2;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
@@ -618,6 +628,31 @@ int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream);
 /* x[0..n) *= *scalar_device unless it is exactly 1 (decided on the device: no host synchronisation).  Used for the incoming gradient of the fused
  * cross-entropy (`loss.backward()` hands a 1; `(loss / k).backward()` a 1 / k) - replaces a float(tensor) comparison on the host.              */
 int cvcs_scale_unless_one(float* x, int64_t n, const float* scalar_device, void* stream);
+/* ---- BatchNorm behind a 1x1 convolution WITHOUT materialising the convolution output (ABI 13) -----------------------------------
+ * replaces: the last conv1x1 -> nn.BatchNorm2d -> (+ shortcut) -> ReLU of a ResNet bottleneck (torchvision Bottleneck, the encoders of
+ * S/nets.py:234-311) in train mode, forward and backward, for y = W a over the M pixels of a map (a: [M][m] bf16, W: [C][m] bf16).
+ * The batch statistics of y are functions of the m x m second-moment ("Gram") matrix of a: mean_c = w_c . s / M,
+ * E[y_c^2] = w_c^T G w_c / M with G = sum_p a_p a_p^T, s = sum_p a_p - so y (4x wider than a in a bottleneck) is never written or read:
+ *   cvcs_gram              G (f64 [m][m]) and s (f64 [m]) of a view: one streaming pass on the matrix cores (partial slabs summed in f64,
+ *                          fixed order); workspace = cvcs_gram_workspace_floats(M, m) floats
+ *   cvcs_bn_gram_finalize  what cvcs_bn_finalize(train=1) does, from (G, s): scale / shift / saved mean / invstd / running statistics;
+ *                          also Q = W G (f32 [C][m]) for the backward
+ *   (forward: cvcs_conv2d with pre_scale / pre_shift (+ res) applies the BatchNorm (+ shortcut, ReLU) in the conv's epilogue)
+ *   cvcs_bn_gram_bwd       given R = dz^T a (f32 [C][m], the plain weight-gradient GEMM of dz against a) and sum_dz (f32 [C], its dbias):
+ *                          sum_p dz_c y_c = w_c . R_c, so dgamma / dbeta need no pass over y either; with dy = alpha dz + beta0 + kappa y
+ *                          (the BatchNorm backward, per channel) the weight gradient is dW_c = alpha_c R_c + beta0_c s + kappa_c Q_c, and the
+ *                          data gradient W^T dy = (W^T diag(alpha)) dz + (W^T diag(kappa) W) a + W^T beta0: ONE GEMM over the two sources
+ *                          [dz | a] (cvcs_conv_desc.in2) with the packed weight wd2 [m][C + m] bf16 and bias [m] written here (first C columns)
+ *                          and by cvcs_bn_gram_mmat (last m columns + bias), coefficients kappa / beta0 in coef [2][C].                  */
+int64_t cvcs_gram_workspace_floats(int64_t M, int C);
+int cvcs_gram(const void* x, int64_t x_ld, int64_t M, int C, double* gram, double* colsum, float* workspace, void* stream);
+int cvcs_bn_gram_finalize(const double* gram, const double* colsum, const void* w_bf16, int C, int m, int64_t M,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          float* scale, float* shift, float* save_mean, float* save_invstd, float* q_out, void* stream);
+int cvcs_bn_gram_bwd(const float* r, const float* sum_dz, const void* w_bf16, const float* q, const double* colsum, int C, int m, int64_t M,
+                     const float* scale, const float* save_mean, const float* save_invstd,
+                     float* dgamma, float* dbeta, float* dw, void* wd2_bf16, float* coef, void* stream);
+int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, void* stream);
 /* A recorded launch plan driven from C (host time per step < 0.5 ms).  A plan is the list of launch entry points of
  * THIS header that one pass of a network issues for one input shape, with their arguments (every pointer a persistent buffer).  cvcs_call holds one
  * launch: the function, its integer-class arguments in declaration order WITHOUT the trailing stream (pointers, int, int64_t), and its float
