@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("in_row_pitch", C.c_int64), ("in_img_pitch", C.c_int64),
         ("res", C.c_void_p), ("res_ld", C.c_int64), ("res_scale", C.c_void_p), ("res_shift", C.c_void_p),
         ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32),
+        ("mask", C.c_void_p), ("mask_ld", C.c_int64),
     ]
 
 
@@ -239,7 +240,8 @@ SIGNATURES = {
     "cvcs_gram": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     "cvcs_bn_gram_finalize": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_gram_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "cvcs_bn_gram_mmat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "cvcs_bn_gram_mmat_workspace_floats": (_i64, [_i, _i]),
+    "cvcs_bn_gram_mmat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "cvcs_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
     "cvcs_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }
@@ -250,7 +252,7 @@ _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvc
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
             "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_dwconv_rows", "cvcs_dwconv_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay",
-            "cvcs_gram_workspace_floats"}
+            "cvcs_gram_workspace_floats", "cvcs_bn_gram_mmat_workspace_floats"}
 C_REPLAY = os.environ.get("CVCS_C_REPLAY", "1") == "1"     # single-stream replays without timers run from C (cvcs_replay)
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 

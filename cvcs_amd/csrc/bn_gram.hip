@@ -19,15 +19,17 @@ namespace cvcs {
 
 constexpr int kGfCB = 8;      // channels per workgroup of the forward finalize
 
-// One workgroup = kGfCB output channels.  v[cb][j] = sum_k G[k][j] w[c][k] (thread = column j: coalesced reads of G's rows, G symmetric),
+// One workgroup = kGfCB output channels.  v[cb][j] = sum_k G[k][j] w[c][k] (a thread owns column j: coalesced reads of G's rows, G symmetric),
 // then q_c = sum_j v[cb][j] w[c][j] and mean_c = sum_k w[c][k] s[k] / M.  All in f64: var = q / M - mean^2 cancels.
+// The chain is latency-bound (one dependent L2 read per k): for m < 256 the k range is split over the 256 / m thread groups of the workgroup and
+// merged through LDS in group order; every thread keeps 8 independent loads in flight.
 __global__ __launch_bounds__(256) void bn_gram_finalize_kernel(const double* __restrict__ G, const double* __restrict__ s, const bf16_t* __restrict__ W,
                                                               int C, int m, int64_t M, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* rmean, float* rvar, float momentum, float eps,
                                                               float* scale, float* shift, float* save_mean, float* save_invstd, float* q_out) {
   extern __shared__ double sm[];
   double* wl = sm;                      // [kGfCB][m]
-  double* red = sm + kGfCB * m;         // [2][kGfCB][256]
+  double* red = sm + kGfCB * m;         // [2][kGfCB][256], also the [groups][kGfCB][m] merge buffer of the k split
   const int c0 = blockIdx.x * kGfCB, tid = threadIdx.x;
   for (int i = tid; i < kGfCB * m; i += 256) {
     const int cb = i / m, k = i - cb * m;
@@ -37,31 +39,71 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_kernel(const double* __r
   double pq[kGfCB], pm[kGfCB];
 #pragma unroll
   for (int cb = 0; cb < kGfCB; ++cb) { pq[cb] = 0.0; pm[cb] = 0.0; }
-  for (int j = tid; j < m; j += 256) {
+  const int groups = m >= 256 ? 1 : 256 / m;          // thread groups sharing a column
+  const int jt = m >= 256 ? tid : tid % m, kg = m >= 256 ? 0 : tid / m;
+  const int kper = m / groups;                          // (m and groups are powers of two times 32 / 64: m % groups == 0 for m = 32 ... 512)
+  for (int j = jt; j < m; j += 256) {
     double v[kGfCB];
 #pragma unroll
     for (int cb = 0; cb < kGfCB; ++cb) v[cb] = 0.0;
-    for (int k = 0; k < m; ++k) {
+    const int kb = kg * kper, ke = kb + kper;
+    int k = kb;
+    for (; k + 8 <= ke; k += 8) {
+      double g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g[u] = G[(int64_t)(k + u) * m + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int cb = 0; cb < kGfCB; ++cb) v[cb] += g[u] * wl[cb * m + k + u];
+    }
+    for (; k < ke; ++k) {
       const double g = G[(int64_t)k * m + j];
 #pragma unroll
       for (int cb = 0; cb < kGfCB; ++cb) v[cb] += g * wl[cb * m + k];
     }
-    const double sj = s[j];
+    if (groups > 1) {
+      // merge the k ranges in group order (one j per thread when m < 256)
 #pragma unroll
-    for (int cb = 0; cb < kGfCB; ++cb) {
-      if (c0 + cb < C) q_out[(int64_t)(c0 + cb) * m + j] = (float)v[cb];
-      pq[cb] += v[cb] * wl[cb * m + j];
-      pm[cb] += sj * wl[cb * m + j];
+      for (int cb = 0; cb < kGfCB; ++cb) red[(kg * kGfCB + cb) * m + j] = v[cb];
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int cb = 0; cb < kGfCB; ++cb) {
+          double t = red[cb * m + j];
+          for (int q = 1; q < groups; ++q) t += red[(q * kGfCB + cb) * m + j];
+          v[cb] = t;
+        }
+      }
+      __syncthreads();
+    }
+    if (kg == 0) {
+      const double sj = s[j];
+#pragma unroll
+      for (int cb = 0; cb < kGfCB; ++cb) {
+        if (c0 + cb < C) q_out[(int64_t)(c0 + cb) * m + j] = (float)v[cb];
+        pq[cb] += v[cb] * wl[cb * m + j];
+        pm[cb] += sj * wl[cb * m + j];
+      }
     }
   }
 #pragma unroll
   for (int cb = 0; cb < kGfCB; ++cb) { red[cb * 256 + tid] = pq[cb]; red[(kGfCB + cb) * 256 + tid] = pm[cb]; }
   __syncthreads();
+  // 16 lanes per channel sum the 256 per-thread partials (threads that own no column hold zeros), merged in lane order
+  {
+    const int cb = tid >> 4, l = tid & 15;
+    double q = 0.0, mu = 0.0;
+    if (cb < kGfCB)
+      for (int t = l; t < 256; t += 16) { q += red[cb * 256 + t]; mu += red[(kGfCB + cb) * 256 + t]; }
+    __syncthreads();
+    if (cb < kGfCB) { red[cb * 16 + l] = q; red[(kGfCB + cb) * 16 + l] = mu; }
+    __syncthreads();
+  }
   if (tid < kGfCB && c0 + tid < C) {
     const int c = c0 + tid;
     double q = 0.0, mu = 0.0;
-    const int n = m < 256 ? m : 256;     // (threads beyond m contributed zeros)
-    for (int t = 0; t < n; ++t) { q += red[tid * 256 + t]; mu += red[(kGfCB + tid) * 256 + t]; }
+    for (int t = 0; t < 16; ++t) { q += red[tid * 16 + t]; mu += red[(kGfCB + tid) * 16 + t]; }
     const double Md = (double)M;
     mu /= Md;
     double var = q / Md - mu * mu;
@@ -127,44 +169,60 @@ __global__ __launch_bounds__(256) void bn_gram_bwd_kernel(const float* __restric
   }
 }
 
-// Mmat[j][k] = sum_c kappa_c w_cj w_ck -> wd2[j][C + k]; bias[j] = sum_c beta0_c w_cj.  32 x 32 outputs per workgroup, 2 x 2 per thread.
-__global__ __launch_bounds__(256) void bn_gram_mmat_kernel(const bf16_t* __restrict__ W, const float* __restrict__ coef, int C, int m, bf16_t* wd2,
-                                                          float* bias) {
-  constexpr int CK = 32;
-  __shared__ float wj[CK][33], wk[CK][33], kap[CK], b0[CK];
-  const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+// Mmat[j][k] = sum_c kappa_c w_cj w_ck -> wd2[j][C + k]; bias[j] = sum_c beta0_c w_cj.  Latency matters more than FLOPs here (the launch sits
+// on the backward's critical chain): one workgroup = a 32 x 32 output tile x ONE chunk of kMmCK channels, partial tiles [chunk][m][m] (+ bias rows
+// [chunk][m]) to a workspace; bn_gram_mmat_reduce_kernel sums the chunks in order and writes the bf16 columns.
+constexpr int kMmCK = 64;
+__global__ __launch_bounds__(256) void bn_gram_mmat_kernel(const bf16_t* __restrict__ W, const float* __restrict__ coef, int C, int m, float* part) {
+  __shared__ float wj[kMmCK][33], wk[kMmCK][33], b0[kMmCK];
+  const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32, cc = blockIdx.z * kMmCK;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  float bacc = 0.f;
-  const bool do_bias = blockIdx.x == 0;
-  for (int cc = 0; cc < C; cc += CK) {
-    for (int i = threadIdx.x; i < CK * 32; i += 256) {
-      const int r = i >> 5, q = i & 31;
-      const int c = cc + r;
-      const bool ok = c < C;
-      const float kv = ok ? coef[c] : 0.f;
-      wj[r][q] = ok ? bf16_to_f32(W[(int64_t)c * m + j0 + q]) : 0.f;
-      wk[r][q] = ok ? bf16_to_f32(W[(int64_t)c * m + k0 + q]) * kv : 0.f;
-      if (q == 0) { kap[r] = kv; b0[r] = ok ? coef[C + c] : 0.f; }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < CK; ++r) {
-      const float a0 = wj[r][ty], a1 = wj[r][ty + 16], c0 = wk[r][tx], c1 = wk[r][tx + 16];
-      acc[0][0] += a0 * c0; acc[0][1] += a0 * c1; acc[1][0] += a1 * c0; acc[1][1] += a1 * c1;
-    }
-    if (do_bias && threadIdx.x < 32) {
-#pragma unroll 8
-      for (int r = 0; r < CK; ++r) bacc += b0[r] * wj[r][threadIdx.x];
-    }
-    __syncthreads();
+  for (int i = threadIdx.x; i < kMmCK * 32; i += 256) {
+    const int r = i >> 5, q = i & 31;
+    const int c = cc + r;
+    const bool ok = c < C;
+    const float kv = ok ? coef[c] : 0.f;
+    wj[r][q] = ok ? bf16_to_f32(W[(int64_t)c * m + j0 + q]) : 0.f;
+    wk[r][q] = ok ? bf16_to_f32(W[(int64_t)c * m + k0 + q]) * kv : 0.f;
+    if (q == 0) b0[r] = ok ? coef[C + c] : 0.f;
   }
-  const int ktot = C + m;
+  __syncthreads();
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll 8
+  for (int r = 0; r < kMmCK; ++r) {
+    const float a0 = wj[r][ty], a1 = wj[r][ty + 16], c0 = wk[r][tx], c1 = wk[r][tx + 16];
+    acc[0][0] += a0 * c0; acc[0][1] += a0 * c1; acc[1][0] += a1 * c0; acc[1][1] += a1 * c1;
+  }
+  float* pt = part + (int64_t)blockIdx.z * ((int64_t)m * m + m);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) wd2[(int64_t)(j0 + ty + 16 * a) * ktot + C + k0 + tx + 16 * b] = f32_to_bf16(acc[a][b]);
-  if (do_bias && threadIdx.x < 32) bias[j0 + threadIdx.x] = bacc;
+    for (int b = 0; b < 2; ++b) pt[(int64_t)(j0 + ty + 16 * a) * m + k0 + tx + 16 * b] = acc[a][b];
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    float bacc = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < kMmCK; ++r) bacc += b0[r] * wj[r][threadIdx.x];
+    pt[(int64_t)m * m + j0 + threadIdx.x] = bacc;
+  }
+}
+__global__ __launch_bounds__(256) void bn_gram_mmat_reduce_kernel(const float* __restrict__ part, int nchunk, int C, int m, bf16_t* wd2, float* bias) {
+  const int64_t total = (int64_t)m * m + m;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  float a = 0.f;
+  int z = 0;
+  for (; z + 4 <= nchunk; z += 4) {
+    const float v0 = part[(int64_t)z * total + id], v1 = part[(int64_t)(z + 1) * total + id];
+    const float v2 = part[(int64_t)(z + 2) * total + id], v3 = part[(int64_t)(z + 3) * total + id];
+    a += v0; a += v1; a += v2; a += v3;
+  }
+  for (; z < nchunk; ++z) a += part[(int64_t)z * total + id];
+  if (id < (int64_t)m * m) {
+    const int j = (int)(id / m), k = (int)(id - (int64_t)j * m);
+    wd2[(int64_t)j * (C + m) + C + k] = f32_to_bf16(a);
+  } else {
+    bias[id - (int64_t)m * m] = a;
+  }
 }
 
 }  // namespace cvcs
@@ -177,7 +235,7 @@ extern "C" int cvcs_bn_gram_finalize(const double* gram, const double* colsum, c
   CVCS_CHECK_ARG(gram && colsum && w_bf16 && gamma && beta && running_mean && running_var && scale && shift && save_mean && save_invstd && q_out,
                  "cvcs_bn_gram_finalize: null argument");
   CVCS_CHECK_ARG(C > 0 && m >= 32 && m % 32 == 0 && m <= 512 && M > 0, "cvcs_bn_gram_finalize: C=%d m=%d (m: a multiple of 32 up to 512)", C, m);
-  const size_t lds = (size_t)(kGfCB * m + 2 * kGfCB * 256) * sizeof(double);
+  const size_t lds = (size_t)(kGfCB * m + 2 * kGfCB * 256) * sizeof(double);      // (the k-split merge buffer [256 / m][kGfCB][m] has the same size)
   hipLaunchKernelGGL(bn_gram_finalize_kernel, dim3((unsigned)cdiv(C, kGfCB)), dim3(256), lds, (hipStream_t)stream, gram, colsum, (const bf16_t*)w_bf16, C, m, M,
                      gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, q_out);
   CVCS_CHECK_LAUNCH("cvcs_bn_gram_finalize");
@@ -196,11 +254,20 @@ extern "C" int cvcs_bn_gram_bwd(const float* r, const float* sum_dz, const void*
   return CVCS_OK;
 }
 
-extern "C" int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, void* stream) {
-  CVCS_CHECK_ARG(w_bf16 && coef && wd2_bf16 && bias, "cvcs_bn_gram_mmat: null argument");
+extern "C" int64_t cvcs_bn_gram_mmat_workspace_floats(int C, int m) {
+  if (C <= 0 || m < 32 || m % 32 != 0 || m > 512) return CVCS_EINVAL;
+  return cdiv(C, kMmCK) * ((int64_t)m * m + m);
+}
+
+extern "C" int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, float* workspace, void* stream) {
+  CVCS_CHECK_ARG(w_bf16 && coef && wd2_bf16 && bias && workspace, "cvcs_bn_gram_mmat: null argument");
   CVCS_CHECK_ARG(C > 0 && m >= 32 && m % 32 == 0 && m <= 512, "cvcs_bn_gram_mmat: C=%d m=%d", C, m);
-  hipLaunchKernelGGL(bn_gram_mmat_kernel, dim3((unsigned)(m / 32), (unsigned)(m / 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_bf16, coef, C, m,
-                     (bf16_t*)wd2_bf16, bias);
+  const int nchunk = (int)cdiv(C, kMmCK);
+  hipLaunchKernelGGL(bn_gram_mmat_kernel, dim3((unsigned)(m / 32), (unsigned)(m / 32), (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)w_bf16, coef, C, m, workspace);
   CVCS_CHECK_LAUNCH("cvcs_bn_gram_mmat");
+  hipLaunchKernelGGL(bn_gram_mmat_reduce_kernel, dim3((unsigned)cdiv((int64_t)m * m + m, 256)), dim3(256), 0, (hipStream_t)stream, workspace, nchunk, C, m,
+                     (bf16_t*)wd2_bf16, bias);
+  CVCS_CHECK_LAUNCH("cvcs_bn_gram_mmat(reduce)");
   return CVCS_OK;
 }

@@ -55,6 +55,7 @@ struct ConvArgs {
   // ABI 13 (1x1 / stride 1): residual tile added between the pre-affine and the ReLU (taps kernel); second contraction source
   const char* res; int64_t res_ld; const float* res_scale; const float* res_shift;
   const char* in2; int64_t in2_ld; int Cin2;
+  const char* mask; int64_t mask_ld;   // taps kernel: out = (mask > 0) ? value : 0 (the ReLU backward of the activation the gradient belongs to)
 };
 
 template <typename T> struct Mma;
@@ -1251,12 +1252,19 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
     for (int j = 0; j < 4; ++j) {
       asm volatile("" ::: "memory");
       const int ch = n0 + wn * 64 + j * 16 + fg * 4;
-      uint2 rv[4];
+      uint2 rv[4], mv[4];
       if (p.res) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           int m = m0 + wm * 64 + i * 16 + fr; m = m < p.M ? m : p.M - 1;
           rv[i] = *reinterpret_cast<const uint2*>(p.res + ((int64_t)m * p.res_ld + ch) * ES);
+        }
+      }
+      if (p.mask) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int m = m0 + wm * 64 + i * 16 + fr; m = m < p.M ? m : p.M - 1;
+          mv[i] = *reinterpret_cast<const uint2*>(p.mask + ((int64_t)m * p.mask_ld + ch) * ES);
         }
       }
       if (p.pre_scale) {
@@ -1280,6 +1288,16 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
           acc[i][j][1] += __uint_as_float(u.x & 0xffff0000u) * rs[1] + rt[1];
           acc[i][j][2] += __uint_as_float(u.y << 16) * rs[2] + rt[2];
           acc[i][j][3] += __uint_as_float(u.y & 0xffff0000u) * rs[3] + rt[3];
+        }
+      }
+      if (p.mask) {      // bf16 > 0 <=> sign bit clear and not zero
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint2 u = mv[i];
+          acc[i][j][0] = __uint_as_float(u.x << 16) > 0.f ? acc[i][j][0] : 0.f;
+          acc[i][j][1] = __uint_as_float(u.x & 0xffff0000u) > 0.f ? acc[i][j][1] : 0.f;
+          acc[i][j][2] = __uint_as_float(u.y << 16) > 0.f ? acc[i][j][2] : 0.f;
+          acc[i][j][3] = __uint_as_float(u.y & 0xffff0000u) > 0.f ? acc[i][j][3] : 0.f;
         }
       }
     }
@@ -1674,6 +1692,11 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   }
   a.res = (const char*)d->res; a.res_ld = d->res_ld; a.res_scale = d->res_scale; a.res_shift = d->res_shift;
   a.in2 = (const char*)d->in2; a.in2_ld = d->in2_ld; a.Cin2 = d->in2 ? d->Cin2 : 0;
+  a.mask = (const char*)d->mask; a.mask_ld = d->mask_ld;
+  if (d->mask) {
+    CVCS_CHECK_ARG(use_taps(d) && d->KH == 1 && !d->stat_sum && !d->relu && !d->pixel_shuffle, "cvcs_conv2d: mask is built for bf16 1x1 launches with Cout %% 128 == 0");
+    CVCS_CHECK_ARG(((uintptr_t)d->mask % 8) == 0 && d->mask_ld >= d->Cout && (d->mask_ld * es) % 8 == 0, "cvcs_conv2d: mask view");
+  }
   if (d->res || d->in2) {
     const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->dil == 1 && !aniso && !pitched && !d->pixel_shuffle;
     CVCS_CHECK_ARG(k1 && d->dtype == CVCS_BF16 && cin_valid == d->Cin, "cvcs_conv2d: res / in2 are built for bf16 1x1 / stride 1 launches");
@@ -1734,7 +1757,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
-  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
-  CVCS_CHECK_ARG(!d->res, "cvcs_conv2d: the residual epilogue runs on the 1x1 taps kernel only");
+  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res || d->mask) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
+  CVCS_CHECK_ARG(!d->res && !d->mask, "cvcs_conv2d: the residual / mask epilogue runs on the 1x1 taps kernel only");
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

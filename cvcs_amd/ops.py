@@ -155,7 +155,7 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None) -> 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
            pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None,
-           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None):
+           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None, mask: View | None = None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...).
     bn_bwd = (y view, scale, shift, mean, invstd, mode, part_dz, part_dzx): the launch also takes the first pass of the
@@ -167,6 +167,10 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         d.res, d.res_ld = res.ptr, res.ld
         if res_affine is not None:
             d.res_scale, d.res_shift = res_affine[0].data_ptr(), res_affine[1].data_ptr()
+    if mask is not None:
+        # ReLU backward in the epilogue: out = value * (mask > 0)
+        assert (mask.B, mask.H, mask.W, mask.C) == (x.B, Ho, Wo, Cout) and mask.t.dtype == x.t.dtype
+        d.mask, d.mask_ld = mask.ptr, mask.ld
     if x2 is not None:
         # second contraction source of the same pixels (bf16 1x1): wt rows are x.C + x2.C long
         assert (x2.B, x2.H, x2.W) == (x.B, x.H, x.W) and x2.t.dtype == x.t.dtype and wt.shape[2] == x.C + x2.C
@@ -522,11 +526,19 @@ def bn_gram_bwd(r, sum_dz, w, q, s, M, scale, save_mean, save_invstd, dgamma, db
                                       wd2.data_ptr(), coef.data_ptr(), _stream()), "cvcs_bn_gram_bwd")
 
 
-def bn_gram_mmat(w, coef, wd2, bias):
+def bn_gram_mmat_workspace_floats(C_: int, m: int) -> int:
+    return _lib.lib().cvcs_bn_gram_mmat_workspace_floats(C_, m)
+
+
+def bn_gram_mmat(w, coef, wd2, bias, workspace=None):
     """the `a` columns of wd2 (w^T diag(kappa) w) and the data gradient's bias w^T beta0 (f32 [m])"""
     C_, m = w.shape[-2], w.shape[-1]
     assert bias.dtype == torch.float32 and bias.numel() == m
-    check(_lib.lib().cvcs_bn_gram_mmat(w.data_ptr(), coef.data_ptr(), C_, m, wd2.data_ptr(), bias.data_ptr(), _stream()), "cvcs_bn_gram_mmat")
+    if workspace is None:
+        workspace = torch.empty(bn_gram_mmat_workspace_floats(C_, m), dtype=torch.float32, device=w.device)
+    assert workspace.dtype == torch.float32 and workspace.numel() >= bn_gram_mmat_workspace_floats(C_, m)
+    check(_lib.lib().cvcs_bn_gram_mmat(w.data_ptr(), coef.data_ptr(), C_, m, wd2.data_ptr(), bias.data_ptr(), workspace.data_ptr(), _stream()),
+          "cvcs_bn_gram_mmat")
 
 
 # ------------------------------------------------------------------------------------------------ residual networks

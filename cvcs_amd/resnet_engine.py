@@ -128,6 +128,7 @@ class ResNetUNetEngine:
         # bottleneck tails without a stored conv3 output: BatchNorm statistics from the Gram matrix of conv3's input, BatchNorm + shortcut +
         # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
         self.gram_bn = os.environ.get("CVCS_GRAM_BN", "1") == "1"
+        self.fuse_tail_dz = os.environ.get("CVCS_FUSE_TAIL_DZ", "1") == "1"   # a Gram tail's dz out of the consumer block's first data-gradient launch (_tail_fusable)
         self.gram_max_m = int(os.environ.get("CVCS_GRAM_MAX_M", "256"))   # widest conv3 input that takes the path (the finalizes are O(C m^2))
         # Weight gradients are off the critical chain of backward (dy -> data gradient -> BatchNorm backward of the layer below): they
         # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
@@ -409,6 +410,8 @@ class ResNetUNetEngine:
             self._tail(ut, ud, h, out, train)
         self.relu_order.append(out if self._grid == 1 else GridView(out, self._grid))
         o = Act(out)
+        if getattr(ut, "gram", False):
+            o.tail_dz, o.dz_ready = p + ".dz", None      # (its tail backward needs no BatchNorm reduce: the consumer's data gradient may write dz, _tail_fusable)
         if train:
             def bwd():
                 dz = ops.view(self._act(p + ".dz", out.B, out.H, out.W, out.C))
@@ -416,7 +419,10 @@ class ResNetUNetEngine:
                 if getattr(ut, "gram", False):
                     # no pass over a conv3 output: the tail's backward is the gradient sum under the ReLU mask (+ the reduce pass of the
                     # projection shortcut's BatchNorm, which still has a stored output)
-                    if ud is not None and self.fuse_tail_bn:
+                    if o.dz_ready is not None:
+                        assert not o.grads
+                        dz = o.dz_ready           # written by the consumer block's first data-gradient launch
+                    elif ud is not None and self.fuse_tail_bn:
                         n_ = ops.bn_bwd_rows(out.B * out.H * out.W) * out.C
                         pz = [self._scratch(f"tz{i}", n_) for i in range(2)]
                         rows_t = ops.relu_bwd_sum_bn(o.v, o.grads, dz, [(ud.y, self.bn[ud.bn].mean, self.bn[ud.bn].invstd)], pz[0], pz[1:2])
@@ -424,14 +430,23 @@ class ResNetUNetEngine:
                     else:
                         ops.relu_bwd_sum(o.v, o.grads, dz)
                     last_in.grads.append((self._gram_bwd(ut, dz, p + ".g_t"), False))
+                    fz, tail_done = None, False
                     for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
                         assert len(aout.grads) == 1
-                        dy = self._unit_bwd(u, aout.grads[0][0], 0)
-                        xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
+                        dy = self._unit_bwd(u, aout.grads[0][0], 0, fused=fz)
+                        fz = None
+                        if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
+                            gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
+                            xin.grads.append((gx, half))
+                        elif n_ == 0 and ud is None and self._tail_fusable(h, u):
+                            self._dgrad_into_tail(u, dy, h, dz)
+                            tail_done = True
+                        else:
+                            xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
                     if ud is not None:
                         dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
                         h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
-                    else:
+                    elif not tail_done:
                         h.grads.append((dz, False))
                     self._ready(p + ".conv1.weight")
                     return
@@ -455,6 +470,7 @@ class ResNetUNetEngine:
                     last_in.grads.append((gx, half))
                 else:
                     last_in.grads.append(self._dgrad(ut, dy, p + ".g_t"))
+                tail_done = False
                 for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
                     assert len(aout.grads) == 1
                     dy = self._unit_bwd(u, aout.grads[0][0], 0, fused=fz)
@@ -462,12 +478,15 @@ class ResNetUNetEngine:
                     if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
                         gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
                         xin.grads.append((gx, half))
+                    elif n_ == 0 and ud is None and self._tail_fusable(h, u):
+                        self._dgrad_into_tail(u, dy, h, dz)
+                        tail_done = True
                     else:
                         xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
                 if ud is not None:
                     dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
                     h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
-                else:
+                elif not tail_done:
                     h.grads.append((dz, False))
                 self._ready(p + ".conv1.weight")
             tape.append(bwd)
@@ -517,13 +536,29 @@ class ResNetUNetEngine:
         ops.conv2d_wgrad(a, dz, R, 1, 1, 1, 0, self._scratch("wg_ws", need), dbias=sdz)
         ops.bn_gram_bwd(R, sdz, wf, u.gram_q, u.gram_s, M, st.scale, st.mean, st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
                         self.G[u.conv + ".weight"], wd2, coef)
-        ops.bn_gram_mmat(wf, coef, wd2, bias2)
+        ops.bn_gram_mmat(wf, coef, wd2, bias2, self._scratch("gram_mm", ops.bn_gram_mmat_workspace_floats(C_, m)))
         gx = ops.view(self._act(name, a.B, a.H, a.W, m))
         ops.SCOPE = "enc"
         ops.conv2d(dz, wd2, bias2, gx, 1, 1, x2=a)
         if self.keep_all:
             self.bwd_gram[u.conv] = dict(unit=u, dz=dz, gx=gx)
         return gx
+
+    def _tail_fusable(self, h: Act, u1: Unit):
+        """can the data-gradient launch of an identity block's first 1x1 conv write the PREVIOUS block's dz = (g_conv1 + g_shortcut) * (out > 0)
+        itself?  The previous block must be a Gram tail (its backward needs no BatchNorm reduce over dz) whose output has no other consumer
+        (the last block of a stage also feeds the decoder), bf16, a channel count the 1x1 taps kernel tiles"""
+        return (self.fuse_tail_dz and getattr(h, "tail_dz", None) is not None and not h.grads and u1.k == 1 and u1.stride == 1 and
+                self.dtype == torch.bfloat16 and h.v.C % 128 == 0 and not getattr(u1, "half_out", False))
+
+    def _dgrad_into_tail(self, u1: Unit, dy: View, h: Act, dz_self: View):
+        v = h.v
+        dzk = ops.view(self._act(h.tail_dz, v.B, v.H, v.W, v.C))
+        ops.SCOPE = "enc"
+        ops.conv2d(dy, self.packed[u1.conv]["wd"], None, dzk, 1, 1, res=dz_self, mask=v)
+        h.dz_ready = dzk
+        if self.keep_all:
+            self.bwd_units[u1.conv]["gx_tail"] = (dzk, dz_self, v)
 
     # ------------------------------------------------------------------------------------------------ backward pieces
     def _fusable(self, producer: Unit, consumer: Unit):

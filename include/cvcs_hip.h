@@ -107,6 +107,10 @@ typedef struct {
   const void* res;   int64_t res_ld;
   const float* res_scale;  const float* res_shift;
   const void* in2;   int64_t in2_ld;  int32_t Cin2;
+  /* mask: out = (mask[p, n] > 0) ? value : 0 after everything else - the ReLU backward of the activation this gradient belongs to.  With
+   * res = the gradient arriving over the identity shortcut, the data-gradient launch of a block's first 1x1 conv writes the PREVIOUS block's
+   * dz = (g_conv1 + g_shortcut) * (out > 0) directly (cvcs_relu_bwd_sum without its pass over three tensors).                  */
+  const void* mask;  int64_t mask_ld;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
@@ -652,7 +656,8 @@ int cvcs_bn_gram_finalize(const double* gram, const double* colsum, const void* 
 int cvcs_bn_gram_bwd(const float* r, const float* sum_dz, const void* w_bf16, const float* q, const double* colsum, int C, int m, int64_t M,
                      const float* scale, const float* save_mean, const float* save_invstd,
                      float* dgamma, float* dbeta, float* dw, void* wd2_bf16, float* coef, void* stream);
-int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, void* stream);
+int64_t cvcs_bn_gram_mmat_workspace_floats(int C, int m);
+int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, float* workspace, void* stream);
 /* A recorded launch plan driven from C (host time per step < 0.5 ms).  A plan is the list of launch entry points of
  * THIS header that one pass of a network issues for one input shape, with their arguments (every pointer a persistent buffer).  cvcs_call holds one
  * launch: the function, its integer-class arguments in declaration order WITHOUT the trailing stream (pointers, int, int64_t), and its float

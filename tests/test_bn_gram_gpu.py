@@ -171,3 +171,21 @@ def test_backward_of_conv1x1_batchnorm_without_the_conv_output(case):
     close(dgamma.cpu(), gam.grad, 2e-4, "dgamma")
     close(dw.cpu(), Wt.grad, 2e-4, "dW")
     close(da.torch().float().cpu().reshape(M, m), A.grad, 2.0 ** -7, "da")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (1, 19, 13, 128, 512)])
+def test_data_gradient_that_writes_the_previous_blocks_dz(case):
+    """dz = (W x + g_shortcut) * (out > 0) in the epilogue of the 1x1 data-gradient launch (cvcs_conv_desc.res + mask): the tail backward of the
+    block below without its pass over three tensors"""
+    B, H, W, m, C_ = case
+    g = torch.Generator().manual_seed(m)
+    dy = _rq(torch.randn(B, H, W, m, generator=g))
+    w = _rq(torch.randn(C_, m, generator=g) / m ** 0.5)
+    gs = _rq(torch.randn(B, H, W, C_, generator=g))
+    out_act = _rq(torch.randn(B, H, W, C_, generator=g).relu())      # half of it exact zeros
+    dz = ops.view(torch.zeros(B, H, W, C_, dtype=BF, device=DEV))
+    ops.conv2d(_dev_view(dy), w.to(BF).to(DEV).view(1, C_, m), None, dz, 1, 1, res=_dev_view(gs, 8, 0), mask=_dev_view(out_act, 0, 8))
+    torch.cuda.synchronize()
+    ref = (dy.double() @ w.double().T + gs.double()) * (out_act > 0)
+    close(dz.torch().float().cpu(), ref, 2.0 ** -8, "fused tail backward")
+    assert (dz.torch().float().cpu()[out_act == 0] == 0).all()

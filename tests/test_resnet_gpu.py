@@ -616,7 +616,7 @@ def test_backward_layer_by_layer(arch, precision, B, S):
     torch.cuda.synchronize()
     f32 = precision == "fp32"
     t_sum, t_dy = (2e-5, 2e-5) if f32 else (2e-3, None)
-    worst = {}
+    worst, n_tail = {}, 0
     for conv, r in eng.bwd_units.items():
         u, g, mode, dy = r["unit"], r["g"], r["mode"], r["dy"]
         y = from_nhwc(u.y.torch()).double()
@@ -656,9 +656,19 @@ def test_backward_layer_by_layer(arch, precision, B, S):
             if u.k == 1 and u.stride == 2:
                 gx_ref = gx_ref[:, :, ::2, ::2]
             e["gx"] = rel_l2(got, gx_ref) if f32 else (got - gx_ref).abs().max().item() / gx_ref.abs().max().item() / 2.0 ** -8 * 2e-3
+        if "gx_tail" in r:
+            # the data gradient of an identity block's first 1x1 conv wrote the PREVIOUS block's dz = (g_conv1 + g_shortcut) * (out > 0) itself
+            dzk, dzs, mv = r["gx_tail"]
+            wq = w if f32 else w.to(torch.bfloat16).float()
+            want = (torch.nn.grad.conv2d_input(x.shape, wq.double(), got_dy, stride=stride, padding=pad) + from_nhwc(dzs.torch()).double()) * \
+                (from_nhwc(mv.torch()) > 0)
+            e["gx_tail"] = (from_nhwc(dzk.torch()).double() - want).abs().max().item() / want.abs().max().item() / 2.0 ** -8 * 2e-3
+            n_tail += 1
         for kk, v in e.items():
             worst[kk] = max(worst.get(kk, (0.0, "")), (v, conv))
         assert all(v <= t_sum for v in e.values()), (conv, e)
+    if arch == "resnet50" and not f32:
+        assert n_tail == (10 if eng.gram_bn and eng.fuse_tail_dz else 0)     # the identity blocks of stages 1-3 write their predecessor's dz
     # the tails that never store a conv3 output: dgamma, dbeta, dW and the data gradient of conv3 -> bn3 against float64 autograd of the same
     # sub-graph from the STORED a2 and dz (the conv output recomputed in float64 from the bf16 operands)
     for conv, r in eng.bwd_gram.items():
