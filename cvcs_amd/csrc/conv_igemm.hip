@@ -1241,64 +1241,22 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
   }
 
   // ---- epilogue: acc[i][j][r] = pixel row wm*64 + i*16 + fr, channel wn*64 + j*16 + fg*4 + r (bias already inside)
-  // A BatchNorm applied here (cvcs_bn_gram_finalize: statistics known BEFORE the launch) and the block's shortcut added in f32: the
-  // tail of a bottleneck block without a stored conv output.  The residual is read in accumulator layout: 8 bytes per (pixel, 4
-  // channels), the four j of a lane cover one 128-byte line of its pixel row.
+  // A BatchNorm applied here (cvcs_bn_gram_finalize: statistics known BEFORE the launch): the tail of a bottleneck block without a stored
+  // conv output.  (One 16-channel column group at a time behind a compiler barrier: hoisted above the main loop, the vector loads cost the
+  // kernel its second workgroup per CU.)  The shortcut / ReLU mask are applied in the store walk below, where a thread owns whole 16-byte
+  // chunks of pixel rows: read in accumulator layout (8 bytes per lane, 16 rows per instruction) they cost 4x the cache-line requests.
   if constexpr (EPI) {
-    // (register-lean: one 16-channel column group j at a time - its scale / shift vectors, the four residual chunks of the lane's pixel
-    //  rows - and a compiler barrier in front of each group so that the loads are not hoisted above the main loop: hoisted, the kernel
-    //  needed 174 registers and lost its second workgroup per CU)
+    if (p.pre_scale) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      asm volatile("" ::: "memory");
-      const int ch = n0 + wn * 64 + j * 16 + fg * 4;
-      uint2 rv[4], mv[4];
-      if (p.res) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int m = m0 + wm * 64 + i * 16 + fr; m = m < p.M ? m : p.M - 1;
-          rv[i] = *reinterpret_cast<const uint2*>(p.res + ((int64_t)m * p.res_ld + ch) * ES);
-        }
-      }
-      if (p.mask) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int m = m0 + wm * 64 + i * 16 + fr; m = m < p.M ? m : p.M - 1;
-          mv[i] = *reinterpret_cast<const uint2*>(p.mask + ((int64_t)m * p.mask_ld + ch) * ES);
-        }
-      }
-      if (p.pre_scale) {
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("" ::: "memory");
+        const int ch = n0 + wn * 64 + j * 16 + fg * 4;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pre_scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pre_shift + ch);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * sc[r] + sh[r];
-      }
-      if (p.res) {
-        f32x4 rs = (f32x4){1.f, 1.f, 1.f, 1.f}, rt = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.res_scale) {
-          rs = *reinterpret_cast<const f32x4*>(p.res_scale + ch);
-          rt = *reinterpret_cast<const f32x4*>(p.res_shift + ch);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint2 u = rv[i];
-          acc[i][j][0] += __uint_as_float(u.x << 16) * rs[0] + rt[0];
-          acc[i][j][1] += __uint_as_float(u.x & 0xffff0000u) * rs[1] + rt[1];
-          acc[i][j][2] += __uint_as_float(u.y << 16) * rs[2] + rt[2];
-          acc[i][j][3] += __uint_as_float(u.y & 0xffff0000u) * rs[3] + rt[3];
-        }
-      }
-      if (p.mask) {      // bf16 > 0 <=> sign bit clear and not zero
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint2 u = mv[i];
-          acc[i][j][0] = __uint_as_float(u.x << 16) > 0.f ? acc[i][j][0] : 0.f;
-          acc[i][j][1] = __uint_as_float(u.x & 0xffff0000u) > 0.f ? acc[i][j][1] : 0.f;
-          acc[i][j][2] = __uint_as_float(u.y << 16) > 0.f ? acc[i][j][2] : 0.f;
-          acc[i][j][3] = __uint_as_float(u.y & 0xffff0000u) > 0.f ? acc[i][j][3] : 0.f;
-        }
       }
     }
   }
@@ -1350,7 +1308,8 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
         *reinterpret_cast<uint2*>(smem + (wm * 64 + i * 16 + fr) * OROW + (wn * 64 + j * 16 + fg * 4) * ES) = u;
       }
   };
-  if (p.relu) stage(std::true_type{}); else stage(std::false_type{});   // wave-uniform
+  const bool walk_epi = EPI && (p.res != nullptr || p.mask != nullptr);      // shortcut / mask (and then the ReLU) in the store walk
+  if (p.relu && !walk_epi) stage(std::true_type{}); else stage(std::false_type{});   // wave-uniform
   __syncthreads();
   {
     constexpr int CPR = BN * ES / 16;   // 16
@@ -1369,6 +1328,43 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
     int m = m0 + lrow0;
     int ox = m % p.Wo, t = m / p.Wo;
     int oy = t % p.Ho, b = t / p.Ho;
+    if constexpr (EPI) {
+      if (walk_epi) {
+        // out = relu?(staged + (res | res_scale * res + res_shift)) * (mask > 0): the staged value is the bf16-rounded BatchNorm output (the
+        // stored conv output of the unfused path was rounded too), the sum is taken in f32
+        u32x4 rr[8], mk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int mr = m0 + lrow0 + k * RPT; mr = mr < p.M ? mr : p.M - 1;
+          if (p.res) rr[k] = *reinterpret_cast<const u32x4*>(p.res + ((int64_t)mr * p.res_ld + n) * ES);
+          if (p.mask) mk[k] = *reinterpret_cast<const u32x4*>(p.mask + ((int64_t)mr * p.mask_ld + n) * ES);
+        }
+        float rs[8], rt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { rs[e] = p.res_scale ? p.res_scale[n + e] : 1.f; rt[e] = p.res_scale ? p.res_shift[n + e] : 0.f; }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float f[8], g[8];
+          Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, v[k]), f);
+          if (p.res) {
+            Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, rr[k]), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e] * rs[e] + rt[e];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+          }
+          if (p.mask) {
+            Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, mk[k]), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = g[e] > 0.f ? f[e] : 0.f;
+          }
+          v[k] = __builtin_bit_cast(u32x4, Elem<bf16_t>::pack(f));
+        }
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1695,7 +1691,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.mask = (const char*)d->mask; a.mask_ld = d->mask_ld;
   if (d->mask) {
     CVCS_CHECK_ARG(use_taps(d) && d->KH == 1 && !d->stat_sum && !d->relu && !d->pixel_shuffle, "cvcs_conv2d: mask is built for bf16 1x1 launches with Cout %% 128 == 0");
-    CVCS_CHECK_ARG(((uintptr_t)d->mask % 8) == 0 && d->mask_ld >= d->Cout && (d->mask_ld * es) % 8 == 0, "cvcs_conv2d: mask view");
+    CVCS_CHECK_ARG(((uintptr_t)d->mask % 16) == 0 && d->mask_ld >= d->Cout && (d->mask_ld * es) % 16 == 0, "cvcs_conv2d: mask view");
   }
   if (d->res || d->in2) {
     const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->dil == 1 && !aniso && !pitched && !d->pixel_shuffle;
@@ -1703,7 +1699,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   }
   if (d->res) {
     CVCS_CHECK_ARG(use_taps(d) && !d->stat_sum, "cvcs_conv2d: a residual epilogue needs Cout %% 128 == 0 and no statistics");
-    CVCS_CHECK_ARG(((uintptr_t)d->res % 8) == 0 && d->res_ld >= d->Cout && (d->res_ld * es) % 8 == 0, "cvcs_conv2d: res view");
+    CVCS_CHECK_ARG(((uintptr_t)d->res % 16) == 0 && d->res_ld >= d->Cout && (d->res_ld * es) % 16 == 0, "cvcs_conv2d: res view");
     CVCS_CHECK_ARG((d->res_scale == nullptr) == (d->res_shift == nullptr), "cvcs_conv2d: res_scale / res_shift go together");
   } else {
     CVCS_CHECK_ARG(!d->res_scale && !d->res_shift, "cvcs_conv2d: res_scale without res");

@@ -99,7 +99,8 @@ def test_batchnorm_statistics_from_the_gram_matrix(case):
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (1, 19, 13, 128, 128), (3, 8, 8, 256, 1024)])
 def test_conv1x1_with_batchnorm_and_shortcut_in_the_epilogue(case, res_affine):
     """out = relu(scale * (a W^T) + shift + shortcut) in ONE launch (no stored conv output), the shortcut optionally through its own affine
-    (the projection shortcut's BatchNorm) - against f64 from the same bf16 operands, to bf16 storage rounding"""
+    (the projection shortcut's BatchNorm) - against f64 from the same bf16 operands.  Two bf16 roundings (the BatchNorm output staged in
+    LDS, then the stored sum - the unfused path rounded the stored conv output and the stored sum): 1.5 x 2^-8 of max, measured 1.1"""
     B, H, W, m, C_ = case
     a, w, gamma, beta = _problem(B, H, W, m, C_, seed=7 * m + C_)
     g = torch.Generator().manual_seed(1)
@@ -114,7 +115,7 @@ def test_conv1x1_with_batchnorm_and_shortcut_in_the_epilogue(case, res_affine):
     y = a.double() @ w.double().T
     rr = r.double() * rs.double() + rt.double() if res_affine else r.double()
     ref = (y * sc.double() + sh.double() + rr).relu()
-    close(out.torch().float().cpu(), ref, 2.0 ** -8, "fused tail")
+    close(out.torch().float().cpu(), ref, 1.5 * 2.0 ** -8, "fused tail")
     assert out.t[..., :8].abs().max().item() == 0 and out.t[..., 8 + C_:].abs().max().item() == 0, "wrote outside its channel range"
 
 
@@ -187,5 +188,5 @@ def test_data_gradient_that_writes_the_previous_blocks_dz(case):
     ops.conv2d(_dev_view(dy), w.to(BF).to(DEV).view(1, C_, m), None, dz, 1, 1, res=_dev_view(gs, 8, 0), mask=_dev_view(out_act, 0, 8))
     torch.cuda.synchronize()
     ref = (dy.double() @ w.double().T + gs.double()) * (out_act > 0)
-    close(dz.torch().float().cpu(), ref, 2.0 ** -8, "fused tail backward")
+    close(dz.torch().float().cpu(), ref, 1.5 * 2.0 ** -8, "fused tail backward")
     assert (dz.torch().float().cpu()[out_act == 0] == 0).all()

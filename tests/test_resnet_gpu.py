@@ -531,7 +531,7 @@ def check_gram_tail(eng, u):
     want = F.relu(ref * bc(st.scale) + bc(st.shift) + r)
     got = from_nhwc(u.out.torch())
     e = (got - want).abs().max().item() / want.abs().max().item()
-    assert e <= 2.0 ** -8, f"{u.conv}: fused block tail off by {e:.3e} of its max"
+    assert e <= 1.5 * 2.0 ** -8, f"{u.conv}: fused block tail off by {e:.3e} of its max"      # (two bf16 roundings: the staged BatchNorm output, the stored sum)
     return e
 
 
@@ -666,7 +666,7 @@ def test_backward_layer_by_layer(arch, precision, B, S):
             n_tail += 1
         for kk, v in e.items():
             worst[kk] = max(worst.get(kk, (0.0, "")), (v, conv))
-        assert all(v <= t_sum for v in e.values()), (conv, e)
+        assert all(v <= (1.5 * t_sum if kk == "gx_tail" else t_sum) for kk, v in e.items()), (conv, e)
     if arch == "resnet50" and not f32:
         assert n_tail == (10 if eng.gram_bn and eng.fuse_tail_dz else 0)     # the identity blocks of stages 1-3 write their predecessor's dz
     # the tails that never store a conv3 output: dgamma, dbeta, dW and the data gradient of conv3 -> bn3 against float64 autograd of the same
