@@ -145,6 +145,7 @@ SIGNATURES = {
     "cvcs_deconv_unpack_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cvcs_relu_bwd_sum_bn": (_i, [C.POINTER(TailBwdDesc), _vp]),
     "cvcs_scale_unless_one": (_i, [_vp, _i64, _vp, _vp]),
+    "cvcs_scale_unless_one_bf16": (_i, [_vp, _i64, _vp, _vp]),
     "cvcs_sizeof_call": (_i, []),
     "cvcs_replay": (_i, [_vp, _i, _vp, C.POINTER(C.c_int)]),
     "cvcs_gather_weights": (_i, [_vp, _i, _i, _vp]),
@@ -242,6 +243,8 @@ SIGNATURES = {
     "cvcs_bn_gram_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_gram_mmat_workspace_floats": (_i64, [_i, _i]),
     "cvcs_bn_gram_mmat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "cvcs_head_ce_rows": (_i, [_i64]),
+    "cvcs_head_ce": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i64, _vp, _vp, _vp, _i, _vp]),
     "cvcs_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
     "cvcs_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }
@@ -252,7 +255,7 @@ _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvc
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
             "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_dwconv_rows", "cvcs_dwconv_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay",
-            "cvcs_gram_workspace_floats", "cvcs_bn_gram_mmat_workspace_floats"}
+            "cvcs_gram_workspace_floats", "cvcs_bn_gram_mmat_workspace_floats", "cvcs_head_ce_rows"}
 C_REPLAY = os.environ.get("CVCS_C_REPLAY", "1") == "1"     # single-stream replays without timers run from C (cvcs_replay)
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 

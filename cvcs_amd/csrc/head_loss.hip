@@ -738,6 +738,229 @@ __global__ __launch_bounds__(256) void thin_head_bwd_kernel(const char* x, int64
   }
 }
 
+
+// ===================================================================================================================
+// 1x1 head + softmax cross-entropy + their backward in ONE pass over the last decoder activation (bf16, C = 16 / 32 / 64 channels,
+// NC <= 32 classes): S/train.py:121-123 (`net(x)` ... `criterion(...)` ... `loss.backward()`) without the [B, NC, H, W] f32 logits and their
+// gradient ever touching HBM - per step of the 32 x 512^2 headline that is 2 x 537 MB written and 2 x 537 MB read back.
+//
+// Everything is a chain of v_mfma_f32_16x16x16_bf16 tiles over 16 pixels whose register layouts feed each other without leaving the lane:
+//   S^T [class][pixel] = W x^T            A = W rows (hi + lo bf16 parts of the f32 weights: exact to 2^-17), B = x^T: lane (pixel l%16,
+//                                         channels 4g..4g+3) IS an 8-byte global load; D: lane (pixel l%16) holds classes 4g..4g+3
+//   softmax over the classes of a pixel = the lane's 4 values x the 4 lane groups (two xor-shuffles); loss, dl = (p - onehot) w_t / den
+//   dx^T [channel][pixel] = W^T dl^T      B = dl^T: k = class 4g..4g+3 of pixel l%16 = exactly the D layout above (hi + lo parts);
+//                                         D: lane (pixel l%16, channels 4g..4g+3) = an 8-byte global store
+//   dW [class][channel] += dl^T x         K = pixels: both operands transposed through a 512-byte LDS tile per wave (ds_read_b64_tr_b16)
+// f32 accumulation everywhere; partial dW | db rows per workgroup and the loss numerator per workgroup are reduced in fixed order.
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mma16(const uint2& a, const uint2& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, a), __builtin_bit_cast(bf16x4_t, b), c, 0, 0, 0);
+}
+// four f32 -> the bf16 heads and the bf16 remainders (v = hi + lo to 2^-17 relative)
+__device__ __forceinline__ void split4(const float* v, uint2& hi, uint2& lo) {
+  float h[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bf16_t b = f32_to_bf16(v[k]);
+    h[k] = v[k];
+    l[k] = v[k] - bf16_to_f32(b);
+  }
+  hi.x = pack2_bf16(h[0], h[1]); hi.y = pack2_bf16(h[2], h[3]);
+  lo.x = pack2_bf16(l[0], l[1]); lo.y = pack2_bf16(l[2], l[3]);
+}
+__device__ __forceinline__ uint2 tr_read16(unsigned addr) {
+  uint2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <int C, int NT>
+__global__ __launch_bounds__(256) void head_ce_kernel(const char* __restrict__ x, int64_t x_ld, int64_t P, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int NC, const void* target, int is_u8,
+                                                     const float* __restrict__ cw, int ignore, float grad_scale, char* dx, int64_t dx_ld,
+                                                     float* part_dw, float* ws, int R) {
+  constexpr int CT = C / 16;
+  constexpr int ROW = NT * 16 * C + NT * 16;          // floats of a wave's partial row in LDS: dW[NT*16][C] | db[NT*16]
+  __shared__ __attribute__((aligned(16))) char tiles[4][(CT + 2 * NT) * 512];
+  __shared__ float comb[4][ROW];
+  __shared__ float sbuf[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)tiles[wave];
+  const unsigned wr_off = fr * 32 + g * 8;                          // this lane's 8 bytes of a [16 pixels][32 B] tile
+  const unsigned tr_off = (4 * g + (fr >> 2)) * 32 + (fr & 3) * 8;  // transposed read: column fr, rows 4g..4g+3
+
+  // ---- weight fragments (constant for the kernel)
+  uint2 Whi[NT][CT], Wlo[NT][CT], WThi[CT][NT], WTlo[CT][NT];
+  f32x4 b0[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      float v[4], t[4];
+      const int n = nt * 16 + fr;                  // A of S^T: row = class fr, k = channels 4g..4g+3
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = n < NC ? w[(int64_t)n * C + ct * 16 + 4 * g + k] : 0.f;
+      split4(v, Whi[nt][ct], Wlo[nt][ct]);
+      const int c = ct * 16 + fr;                  // A of dx^T: row = channel fr, k = classes 4g..4g+3
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int nn = nt * 16 + 4 * g + k; t[k] = nn < NC ? w[(int64_t)nn * C + c] : 0.f; }
+      split4(t, WThi[ct][nt], WTlo[ct][nt]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int n = nt * 16 + 4 * g + r; b0[nt][r] = n < NC ? bias[n] : 0.f; }
+  }
+  const float den = ws[0];
+  const float gmul = den > 0.f ? grad_scale / den : 0.f;      // (an all-ignored batch: NaN loss, ZERO gradient - as torch)
+
+  f32x4 dW[NT][CT];
+  float db[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dW[nt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) db[nt][r] = 0.f;
+  }
+  float num = 0.f;
+
+  const int64_t ntiles = (P + 15) / 16;
+  const int64_t tstep = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  // software pipeline: the loads of tile i + 1 are in flight while tile i is computed
+  uint2 bx[CT], bxn[CT];
+  int tg = 0, tgn = 0;
+  auto fetch = [&](int64_t tl, uint2* bxx, int& tt) {
+    int64_t p = tl * 16 + fr; p = p < P ? p : P - 1;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bxx[ct] = *reinterpret_cast<const uint2*>(x + (p * x_ld + ct * 16 + 4 * g) * 2);
+    tt = load_target(target, is_u8, p);
+  };
+  if (tile < ntiles) fetch(tile, bx, tg);
+  for (; tile < ntiles; tile += tstep) {
+    if (tile + tstep < ntiles) fetch(tile + tstep, bxn, tgn);
+    const int64_t p = tile * 16 + fr;
+    const bool pok = p < P;
+    // ---- logits (transposed): lane = pixel fr, classes nt*16 + 4g + r
+    f32x4 S[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      S[nt] = b0[nt];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        S[nt] = mma16(Whi[nt][ct], bx[ct], S[nt]);
+        S[nt] = mma16(Wlo[nt][ct], bx[ct], S[nt]);
+      }
+    }
+    const int t = tg;
+    const bool valid = pok && (t != ignore) && ((unsigned)t < (unsigned)NC);
+    const float wt = valid ? (cw ? cw[t] : 1.f) : 0.f;
+    float m = -INFINITY, zt = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt * 16 + 4 * g + r;
+        if (n < NC) { m = fmaxf(m, S[nt][r]); zt = (n == t) ? S[nt][r] : zt; }
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+    zt += __shfl_xor(zt, 16, 64); zt += __shfl_xor(zt, 32, 64);
+    float se = 0.f;
+    f32x4 e[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt * 16 + 4 * g + r;
+        e[nt][r] = n < NC ? expf(S[nt][r] - m) : 0.f;
+        se += e[nt][r];
+      }
+    se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+    const float lse = m + logf(se), inv_se = 1.f / se;
+    if (valid && g == 0) num += wt * (lse - zt);
+    // ---- dl = (softmax - onehot) * w_t / den, split into bf16 head + remainder
+    const float f = wt * gmul;
+    uint2 dlh[NT], dll[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt * 16 + 4 * g + r;
+        d[r] = (valid && n < NC) ? f * (e[nt][r] * inv_se - ((n == t) ? 1.f : 0.f)) : 0.f;
+        db[nt][r] += d[r];
+      }
+      split4(d, dlh[nt], dll[nt]);
+    }
+    // ---- dx (transposed): lane = pixel fr, channels ct*16 + 4g + r
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        a = mma16(WThi[ct][nt], dlh[nt], a);
+        a = mma16(WThi[ct][nt], dll[nt], a);
+        a = mma16(WTlo[ct][nt], dlh[nt], a);
+      }
+      if (pok) {
+        uint2 o;
+        o.x = pack2_bf16(a[0], a[1]); o.y = pack2_bf16(a[2], a[3]);
+        *reinterpret_cast<uint2*>(dx + (p * dx_ld + ct * 16 + 4 * g) * 2) = o;
+      }
+    }
+    // ---- dW += dl^T x: both operands through this wave's LDS tiles, read back transposed (K = the 16 pixels)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the previous tile's transposed reads are done)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const uint2 xv = pok ? bx[ct] : make_uint2(0u, 0u);
+      asm volatile("ds_write_b64 %0, %1" : : "v"(lds_w + ct * 512 + wr_off), "v"(xv) : "memory");
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      asm volatile("ds_write_b64 %0, %1" : : "v"(lds_w + (CT + 2 * nt) * 512 + wr_off), "v"(dlh[nt]) : "memory");
+      asm volatile("ds_write_b64 %0, %1" : : "v"(lds_w + (CT + 2 * nt + 1) * 512 + wr_off), "v"(dll[nt]) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint2 xt[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) xt[ct] = tr_read16(lds_w + ct * 512 + tr_off);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint2 ah = tr_read16(lds_w + (CT + 2 * nt) * 512 + tr_off), al = tr_read16(lds_w + (CT + 2 * nt + 1) * 512 + tr_off);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        dW[nt][ct] = mma16(ah, xt[ct], dW[nt][ct]);
+        dW[nt][ct] = mma16(al, xt[ct], dW[nt][ct]);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bx[ct] = bxn[ct];
+    tg = tgn;
+  }
+
+  // ---- per-workgroup partial row [NC*C | NC]: the four waves merged in wave order.  dW D layout: lane (channel ct*16 + fr, classes nt*16+4g+r)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) comb[wave][(nt * 16 + 4 * g + r) * C + ct * 16 + fr] = dW[nt][ct][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = db[nt][r];                        // over the 16 pixels (lanes) of the group
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      if (fr == 0) comb[wave][NT * 16 * C + nt * 16 + 4 * g + r] = s;
+    }
+  }
+  num = block_sum_256(num, sbuf);                 // (contains the barrier that publishes comb)
+  if (tid == 0) ws[2 + R + blockIdx.x] = num;
+  float* row = part_dw + (int64_t)blockIdx.x * (NC * C + NC);
+  for (int i = tid; i < NC * C + NC; i += 256) {
+    const int src = i < NC * C ? i : NT * 16 * C + (i - NC * C);
+    row[i] = (comb[0][src] + comb[1][src]) + (comb[2][src] + comb[3][src]);
+  }
+}
+
 }  // namespace cvcs
 
 using namespace cvcs;
@@ -976,5 +1199,33 @@ extern "C" int cvcs_label_histogram(const uint8_t* labels, int64_t n, int K, int
   hipLaunchKernelGGL(label_histogram_kernel, dim3(pix_grid(n, 1024)), dim3(256), 0, (hipStream_t)stream, labels, n, K,
                      reinterpret_cast<unsigned long long*>(counts));
   CVCS_CHECK_LAUNCH("cvcs_label_histogram");
+  return CVCS_OK;
+}
+
+// the partial dW | db rows cvcs_head_ce writes (one per workgroup), also the row count of its loss-numerator partials
+extern "C" int cvcs_head_ce_rows(int64_t P) { return ce_rows(P); }
+
+extern "C" int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                            const void* target, int target_is_u8, const float* class_weight, int ignore_index, float grad_scale,
+                            void* dx, int64_t dx_ld, float* part_dw, float* workspace, float* loss_out, int dtype, void* stream) {
+  CVCS_CHECK_ARG(x && w && bias && target && dx && part_dw && workspace && loss_out, "cvcs_head_ce: null argument");
+  CVCS_CHECK_ARG(dtype == CVCS_BF16, "cvcs_head_ce: built for bf16 activations (the f32 parity path keeps its logits)");
+  CVCS_CHECK_ARG(C == 16 || C == 32 || C == 64, "cvcs_head_ce: C=%d (16 | 32 | 64 input channels)", C);
+  CVCS_CHECK_ARG(NC >= 1 && NC <= kMaxNC, "cvcs_head_ce: NC=%d out of [1,%d]", NC, kMaxNC);
+  CVCS_CHECK_ARG(B > 0 && H > 0 && W > 0 && x_ld >= C && dx_ld >= C && (x_ld * 2) % 8 == 0 && (dx_ld * 2) % 8 == 0 &&
+                 ((uintptr_t)x % 8) == 0 && ((uintptr_t)dx % 8) == 0, "cvcs_head_ce: views");
+  const int64_t P = (int64_t)B * H * W;
+  const int R = ce_rows(P);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_weight_kernel, dim3(R), dim3(256), 0, st, target, target_is_u8, P, NC, class_weight, ignore_index, workspace);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 0, loss_out);
+#define LAUNCH_HC(C_, NT_)                                                                                                               \
+  hipLaunchKernelGGL((head_ce_kernel<C_, NT_>), dim3(R), dim3(256), 0, st, (const char*)x, x_ld, P, w, bias, NC, target, target_is_u8,    \
+                     class_weight, ignore_index, grad_scale, (char*)dx, dx_ld, part_dw, workspace, R)
+  if (NC <= 16) { if (C == 16) LAUNCH_HC(16, 1); else if (C == 32) LAUNCH_HC(32, 1); else LAUNCH_HC(64, 1); }
+  else          { if (C == 16) LAUNCH_HC(16, 2); else if (C == 32) LAUNCH_HC(32, 2); else LAUNCH_HC(64, 2); }
+#undef LAUNCH_HC
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 1, loss_out);
+  CVCS_CHECK_LAUNCH("cvcs_head_ce");
   return CVCS_OK;
 }

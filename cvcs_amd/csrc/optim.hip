@@ -60,9 +60,23 @@ __global__ __launch_bounds__(256) void scale_unless_one_kernel(float* x, int64_t
   if (v == 1.0f) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= v;
 }
+__global__ __launch_bounds__(256) void scale_unless_one_bf16_kernel(bf16_t* x, int64_t n, const float* __restrict__ scalar) {
+  const float v = *scalar;
+  if (v == 1.0f) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = f32_to_bf16(bf16_to_f32(x[i]) * v);
+}
 }  // namespace cvcs
 
 using namespace cvcs;
+
+extern "C" int cvcs_scale_unless_one_bf16(void* x, int64_t n, const float* scalar_device, void* stream) {
+  CVCS_CHECK_ARG(x && scalar_device && n > 0, "cvcs_scale_unless_one_bf16: bad argument");
+  int64_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(scale_unless_one_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n, scalar_device);
+  CVCS_CHECK_LAUNCH("cvcs_scale_unless_one_bf16");
+  return CVCS_OK;
+}
 
 extern "C" int cvcs_scale_unless_one(float* x, int64_t n, const float* scalar_device, void* stream) {
   CVCS_CHECK_ARG(x && scalar_device && n > 0, "cvcs_scale_unless_one: bad argument");

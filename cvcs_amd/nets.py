@@ -11,6 +11,7 @@ optimiser updates them in a single launch and data-parallel training all-reduces
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -78,14 +79,72 @@ def _descend(root: nn.Module, dotted: str):
     return m, parts[-1]
 
 
+LAZY_HEAD = os.environ.get("CVCS_LAZY_HEAD", "1") == "1"
+# attribute reads / methods that look at a tensor's metadata only: they do not make a LazyLogits handle run the head
+_META_GETTERS = {"shape", "dtype", "device", "requires_grad", "grad_fn", "is_cuda", "ndim", "layout", "is_leaf", "names", "grad", "output_nr",
+                 "_version", "is_sparse", "is_quantized", "is_meta", "is_mkldnn", "is_nested", "_backward_hooks", "retains_grad", "_grad_fn", "_grad"}
+_META_METHODS = {"size", "dim", "stride", "numel", "nelement", "ndimension", "element_size", "is_contiguous", "storage_offset", "requires_grad_",
+                 "register_hook", "retain_grad", "is_floating_point", "is_complex", "get_device", "_is_view", "is_shared", "has_names", "__len__",
+                 "type", "is_same_size", "__format__"}
+
+
+class LazyLogits(torch.Tensor):
+    """The logits `net(x)` returns in train mode (S/train.py:121) as a HANDLE: the engine-owned [B, NC, S, S] f32 buffer whose content - the
+    1x1 head's output - is computed the first time anything reads it.  `utils.CrossEntropyLoss` recognises an unread handle and launches
+    cvcs_head_ce instead: head, softmax cross-entropy and their backward in one pass over the last decoder activation, so that in the
+    reference's loop `logits = net(x); loss = criterion(logits, y); loss.backward()` the logits and their gradient never exist in memory.
+    Every other use - printing, `.argmax(1)`, a user's own loss, `.cpu()` - sees an ordinary tensor."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        meta = (name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in _META_GETTERS) or name in _META_METHODS
+        if not meta:
+            for a in args:
+                if isinstance(a, LazyLogits):
+                    a.materialize()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+    def materialize(self):
+        st = self.__dict__.get("_cvcs_lazy")
+        if st is not None and not st["mat"]:
+            st["mat"] = True
+            if st["serial"] == st["engine"].fwd_serial:      # (a later forward has overwritten the activations: the handle is stale, as the buffer was before)
+                st["engine"].materialize_logits()
+
+
+def lazy_state(t):
+    """the state of a LazyLogits handle that nobody has read or consumed yet and whose forward pass is still the engine's last one, else None.
+    A handle whose loss was fused still materialises when somebody reads it afterwards (the activations live until the next forward)."""
+    if type(t) is not LazyLogits:
+        return None
+    st = t.__dict__.get("_cvcs_lazy")
+    if st is None or st["mat"] or st["fused"] or st["serial"] != st["engine"].fwd_serial:
+        return None
+    return st
+
+
+def lazy_fused(t) -> bool:
+    return type(t) is LazyLogits and bool(t.__dict__.get("_cvcs_lazy", {}).get("fused"))
+
+
 class _UNetFunction(torch.autograd.Function):
     """glue so that the reference's `loss.backward()` (S/train.py:125) reaches the HIP backward pass."""
 
     @staticmethod
     def forward(ctx, anchor, x, net):
         ctx.net = net
+        eng = net._engine
+        shape = (x.shape[0], net.num_classes, x.shape[2], x.shape[3])
+        if LAZY_HEAD and getattr(eng, "lazy_head_ok", None) is not None and eng.lazy_head_ok():
+            buf = eng.forward(x, train=True, lazy=True).view(-1).view(shape)
+            t = torch.Tensor._make_subclass(LazyLogits, buf, False)
+            t.__dict__["_cvcs_lazy"] = dict(engine=eng, serial=eng.fwd_serial, mat=False, fused=False)
+            return t
         # the returned tensor aliases an engine-owned buffer: valid until the next forward of this network
-        return net._engine.forward(x, train=True).view(-1).view(x.shape[0], net.num_classes, x.shape[2], x.shape[3])
+        return eng.forward(x, train=True).view(-1).view(shape)
 
     @staticmethod
     def backward(ctx, dlogits):

@@ -950,6 +950,29 @@ def head_bwd(x: View, dlogits, w, dx: View, part_dw):
                                    part_dw.data_ptr(), x.code, _stream()), "cvcs_head_bwd")
 
 
+def head_ce_rows(P: int) -> int:
+    return _lib.lib().cvcs_head_ce_rows(P)
+
+
+def head_ce_ok(x: View, NC: int) -> bool:
+    """can cvcs_head_ce take this head?  bf16 activations with 16 / 32 / 64 channels, at most 32 classes"""
+    return x.code == BF16 and x.C in (16, 32, 64) and 1 <= NC <= 32
+
+
+def head_ce(x: View, w, bias, target, class_weight, ignore_index, grad_scale, dx: View, part_dw, workspace, loss_out):
+    """1x1 head + softmax cross-entropy + their backward in one pass over x: loss_out[0] <- mean CE, dx <- d loss / d x, part_dw <-
+    head_ce_rows(P) partial rows [NC*C | NC] of dW | db.  No logits, no logit gradient."""
+    NC = w.shape[0]
+    P = x.B * x.H * x.W
+    assert head_ce_ok(x, NC) and (dx.B, dx.H, dx.W, dx.C) == (x.B, x.H, x.W, x.C) and dx.code == BF16
+    assert target.is_contiguous() and target.dtype in (torch.uint8, torch.int64) and target.numel() == P
+    assert part_dw.numel() >= head_ce_rows(P) * (NC * x.C + NC) and workspace.numel() >= ce_workspace_floats(P)
+    _tag_hbm("head_ce", P * (x.C * 2 * 2 + target.element_size()))
+    check(_lib.lib().cvcs_head_ce(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), bias.data_ptr(), NC, target.data_ptr(),
+                                  int(target.dtype == torch.uint8), _ptr(class_weight), ignore_index, grad_scale, dx.ptr, dx.ld,
+                                  part_dw.data_ptr(), workspace.data_ptr(), loss_out.data_ptr(), x.code, _stream()), "cvcs_head_ce")
+
+
 def ce_workspace_floats(P: int) -> int:
     return _lib.lib().cvcs_ce_workspace_floats(P)
 
@@ -1241,7 +1264,10 @@ def deconv_unpack_grad(dw, db4, k, p, CP, layout, gw, gb):
 
 def scale_unless_one(x: torch.Tensor, scalar: torch.Tensor):
     """x *= scalar (a one-element f32 tensor ON THE DEVICE) unless it is exactly 1 - decided by the kernel, no host round trip"""
-    assert x.dtype == torch.float32 and x.is_contiguous() and scalar.dtype == torch.float32 and scalar.numel() == 1 and scalar.device == x.device
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and scalar.dtype == torch.float32 and scalar.numel() == 1 and scalar.device == x.device
+    if x.dtype == torch.bfloat16:
+        check(_lib.lib().cvcs_scale_unless_one_bf16(x.data_ptr(), x.numel(), scalar.data_ptr(), _stream()), "cvcs_scale_unless_one_bf16")
+        return
     check(_lib.lib().cvcs_scale_unless_one(x.data_ptr(), x.numel(), scalar.data_ptr(), _stream()), "cvcs_scale_unless_one")
 
 

@@ -140,6 +140,9 @@ class ResNetUNetEngine:
         self._dy_reader = {}             # dy scratch buffer -> index of the side launch that read it last (this recording)
         self._dy_toggle = 0
         self.keep_all = False            # tests: every backward intermediate in its own buffer (no scratch reuse) + a registry
+        self.fwd_serial = 0              # forward passes so far (a nets.LazyLogits handle is current while it matches)
+        self._head_pending = self._head_done = False
+        self._head_rows = 0
         self.bwd_units = {}
         self.bwd_gram = {}               # keep_all: the Gram-path tails (dz, data gradient) by conv name
 
@@ -871,13 +874,50 @@ class ResNetUNetEngine:
         self._saved_train = train
         return self._last_act[key]
 
-    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
-        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)"""
+    def forward(self, x: torch.Tensor, train: bool, lazy: bool = False) -> torch.Tensor:
+        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine).
+        lazy (train mode): the head is NOT run - the returned buffer is filled by materialize_logits() if anybody reads the logits; a loss that
+        recognises the handle (utils.CrossEntropyLoss) calls head_ce() instead and the logits never exist (nets.LazyLogits)"""
         if self.shape != (x.shape[0], x.shape[2]):
             self._last_act = {}
         h = self._forward_backbone(x, train)
-        ops.head_fwd(h.v, self.P["segmentation_head.0.weight"].view(self.NC, self.dec[-1]), self.P["segmentation_head.0.bias"], self.logits)
+        self.fwd_serial += 1
+        self._head_done = False
+        self._head_pending = bool(lazy and train and self.lazy_head_ok())
+        if not self._head_pending:
+            ops.head_fwd(h.v, self.P["segmentation_head.0.weight"].view(self.NC, self.dec[-1]), self.P["segmentation_head.0.bias"], self.logits)
         return self.logits
+
+    def lazy_head_ok(self) -> bool:
+        """(the engines derived from this one - DeepLab, Swin + UPerNet, Segformer, MobileNet - have other heads: their logits stay eager)"""
+        return type(self) is ResNetUNetEngine and self.dtype == torch.bfloat16 and self.dec[-1] in (16, 32, 64) and self.NC <= 32
+
+    def materialize_logits(self):
+        if self._head_pending:
+            h = self._last_act["fwd_train"]
+            ops.head_fwd(h.v, self.P["segmentation_head.0.weight"].view(self.NC, self.dec[-1]), self.P["segmentation_head.0.bias"], self.logits)
+            self._head_pending = False
+
+    def head_ce(self, target, class_weight, ignore_index, workspace, loss_out):
+        """head + cross-entropy + the head's backward in one pass over the last decoder activation (cvcs_head_ce): the gradient w.r.t. that
+        activation and the partial dW | db rows are kept for backward(), which then needs no logit gradient"""
+        B, S = self.shape
+        h = self._last_act["fwd_train"]
+        NC, CH = self.NC, self.dec[-1]
+        rows = ops.head_ce_rows(B * S * S)
+        part = self._scratch("head_part", rows * (NC * CH + NC))
+        gh = ops.view(self._act("head.gx", B, S, S, CH))
+        ops.head_ce(h.v, self.P["segmentation_head.0.weight"].view(NC, CH), self.P["segmentation_head.0.bias"], target, class_weight, ignore_index,
+                    1.0, gh, part, workspace, loss_out)
+        self._head_done, self._head_rows = True, rows
+
+    def scale_head_grads(self, gout):
+        """the loss was scaled / combined by further autograd ops: its incoming gradient (a device scalar) multiplies what head_ce produced"""
+        B, S = self.shape
+        NC, CH = self.NC, self.dec[-1]
+        g = gout.detach().to(device=self.dev, dtype=torch.float32).reshape(1).contiguous()
+        ops.scale_unless_one(self._act("head.gx", B, S, S, CH), g)
+        ops.scale_unless_one(self._scratch("head_part", self._head_rows * (NC * CH + NC)), g)
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
         if self.shape != (x.shape[0], x.shape[2]):
@@ -895,10 +935,16 @@ class ResNetUNetEngine:
         NC = self.NC
         h = self._last_act["fwd_train"]
         CH = self.dec[-1]
-        rows = ops.head_bwd_rows(B * S * S)
-        part = self._scratch("head_part", rows * (NC * CH + NC))
         gh = ops.view(self._act("head.gx", B, S, S, CH))
-        ops.head_bwd(h.v, dlogits.contiguous(), self.P["segmentation_head.0.weight"].view(NC, CH), gh, part)
+        if self._head_done:       # head_ce() already produced gh and the partial rows
+            rows = self._head_rows
+            part = self._scratch("head_part", rows * (NC * CH + NC))
+            self._head_done = False
+        else:
+            assert not self._head_pending or dlogits is not None
+            rows = ops.head_bwd_rows(B * S * S)
+            part = self._scratch("head_part", rows * (NC * CH + NC))
+            ops.head_bwd(h.v, dlogits.contiguous(), self.P["segmentation_head.0.weight"].view(NC, CH), gh, part)
         gw, gb = self.G["segmentation_head.0.weight"], self.G["segmentation_head.0.bias"]
         assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4
         ops.colsum_finalize(part, rows, NC * CH + NC, gw)

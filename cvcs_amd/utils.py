@@ -96,6 +96,21 @@ class _CEFunction(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         if crit._ws is None or crit._ws.numel() < ops.ce_workspace_floats(P) or crit._ws.device != dev:
             crit._ws = torch.empty(ops.ce_workspace_floats(P), dtype=torch.float32, device=dev)
+        ctx.crit, ctx.lazy = crit, None
+        lz = nets.lazy_state(logits)
+        if lz is not None and crit.sync is None:
+            # the logits are an unread handle (nets.LazyLogits): head + cross-entropy + their backward in ONE pass over the last decoder
+            # activation - neither the logits nor their gradient are ever written
+            w = crit.weight
+            if w is not None and w.device != dev:
+                w = crit.weight = w.to(dev)
+            lz["fused"] = True
+            lz["engine"].head_ce(target.contiguous(), w, crit.ignore_index, crit._ws, loss)
+            ctx.lazy, ctx.shape = lz, tuple(logits.shape)
+            return loss[0]
+        if nets.lazy_fused(logits) and logits.requires_grad:
+            raise RuntimeError("a second differentiable loss on logits whose first cross-entropy was fused with the head (nets.LazyLogits): "
+                               "set CVCS_LAZY_HEAD=0 to keep eager logits")
         need_grad = logits.requires_grad
         if need_grad and (crit._dl is None or crit._dl.shape != logits.shape or crit._dl.device != dev):
             crit._dl = torch.empty_like(logits)
@@ -114,11 +129,15 @@ class _CEFunction(torch.autograd.Function):
             ops.ce_fwd_bwd(logits, target, w, crit.ignore_index, float(crit.sync.world), loss,
                            crit._dl if need_grad else None, crit._ws, external_denominator=True)
             crit.sync.all_reduce(loss)
-        ctx.crit = crit
         return loss[0]
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.lazy is not None:
+            # the head's gradients already exist inside the engine (head_ce); autograd only needs a tensor of the logits' shape to hand on
+            if not ctx.crit.unit_grad:
+                ctx.lazy["engine"].scale_head_grads(gout)
+            return torch.zeros(1, dtype=torch.float32, device=gout.device).expand(ctx.shape), None, None
         dl = ctx.crit._dl   # d(loss)/d(logits) was produced by the forward launch
         if not ctx.crit.unit_grad:
             # chained through further autograd ops: scale by the incoming gradient - compared with 1 ON THE DEVICE (no host round trip)

@@ -632,6 +632,8 @@ int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream);
 /* x[0..n) *= *scalar_device unless it is exactly 1 (decided on the device: no host synchronisation).  Used for the incoming gradient of the fused
  * cross-entropy (`loss.backward()` hands a 1; `(loss / k).backward()` a 1 / k) - replaces a float(tensor) comparison on the host.              */
 int cvcs_scale_unless_one(float* x, int64_t n, const float* scalar_device, void* stream);
+/* the same on a contiguous bf16 buffer (the head's data gradient written by cvcs_head_ce before the incoming gradient of the loss is known) */
+int cvcs_scale_unless_one_bf16(void* x, int64_t n, const float* scalar_device, void* stream);
 /* ---- BatchNorm behind a 1x1 convolution WITHOUT materialising the convolution output (ABI 13) -----------------------------------
  * replaces: the last conv1x1 -> nn.BatchNorm2d -> (+ shortcut) -> ReLU of a ResNet bottleneck (torchvision Bottleneck, the encoders of
  * S/nets.py:234-311) in train mode, forward and backward, for y = W a over the M pixels of a map (a: [M][m] bf16, W: [C][m] bf16).
@@ -658,6 +660,17 @@ int cvcs_bn_gram_bwd(const float* r, const float* sum_dz, const void* w_bf16, co
                      float* dgamma, float* dbeta, float* dw, void* wd2_bf16, float* coef, void* stream);
 int64_t cvcs_bn_gram_mmat_workspace_floats(int C, int m);
 int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, float* workspace, void* stream);
+/* ---- 1x1 head + cross-entropy + their backward in ONE pass (ABI 13) ----------------------------------------------------------------
+ * replaces: `logits = net(x)` (the head nn.Conv2d(C, NC, 1), S/nets.py:172), `criterion(logits, target)` (nn.CrossEntropyLoss, S/utils.py:230,238)
+ * and the head's half of `loss.backward()` (S/train.py:121-125) for bf16 activations with C = 16 | 32 | 64 channels and NC <= 32 classes:
+ * the [B, NC, H, W] f32 logits and their gradient are never written.  x: the last decoder activation [B*H*W][C] (view), target as cvcs_ce_fwd_bwd,
+ * w f32 [NC][C], bias f32 [NC].  Writes loss_out (mean over the non-ignored pixels, class weights as S/utils.py:230), dx (the gradient
+ * w.r.t. x, bf16 view) and cvcs_head_ce_rows(P) partial rows [NC*C | NC] of dW | db (summed by cvcs_colsum_finalize, as cvcs_head_bwd's).
+ * workspace: cvcs_ce_workspace_floats(P) floats.  grad_scale multiplies the gradients (1 for a plain loss.backward()).                  */
+int cvcs_head_ce_rows(int64_t P);
+int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+                 const void* target, int target_is_u8, const float* class_weight, int ignore_index, float grad_scale,
+                 void* dx, int64_t dx_ld, float* part_dw, float* workspace, float* loss_out, int dtype, void* stream);
 /* A recorded launch plan driven from C (host time per step < 0.5 ms).  A plan is the list of launch entry points of
  * THIS header that one pass of a network issues for one input shape, with their arguments (every pointer a persistent buffer).  cvcs_call holds one
  * launch: the function, its integer-class arguments in declaration order WITHOUT the trailing stream (pointers, int, int64_t), and its float
