@@ -48,6 +48,8 @@ FAMILY_KERNEL = {
     "hbm_se": "squeeze-excite passes of MobileNetV3 (se_scale forward / backward, image_dot)",
     "sr_attention": "sr_attn_* kernels (spatial-reduction attention forward / backward, VALU; FLOPs = 4 N Nk C forward, 10 N Nk C backward)",
     "hbm_quantize_fp8": "quantize_fp8_kernel (bf16 -> fp8 image + amax of the tensors the fp8 convolutions read)",
+    "hbm_gram": "cvcs_gram (second-moment matrix of a bottleneck's conv3 input on the matrix cores: the BatchNorm statistics of the conv3 output without that output; algorithmic bytes = one read of the input)",
+    "hbm_head_ce": "head_ce_kernel (1x1 head + softmax cross-entropy + their backward in one pass: reads the last decoder activation and the labels, writes its gradient)",
 }
 
 
@@ -135,7 +137,7 @@ def parity_at_dtype(net, name, nc, tile, dev, variant="b0"):
     lab, ref = got.argmax(1), want.argmax(1)
     top2 = want.topk(2, dim=1).values
     bad = lab != ref
-    return {"against": "f32 CPU oracle at the same parameters, eval mode, 1 structured synthetic tile of the benchmarked size",
+    return {"against": "f32 CPU oracle at the same (initial) parameters, eval mode, 1 structured synthetic tile of the benchmarked size",
             "logit_err_max": round(d.abs().max().item() / scale, 6), "logit_err_rms": round(d.pow(2).mean().sqrt().item() / scale, 6),
             "unit": "fraction of max|logit|", "labels_differing": int(bad.sum()), "labels_total": int(lab.numel()),
             "largest_oracle_top2_margin_among_them": round(((top2[:, 0] - top2[:, 1])[bad].max().item() / scale) if bool(bad.any()) else 0.0, 6),
@@ -167,6 +169,8 @@ def main():
                     help="fp8 = mixed bf16 / fp8 convolutions (BASELINE configs[4]; ResNet-UNets and the UPerNet head of Swin + UPerNet)")
     ap.add_argument("--segformer-variant", default="b0", choices=["b0", "b3"], help="SegformerMod: b0 = SegformerConfig() (the reference's pretrained=False branch), "
                     "b3 = the architecture of the checkpoint its default pretrained=True fetches")
+    ap.add_argument("--decoder-channels", default=None, help="ResNet-UNets: the five decoder widths, e.g. 256,128,64,64,64 (the widths of rounds 1-2; "
+                    "default 256,128,64,32,16 since round 3 - config key `decoder_channels`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     a = ap.parse_args()
@@ -197,8 +201,16 @@ def main():
     cfg = {"net": a.net, "num_classes": a.classes, "precision": a.precision, "loss": "CEL", "ignore_background": True,
            "opt": "SGD2", "epochs": 20, "device": "gpu", "segformer_variant": a.segformer_variant}
     NC = a.classes + 1
+    dec = None
+    if a.decoder_channels:
+        assert a.net.startswith("Resnet") and a.net.endswith("Unet"), "--decoder-channels is a key of the ResNet-UNets"
+        dec = cfg["decoder_channels"] = [int(c) for c in a.decoder_channels.split(",")]
     torch.manual_seed(0)
     net = utils.load_network(cfg, dev)
+    parity = None
+    if world == 1 and not a.no_cpu_baseline:
+        # at INITIALISATION, before the timed schedule trains the network on uniform-random labels (outside every timed region)
+        parity = parity_at_dtype(net, a.net, NC, a.tile, dev, a.segformer_variant)
     crit = utils.load_loss(cfg, dev)
     opt, sched = utils.load_optimizer(cfg, net)
     if world > 1:
@@ -260,8 +272,9 @@ def main():
 
     if rank == 0:
         peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
-        model = {"Resnet50Unet": "ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder 256/128/64/32/16 - the common public widths -, 1x1 head)",
-                 "Resnet18Unet": "ResNet18-UNet", "Resnet34Unet": "ResNet34-UNet",
+        widths = "/".join(str(c) for c in (dec or getattr(net, "decoder_channels", ())))
+        model = {"Resnet50Unet": f"ResNet50-UNet (ResNet-50 v1.5 encoder, bilinear-upsample decoder {widths}, 1x1 head)",
+                 "Resnet18Unet": f"ResNet18-UNet (decoder {widths})", "Resnet34Unet": f"ResNet34-UNet (decoder {widths})",
                  "DeepLabV3Plus": "DeepLabV3+ (ResNet-50 v1.5 at output stride 16, ASPP rates 6/12/18, 64-channel low-level branch)",
                  "Resnet101": "DeepLabV3-ResNet101 (the reference's factory name Resnet101, S/nets.py:234-257; output stride 8, ASPP 12/24/36)",
                  "SwinTUperNet": "Swin-T + UPerNet (BASELINE configs[3]: embed 96, depths 2/2/6/2, window 7; UPerNet hidden 512, pool scales 1/2/3/6)",
@@ -280,7 +293,7 @@ def main():
                                    f"{a.tile}x{a.tile} u8 tiles, batch {a.batch}/GPU, "
                                    + ("mixed bf16 / fp8 MFMA convs (fp8: 3x3 stride-1 layers with channel counts % 128 == 0, forward + data gradient)"
                                       if a.precision == "fp8" else f"{a.precision} MFMA convs") + ", f32 accumulate/master",
-                       "global_batch": world * a.batch, "tile": a.tile, "num_classes": NC,
+                       "global_batch": world * a.batch, "tile": a.tile, "num_classes": NC, "decoder_channels": list(dec or getattr(net, "decoder_channels", ())) or None,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "loss": round(last_loss, 5),
             "median_ms_per_step": round(statistics.median(per_step), 3),
@@ -340,9 +353,11 @@ def main():
             tot = sum(f["ms"] for f in mf.values()) / psteps
             out["mfma_kernels_share_of_step"] = round(tot / (1e3 * dt / a.steps), 3)
             out["algorithmic_gflop_per_step"] = round(sum(f["flops"] for f in mf.values()) / psteps / 1e9, 1)
+            # (carried in `config` too: tiles/s of two rounds compare only at equal work per tile - rounds 2 -> 3 changed the decoder widths)
+            out["config"]["algorithmic_gflop_per_tile"] = round(sum(f["flops"] for f in mf.values()) / psteps / 1e9 / a.batch, 2)
             out["step_tflops"] = round(sum(f["flops"] for f in mf.values()) / psteps * a.steps / dt / 1e12, 1)
         if world == 1 and not a.no_cpu_baseline:
-            out["parity_at_dtype"] = parity_at_dtype(net, a.net, NC, a.tile, dev, a.segformer_variant)
+            out["parity_at_dtype"] = parity
             out["cpu_baseline"] = cpu_baseline(a.net, NC, a.tile, 2, 2, a.segformer_variant)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -208,6 +208,7 @@ SIGNATURES = {
     "cvcs_bn_bwd_coeffs": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "cvcs_bn_act": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp]),
     "cvcs_bn_bwd_rows": (_i, [_i64]),
+    "cvcs_bn_bwd_chunk_lanes": (_i, [_i, _i]),
     "cvcs_bn_bwd_reduce": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "cvcs_bn_bwd_finalize": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_bwd_apply": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64,
@@ -255,7 +256,7 @@ _QUERIES = {"cvcs_last_error", "cvcs_abi_version", "cvcs_sizeof_conv_desc", "cvc
             "cvcs_wgrad_slices", "cvcs_wgrad_workspace_floats", "cvcs_wgrad_takes_bias", "cvcs_bn_finalize_workspace_floats", "cvcs_bn_bwd_rows",
             "cvcs_head_bwd_rows", "cvcs_ce_workspace_floats", "cvcs_linear_head_bwd_rows", "cvcs_gn_rows", "cvcs_layernorm_rows",
             "cvcs_window_attention_bwd_workspace_floats", "cvcs_dwconv3x3_wgrad_rows", "cvcs_dwconv_rows", "cvcs_dwconv_wgrad_rows", "cvcs_sr_attention_bwd_workspace", "cvcs_sizeof_call", "cvcs_replay",
-            "cvcs_gram_workspace_floats", "cvcs_bn_gram_mmat_workspace_floats", "cvcs_head_ce_rows"}
+            "cvcs_gram_workspace_floats", "cvcs_bn_gram_mmat_workspace_floats", "cvcs_head_ce_rows", "cvcs_bn_bwd_chunk_lanes"}
 C_REPLAY = os.environ.get("CVCS_C_REPLAY", "1") == "1"     # single-stream replays without timers run from C (cvcs_replay)
 pending_tag = None         # (kernel family, algorithmic flops) of the NEXT launch, set by ops.conv2d / ops.conv2d_wgrad
 

@@ -899,6 +899,23 @@ extern "C" int cvcs_bn_bwd_rows(int64_t M) {
   return (int)(r < 1 ? 1 : (r > cap ? cap : r));
 }
 
+// Channel-chunk lanes per workgroup of the BatchNorm-backward passes: the largest divisor of the row's 16-byte chunk count up to kBnBwdChunks, so
+// that gridDim.y * lanes covers a pixel row EXACTLY; the 256 / lanes pixel lanes then leave 256 - lanes * (256 / lanes) threads idle, which
+// the kernel keeps out of the pixel loop (`items = pl < PL ? ... : 0`).  History (round 3, the MobileNet bring-up at 4 x 64^2 in f32): an
+// interim rule lanes = min(chunks, 32) admitted widths like 96 (24 chunks of 4 floats: 10 pixel lanes, 16 threads left over) while the kernel
+// had no such guard - the left-over threads took pixel lane 10, i.e. pixels of the NEXT workgroup and, in the last workgroup of the 4 x 4-pixel
+// maps, up to 3 grid strides past the last pixel of y and g: the "memory access fault" of that session (last launch cvcs_bn_bwd_reduce).
+extern "C" int cvcs_bn_bwd_chunk_lanes(int C, int dtype) {
+  if (!DT_OK(dtype) || C <= 0) return CVCS_EINVAL;
+  const int V = dtype == CVCS_F32 ? 4 : 8;
+  if (C % V != 0) return CVCS_EINVAL;
+  const int CC = C / V;
+  int ccw = 1;      // (powers of two and multiples of 32 use every thread)
+  for (int d = 1; d <= kBnBwdChunks && d <= CC; ++d)
+    if (CC % d == 0) ccw = d;
+  return ccw;
+}
+
 static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld, const void* g1, int64_t g1_ld,
                          const void* g2, int64_t g2_ld, int B, int H, int W, int C, const float* scale, const float* shift,
                          const float* mean, const float* invstd, const float* ca, const float* cb, int mode, void* dy,
@@ -923,9 +940,7 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   CVCS_CHECK_ARG(scale && shift && mean && invstd && part0 && (apply ? (ca && cb) : part1 != nullptr), "%s: null argument", fn);
   BnBwdArgs a{(const char*)y, (const char*)g1, (const char*)g2, (char*)dy, y_ld, g1_ld, g2_ld, dy_ld, scale, shift, mean,
               invstd, ca, cb, part0, part1, B, H, W, C, mode, 0, q8};
-  int ccw = 1;      // the largest divisor of CC up to kBnBwdChunks (powers of two and multiples of 32 use every thread)
-  for (int d = 1; d <= kBnBwdChunks && d <= CC; ++d)
-    if (CC % d == 0) ccw = d;
+  const int ccw = cvcs_bn_bwd_chunk_lanes(C, dtype);
   a.ccw = ccw;
   dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)B * H * W), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;

@@ -86,6 +86,9 @@ class SyntheticLoader:
     def get_iterable_chunk(self, idx, random_tps=None, device=None, batch_size=None, shard=None):
         """device=None: the reference's contract - an iterable of per-tile tuples for a DataLoader.  device given: the tiles
         of the chunk are uploaded once and the iterable yields whole batches resident on the device (see DeviceTiles)."""
+        if random_tps:
+            raise ValueError("random_tps (random rescaled crops of the full images, S/dataset.py:173-198) needs a dataset of full images: "
+                             "the synthetic loader generates tiles, not images")
         patches = []
         for image in self.chunks[idx]:
             g = torch.Generator().manual_seed(self.seed * 100003 + image)
@@ -186,11 +189,29 @@ class Loader:
         decoded = [self._decode(i) for i in self.chunks[idx]]
         items = self.plan_items(idx)
         p = self.patch_size
+        # random_tps = [(aug_size, percentage), ...] (S/dataset.py:173-198, read at S/train.py:109): extra random rescaled crops, appended and
+        # shuffled in; planned from the chunk's own generator, so every rank and both paths below serve the same tiles
+        rng = random.Random(((self.seed * 1000003 + self.epoch) * 1000003 + idx) * 31 + 7)
+        extra = plan_random_tps(random_tps, len(items), len(decoded), self.H, self.W, rng)
         if device is not None and torch.device(device).type == "cuda":
-            return DeviceChunk([im.to(device) for im, _ in decoded], [m.to(device) for _, m in decoded], p, batch_size or 1,
-                               items=items, shard=shard)
+            images, masks = [im.to(device) for im, _ in decoded], [m.to(device) for _, m in decoded]
+            if extra:
+                # the rescaled crops become one more resident "image": a strip of p x p tiles the gather launch reads like any other source
+                tiles = [resize_tile(images[pos][:, y:y + a, x:x + a], masks[pos][y:y + a, x:x + a], p) for pos, y, x, a in extra]
+                images.append(torch.cat([t[0] for t in tiles], dim=1).contiguous())
+                masks.append(torch.cat([t[1] for t in tiles], dim=0).contiguous())
+                items = items + [(len(decoded), j * p, 0) for j in range(len(extra))]
+                rng.shuffle(items)
+            return DeviceChunk(images, masks, p, batch_size or 1, items=items, shard=shard)
         patches = [(crop_zero_filled(decoded[pos][0], y, x, p), crop_zero_filled(decoded[pos][1], y, x, p), torch.zeros(1), torch.zeros(1))
                    for pos, y, x in items]
+        if extra:
+            for pos, y, x, a in extra:
+                im, m = resize_tile(decoded[pos][0][:, y:y + a, x:x + a], decoded[pos][1][y:y + a, x:x + a], p)
+                patches.append((im, m, torch.zeros(1), torch.zeros(1)))
+            order = list(range(len(patches)))
+            rng.shuffle(order)
+            patches = [patches[j] for j in order]
         return _Chunk(patches)
 
     def get_class_weights(self, classes, ignore_background=False):
@@ -207,6 +228,28 @@ class Loader:
                     m = self._decode_mask(i).reshape(-1).long()
                     self.count += torch.bincount(m, minlength=classes)[:classes].float()
         return class_weights_from_counts(self.count, ignore_background)
+
+
+def resize_tile(img: torch.Tensor, mask: torch.Tensor, p: int):
+    """the reference's two resizers on a random rescaled crop (S/dataset.py:129-130,192-195): image `v2.Resize(p, BILINEAR)` (antialiased,
+    rounded back to u8), index mask `v2.Resize(p, NEAREST_EXACT)`.  img u8 [3,a,a], mask u8 [a,a] (host or device) -> u8 [3,p,p], u8 [p,p]"""
+    f = torch.nn.functional.interpolate(img[None].float(), size=(p, p), mode="bilinear", align_corners=False, antialias=True)[0]
+    m = torch.nn.functional.interpolate(mask[None, None].float(), size=(p, p), mode="nearest-exact")[0, 0]
+    return f.round().clamp(0, 255).to(torch.uint8), m.to(torch.uint8)
+
+
+def plan_random_tps(random_tps, n_tiles, n_images, H, W, rng):
+    """S/dataset.py:173-198: for every (aug_size, percentage) add int(percentage * n_tiles) random aug_size x aug_size crops of random images
+    of the chunk (each later resized to the patch size).  The draws come from `rng` (seeded with (seed, epoch, chunk)): every rank and both the
+    host and the device path plan the same crops.  -> [(position in the chunk, top, left, aug_size)]"""
+    extra = []
+    for aug_size, percentage in random_tps or ():
+        aug_size = int(aug_size)
+        if not 0 < aug_size < min(H, W):
+            raise ValueError(f"random_tps: crop size {aug_size} does not fit a {H} x {W} image")
+        for _ in range(int(percentage * n_tiles)):
+            extra.append((rng.randint(0, n_images - 1), rng.randint(0, H - 1 - aug_size), rng.randint(0, W - 1 - aug_size), aug_size))
+    return extra
 
 
 def crop_zero_filled(t: torch.Tensor, y: int, x: int, p: int):

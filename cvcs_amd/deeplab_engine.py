@@ -136,16 +136,16 @@ class DeepLabEngine(ResNetUNetEngine):
     def _plan(self, B, S):
         if self.shape != (B, S):
             assert S % 32 == 0, "tile side must be a multiple of 32"
+            known = (B, S) in self._shape_cache
             super()._plan(B, S)
-            f = 4 if self.plus else self.os
-            self.logits_lo = torch.empty((B, self.NC, S // f, S // f), dtype=torch.float32, device=self.dev)
-            self.dlogits_lo = torch.empty_like(self.logits_lo)
+            if not known:
+                f = 4 if self.plus else self.os
+                self.logits_lo = torch.empty((B, self.NC, S // f, S // f), dtype=torch.float32, device=self.dev)
+                self.dlogits_lo = torch.empty_like(self.logits_lo)
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
         if train and x.shape[0] < 2:   # (torchvision's ASPPPooling BatchNorm raises the same on a 1x1 map of one image)
             raise ValueError("Expected more than 1 value per channel when training: DeepLab needs a batch of at least 2 tiles")
-        if self.shape != (x.shape[0], x.shape[2]):
-            self._last_act = {}
         h = self._forward_backbone(x, train)
         w = self.P["classifier.weight"].view(self.NC, 256)
         ops.linear_head_fwd(h.v, w, self.P["classifier.bias"], logits=self.logits_lo)

@@ -181,6 +181,7 @@ class MobileNetEngine(DeepLabEngine):
         self.one = torch.ones(cmax, dtype=torch.float32, device=dev)
         self.zero = torch.zeros(cmax, dtype=torch.float32, device=dev)
         self._rec, self._bufs, self.shape, self.gn = {}, {}, None, {}
+        self._shape_cache.clear()
 
     def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)

@@ -213,8 +213,8 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     fam = ("conv3x3_halo_bn_bwd" if bn_bwd is not None else "conv3x3_halo") if halo else ("conv_taps" if taps else "conv_igemm")
     if SCOPE:
         fam = f"{fam}:{SCOPE}"
-    tag = (fam, float(flops) if flops is not None else
-           2.0 * x.B * Ho * Wo * Cout * (cin_real or ((x.C + (x2.C if x2 is not None else 0)) if virt is None else 21)) * KH * KW)
+    # (a second contraction source carries the BatchNorm-backward correction of the Gram path: extra work of that formulation, not algorithmic)
+    tag = (fam, float(flops) if flops is not None else 2.0 * x.B * Ho * Wo * Cout * (cin_real or (x.C if virt is None else 21)) * KH * KW)
     if _lib._recording is not None:
         _lib.pending_tag = tag
     elif TIMERS is not None:

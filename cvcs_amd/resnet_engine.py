@@ -23,6 +23,7 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import os
 
@@ -122,6 +123,7 @@ class ResNetUNetEngine:
         self._tape = None
         self._saved_train = False
         self._last_act = {}
+        self._shape_cache = collections.OrderedDict()
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
         self.gather_shortcut = os.environ.get("CVCS_GATHER_SHORTCUT", "1") == "1"   # stride-2 projection shortcuts on compact even-pixel maps (_block)
         self.fuse_tail_bn = os.environ.get("CVCS_FUSE_TAIL_BN", "1") == "1"  # the residual tails' BatchNorm reduce passes on relu_bwd_sum (_block)
@@ -176,6 +178,7 @@ class ResNetUNetEngine:
         self.one = torch.ones(cmax, dtype=torch.float32, device=dev)
         self.zero = torch.zeros(cmax, dtype=torch.float32, device=dev)
         self._rec, self._bufs, self.shape = {}, {}, None
+        self._shape_cache = collections.OrderedDict()
         self.gn = {}                     # GroupNorm state per layer (allocated per batch size at plan time)
 
     def enable_sync_bn(self, sync):
@@ -189,6 +192,7 @@ class ResNetUNetEngine:
         self._sync_mom = torch.empty(3 * cmax, dtype=torch.float64, device=self.dev)
         self._sync_sums = torch.empty(2 * cmax, dtype=torch.float32, device=self.dev)
         self._rec = {}            # plans recorded without the exchanges are stale
+        self._shape_cache.clear()
 
     def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
@@ -838,12 +842,35 @@ class ResNetUNetEngine:
             tape.append(stem_bwd)
         return f1, p0
 
+    # everything an input shape owns: recorded plans, activation buffers, the views the plans were recorded against
+    SHAPE_STATE = ("_rec", "_bufs", "gn", "logits", "logits_lo", "dlogits_lo", "_last_act", "_tape", "_last", "units", "relu_order", "_q8",
+                   "_saved_train", "_head_pending", "_head_done", "_head_rows", "hs_order")
+    PLAN_CACHE = int(os.environ.get("CVCS_PLAN_CACHE", "3"))      # input shapes kept alive (least recently used one dropped)
+
+    def _switch_shape(self, B, S) -> bool:
+        """make (B, S) the current input shape.  The state of the shape being left - buffers and recorded launch plans - is parked and comes
+        back when that shape returns (train -> eval_model / validation_loss -> train every epoch: no re-allocation, no re-recording; under N
+        ranks no rank stalls the others re-planning).  -> True when (B, S) is new and its state has to be built"""
+        st = self._shape_cache.pop((B, S), None)
+        if self.shape is not None:
+            self._shape_cache[self.shape] = {a: getattr(self, a) for a in self.SHAPE_STATE if hasattr(self, a)}
+            self._shape_cache.move_to_end(self.shape)
+            while len(self._shape_cache) > max(self.PLAN_CACHE - 1, 0):
+                self._shape_cache.popitem(last=False)
+        self.shape = (B, S)
+        if st is None:
+            self._last_act, self._head_pending, self._head_done = {}, False, False
+            return True
+        for a, v in st.items():
+            setattr(self, a, v)
+        return False
+
     def _plan(self, B, S):
         if self.shape != (B, S):
             assert S % 32 == 0, "tile side must be a multiple of 32 (the encoder reduces the resolution 32 times)"
-            self.shape = (B, S)
-            self._rec, self._bufs, self.gn = {}, {}, {}
-            self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
+            if self._switch_shape(B, S):
+                self._rec, self._bufs, self.gn = {}, {}, {}
+                self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
 
     def _run(self, key, fn):
         """first time: run fn() eagerly while recording its launches; afterwards replay the recording"""
@@ -878,8 +905,6 @@ class ResNetUNetEngine:
         """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine).
         lazy (train mode): the head is NOT run - the returned buffer is filled by materialize_logits() if anybody reads the logits; a loss that
         recognises the handle (utils.CrossEntropyLoss) calls head_ce() instead and the logits never exist (nets.LazyLogits)"""
-        if self.shape != (x.shape[0], x.shape[2]):
-            self._last_act = {}
         h = self._forward_backbone(x, train)
         self.fwd_serial += 1
         self._head_done = False
@@ -920,8 +945,6 @@ class ResNetUNetEngine:
         ops.scale_unless_one(self._scratch("head_part", self._head_rows * (NC * CH + NC)), g)
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
-        if self.shape != (x.shape[0], x.shape[2]):
-            self._last_act = {}
         h = self._forward_backbone(x, False)
         ops.head_argmax(h.v, self.P["segmentation_head.0.weight"].view(self.NC, self.dec[-1]), self.P["segmentation_head.0.bias"], labels)
         return labels

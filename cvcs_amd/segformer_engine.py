@@ -188,6 +188,7 @@ class SegformerEngine(SwinUPerNetEngine):
         self.eye = torch.eye(NC, CP, dtype=torch.float32, device=dev).contiguous()
         self.rates_dev = torch.tensor([r for r in self.rates for _ in (0, 1)], dtype=torch.float32, device=dev)
         self._rec, self._bufs, self.shape, self.gn = {}, {}, None, {}
+        self._shape_cache.clear()
 
     def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
@@ -505,9 +506,9 @@ class SegformerEngine(SwinUPerNetEngine):
     def _plan(self, B, S):
         if self.shape != (B, S):
             assert S % 32 == 0, "tile side must be a multiple of 32"
-            self.shape = (B, S)
-            self._rec, self._bufs, self.gn = {}, {}, {}
-            self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
+            if self._switch_shape(B, S):
+                self._rec, self._bufs, self.gn = {}, {}, {}
+                self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
 
     def _forward_backbone(self, x, train):
         B, C_, S, S2 = x.shape
@@ -528,15 +529,11 @@ class SegformerEngine(SwinUPerNetEngine):
         return self._last_act[key]
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
-        if self.shape != (x.shape[0], x.shape[2]):
-            self._last_act = {}
         h = self._forward_backbone(x, train)
         ops.planes_from_nhwc(h.v, self.NC, self.logits)
         return self.logits
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
-        if self.shape != (x.shape[0], x.shape[2]):
-            self._last_act = {}
         h = self._forward_backbone(x, False)
         ops.head_argmax(h.v, self.eye, self.zero[:self.NC], labels)
         return labels

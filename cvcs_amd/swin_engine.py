@@ -96,6 +96,7 @@ class SwinUPerNetEngine(ResNetUNetEngine):
         self.one = torch.ones(4096, dtype=torch.float32, device=dev)
         self.zero = torch.zeros(4096, dtype=torch.float32, device=dev)
         self._rec, self._bufs, self.shape, self.gn = {}, {}, None, {}
+        self._shape_cache.clear()
 
     def refresh_weights(self, train=True):
         ops.pack_conv_weights(self._pack_table[0], self._pack_table[1], self.dtype)
@@ -388,11 +389,11 @@ class SwinUPerNetEngine(ResNetUNetEngine):
     def _plan(self, B, S):
         if self.shape != (B, S):
             assert S % 32 == 0, "tile side must be a multiple of 32"
-            self.shape = (B, S)
-            self._rec, self._bufs, self.gn = {}, {}, {}
-            self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
-            self.logits_lo = torch.empty((B, self.NC, S // 4, S // 4), dtype=torch.float32, device=self.dev)
-            self.dlogits_lo = torch.empty_like(self.logits_lo)
+            if self._switch_shape(B, S):
+                self._rec, self._bufs, self.gn = {}, {}, {}
+                self.logits = torch.empty((B, self.NC, S, S), dtype=torch.float32, device=self.dev)
+                self.logits_lo = torch.empty((B, self.NC, S // 4, S // 4), dtype=torch.float32, device=self.dev)
+                self.dlogits_lo = torch.empty_like(self.logits_lo)
 
     def _forward_backbone(self, x, train):
         B, C_, S, S2 = x.shape
@@ -411,8 +412,6 @@ class SwinUPerNetEngine(ResNetUNetEngine):
         return self._last_act[key]
 
     def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
-        if self.shape != (x.shape[0], x.shape[2]):
-            self._last_act = {}
         h = self._forward_backbone(x, train)
         ops.linear_head_fwd(h.v, self.P[self.head_name + ".weight"].view(self.NC, HIDDEN), self.P[self.head_name + ".bias"], logits=self.logits_lo)
         ops.resize_bilinear_nchw_fwd(self.logits_lo, self.logits, 4)

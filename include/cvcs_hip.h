@@ -186,6 +186,9 @@ int cvcs_bn_act(const void* y, int64_t y_ld, int B, int H, int W, int C,
  * cvcs_bn_bwd_finalize -> dgamma, dbeta and the two per-channel coefficients;
  * pass 2 -> dy (gradient w.r.t. the conv output) and partial column sums of dy (conv bias gradient).        */
 int cvcs_bn_bwd_rows(int64_t M);
+/* channel-chunk lanes per workgroup of the two passes for a C-channel tensor (a divisor of C's 16-byte chunk count, <= 32): any C that is a
+ * multiple of the chunk is accepted (96, 160, 224, 480, 672, 960 of MobileNetV3 included); exported so that the rule is testable without a GPU */
+int cvcs_bn_bwd_chunk_lanes(int C, int dtype);
 int cvcs_bn_bwd_reduce(const void* y, int64_t y_ld, const void* g1, int64_t g1_ld, const void* g2, int64_t g2_ld,
                        int B, int H, int W, int C, const float* scale, const float* shift,
                        const float* save_mean, const float* save_invstd, int mode,

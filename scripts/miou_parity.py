@@ -15,29 +15,29 @@ from oracle import unet_oracle as O  # noqa: E402
 NC, B, DEV = 5, 8, "cuda:0"
 
 
-def _setup(model, precision, emulate=False):
+def _setup(model, precision, emulate=False, seed=3):
     """(oracle trainer, oracle eval-forward, HIP network) of one model family, same initial parameters.  emulate: the oracle TRAINS in its
     bf16-emulation mode (the yardstick for how far two correct bf16 runs of this schedule land from the f32 one)"""
     if model in ("Unetv2", "Unet"):
-        tr = O.OracleTrainer(model, NC, opt="SGD2", ignore_index=0, seed=3)
+        tr = O.OracleTrainer(model, NC, opt="SGD2", ignore_index=0, seed=seed)
         fwd = lambda p, x: O.unet_forward(p, x, model, train=False)   # noqa: E731
-        net, p0 = (nets.Urnetv2 if model == "Unetv2" else nets.Urnet)(NC, precision), O.init_params(model, NC, seed=3)
+        net, p0 = (nets.Urnetv2 if model == "Unetv2" else nets.Urnet)(NC, precision), O.init_params(model, NC, seed=seed)
     elif model in ("Resnet18Unet", "Resnet50Unet"):
         from oracle import resnet_unet_oracle as R
         arch = "resnet18" if model == "Resnet18Unet" else "resnet50"
-        tr = R.OracleTrainer(arch, NC, opt="SGD2", ignore_index=0, seed=3)
+        tr = R.OracleTrainer(arch, NC, opt="SGD2", ignore_index=0, seed=seed)
         fwd = lambda p, x: R.forward(p, x, arch, train=False)         # noqa: E731
-        net, p0 = getattr(nets, model)(NC, precision), R.init_params(arch, NC, seed=3)
+        net, p0 = getattr(nets, model)(NC, precision), R.init_params(arch, NC, seed=seed)
     elif model == "DeepLabV3Plus":
         from oracle import deeplab_oracle as D
-        tr = D.OracleTrainer("resnet50", NC, "SGD2", ignore_index=0, seed=3, output_stride=16, plus=True)
+        tr = D.OracleTrainer("resnet50", NC, "SGD2", ignore_index=0, seed=seed, output_stride=16, plus=True)
         fwd = lambda p, x: D.forward(p, x, "resnet50", train=False, output_stride=16, plus=True)   # noqa: E731
-        net, p0 = nets.DeepLabV3Plus(NC, precision), D.init_params("resnet50", NC, seed=3, plus=True)
+        net, p0 = nets.DeepLabV3Plus(NC, precision), D.init_params("resnet50", NC, seed=seed, plus=True)
     elif model == "TSwin":
         from oracle import swin_upernet_oracle as W
-        tr = W.OracleTrainer(NC, opt="SGD2", ignore_index=0, seed=3, emulate_bf16=emulate)
+        tr = W.OracleTrainer(NC, opt="SGD2", ignore_index=0, seed=seed, emulate_bf16=emulate)
         fwd = lambda p, x: W.forward(p, x, train=False, emulate_bf16=emulate)   # noqa: E731
-        net, p0 = nets.SwinTUperNet(NC, precision), W.init_params(NC, seed=3)
+        net, p0 = nets.SwinTUperNet(NC, precision), W.init_params(NC, seed=seed)
     else:
         raise ValueError(model)
     net.load_state_dict(p0, strict=False)
@@ -58,11 +58,12 @@ def oracle_only(steps, S, model, emulate):
     return O.metrics(conf)
 
 
-def run(precision="bf16", steps=40, S=64, verbose=True, model="Unetv2"):
+def run(precision="bf16", steps=40, S=64, verbose=True, model="Unetv2", seed=0):
+    """seed: another member of the ensemble - other initial parameters and other training tiles (the held-out set stays the same)"""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    train = [O.synthetic_tiles(B, S, NC, seed=100 + i, structured=True) for i in range(8)]
+    train = [O.synthetic_tiles(B, S, NC, seed=100 + i + 1000 * seed, structured=True) for i in range(8)]
     held = [O.synthetic_tiles(B, S, NC, seed=900 + i, structured=True) for i in range(4)]
-    tr, fwd, net = _setup(model, precision)
+    tr, fwd, net = _setup(model, precision, seed=3 + seed)
     crit = utils.CrossEntropyLoss(ignore_index=0)
     opt, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
     net.train()

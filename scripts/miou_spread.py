@@ -9,6 +9,20 @@ spec = importlib.util.spec_from_file_location("miou_parity", os.path.join(os.pat
 mod = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(mod)
 model, precision, S = sys.argv[1], sys.argv[2], int(sys.argv[3])
-for steps in map(int, sys.argv[4:]):
-    m_o, m_h = mod.run(precision, steps=steps, S=S, verbose=False, model=model)
-    print(f"{model} {precision} {steps} steps: oracle mIoU {100 * m_o['mIoU']:.3f}  HIP {100 * m_h['mIoU']:.3f}  difference {100 * (m_h['mIoU'] - m_o['mIoU']):+.3f} points", flush=True)
+args = sys.argv[4:]
+seeds = [0]
+if "seeds" in args:          # ... steps ... seeds 0 1 2 3 4: the ensemble over initial parameters / training tiles
+    i = args.index("seeds")
+    args, seeds = args[:i], [int(a) for a in args[i + 1:]]
+import time
+for steps in map(int, args):
+    d = []
+    for seed in seeds:
+        t0 = time.time()
+        m_o, m_h = mod.run(precision, steps=steps, S=S, verbose=False, model=model, seed=seed)
+        d.append(100 * (m_h["mIoU"] - m_o["mIoU"]))
+        print(f"{model} {precision} {steps} steps seed {seed}: oracle mIoU {100 * m_o['mIoU']:.3f}  HIP {100 * m_h['mIoU']:.3f}  difference {d[-1]:+.3f} points  ({time.time() - t0:.0f}s)", flush=True)
+    if len(d) > 1:
+        mean = sum(d) / len(d)
+        sd = (sum((x - mean) ** 2 for x in d) / (len(d) - 1)) ** 0.5
+        print(f"{model} {precision} {steps} steps: mean difference {mean:+.3f} points over {len(d)} seeds, standard deviation {sd:.3f}", flush=True)

@@ -160,3 +160,45 @@ def test_check_turns_a_status_into_an_exception(lib):
     assert lib.cvcs_conv2d(None, None) == -1
     with pytest.raises(_lib.CvcsError, match="null descriptor"):
         _lib.check(-1, "cvcs_conv2d")
+
+
+def test_batchnorm_backward_lane_rule_covers_every_channel_count_exactly(lib):
+    """the geometry behind round 3's memory-access fault (MobileNet bring-up, cvcs_bn_bwd_reduce on 4 x 4-pixel f32 maps of 96 channels): the
+    channel-chunk lanes of a workgroup must DIVIDE the row's 16-byte chunk count, so that gridDim.y * lanes covers a pixel row exactly and no
+    thread is handed a chunk (or, through the left-over pixel lane, a pixel) beyond the tensor - for every width, not only powers of two"""
+    for dtype, V in ((_lib.F32, 4), (_lib.BF16, 8)):
+        for C_ in range(V, 2049, V):
+            lanes = lib.cvcs_bn_bwd_chunk_lanes(C_, dtype)
+            CC = C_ // V
+            assert 1 <= lanes <= 32 and CC % lanes == 0, (C_, dtype, lanes)
+            assert lanes * (256 // lanes) <= 256          # the pixel lanes fit the workgroup; the remainder idles (kernel: `pl < PL`)
+        assert lib.cvcs_bn_bwd_chunk_lanes(V + 1, dtype) == -1 and lib.cvcs_bn_bwd_chunk_lanes(0, dtype) == -1
+    assert lib.cvcs_bn_bwd_chunk_lanes(96, _lib.F32) == 24 and lib.cvcs_bn_bwd_chunk_lanes(960, _lib.F32) == 30
+
+
+def test_round4_entry_points_reject_bad_arguments(lib):
+    keep, a = _buf(1 << 16)
+    # residual / second-source / mask epilogues are bf16 1x1 features of cvcs_conv2d
+    d = _desc(a, res=a, res_ld=64)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"1x1" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, Cout=128, out_ld=128, res=a, res_ld=64)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"res view" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, Cout=64, res=a, res_ld=64)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"residual epilogue needs" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, in2=a, in2_ld=32, Cin2=24)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"in2 view" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, Cout=64, mask=a, mask_ld=64)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"mask" in lib.cvcs_last_error()
+    # Gram matrix: channels in multiples of 64
+    assert lib.cvcs_gram_workspace_floats(1024, 48) == -1 and lib.cvcs_gram_workspace_floats(0, 64) == -1
+    assert lib.cvcs_gram_workspace_floats(1024, 64) > 0
+    assert lib.cvcs_gram(a, 48, 1024, 48, a, a, a, None) == -1 and b"multiple of 64" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_gram_finalize(a, a, a, 256, 48, 100, a, a, a, a, 0.1, 1e-5, a, a, a, a, a, None) == -1
+    assert lib.cvcs_bn_gram_bwd(a, a, a, a, a, 250, 64, 100, a, a, a, a, a, a, a, a, None) == -1 and b"C=250" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_gram_mmat_workspace_floats(256, 40) == -1
+    # fused head + cross-entropy: bf16, 16 / 32 / 64 channels, at most 32 classes
+    args = lambda C_=16, NC=16, dt=_lib.BF16: (a, C_, 1, 8, 8, C_, a, a, NC, a, 1, None, 0, 1.0, a, C_, a, a, a, dt, None)   # noqa: E731
+    assert lib.cvcs_head_ce(*args(dt=_lib.F32)) == -1 and b"bf16" in lib.cvcs_last_error()
+    assert lib.cvcs_head_ce(*args(C_=48)) == -1 and b"C=48" in lib.cvcs_last_error()
+    assert lib.cvcs_head_ce(*args(NC=40)) == -1 and b"NC=40" in lib.cvcs_last_error()
+    assert lib.cvcs_head_ce_rows(1 << 20) == 1024

@@ -137,8 +137,10 @@ def _build_fp8(NC, seed=3, precision="fp8"):
     return net.to(DEV)
 
 
-def test_fp8_network_layer_by_layer_forward_and_backward():
-    """precision "fp8" of ResNet50-UNet (BASELINE configs[4]) at 2 x 256 x 256, one train step, LAYER BY LAYER from the path's OWN stored
+@pytest.mark.parametrize("NC,B,S", [(16, 2, 256), (21, 1, 1024)], ids=["2x256x256", "cfg5 as named: 1024x1024, 20 classes"])
+def test_fp8_network_layer_by_layer_forward_and_backward(NC, B, S):
+    """precision "fp8" of ResNet50-UNet (BASELINE configs[4]: "ResNet50-UNet 1024x1024 tiles, 20 classes, mixed bf16/fp8 convs") at 2 x 256 x 256
+    and AS NAMED at 1024 x 1024 with 20 + 1 classes, one train step, LAYER BY LAYER from the path's OWN stored
     operands (no error amplification): (1) which layers run fp8 = the oracle's eligibility rule; (2) every fp8 image is the emulation's
     quantisation of the bf16 tensor it was taken from, bit for bit, at the slot's scale, and the scale is 2 amax / fmax of that tensor
     (first step: calibrated on itself); (3) every fp8 conv output / data gradient equals a float64 convolution of the stored fp8 operands
@@ -146,7 +148,6 @@ def test_fp8_network_layer_by_layer_forward_and_backward():
     from cvcs_amd import utils
     from oracle import resnet_unet_oracle as R
     from oracle import unet_oracle as O
-    NC, B, S = 16, 2, 256
     net = _build_fp8(NC)
     net._ensure_flat()
     eng = net._engine

@@ -80,3 +80,38 @@ def test_class_weights_from_the_loader(gid_dir):
     for i in range(3):
         counts += torch.bincount(ld._decode(i)[1].reshape(-1).long(), minlength=6).float()
     assert torch.allclose(w, dataset.class_weights_from_counts(counts, True)) and w[0] == 0
+
+
+def test_random_tps_adds_rescaled_crops_of_the_full_images(gid_dir):
+    """`random_tps = [(aug_size, percentage)]` (S/dataset.py:173-198, read at S/train.py:109): int(percentage * tiles) extra crops of
+    aug_size x aug_size pixels from random images of the chunk, image resized bilinearly (antialiased) and index mask by nearest-exact to the
+    patch size, shuffled in - planned from (seed, epoch, chunk): two loaders serve the same tiles; the synthetic loader (no full images) refuses"""
+    mk = lambda: dataset.Loader(gid_dir, chunk_size=2, random_shift=False, patch_size=224, seed=5)   # noqa: E731
+    a, b = mk(), mk()
+    base = list(a.get_iterable_chunk(0))
+    aug = list(a.get_iterable_chunk(0, random_tps=[(300, 0.5), (100, 0.25)]))
+    aug_b = list(b.get_iterable_chunk(0, random_tps=[(300, 0.5), (100, 0.25)]))
+    n = len(base)
+    assert len(aug) == n + int(0.5 * n) + int(0.25 * n)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(aug, aug_b))
+    assert all(t[0].shape == (3, 224, 224) and t[0].dtype == torch.uint8 and t[1].shape == (224, 224) and t[1].dtype == torch.uint8 for t in aug)
+    # the plain tiles are all still there; the extra ones are resized crops: every one equals resize_tile of SOME planned window
+    key = lambda t: (t[0].sum().item(), t[1].sum().item())   # noqa: E731
+    plain = {key(t) for t in base}
+    extra = [t for t in aug if key(t) not in plain]
+    assert len(extra) == int(0.5 * n) + int(0.25 * n)
+    import random
+    rng = random.Random(((5 * 1000003 + 0) * 1000003 + 0) * 31 + 7)
+    plan = dataset.plan_random_tps([(300, 0.5), (100, 0.25)], n, 2, a.H, a.W, rng)
+    decoded = [a._decode(i) for i in a.chunks[0]]
+    want = {key(dataset.resize_tile(decoded[pos][0][:, y:y + s, x:x + s], decoded[pos][1][y:y + s, x:x + s], 224)) for pos, y, x, s in plan}
+    assert {key(t) for t in extra} == want
+    # a mask resized by nearest-exact only contains labels of its window
+    for pos, y, x, s in plan[:3]:
+        _, m = dataset.resize_tile(decoded[pos][0][:, y:y + s, x:x + s], decoded[pos][1][y:y + s, x:x + s], 224)
+        assert set(m.unique().tolist()) <= set(decoded[pos][1][y:y + s, x:x + s].unique().tolist())
+    with pytest.raises(ValueError):
+        a.get_iterable_chunk(0, random_tps=[(1000, 0.1)])          # larger than the image
+    syn = dataset.SyntheticLoader(4, 2, 64, 5, tiles_per_image=4, seed=1)
+    with pytest.raises(ValueError):
+        syn.get_iterable_chunk(0, random_tps=[(32, 0.5)])

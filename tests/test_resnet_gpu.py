@@ -714,3 +714,45 @@ def test_training_is_bitwise_reproducible_and_learns():
         runs.append((losses, net.flat_parameters()[0].clone()))
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert runs[0][0][-1] < 0.6 * runs[0][0][0], runs[0][0]
+
+
+def test_plans_and_buffers_survive_a_change_of_input_shape():
+    """train -> evaluate on another batch shape -> train (what `train.py` does every epoch around `eval_model` / `validation_loss`,
+    S/train.py:134-150): the launch plans and activation buffers of a shape are parked while another shape runs and come back untouched -
+    no re-recording, no re-allocation (resnet_engine._switch_shape, 3 shapes by default) - and the interrupted run is bitwise the uninterrupted one"""
+    img, lab = O.synthetic_tiles(4, 64, 5, seed=2, structured=True)
+    img, lab = img.to(DEV), lab.to(DEV)
+
+    def run(interrupt):
+        torch.manual_seed(0)
+        net = _build("resnet18", 5, "bf16")
+        crit = utils.CrossEntropyLoss(ignore_index=0)
+        optim, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 20}, net)
+        losses, ids = [], []
+        for step in range(4):
+            net.train()
+            loss = crit(net(img, None), lab)
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+            losses.append(loss.item())
+            eng = net._engine
+            ids.append((id(eng._rec["fwd_train"]), id(eng._rec["bwd"]), id(eng._bufs), eng.logits.data_ptr()))
+            if interrupt:
+                net.eval()
+                with torch.no_grad():
+                    net.predict_labels(img[:1])            # (1, 64)
+                    net(img[:2], None)                      # (2, 64)
+                assert eng.shape == (2, 64) and (4, 64) in eng._shape_cache
+        return losses, ids, net.flat_parameters()[0].clone(), net
+
+    l0, _, p0, _ = run(False)
+    l1, ids, p1, net = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+    assert len(set(ids[1:])) == 1, "a shape that came back was re-planned"        # (the first step records, every later one replays the same objects)
+    # a fourth shape evicts the least recently used one
+    eng = net._engine
+    net.eval()
+    with torch.no_grad():
+        net.predict_labels(img[:3])
+    assert len(eng._shape_cache) == eng.PLAN_CACHE - 1 and (4, 64) not in eng._shape_cache
