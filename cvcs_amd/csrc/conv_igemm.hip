@@ -1428,8 +1428,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
   const int xpx = lane / XCH, xch = lane % XCH;
   const bool kvalid = fg * 16 < CI * 2;            // this lane's 16 bytes of K exist in the input (a 16-channel input fills k-groups 0, 1)
 
-  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-    const int b = t / tpi, tr = t - b * tpi;
+  // Two halo buffers: the LDS-DMA of tile t + 1 is issued before tile t is computed and lands while its MFMAs, statistics and stores run
+  // (single-buffered, a workgroup alternated between waiting for its halo and computing: 2.2-3.3 TB/s on layers that are pure HBM traffic)
+  auto stage_halo = [&](int tt, unsigned base) {
+    const int b = tt / tpi, tr = tt - b * tpi;
     const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
     for (int pi = wave; pi < NX; pi += 4) {
       const int r = pi * XPP + xpx;
@@ -1438,9 +1440,17 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
       const char* src = (r < XPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
                             ? p.in + ((((int64_t)b * p.H + iy) * p.W + ix) * p.in_ld) * 2 + xch * 16
                             : reinterpret_cast<const char*>(&g_zero16);
-      dma16(src, lds0 + pi * 1024);
+      dma16(src, base + pi * 1024);
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  int cur = 0;
+  if ((int)blockIdx.x < p.ntiles) stage_halo(blockIdx.x, lds0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    const int b = t / tpi, tr = t - b * tpi;
+    const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
+    if (t + (int)gridDim.x < p.ntiles) stage_halo(t + gridDim.x, lds0 + (cur ^ 1) * XB);
+    const char* hbuf = smem + cur * XB;
     const int y = ty0 + wave;
     f32x4 acc[4][MB];
 #pragma unroll
@@ -1454,7 +1464,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
         const int kh = tap / 3, kw = tap - kh * 3;
         const int hp = (wave + kh) * kTcHC + g * 16 + fr + kw;
         uint4 xv = make_uint4(0u, 0u, 0u, 0u);
-        if (kvalid) xv = *reinterpret_cast<const uint4*>(smem + hp * (CI * 2) + fg * 16);
+        if (kvalid) xv = *reinterpret_cast<const uint4*>(hbuf + hp * (CI * 2) + fg * 16);
         const bf16x8 bfr = __builtin_bit_cast(bf16x8, xv);
 #pragma unroll
         for (int i = 0; i < MB; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][i], bfr, acc[g][i], 0, 0, 0);   // D[co][pixel]
@@ -1511,7 +1521,8 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
         }
       }
     }
-    __syncthreads();            // the halo is free again
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the next halo has landed, every wave is done with this one
+    cur ^= 1;
   }
 }
 
@@ -1727,7 +1738,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     ta.tiles_x = (int)cdiv(d->W, kTcTW); ta.tiles_y = (int)cdiv(d->H, kTcTH); ta.ntiles = d->B * ta.tiles_x * ta.tiles_y;
     const int groups = ta.ntiles < 1024 ? ta.ntiles : 1024;
 #define LAUNCH_TC(CI_, CO_)                                                                                              \
-  hipLaunchKernelGGL((conv3x3_thin_kernel<CI_, CO_>), dim3((unsigned)groups), dim3(256), (kTcHR * kTcHC * (CI_) * 2 + 1023) / 1024 * 1024, st, ta)
+  hipLaunchKernelGGL((conv3x3_thin_kernel<CI_, CO_>), dim3((unsigned)groups), dim3(256), 2 * ((kTcHR * kTcHC * (CI_) * 2 + 1023) / 1024 * 1024), st, ta)
     if (cin_valid == 16 && d->Cout == 16) LAUNCH_TC(16, 16);
     else if (cin_valid == 16) LAUNCH_TC(16, 32);
     else if (d->Cout == 16) LAUNCH_TC(32, 16);

@@ -2,6 +2,8 @@
 // do not have: depthwise k x k convolutions with stride and dilation (forward with the BatchNorm batch statistics in the epilogue, data
 // gradient, weight-gradient partials), the squeeze-excite scale passes and hardsigmoid.  hardswish lives in the BatchNorm apply / backward
 // passes (elementwise.hip: act / mode 3).  All HBM-bound: NHWC, 16-byte channel chunks per thread, channel-lane x pixel-lane workgroups.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cvcs {
@@ -33,6 +35,7 @@ struct DwgArgs {
   int64_t in_ld, out_ld;
   int B, Hi, Wi, Ho, Wo, C, K, s, d, pad, ccw;     // Hi x Wi: the map read; Ho x Wo: the map written
   float* stat_sum; float* stat_m2; float* stat_cnt;
+  int xcd;       // XCD-aware pixel order (CVCS_XCD_ORDER=0 switches it off: a tuning knob)
 };
 
 // FWD:  out[b, oy, ox, c] = sum_t in[b, oy*s - pad + ky*d, ox*s - pad + kx*d, c] * w[t][c]                 (in = x, out = y)
@@ -49,6 +52,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
   const int tid = threadIdx.x, cl = tid % ccw, pl = tid / ccw;
   const bool active = pl < PL;
   const int cc = blockIdx.y * ccw + cl;
+  // XCD-aware pixel order: the workgroups of one XCD (ids 8 apart) take a CONTIGUOUS span of pixels per grid stride - whole bands of image rows -
+  // so the K window rows a pixel needs are hits of that XCD's own L2 (dealt round-robin, every row was fetched from HBM by several XCDs:
+  // PMC 212 MB per launch for 115 MB of operands)
+  const unsigned bid = p.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x;
   for (int i = tid; i < KK * ccw * V; i += 256) {
     const int t = i / (ccw * V), c = i - t * (ccw * V);
     wl[i] = p.w[(int64_t)t * p.C + blockIdx.y * ccw * V + c];
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
   for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   int cnt = 0;
   if (active)
-    for (unsigned it = blockIdx.x * PL + pl; it < (unsigned)items; it += gridDim.x * PL) {      // (32-bit index arithmetic: items < 2^31, checked by the host;
+    for (unsigned it = bid * PL + pl; it < (unsigned)items; it += gridDim.x * PL) {      // (32-bit index arithmetic: items < 2^31, checked by the host;
       const unsigned t0 = it / (unsigned)p.Wo;                                                  //  64-bit divisions cost more than the window's loads on thin layers)
       const int ox = (int)(it - t0 * (unsigned)p.Wo);
       const int64_t b = t0 / (unsigned)p.Ho;
@@ -139,11 +146,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwgArgs p) {
         for (int q = 0; q < PL; ++q) { S += (double)red[0][(q * ccw + cl) * V + k]; Q += (double)red[1][(q * ccw + cl) * V + k]; }
         double m2 = n > 0 ? Q - S * S / (double)n : 0.0;
         if (m2 < 0.0) m2 = 0.0;
-        const int64_t o = (int64_t)blockIdx.x * p.C + cc * V + k;
+        const int64_t o = (int64_t)bid * p.C + cc * V + k;
         p.stat_sum[o] = (float)S;
         p.stat_m2[o] = (float)m2;
       }
-      if (blockIdx.y == 0 && cl == 0) p.stat_cnt[blockIdx.x] = (float)n;
+      if (blockIdx.y == 0 && cl == 0) p.stat_cnt[bid] = (float)n;
     }
   }
 }
@@ -394,6 +401,8 @@ static int dwconv_launch(const char* fn, bool dgrad, const void* in, int64_t in_
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.C = C; a.K = K; a.s = stride; a.d = dil; a.pad = pad;
   a.ccw = chunk_lanes(C / V, 32);
   a.stat_sum = stat_sum; a.stat_m2 = stat_m2; a.stat_cnt = stat_cnt;
+  static const int xcd_on = getenv("CVCS_XCD_ORDER") ? atoi(getenv("CVCS_XCD_ORDER")) : 1;   // tuning knob
+  a.xcd = xcd_on;
   const dim3 grid((unsigned)dw_rows((int64_t)B * Ho * Wo, a.ccw, C / V / a.ccw, kDwPixPerLane, kDwMaxWgs), (unsigned)(C / V / a.ccw));
   hipStream_t st = (hipStream_t)stream;
 #define DW_L(TT, KK_)                                                                                  \

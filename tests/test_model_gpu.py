@@ -127,8 +127,15 @@ def test_fp32_path_replays_the_large_reference_golden(golden_dir, tag, variant, 
     if adam:
         # eval-mode logits of 1e5 after three Adam steps: the running statistics have seen three batches whose statistics Adam's +-lr
         # steps on noise-level gradients moved at random (tests/test_oracle_golden.py shows torch itself does not reproduce them across
-        # thread counts).  Nothing to assert beyond finiteness; the SGD2 twins of this test carry the eval-mode statement
-        assert np.isfinite(ev).all() and err <= 1.0 * scale
+        # thread counts), so the reference's END POINT is not a yardstick.  What is one: the eval-mode forward of the pinned oracle at THIS
+        # run's own end point (its parameters and running statistics) - the statement "eval mode after ADAM1 training is computed right"
+        # without the trajectory noise; the SGD2 twins of this test carry the comparison with the reference's end point
+        p_end = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            want = O.unet_forward(p_end, torch.tensor(g["img"]).float(), variant, train=False).numpy()
+        assert np.isfinite(ev).all()
+        e_own = np.abs(ev - want).max() / max(1.0, np.abs(want).max())
+        assert e_own <= 1e-3, f"eval logits at the run's own ADAM1 end point: {e_own:.2e} of max|logit| from the oracle at the same parameters"
         return
     assert err <= 1e-2 * scale
     bad = ev.argmax(1) != g["labels_eval"]
@@ -352,16 +359,34 @@ def test_data_parallel_single_rank_matches_plain_training():
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_heldout_miou_after_training_matches_cpu_reference(precision):
-    """north star: mIoU on a held-out synthetic set vs the CPU reference (S/utils.py:311-364 definition) after the
-    same 40-step SGD2 schedule on structured tiles.  f32: the north star's 0.1 points.  bf16: the end point of this schedule is a chaotic
-    function of rounding - over schedules of 36 ... 44 steps this build lands -0.15 ... -0.07 points from the f32 oracle, the build of one
-    day earlier (same kernels up to compiler scheduling, every per-kernel test green on both) +0.13 / +0.10 / +0.09 at 38 / 40 / 42 steps
-    (`scripts/miou_spread.py`, profiles/r03_miou_spread_unetv2_bf16.txt); the curve still rises 0.07 points per step there.  Held to 0.2."""
+    """north star: mIoU on a held-out synthetic set vs the CPU reference (S/utils.py:311-364 definition) after the same 40-step SGD2
+    schedule on structured tiles, within 0.1 points.  f32: one run.  bf16: the end point of ONE bf16 trajectory is a chaotic function of
+    rounding (round 3: two builds of the same kernels at -0.11 and +0.10 on the same schedule), so the statement is made about the MEAN
+    over an ensemble of six runs (other initial parameters, other training tiles, the same held-out set): measured on the MI355X
+    -0.114 / +0.064 / +0.025 / +0.005 / +0.095 / -0.043 -> mean +0.005, standard deviation 0.076 (profiles/r04_miou_ensembles.txt); a bias of
+    the bf16 path of 0.1 points would sit three standard errors from that.  Every member must also stay within 0.3 (four deviations)."""
+    if precision == "fp32":
+        m_o, m_h = _miou_parity().run(precision, steps=40, S=64, verbose=False)
+        assert m_o["mIoU"] > 0.9, "the schedule must actually learn the task"
+        assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= 0.1, (m_o["mIoU"], m_h["mIoU"])
+        return
+    mean, sd, d = _miou_ensemble("Unetv2", "bf16", 40, 64, range(6))
+    assert abs(mean) <= 0.1, (mean, d)
+
+
+def _miou_ensemble(model, precision, steps, S, seeds, learn=0.9):
+    """(mean, standard deviation, members) of HIP - oracle held-out mIoU in points over runs that differ in initial parameters and training tiles"""
     mod = _miou_parity()
-    m_o, m_h = mod.run(precision, steps=40, S=64, verbose=False)
-    assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
-    bound = 0.1 if precision == "fp32" else 0.2
-    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= bound, (m_o["mIoU"], m_h["mIoU"])
+    d = []
+    for seed in seeds:
+        m_o, m_h = mod.run(precision, steps=steps, S=S, verbose=False, model=model, seed=seed)
+        assert m_o["mIoU"] > learn, "the schedule must actually learn the task"
+        d.append(100 * (m_h["mIoU"] - m_o["mIoU"]))
+    mean = sum(d) / len(d)
+    sd = (sum((x - mean) ** 2 for x in d) / max(len(d) - 1, 1)) ** 0.5
+    print(f"{model} {precision} {steps} steps: HIP - oracle held-out mIoU {[round(x, 3) for x in d]} points, mean {mean:+.3f}, standard deviation {sd:.3f}")
+    assert all(abs(x) <= 0.3 for x in d), d
+    return mean, sd, d
 
 
 def _miou_parity():
@@ -372,22 +397,18 @@ def _miou_parity():
     return mod
 
 
-@pytest.mark.parametrize("model,precision,steps,S", [("Resnet18Unet", "bf16", 40, 64), ("DeepLabV3Plus", "bf16", 120, 128), ("TSwin", "bf16", 100, 128)])
-def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, precision, steps, S):
-    """the same for BASELINE's model families (measured on the MI355X: ResNet18-UNet bf16 0.012, ResNet50-UNet bf16 0.005, DeepLabV3+ bf16
-    0.005, Swin-T + UPerNet f32 0.030 points - the last one takes 70 s of CPU oracle time and is left to `scripts/miou_parity.py fp32 120 128
-    TSwin`).  Swin-T + UPerNet in bf16: this round's build lands -0.02 / -0.08 / -0.01 points from the f32 oracle after 100 / 110 / 120 steps
-    (`scripts/miou_spread.py TSwin bf16 128 100 110 120`, profiles/r03_miou_spread_swint_bf16.txt); the builds of rounds 1-2 measured 0.15-0.24 on
-    the same schedules and the oracle TRAINED in its own forward-only bf16 emulation lands 0.08 away - the end point of a bf16 trajectory moves by
-    +-0.15 points with the build (profiles/r03_miou_spread_unetv2_bf16.txt: two builds of the same kernels on either side of the oracle).
-    Asserted at 0.25 on the 100-step schedule (~80 s, most of it the CPU oracle)."""
-    m_o, m_h = _miou_parity().run(precision, steps=steps, S=S, verbose=False, model=model)
-    assert m_o["mIoU"] > 0.85, "the schedule must actually learn the task"
-    # DeepLabV3+ after 120 bf16 steps is a chaotic trajectory (tests/test_dataparallel_gpu.py measures it: the SAME f32 step with the tiles in
-    # reverse order lands 2 % away in loss): three builds that differ only in the summation order of the BatchNorm-backward partial sums
-    # measured 0.005, 0.06 and 0.135 points here.  The north star's 0.1 is asserted for the ResNet-UNet twin and the f32 paths; this one is held to 0.2
-    bound = {"DeepLabV3Plus": 0.2, "TSwin": 0.25}.get(model, 0.1)
-    assert abs(m_o["mIoU"] - m_h["mIoU"]) * 100 <= bound, (m_o["mIoU"], m_h["mIoU"])
+@pytest.mark.parametrize("model,steps,S,seeds", [("Resnet18Unet", 40, 64, 4), ("Resnet50Unet", 60, 128, 3), ("DeepLabV3Plus", 120, 128, 5), ("TSwin", 100, 128, 1)])
+def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, steps, S, seeds):
+    """the same for BASELINE's model families in bf16, each as the MEAN over an ensemble of runs (other initial parameters and training tiles),
+    within the north star's 0.1 points of the f32 CPU oracle trained on the same tiles (mIoU definition: S/utils.py:311-364).  Measured on the
+    MI355X (profiles/r04_miou_ensembles.txt): ResNet18-UNet +0.029 / +0.027 / +0.016 / +0.047 (mean +0.030, standard deviation 0.013);
+    ResNet50-UNet at 128^2 - the headline model, on the round-4 path without stored conv3 outputs / logits - -0.004 / -0.067 / +0.025 / +0.034
+    (mean -0.003, s.d. 0.046; the stored-y3 / eager-logits path on the same seeds: -0.001, s.d. 0.054); DeepLabV3+ +0.093 / -0.260 / +0.029 over
+    three seeds (s.d. 0.19: its image-pooling BatchNorm averages B = 8 values and its reversed-tile-order run already lands 2 % away in loss -
+    five members here); Swin-T + UPerNet -0.021 / +0.002 / +0.006 (s.d. 0.014: one member is a 7-sigma statement and costs a minute of CPU
+    oracle time).  Rounds 1-3 asserted one end point per model at 0.2-0.25."""
+    mean, sd, d = _miou_ensemble(model, "bf16", steps, S, range(seeds), learn=0.85)
+    assert abs(mean) <= 0.1, (model, mean, d)
 
 
 @pytest.mark.parametrize("variant,B,S", [("Unetv2", 4, 128), ("Unet", 2, 128), ("Unetv2", 2, 256)])
