@@ -245,7 +245,7 @@ SIGNATURES = {
     "cvcs_bn_gram_mmat_workspace_floats": (_i64, [_i, _i]),
     "cvcs_bn_gram_mmat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "cvcs_head_ce_rows": (_i, [_i64]),
-    "cvcs_head_ce": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i64, _vp, _vp, _vp, _i, _vp]),
+    "cvcs_head_ce": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i64, _vp, _vp, _vp, _i, _vp]),
     "cvcs_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
     "cvcs_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }

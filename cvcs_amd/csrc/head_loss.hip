@@ -776,7 +776,7 @@ __device__ __forceinline__ uint2 tr_read16(unsigned addr) {
 
 template <int C, int NT>
 __global__ __launch_bounds__(256) void head_ce_kernel(const char* __restrict__ x, int64_t x_ld, int64_t P, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, int NC, const void* target, int is_u8,
+                                                     const float* __restrict__ wdx, const float* __restrict__ bias, int NC, const void* target, int is_u8,
                                                      const float* __restrict__ cw, int ignore, float grad_scale, char* dx, int64_t dx_ld,
                                                      float* part_dw, float* ws, int R) {
   constexpr int CT = C / 16;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const char* __restrict__ x
       split4(v, Whi[nt][ct], Wlo[nt][ct]);
       const int c = ct * 16 + fr;                  // A of dx^T: row = channel fr, k = classes 4g..4g+3
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const int nn = nt * 16 + 4 * g + k; t[k] = nn < NC ? w[(int64_t)nn * C + c] : 0.f; }
+      for (int k = 0; k < 4; ++k) { const int nn = nt * 16 + 4 * g + k; t[k] = nn < NC ? wdx[(int64_t)nn * C + c] : 0.f; }
       split4(t, WThi[ct][nt], WTlo[ct][nt]);
     }
 #pragma unroll
@@ -1205,7 +1205,7 @@ extern "C" int cvcs_label_histogram(const uint8_t* labels, int64_t n, int K, int
 // the partial dW | db rows cvcs_head_ce writes (one per workgroup), also the row count of its loss-numerator partials
 extern "C" int cvcs_head_ce_rows(int64_t P) { return ce_rows(P); }
 
-extern "C" int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+extern "C" int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* w_dx, const float* bias, int NC,
                             const void* target, int target_is_u8, const float* class_weight, int ignore_index, float grad_scale,
                             void* dx, int64_t dx_ld, float* part_dw, float* workspace, float* loss_out, int dtype, void* stream) {
   CVCS_CHECK_ARG(x && w && bias && target && dx && part_dw && workspace && loss_out, "cvcs_head_ce: null argument");
@@ -1220,7 +1220,7 @@ extern "C" int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, in
   hipLaunchKernelGGL(ce_weight_kernel, dim3(R), dim3(256), 0, st, target, target_is_u8, P, NC, class_weight, ignore_index, workspace);
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(64), 0, st, workspace, R, 0, loss_out);
 #define LAUNCH_HC(C_, NT_)                                                                                                               \
-  hipLaunchKernelGGL((head_ce_kernel<C_, NT_>), dim3(R), dim3(256), 0, st, (const char*)x, x_ld, P, w, bias, NC, target, target_is_u8,    \
+  hipLaunchKernelGGL((head_ce_kernel<C_, NT_>), dim3(R), dim3(256), 0, st, (const char*)x, x_ld, P, w, w_dx ? w_dx : w, bias, NC, target, target_is_u8,    \
                      class_weight, ignore_index, grad_scale, (char*)dx, dx_ld, part_dw, workspace, R)
   if (NC <= 16) { if (C == 16) LAUNCH_HC(16, 1); else if (C == 32) LAUNCH_HC(32, 1); else LAUNCH_HC(64, 1); }
   else          { if (C == 16) LAUNCH_HC(16, 2); else if (C == 32) LAUNCH_HC(32, 2); else LAUNCH_HC(64, 2); }

@@ -56,6 +56,9 @@ class UNetEngine:
         self.Bf = None  # name -> f32 buffer (running stats)
         self.packed = {}
         self._saved_train = False
+        self.fwd_serial = 0              # forward passes so far (a nets.LazyLogits handle is current while it matches)
+        self._head_pending = self._head_done = False
+        self._head_rows, self._head_in, self._head_w = 0, None, None
         self._pack_table = None   # device table of (master weight, packed operands) built at first use
         self.sync_bn = None             # parallel.SyncStats: batch-norm statistics over all ranks' tiles (None: per rank)
         self._sync_mom = self._sync_sums = None   # its exchange buffers (allocated by enable_sync_bn)
@@ -211,7 +214,7 @@ class UNetEngine:
         self.stat_cnt = torch.empty(max(r for r, _ in rows_c), dtype=torch.float32, device=dev)
         rows1 = ops.bn_bwd_rows(M1)
         self.part = [torch.empty(rows1 * 1024, dtype=torch.float32, device=dev) for _ in range(3)]
-        self.head_part = torch.empty(ops.head_bwd_rows(M1) * (self.NC * 64 + self.NC), dtype=torch.float32, device=dev)
+        self.head_part = torch.empty(max(ops.head_bwd_rows(M1), ops.head_ce_rows(M1)) * (self.NC * 64 + self.NC), dtype=torch.float32, device=dev)
         # wgrad split-K workspace: the maximum over all layers
         need = 0
         for (Bc, Ho, Cout, Cin, K, st) in self._wgrad_shapes(B):
@@ -371,8 +374,10 @@ class UNetEngine:
         self._saved_train = train
         return prev
 
-    def forward(self, x: torch.Tensor, train: bool) -> torch.Tensor:
-        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine)."""
+    def forward(self, x: torch.Tensor, train: bool, lazy: bool = False) -> torch.Tensor:
+        """x: NCHW u8 | f32 [B,3,S,S] on the device -> NCHW f32 logits [B,NC,S,S] (owned by the engine).
+        lazy (train mode, bf16): the head is NOT run - materialize_logits() fills the buffer if anybody reads it, a loss that recognises the
+        handle calls head_ce() and the logits never exist (nets.LazyLogits; S/train.py:121-125 unchanged)"""
         prev = self._backbone(x, train)
         hw = self.P["decode_forward4.1.weight"].view(self.NC, 64)
         hb = self.P["decode_forward4.1.bias"]
@@ -380,8 +385,37 @@ class UNetEngine:
             st = self.bn["decode_forward4.0.layer.5"]
             ops.head_fold(hw, hb, st.scale, st.shift, self.head_wf, self.head_bf)
             hw, hb = self.head_wf, self.head_bf
-        ops.head_fwd(prev, hw, hb, self.logits)
+        self.fwd_serial += 1
+        self._head_done = False
+        self._head_in, self._head_w = prev, (hw, hb)
+        self._head_pending = bool(lazy and train and self.lazy_head_ok())
+        if not self._head_pending:
+            ops.head_fwd(prev, hw, hb, self.logits)
         return self.logits
+
+    def lazy_head_ok(self) -> bool:
+        return self.dtype == torch.bfloat16 and self.NC <= 32 and self.sync_bn is None
+
+    def materialize_logits(self):
+        if self._head_pending:
+            ops.head_fwd(self._head_in, self._head_w[0], self._head_w[1], self.logits)
+            self._head_pending = False
+
+    def head_ce(self, target, class_weight, ignore_index, workspace, loss_out):
+        """folded head + cross-entropy + the head's backward in one pass over the last ReLU output (cvcs_head_ce): logits from the folded
+        weights, the gradient w.r.t. the BatchNorm output from the real ones, dW | db partials w.r.t. the folded ones (un-folded in backward)"""
+        B, S = self.shape
+        P_ = B * S * S
+        rows = ops.head_ce_rows(P_)
+        assert self.head_part.numel() >= rows * (self.NC * 64 + self.NC)
+        ops.head_ce(self._head_in, self._head_w[0], self._head_w[1], target, class_weight, ignore_index, 1.0, ops.view(self.g_zb[4]),
+                    self.head_part, workspace, loss_out, w_dx=self.P["decode_forward4.1.weight"].view(self.NC, 64))
+        self._head_done, self._head_rows = True, rows
+
+    def scale_head_grads(self, gout):
+        g = gout.detach().to(device=self.head_part.device, dtype=torch.float32).reshape(1).contiguous()
+        ops.scale_unless_one(self.g_zb[4], g)
+        ops.scale_unless_one(self.head_part, g)
 
     def forward_labels(self, x: torch.Tensor, labels: torch.Tensor):
         """eval-mode prediction: u8 labels [B,S,S] = argmax of the logits, head and argmax fused (no logits tensor)"""
@@ -507,10 +541,14 @@ class UNetEngine:
         B, S = self.shape
         NC = self.NC
         hw = self.P["decode_forward4.1.weight"]
-        rows = ops.head_bwd_rows(B * S * S)
-        # the head saw r (the last ReLU output) through folded weights: dx = W^T dl is the gradient w.r.t. the BatchNorm
-        # output z either way (real W); dW comes out w.r.t. r and is un-folded below
-        ops.head_bwd(ops.view(self.rb[4]), dlogits.contiguous(), hw.view(NC, 64), ops.view(self.g_zb[4]), self.head_part)
+        if self._head_done:       # head_ce() already produced the gradient w.r.t. the BatchNorm output and the partial rows
+            rows = self._head_rows
+            self._head_done = False
+        else:
+            rows = ops.head_bwd_rows(B * S * S)
+            # the head saw r (the last ReLU output) through folded weights: dx = W^T dl is the gradient w.r.t. the BatchNorm
+            # output z either way (real W); dW comes out w.r.t. r and is un-folded below
+            ops.head_bwd(ops.view(self.rb[4]), dlogits.contiguous(), hw.view(NC, 64), ops.view(self.g_zb[4]), self.head_part)
         # head weight [NC,64,1,1] and bias [NC] are adjacent in the flat gradient buffer (registration order)
         gw, gb = self.G["decode_forward4.1.weight"], self.G["decode_forward4.1.bias"]
         assert gb.data_ptr() == gw.data_ptr() + gw.numel() * 4

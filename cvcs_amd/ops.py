@@ -959,7 +959,7 @@ def head_ce_ok(x: View, NC: int) -> bool:
     return x.code == BF16 and x.C in (16, 32, 64) and 1 <= NC <= 32
 
 
-def head_ce(x: View, w, bias, target, class_weight, ignore_index, grad_scale, dx: View, part_dw, workspace, loss_out):
+def head_ce(x: View, w, bias, target, class_weight, ignore_index, grad_scale, dx: View, part_dw, workspace, loss_out, w_dx=None):
     """1x1 head + softmax cross-entropy + their backward in one pass over x: loss_out[0] <- mean CE, dx <- d loss / d x, part_dw <-
     head_ce_rows(P) partial rows [NC*C | NC] of dW | db.  No logits, no logit gradient."""
     NC = w.shape[0]
@@ -968,7 +968,7 @@ def head_ce(x: View, w, bias, target, class_weight, ignore_index, grad_scale, dx
     assert target.is_contiguous() and target.dtype in (torch.uint8, torch.int64) and target.numel() == P
     assert part_dw.numel() >= head_ce_rows(P) * (NC * x.C + NC) and workspace.numel() >= ce_workspace_floats(P)
     _tag_hbm("head_ce", P * (x.C * 2 * 2 + target.element_size()))
-    check(_lib.lib().cvcs_head_ce(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), bias.data_ptr(), NC, target.data_ptr(),
+    check(_lib.lib().cvcs_head_ce(x.ptr, x.ld, x.B, x.H, x.W, x.C, w.data_ptr(), _ptr(w_dx), bias.data_ptr(), NC, target.data_ptr(),
                                   int(target.dtype == torch.uint8), _ptr(class_weight), ignore_index, grad_scale, dx.ptr, dx.ld,
                                   part_dw.data_ptr(), workspace.data_ptr(), loss_out.data_ptr(), x.code, _stream()), "cvcs_head_ce")
 

@@ -669,9 +669,12 @@ int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void*
  * the [B, NC, H, W] f32 logits and their gradient are never written.  x: the last decoder activation [B*H*W][C] (view), target as cvcs_ce_fwd_bwd,
  * w f32 [NC][C], bias f32 [NC].  Writes loss_out (mean over the non-ignored pixels, class weights as S/utils.py:230), dx (the gradient
  * w.r.t. x, bf16 view) and cvcs_head_ce_rows(P) partial rows [NC*C | NC] of dW | db (summed by cvcs_colsum_finalize, as cvcs_head_bwd's).
- * workspace: cvcs_ce_workspace_floats(P) floats.  grad_scale multiplies the gradients (1 for a plain loss.backward()).                  */
+ * workspace: cvcs_ce_workspace_floats(P) floats.  grad_scale multiplies the gradients (1 for a plain loss.backward()).
+ * w_dx (NULL = w): the weights of the data gradient dx = w_dx^T dl when they differ from those of the logits - the reference U-Nets fold their
+ * last BatchNorm into the head (cvcs_head_fold: logits from the folded weights on the pre-BatchNorm activation, dx w.r.t. the BatchNorm output
+ * from the real ones, dW w.r.t. the folded ones, un-folded by cvcs_head_unfold_grad).                                                      */
 int cvcs_head_ce_rows(int64_t P);
-int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* bias, int NC,
+int cvcs_head_ce(const void* x, int64_t x_ld, int B, int H, int W, int C, const float* w, const float* w_dx, const float* bias, int NC,
                  const void* target, int target_is_u8, const float* class_weight, int ignore_index, float grad_scale,
                  void* dx, int64_t dx_ld, float* part_dw, float* workspace, float* loss_out, int dtype, void* stream);
 /* A recorded launch plan driven from C (host time per step < 0.5 ms).  A plan is the list of launch entry points of

@@ -197,7 +197,7 @@ def test_round4_entry_points_reject_bad_arguments(lib):
     assert lib.cvcs_bn_gram_bwd(a, a, a, a, a, 250, 64, 100, a, a, a, a, a, a, a, a, None) == -1 and b"C=250" in lib.cvcs_last_error()
     assert lib.cvcs_bn_gram_mmat_workspace_floats(256, 40) == -1
     # fused head + cross-entropy: bf16, 16 / 32 / 64 channels, at most 32 classes
-    args = lambda C_=16, NC=16, dt=_lib.BF16: (a, C_, 1, 8, 8, C_, a, a, NC, a, 1, None, 0, 1.0, a, C_, a, a, a, dt, None)   # noqa: E731
+    args = lambda C_=16, NC=16, dt=_lib.BF16: (a, C_, 1, 8, 8, C_, a, None, a, NC, a, 1, None, 0, 1.0, a, C_, a, a, a, dt, None)   # noqa: E731
     assert lib.cvcs_head_ce(*args(dt=_lib.F32)) == -1 and b"bf16" in lib.cvcs_last_error()
     assert lib.cvcs_head_ce(*args(C_=48)) == -1 and b"C=48" in lib.cvcs_last_error()
     assert lib.cvcs_head_ce(*args(NC=40)) == -1 and b"NC=40" in lib.cvcs_last_error()

@@ -139,3 +139,70 @@ def test_lazy_logits_handle_through_the_reference_training_step(unit_grad, monke
     # eval mode and no_grad keep returning plain tensors
     net.eval()
     assert type(net(img, None)) is torch.Tensor
+
+
+def test_folded_head_uses_separate_weights_for_the_data_gradient():
+    """the reference U-Nets fold their last BatchNorm into the head (cvcs_head_fold): logits = (W diag(s)) r + (b + W t), the gradient handed
+    on is the one w.r.t. the BatchNorm output z = s r + t, i.e. W^T dl with the REAL weights, dW | db come out w.r.t. the folded ones"""
+    B, H, W, C_, NC = 2, 16, 24, 64, 16
+    g = torch.Generator().manual_seed(9)
+    r = torch.randn(B, H, W, C_, generator=g).relu().to(BF).float()
+    w = torch.randn(NC, C_, generator=g) / 8
+    b = torch.randn(NC, generator=g) * 0.1
+    sc, sh = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.2
+    t = torch.randint(0, NC, (B, H, W), generator=g)
+    wf, bf = w * sc[None, :], b + w @ sh
+    Z = (r.double() * sc.double() + sh.double()).requires_grad_(True)
+    Wt, Bt = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    loss = F.cross_entropy((Z @ Wt.T + Bt).permute(0, 3, 1, 2), t, ignore_index=0)
+    loss.backward()
+    Wf, Bf = wf.double().requires_grad_(True), bf.double().requires_grad_(True)
+    F.cross_entropy((r.double() @ Wf.T + Bf).permute(0, 3, 1, 2), t, ignore_index=0).backward()
+    xv = ops.view(r.to(BF).to(DEV).contiguous())
+    dx = ops.view(torch.zeros(B, H, W, C_, dtype=BF, device=DEV))
+    P = B * H * W
+    rows = ops.head_ce_rows(P)
+    part = torch.empty(rows * (NC * C_ + NC), dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.ce_workspace_floats(P), dtype=torch.float32, device=DEV)
+    lo = torch.empty(1, dtype=torch.float32, device=DEV)
+    ops.head_ce(xv, wf.to(DEV), bf.to(DEV), t.to(torch.uint8).to(DEV), None, 0, 1.0, dx, part, ws, lo, w_dx=w.to(DEV))
+    gw = torch.empty(NC * C_ + NC, dtype=torch.float32, device=DEV)
+    ops.colsum_finalize(part, rows, NC * C_ + NC, gw)
+    torch.cuda.synchronize()
+    assert abs(lo.item() - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+    close(dx.torch().float().cpu(), Z.grad, 2.0 ** -8, "gradient w.r.t. the BatchNorm output")
+    close(gw[:NC * C_].cpu().view(NC, C_), Wf.grad, 2e-5, "dW (folded)")
+    close(gw[NC * C_:].cpu(), Bf.grad, 2e-5, "db (folded)")
+
+
+def test_lazy_logits_handle_on_the_reference_unet():
+    """the reference's own model (S/nets.py:117-199) through its own loop: Unetv2 in bf16, the folded head"""
+    NC, B, S = 16, 2, 64
+    img, lab = O.synthetic_tiles(B, S, NC, seed=3, structured=True)
+    img, lab = img.to(DEV), lab.to(DEV)
+    torch.manual_seed(0)
+    net = nets.Urnetv2(NC, "bf16").to(DEV)
+    crit = utils.CrossEntropyLoss(ignore_index=0)
+    old = nets.LAZY_HEAD
+    try:
+        nets.LAZY_HEAD = False
+        logits_e, loss_e, grad_e = _step(net, img, lab, crit)
+        logits_e = logits_e.detach().clone()
+        nets.LAZY_HEAD = True
+        net.train()
+        logits = net(img, None)
+        eng = net._engine
+        assert type(logits) is nets.LazyLogits and eng._head_pending
+        loss = crit(logits, lab)
+        assert eng._head_done
+        net.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        grad = net.flat_parameters()[1].clone()
+    finally:
+        nets.LAZY_HEAD = old
+    assert abs(loss.item() - loss_e) <= 1e-6 * max(1.0, abs(loss_e))
+    assert (grad - grad_e).norm().item() <= 2e-2 * grad_e.norm().item()
+    hw = eng._goff["decode_forward4.1.weight"]
+    close(grad[hw:hw + NC * 64 + NC].cpu(), grad_e[hw:hw + NC * 64 + NC].cpu(), 1e-4, "head dW | db after un-folding")
+    close(logits.detach().float().cpu(), logits_e.cpu(), 1e-6, "logits read after the fused loss")
