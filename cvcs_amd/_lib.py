@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("res", C.c_void_p), ("res_ld", C.c_int64), ("res_scale", C.c_void_p), ("res_shift", C.c_void_p),
         ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32),
         ("mask", C.c_void_p), ("mask_ld", C.c_int64),
+        ("res2", C.c_void_p), ("res2_ld", C.c_int64), ("res2_half", C.c_int32),
     ]
 
 

@@ -56,6 +56,7 @@ struct ConvArgs {
   const char* res; int64_t res_ld; const float* res_scale; const float* res_shift;
   const char* in2; int64_t in2_ld; int Cin2;
   const char* mask; int64_t mask_ld;   // taps kernel: out = (mask > 0) ? value : 0 (the ReLU backward of the activation the gradient belongs to)
+  const char* res2; int64_t res2_ld; int res2_half;   // taps kernel: a second tile added beside res (optionally at half resolution: even pixels only)
 };
 
 template <typename T> struct Mma;
@@ -1308,7 +1309,7 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
         *reinterpret_cast<uint2*>(smem + (wm * 64 + i * 16 + fr) * OROW + (wn * 64 + j * 16 + fg * 4) * ES) = u;
       }
   };
-  const bool walk_epi = EPI && (p.res != nullptr || p.mask != nullptr);      // shortcut / mask (and then the ReLU) in the store walk
+  const bool walk_epi = EPI && (p.res != nullptr || p.mask != nullptr || p.res2 != nullptr);      // shortcut / mask (and then the ReLU) in the store walk
   if (p.relu && !walk_epi) stage(std::true_type{}); else stage(std::false_type{});   // wave-uniform
   __syncthreads();
   {
@@ -1330,38 +1331,62 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
     int oy = t % p.Ho, b = t / p.Ho;
     if constexpr (EPI) {
       if (walk_epi) {
-        // out = relu?(staged + (res | res_scale * res + res_shift)) * (mask > 0): the staged value is the bf16-rounded BatchNorm output (the
-        // stored conv output of the unfused path was rounded too), the sum is taken in f32
-        u32x4 rr[8], mk[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          int mr = m0 + lrow0 + k * RPT; mr = mr < p.M ? mr : p.M - 1;
-          if (p.res) rr[k] = *reinterpret_cast<const u32x4*>(p.res + ((int64_t)mr * p.res_ld + n) * ES);
-          if (p.mask) mk[k] = *reinterpret_cast<const u32x4*>(p.mask + ((int64_t)mr * p.mask_ld + n) * ES);
-        }
-        float rs[8], rt[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { rs[e] = p.res_scale ? p.res_scale[n + e] : 1.f; rt[e] = p.res_scale ? p.res_shift[n + e] : 0.f; }
+        // out = relu?(staged + (res | res_scale * res + res_shift) + res2) * (mask > 0): the staged value is the bf16-rounded BatchNorm output
+        // (the stored conv output of the unfused path was rounded too), the sum is taken in f32.  res2 may live at HALF resolution (the data
+        // gradient of a 1x1 / stride-2 projection shortcut: it exists at the even pixels only).  Four rows at a time (registers).
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float f[8], g[8];
-          Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, v[k]), f);
-          if (p.res) {
-            Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, rr[k]), g);
+        for (int h = 0; h < 8; h += 4) {
+          u32x4 rr[4], mk[4], r2[4];
+          bool has2[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += g[e] * rs[e] + rt[e];
+          for (int k = 0; k < 4; ++k) {
+            int mr = m0 + lrow0 + (h + k) * RPT; mr = mr < p.M ? mr : p.M - 1;
+            if (p.res) rr[k] = *reinterpret_cast<const u32x4*>(p.res + ((int64_t)mr * p.res_ld + n) * ES);
+            if (p.mask) mk[k] = *reinterpret_cast<const u32x4*>(p.mask + ((int64_t)mr * p.mask_ld + n) * ES);
+            has2[k] = false;
+            if (p.res2) {
+              int64_t r2pix = mr;
+              has2[k] = true;
+              if (p.res2_half) {
+                const int x2 = mr % p.Wo, t2 = mr / p.Wo;
+                const int y2 = t2 % p.Ho, b2 = t2 / p.Ho;
+                has2[k] = !((x2 | y2) & 1);
+                r2pix = ((int64_t)b2 * (p.Ho >> 1) + (y2 >> 1)) * (p.Wo >> 1) + (x2 >> 1);
+              }
+              if (has2[k]) r2[k] = *reinterpret_cast<const u32x4*>(p.res2 + (r2pix * p.res2_ld + n) * ES);
+            }
           }
-          if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-          }
-          if (p.mask) {
-            Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, mk[k]), g);
+          for (int k = 0; k < 4; ++k) {
+            float f[8], g[8];
+            Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, v[h + k]), f);
+            if (p.res) {
+              Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, rr[k]), g);
+              if (p.res_scale) {      // (the projection shortcut's BatchNorm: its vectors come from the scalar / L1 cache per row, not from 16 live registers)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = g[e] > 0.f ? f[e] : 0.f;
+                for (int e = 0; e < 8; ++e) f[e] += g[e] * p.res_scale[n + e] + p.res_shift[n + e];
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+              }
+            }
+            if (has2[k]) {
+              Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, r2[k]), g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] += g[e];
+            }
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
+            if (p.mask) {
+              Elem<bf16_t>::unpack(__builtin_bit_cast(uint4, mk[k]), g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = g[e] > 0.f ? f[e] : 0.f;
+            }
+            v[h + k] = __builtin_bit_cast(u32x4, Elem<bf16_t>::pack(f));
           }
-          v[k] = __builtin_bit_cast(u32x4, Elem<bf16_t>::pack(f));
         }
       }
     }
@@ -1700,6 +1725,12 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.res = (const char*)d->res; a.res_ld = d->res_ld; a.res_scale = d->res_scale; a.res_shift = d->res_shift;
   a.in2 = (const char*)d->in2; a.in2_ld = d->in2_ld; a.Cin2 = d->in2 ? d->Cin2 : 0;
   a.mask = (const char*)d->mask; a.mask_ld = d->mask_ld;
+  a.res2 = (const char*)d->res2; a.res2_ld = d->res2_ld; a.res2_half = d->res2_half;
+  if (d->res2) {
+    CVCS_CHECK_ARG(use_taps(d) && d->KH == 1 && !d->stat_sum && !d->pixel_shuffle, "cvcs_conv2d: res2 is built for bf16 1x1 launches with Cout %% 128 == 0");
+    CVCS_CHECK_ARG(((uintptr_t)d->res2 % 16) == 0 && d->res2_ld >= d->Cout && (d->res2_ld * es) % 16 == 0, "cvcs_conv2d: res2 view");
+    CVCS_CHECK_ARG(!d->res2_half || (d->Ho % 2 == 0 && d->Wo % 2 == 0), "cvcs_conv2d: a half-resolution res2 needs even Ho, Wo");
+  }
   if (d->mask) {
     CVCS_CHECK_ARG(use_taps(d) && d->KH == 1 && !d->stat_sum && !d->relu && !d->pixel_shuffle, "cvcs_conv2d: mask is built for bf16 1x1 launches with Cout %% 128 == 0");
     CVCS_CHECK_ARG(((uintptr_t)d->mask % 16) == 0 && d->mask_ld >= d->Cout && (d->mask_ld * es) % 16 == 0, "cvcs_conv2d: mask view");
@@ -1764,7 +1795,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
-  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res || d->mask) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
-  CVCS_CHECK_ARG(!d->res && !d->mask, "cvcs_conv2d: the residual / mask epilogue runs on the 1x1 taps kernel only");
+  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res || d->mask || d->res2) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
+  CVCS_CHECK_ARG(!d->res && !d->mask && !d->res2, "cvcs_conv2d: the residual / mask epilogue runs on the 1x1 taps kernel only");
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

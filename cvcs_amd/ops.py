@@ -155,7 +155,7 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None) -> 
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
            pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None,
-           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None, mask: View | None = None):
+           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None, mask: View | None = None, res2=None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...).
     bn_bwd = (y view, scale, shift, mean, invstd, mode, part_dz, part_dzx): the launch also takes the first pass of the
@@ -167,6 +167,12 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         d.res, d.res_ld = res.ptr, res.ld
         if res_affine is not None:
             d.res_scale, d.res_shift = res_affine[0].data_ptr(), res_affine[1].data_ptr()
+    if res2 is not None:
+        # a second residual tile, (view, half_resolution): the half-resolution one contributes at the even pixels only
+        r2, half = res2
+        want = (x.B, Ho // 2, Wo // 2, Cout) if half else (x.B, Ho, Wo, Cout)
+        assert (r2.B, r2.H, r2.W, r2.C) == want and r2.t.dtype == x.t.dtype
+        d.res2, d.res2_ld, d.res2_half = r2.ptr, r2.ld, int(half)
     if mask is not None:
         # ReLU backward in the epilogue: out = value * (mask > 0)
         assert (mask.B, mask.H, mask.W, mask.C) == (x.B, Ho, Wo, Cout) and mask.t.dtype == x.t.dtype

@@ -437,24 +437,7 @@ class ResNetUNetEngine:
                     else:
                         ops.relu_bwd_sum(o.v, o.grads, dz)
                     last_in.grads.append((self._gram_bwd(ut, dz, p + ".g_t"), False))
-                    fz, tail_done = None, False
-                    for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
-                        assert len(aout.grads) == 1
-                        dy = self._unit_bwd(u, aout.grads[0][0], 0, fused=fz)
-                        fz = None
-                        if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
-                            gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
-                            xin.grads.append((gx, half))
-                        elif n_ == 0 and ud is None and self._tail_fusable(h, u):
-                            self._dgrad_into_tail(u, dy, h, dz)
-                            tail_done = True
-                        else:
-                            xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
-                    if ud is not None:
-                        dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
-                        h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
-                    elif not tail_done:
-                        h.grads.append((dz, False))
+                    self._block_chain_bwd(chain, h, ud, dz, red_d, None)
                     self._ready(p + ".conv1.weight")
                     return
                 if self.fuse_tail_bn and not getattr(ut, "gn", False):
@@ -477,24 +460,7 @@ class ResNetUNetEngine:
                     last_in.grads.append((gx, half))
                 else:
                     last_in.grads.append(self._dgrad(ut, dy, p + ".g_t"))
-                tail_done = False
-                for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
-                    assert len(aout.grads) == 1
-                    dy = self._unit_bwd(u, aout.grads[0][0], 0, fused=fz)
-                    fz = None
-                    if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
-                        gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
-                        xin.grads.append((gx, half))
-                    elif n_ == 0 and ud is None and self._tail_fusable(h, u):
-                        self._dgrad_into_tail(u, dy, h, dz)
-                        tail_done = True
-                    else:
-                        xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
-                if ud is not None:
-                    dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
-                    h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
-                elif not tail_done:
-                    h.grads.append((dz, False))
+                self._block_chain_bwd(chain, h, ud, dz, red_d, fz)
                 self._ready(p + ".conv1.weight")
             tape.append(bwd)
         return o
@@ -551,21 +517,60 @@ class ResNetUNetEngine:
             self.bwd_gram[u.conv] = dict(unit=u, dz=dz, gx=gx)
         return gx
 
-    def _tail_fusable(self, h: Act, u1: Unit):
-        """can the data-gradient launch of an identity block's first 1x1 conv write the PREVIOUS block's dz = (g_conv1 + g_shortcut) * (out > 0)
-        itself?  The previous block must be a Gram tail (its backward needs no BatchNorm reduce over dz) whose output has no other consumer
-        (the last block of a stage also feeds the decoder), bf16, a channel count the 1x1 taps kernel tiles"""
-        return (self.fuse_tail_dz and getattr(h, "tail_dz", None) is not None and not h.grads and u1.k == 1 and u1.stride == 1 and
-                self.dtype == torch.bfloat16 and h.v.C % 128 == 0 and not getattr(u1, "half_out", False))
+    def _block_chain_bwd(self, chain, h: Act, ud: Unit | None, dz: View, red_d, fz):
+        """backward of a block's conv chain (deepest unit first) and of its shortcut, given dz (the gradient behind the tail's ReLU): BatchNorm
+        backward + weight gradient + data gradient of every unit; the gradients of the block input h are appended to h.grads - or, where
+        _tail_fusable says so, summed and masked by the first conv's data-gradient launch itself (h.dz_ready)"""
+        u1 = chain[0][0]
+        gxd = None
+        if ud is not None and self._tail_fusable(h, u1, ds=True):
+            # (before the chain: the BatchNorm backward of the chain's units reuses the dy scratch this one writes)
+            dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
+            gxd = self._dgrad(ud, dyd, ud.conv + ".gx")
+        tail_done = False
+        for n_, (u, xin, aout) in reversed(list(enumerate(chain))):
+            assert len(aout.grads) == 1
+            dy = self._unit_bwd(u, aout.grads[0][0], 0, fused=fz)
+            fz = None
+            if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
+                gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
+                xin.grads.append((gx, half))
+            elif n_ == 0 and ud is None and self._tail_fusable(h, u):
+                self._dgrad_into_tail(u, dy, h, dz)
+                tail_done = True
+            elif n_ == 0 and gxd is not None:
+                self._dgrad_into_tail(u, dy, h, h.grads[0][0] if h.grads else None, gxd)
+                tail_done = True
+            else:
+                xin.grads.append(self._dgrad(u, dy, u.conv + ".gx"))
+        if ud is not None and gxd is None:
+            dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
+            h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
+        elif ud is None and not tail_done:
+            h.grads.append((dz, False))
 
-    def _dgrad_into_tail(self, u1: Unit, dy: View, h: Act, dz_self: View):
+    def _tail_fusable(self, h: Act, u1: Unit, ds: bool = False):
+        """can the data-gradient launch of a block's first 1x1 conv write the PREVIOUS block's dz = (sum of the gradients of its output) *
+        (out > 0) itself?  The previous block must be a Gram tail (its backward needs no BatchNorm reduce over dz), bf16, a channel count the
+        1x1 taps kernel tiles.  Identity consumer (ds False): dz = (g_conv1 + this block's dz) * mask, the output may have no other consumer.
+        Down-sampling consumer (ds True): dz = (g_conv1 + g_projection [half resolution] + the decoder's skip gradient) * mask."""
+        ok = (self.fuse_tail_dz and getattr(h, "tail_dz", None) is not None and u1.k == 1 and u1.stride == 1 and
+              self.dtype == torch.bfloat16 and h.v.C % 128 == 0 and not getattr(u1, "half_out", False))
+        if not ok:
+            return False
+        if not ds:
+            return not h.grads
+        return len(h.grads) <= 1 and not any(half for _, half in h.grads) and h.v.H % 2 == 0 and h.v.W % 2 == 0
+
+    def _dgrad_into_tail(self, u1: Unit, dy: View, h: Act, res: View | None, res2=None):
         v = h.v
         dzk = ops.view(self._act(h.tail_dz, v.B, v.H, v.W, v.C))
         ops.SCOPE = "enc"
-        ops.conv2d(dy, self.packed[u1.conv]["wd"], None, dzk, 1, 1, res=dz_self, mask=v)
+        ops.conv2d(dy, self.packed[u1.conv]["wd"], None, dzk, 1, 1, res=res, res2=res2, mask=v)
         h.dz_ready = dzk
+        h.grads = []
         if self.keep_all:
-            self.bwd_units[u1.conv]["gx_tail"] = (dzk, dz_self, v)
+            self.bwd_units[u1.conv]["gx_tail"] = (dzk, res, res2, v)
 
     # ------------------------------------------------------------------------------------------------ backward pieces
     def _fusable(self, producer: Unit, consumer: Unit):

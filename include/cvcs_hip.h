@@ -111,6 +111,9 @@ typedef struct {
    * res = the gradient arriving over the identity shortcut, the data-gradient launch of a block's first 1x1 conv writes the PREVIOUS block's
    * dz = (g_conv1 + g_shortcut) * (out > 0) directly (cvcs_relu_bwd_sum without its pass over three tensors).                  */
   const void* mask;  int64_t mask_ld;
+  /* res2: a second tile added beside res (no affine); res2_half = 1: it lives at HALF the resolution and contributes at the even pixels only -
+   * the data gradient of a 1x1 / stride-2 projection shortcut, so that the block below a down-sampling block gets its dz from ONE launch too */
+  const void* res2;  int64_t res2_ld;  int32_t res2_half;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */

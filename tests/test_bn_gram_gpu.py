@@ -190,3 +190,26 @@ def test_data_gradient_that_writes_the_previous_blocks_dz(case):
     ref = (dy.double() @ w.double().T + gs.double()) * (out_act > 0)
     close(dz.torch().float().cpu(), ref, 1.5 * 2.0 ** -8, "fused tail backward")
     assert (dz.torch().float().cpu()[out_act == 0] == 0).all()
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_data_gradient_with_two_more_gradient_sources(half):
+    """dz = (W x + g_a + g_b) * (out > 0) where g_b may live at half resolution (the data gradient of a 1x1 / stride-2 projection shortcut
+    contributes at the even pixels only): cvcs_conv_desc.res + res2 + mask - the tail backward below a down-sampling block in one launch"""
+    B, H, W, m, C_ = 2, 16, 24, 128, 256
+    g = torch.Generator().manual_seed(11 + half)
+    dy = _rq(torch.randn(B, H, W, m, generator=g))
+    w = _rq(torch.randn(C_, m, generator=g) / m ** 0.5)
+    ga = _rq(torch.randn(B, H, W, C_, generator=g))
+    gb = _rq(torch.randn(B, H // 2, W // 2, C_, generator=g)) if half else _rq(torch.randn(B, H, W, C_, generator=g))
+    out_act = _rq(torch.randn(B, H, W, C_, generator=g).relu())
+    dz = ops.view(torch.zeros(B, H, W, C_, dtype=BF, device=DEV))
+    ops.conv2d(_dev_view(dy), w.to(BF).to(DEV).view(1, C_, m), None, dz, 1, 1, res=_dev_view(ga, 8, 0), res2=(_dev_view(gb, 0, 16), half),
+               mask=_dev_view(out_act))
+    torch.cuda.synchronize()
+    tot = dy.double() @ w.double().T + ga.double()
+    if half:
+        tot[:, ::2, ::2, :] += gb.double()
+    else:
+        tot = tot + gb.double()
+    close(dz.torch().float().cpu(), tot * (out_act > 0), 1.5 * 2.0 ** -8, "fused tail backward, three sources")

@@ -658,17 +658,25 @@ def test_backward_layer_by_layer(arch, precision, B, S):
             e["gx"] = rel_l2(got, gx_ref) if f32 else (got - gx_ref).abs().max().item() / gx_ref.abs().max().item() / 2.0 ** -8 * 2e-3
         if "gx_tail" in r:
             # the data gradient of an identity block's first 1x1 conv wrote the PREVIOUS block's dz = (g_conv1 + g_shortcut) * (out > 0) itself
-            dzk, dzs, mv = r["gx_tail"]
+            dzk, res, res2, mv = r["gx_tail"]
             wq = w if f32 else w.to(torch.bfloat16).float()
-            want = (torch.nn.grad.conv2d_input(x.shape, wq.double(), got_dy, stride=stride, padding=pad) + from_nhwc(dzs.torch()).double()) * \
-                (from_nhwc(mv.torch()) > 0)
+            tot = torch.nn.grad.conv2d_input(x.shape, wq.double(), got_dy, stride=stride, padding=pad)
+            if res is not None:                     # the identity shortcut's gradient / the decoder's skip gradient
+                tot = tot + from_nhwc(res.torch()).double()
+            if res2 is not None:                    # the projection shortcut's data gradient: at half resolution, the even pixels only
+                g2 = from_nhwc(res2[0].torch()).double()
+                if res2[1]:
+                    tot[:, :, ::2, ::2] += g2
+                else:
+                    tot = tot + g2
+            want = tot * (from_nhwc(mv.torch()) > 0)
             e["gx_tail"] = (from_nhwc(dzk.torch()).double() - want).abs().max().item() / want.abs().max().item() / 2.0 ** -8 * 2e-3
             n_tail += 1
         for kk, v in e.items():
             worst[kk] = max(worst.get(kk, (0.0, "")), (v, conv))
         assert all(v <= (1.5 * t_sum if kk == "gx_tail" else t_sum) for kk, v in e.items()), (conv, e)
     if arch == "resnet50" and not f32:
-        assert n_tail == (10 if eng.gram_bn and eng.fuse_tail_dz else 0)     # the identity blocks of stages 1-3 write their predecessor's dz
+        assert n_tail == (13 if eng.gram_bn and eng.fuse_tail_dz else 0)     # every block of stages 2-4 but the last two writes its predecessor's dz (stages 1-3)
     # the tails that never store a conv3 output: dgamma, dbeta, dW and the data gradient of conv3 -> bn3 against float64 autograd of the same
     # sub-graph from the STORED a2 and dz (the conv output recomputed in float64 from the bf16 operands)
     for conv, r in eng.bwd_gram.items():
