@@ -131,6 +131,7 @@ class ResNetUNetEngine:
         # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
         self.gram_bn = os.environ.get("CVCS_GRAM_BN", "1") == "1"
         self.fuse_tail_dz = os.environ.get("CVCS_FUSE_TAIL_DZ", "1") == "1"   # a Gram tail's dz out of the consumer block's first data-gradient launch (_tail_fusable)
+        self.gram_512_pixels = int(os.environ.get("CVCS_GRAM_512_PIXELS", "65536"))   # 512-channel conv3 inputs take it from this many pixels on
         self.gram_max_m = int(os.environ.get("CVCS_GRAM_MAX_M", "256"))   # widest conv3 input that takes the path (the finalizes are O(C m^2))
         # Weight gradients are off the critical chain of backward (dy -> data gradient -> BatchNorm backward of the layer below): they
         # are recorded on the plan's side lane and replayed on a second HIP stream, so the MFMA-bound weight-gradient kernels run
@@ -470,9 +471,11 @@ class ResNetUNetEngine:
         """does the block's conv3 -> bn3 -> (+ shortcut) -> ReLU run without a stored conv3 output?  bf16 bottlenecks whose conv3 input is
         64 ... gram_max_m wide; not in exact data-parallel mode (its exchanges are written against per-layer moments) and not when the block
         output also leaves as an fp8 image (the tail pass writes that image)"""
+        # (the O(C m^2) finalizes cost the same whatever the map size: at 512 channels they pay on the large maps of the dilated DeepLab
+        #  encoders - output stride 8: 64^2 pixels x 32 tiles - and lose on the 16^2 maps of the U-Net encoder)
+        m_ok = 64 <= a.C <= self.gram_max_m or (a.C == 512 and self.gram_max_m >= 256 and a.B * a.H * a.W >= self.gram_512_pixels)
         return (self.gram_bn and self.kind == "bottleneck" and self.dtype == torch.bfloat16 and self.sync_bn is None and
-                (p + ".bn3.running_mean") in self.Bf and a.C % 64 == 0 and 64 <= a.C <= self.gram_max_m and out.C % 128 == 0 and
-                self._q8_of(out) is None)
+                (p + ".bn3.running_mean") in self.Bf and a.C % 64 == 0 and m_ok and out.C % 128 == 0 and self._q8_of(out) is None)
 
     def _unit_gram(self, a: View, conv, bn) -> Unit:
         """statistics of bn(conv1x1(a)) from the Gram matrix of a: scale / shift / saved statistics / running statistics, Q = W G kept for
