@@ -28,7 +28,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 peak (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4; same table)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0      # HBM3E spec (6.3 TB/s is what a streaming copy reaches on this chip: MI355X_MICROARCH.md, HBM)
-PMC_FILES = {"Resnet50Unet": "r03_pmc_traffic_resnet50unet_b32_s512_bf16.json", "DeepLabV3Plus": "r02_pmc_traffic_deeplabv3plus_b32_s512_bf16.json", "SwinTUperNet": "r02_pmc_traffic_swintupernet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json",
+PMC_FILES = {"Resnet50Unet": "r04_pmc_traffic_resnet50unet_b32_s512_bf16.json", "DeepLabV3Plus": "r04_pmc_traffic_deeplabv3plus_b32_s512_bf16.json", "SwinTUperNet": "r02_pmc_traffic_swintupernet_b32_s512_bf16.json", "Unetv2": "r01_pmc_traffic_b32_s512_bf16.json",
              "SegformerMod": "r03_pmc_traffic_segformermod_b32_s512_bf16.json", "MobileNet": "r03_pmc_traffic_mobilenet_b32_s512_bf16.json"}
 FAMILY_KERNEL = {
     "conv3x3_halo": "conv3x3_halo_kernel (3x3 / stride 1 forward and data-gradient launches; strided 3x3 data gradients run it on the zero-dilated gradient, counted at their algorithmic FLOPs)",

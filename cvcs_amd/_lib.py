@@ -332,7 +332,8 @@ class Recording:
                         elif isinstance(a, (C.Array, C.Structure)):
                             v = C.addressof(a)
                         elif isinstance(a, C._SimpleCData):
-                            v = a.value or 0
+                            # (a mutable ctypes scalar would be snapshotted here but re-read by the Python replay: no wrapper passes one)
+                            raise TypeError(f"{fn.__name__}: ctypes scalar objects cannot be recorded in a plan (pass a plain int / float)")
                         else:
                             v = C.cast(a, C.c_void_p).value or 0
                         c.i[ni] = v if v < (1 << 63) else v - (1 << 64)
@@ -498,9 +499,32 @@ def _load():
         if (h.cvcs_sizeof_conv_desc() != C.sizeof(ConvDesc) or h.cvcs_sizeof_wgrad_desc() != C.sizeof(WgradDesc) or
                 h.cvcs_sizeof_conv8_desc() != C.sizeof(Conv8Desc)):
             raise CvcsError("descriptor layout of cvcs_amd/_lib.py differs from the one libcvcs_hip.so was compiled with")
+        _check_replay_contract()
         _lib = h
         _proxy = _Proxy(h)
     return _lib
+
+
+def _check_replay_contract():
+    """cvcs_replay (csrc/api.hip) calls every launch entry point through ONE prototype - 28 integer-class slots, then 8 floats - which is only
+    right on the x86-64 System V ABI and only for entry points whose arguments are pointers / int / int64 / uint64 (general registers, then the
+    stack, in order), at most 8 floats (xmm0-7), no double, no struct by value, the stream last.  Enforced here for every entry a plan can record;
+    on another machine the plans are replayed from Python."""
+    global C_REPLAY
+    import platform
+    if platform.machine() not in ("x86_64", "AMD64"):
+        C_REPLAY = False
+        return
+    ints = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_char_p)
+    for name, (res, args) in SIGNATURES.items():
+        if name in _QUERIES:
+            continue
+        assert res is C.c_int and args and args[-1] is C.c_void_p, f"{name}: a launch entry point returns int and takes the stream last"
+        nf = sum(1 for t in args if t is C.c_float)
+        ni = len(args) - 1 - nf
+        for t in args[:-1]:
+            assert t is C.c_float or t in ints or (isinstance(t, type) and issubclass(t, C._Pointer)), f"{name}: argument type {t} cannot go through cvcs_replay"
+        assert nf <= CALL_MAX_FLT and ni < CALL_MAX_INT, f"{name}: {ni} integer-class / {nf} float arguments exceed the cvcs_call record"
 
 
 def check(rc: int, what: str = ""):

@@ -1629,7 +1629,10 @@ static bool use_halo(const cvcs_conv_desc* d) {
 static bool use_taps(const cvcs_conv_desc* d) {
   static const int taps_on = getenv("CVCS_CONV_TAPS") ? atoi(getenv("CVCS_CONV_TAPS")) : 1;   // tuning knob
   if (!taps_on || d->dtype != CVCS_BF16 || d->aniso || d->in_row_pitch || d->in_img_pitch) return false;
-  const bool k1 = d->KH == 1 && d->KW == 1 && d->stride == 1, k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
+  // (1x1 / stride 2: the projection shortcuts of the down-sampling ResNet blocks read the even pixels of their input in place)
+  static const int k1s2_on = getenv("CVCS_TAPS_1X1_S2") ? atoi(getenv("CVCS_TAPS_1X1_S2")) : 1;   // tuning knob
+  const bool k1 = d->KH == 1 && d->KW == 1 && (d->stride == 1 || (d->stride == 2 && k1s2_on && !d->pixel_shuffle && !d->pre_scale)),
+             k2 = d->KH == 2 && d->KW == 2 && d->stride == 2;
   const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
   return (k1 || k2) && d->pad == 0 && d->dil == 1 && d->Cout % 128 == 0 && cin_valid == d->Cin && !(d->stat_sum && d->relu) &&
          (!d->pre_scale || (k1 && !d->stat_sum && !d->pixel_shuffle)) && !d->post_scale && d->H == d->Ho * d->stride && d->W == d->Wo * d->stride &&

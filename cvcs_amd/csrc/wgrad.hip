@@ -40,6 +40,7 @@ struct WgradArgs {
   int ntile_n;                // Cin tiles
   int tiles_mn, xcd_order;    // GEMM kernel: (co, ci) tiles per K-slice; XCD-aware workgroup order (CVCS_XCD_ORDER=0: off)
   float* bias_ws;             // GEMM kernel: partial bias gradients [slice][Cout] (NULL: none)
+  int x_s2;                   // GEMM kernel: x is read at stride 2 (1x1 / stride-2 projection shortcuts: output pixel (b, oy, ox) <- x pixel (b, 2 oy, 2 ox))
 };
 
 __device__ uint4 g_wzero16;  // zero word: LDS-DMA source of padding pixels / absent channels
@@ -321,6 +322,12 @@ __global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgra
         const int ox = (int)(pix % p.W), oy = (int)((pix / p.W) % p.H);
         ok = ok && (unsigned)(oy + p.sh_y) < (unsigned)p.H && (unsigned)(ox + p.sh_x) < (unsigned)p.W;
         pix += sh_lin;
+      }
+      if (p.x_s2 && (wave + NWV * i) >= 4 * MB && ok) {     // an x piece of a stride-2 1x1 layer: (b, oy, ox) of the output pixel -> (b, 2 oy, 2 ox) of x
+        const int ox = (int)(pix % p.Wo);
+        const int64_t t = pix / p.Wo;
+        const int oy = (int)(t % p.Ho);
+        pix = ((t / p.Ho) * p.H + 2 * oy) * p.W + 2 * ox;
       }
       const char* src = ok ? src0[i] + pix * rowb[i] : reinterpret_cast<const char*>(&g_wzero16);
       dma16(src, lds0 + st * STAGE + (wave + NWV * i) * 1024);
@@ -1112,6 +1119,12 @@ static bool gemm_shape(int KH, int KW, int stride, int Cout, int Cin) {
   // (chunks beyond the last channel read zeros, their outputs are not stored) - the 96 * 2^k widths of Swin
   return on && KH == 1 && KW == 1 && stride == 1 && Cout % 8 == 0 && Cin % 8 == 0 && (Cout > 64 || Cin > 64 || (Cout == 64 && Cin == 64));
 }
+// 1x1 / stride 2 / pad 0 on even maps (the projection shortcuts of the down-sampling ResNet blocks): the same GEMM over the OUTPUT pixels, x read
+// at the even pixels in place - no gathered copy of the input (round 3 gathered the even pixels first: cvcs_im2col with a 1x1 window)
+static bool gemm_s2_shape(const cvcs_wgrad_desc* d) {
+  return d->dtype == CVCS_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 2 && d->pad == 0 && d->dil <= 1 && !d->aniso && !d->x_row_pitch && !d->x_img_pitch &&
+         d->H == 2 * d->Ho && d->W == 2 * d->Wo && gemm_shape(1, 1, 1, d->Cout, d->Cin) && !d->dbias;
+}
 static GemmPlan gemm_plan(int B, int Ho, int Wo, int Cout, int Cin) {
   GemmPlan g;
   g.BM = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 128);
@@ -1172,7 +1185,7 @@ static int wgrad_dilated(const cvcs_wgrad_desc* d, hipStream_t st) {
   CVCS_CHECK_ARG(d->x_ld >= d->Cin && d->x_ld * es % 16 == 0 && d->dy_ld >= d->Cout && d->dy_ld * es % 16 == 0 &&
                  ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0, "cvcs_conv2d_wgrad(dilated): views");
   WgradArgs a;
-  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order(); a.bias_ws = nullptr;
+  a.tiles_mn = 1; a.xcd_order = wgrad_xcd_order(); a.bias_ws = nullptr; a.x_s2 = 0;
   a.x = (const char*)d->x; a.dy = (const char*)d->dy;
   a.x_ld = d->x_ld; a.dy_ld = d->dy_ld;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -1252,6 +1265,11 @@ extern "C" int64_t cvcs_wgrad_workspace_floats(const cvcs_wgrad_desc* d) {
 static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d) {
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   int n;
+  if (gemm_s2_shape(d)) {      // (the generic plan of the same descriptor may use more slices: take the larger)
+    const int64_t g = (int64_t)gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice * d->Cout * d->Cin;
+    const int64_t o = (int64_t)cvcs_wgrad_slices(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 2) * d->Cout * d->Cin;
+    return g > o ? g : o;
+  }
   if (thin_wgrad_shape(d)) return (int64_t)thin_wgrad_groups(d) * 4 * 9 * d->Cout * (d->Cin > 32 ? 32 : d->Cin);     // (one 32-channel group at a time)
   if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
     const int a = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 1, 0).nslice;
@@ -1337,8 +1355,11 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
   int nslice_used = pl.nslice;
-  if (d->dtype == CVCS_BF16 && !aniso && !pitched && d->pad == 0 && gemm_shape(d->KH, d->KW, d->stride, d->Cout, d->Cin) &&
-      d->H == d->Ho && d->W == d->Wo) {
+  static const int s2_on = getenv("CVCS_WGRAD_GEMM_S2") ? atoi(getenv("CVCS_WGRAD_GEMM_S2")) : 1;   // tuning knob
+  const bool s2 = s2_on && gemm_s2_shape(d);
+  a.x_s2 = s2 ? 1 : 0;
+  if (s2 || (d->dtype == CVCS_BF16 && !aniso && !pitched && d->pad == 0 && gemm_shape(d->KH, d->KW, d->stride, d->Cout, d->Cin) &&
+             d->H == d->Ho && d->W == d->Wo)) {
     const GemmPlan g = gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin);
     a.ktiles = g.ktiles; a.per_slice = g.per_slice; a.ntile_n = g.ntile_n;
     nslice_used = g.nslice;

@@ -211,7 +211,8 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
     taps = (not halo and x.code == BF16 and virt is None and pad == 0 and dil == 1 and Cout % 128 == 0 and
             not (stats is not None and relu) and post_affine is None and
             (pre_affine is None or ((KH, KW, stride) == (1, 1, 1) and stats is None and not pixel_shuffle)) and
-            ((KH, KW, stride) == (1, 1, 1) or (KH, KW, stride) == (2, 2, 2)))
+            ((KH, KW, stride) == (1, 1, 1) or (KH, KW, stride) == (2, 2, 2) or
+             ((KH, KW, stride) == (1, 1, 2) and x.H % 2 == 0 and x.W % 2 == 0 and pre_affine is None and not pixel_shuffle)))
     # algorithmic FLOPs: zero-padded input channels (the first layer's 3 -> one K-group) do not count; `flops` overrides
     # (a zero-dilated strided data gradient multiplies four times the pixels its convolution has).
     # launches that also carry the first pass of a BatchNorm backward are timed as their own family: their duration is not

@@ -126,6 +126,9 @@ class ResNetUNetEngine:
         self._shape_cache = collections.OrderedDict()
         self.fuse_bn_bwd = os.environ.get("CVCS_FUSE_BN_BWD", "1") == "1"   # see _fusable
         self.gather_shortcut = os.environ.get("CVCS_GATHER_SHORTCUT", "1") == "1"   # stride-2 projection shortcuts on compact even-pixel maps (_block)
+        # bf16: the 1x1 / stride-2 projection shortcuts read the even pixels of their input IN PLACE (taps kernel forward, GEMM weight gradient with
+        # a strided x) - no gathered copy of the input (the f32 parity path and widths off the 128-channel tile keep the round-3 gather)
+        self.strided_shortcut = os.environ.get("CVCS_STRIDED_SHORTCUT", "1") == "1"
         self.fuse_tail_bn = os.environ.get("CVCS_FUSE_TAIL_BN", "1") == "1"  # the residual tails' BatchNorm reduce passes on relu_bwd_sum (_block)
         # bottleneck tails without a stored conv3 output: BatchNorm statistics from the Gram matrix of conv3's input, BatchNorm + shortcut +
         # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
@@ -394,7 +397,9 @@ class ResNetUNetEngine:
             ut = self._unit_gram(a2.v, p + ".conv3", p + ".bn3") if gram else self._unit(a2.v, p + ".conv3", p + ".bn3", 1, 1, 0, train, None)
             chain = [(u1, h, a1), (u2, a1, a2)]
             last_in = a2
-        if has_ds and stride == 2 and self.gather_shortcut:
+        ds_w = self.P[p + ".downsample.0.weight"].shape[0] if has_ds else 0
+        in_place = self.strided_shortcut and self.dtype == torch.bfloat16 and ds_w % 128 == 0 and h.v.H % 2 == 0 and h.v.W % 2 == 0
+        if has_ds and stride == 2 and self.gather_shortcut and not in_place:
             # the projection shortcut of a down-sampling block reads the even pixels only: gather them once (a quarter of h) and the 1x1 /
             # stride-2 conv becomes a plain GEMM - forward on the taps kernel, weight gradient on the GEMM kernel instead of the generic ones
             hs = ops.view(self._act(p + ".hs", B, Ho, Wo, h.v.C))

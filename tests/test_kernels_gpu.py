@@ -63,6 +63,8 @@ CONV_CASES = [
     (2, 18, 40, 32, 32, 3, 1, 1, 1, False),    # thin 32 -> 32
     (4, 128, 128, 32, 16, 3, 1, 1, 1, False),  # thin, > 1024 partial-statistics rows: the two-stage BatchNorm merge with C = 16
     (4, 128, 128, 128, 32, 3, 1, 1, 1, False), # masked halo tile, two-stage merge with C = 32
+    (2, 16, 24, 256, 512, 1, 2, 0, 1, False),  # 1x1 / stride 2 (projection shortcut of a down-sampling block): the taps kernel reads the even pixels in place
+    (3, 8, 8, 64, 128, 1, 2, 0, 1, False),     # 1x1 / stride 2, one K-slice pair, ragged last pixel tile
 ]
 
 
@@ -307,6 +309,9 @@ WGRAD_CASES = [
     (1, 16, 16, 64, 64, 16, 3, 1, 1),    # Cout = 16 on the generic kernel
     (2, 20, 72, 128, 128, 32, 3, 1, 1),  # thin Cout under a wide input (the 128 -> 32 decoder layer): four 32-channel groups of the thin kernel
     (1, 9, 40, 96, 96, 16, 3, 1, 1),     # thin 96 -> 16: three groups, ragged tiles
+    (2, 16, 24, 256, 256, 512, 1, 2, 0), # 1x1 / stride 2 on the GEMM kernel: x read at the even pixels in place (no gathered copy)
+    (3, 8, 12, 64, 64, 128, 1, 2, 0),    # 1x1 / stride 2, ragged last K-tile
+    (2, 8, 8, 64, 64, 64, 1, 1, 0),      # 64 -> 64 1x1 on the 64 x 64 GEMM instance
 ]
 
 
