@@ -1469,9 +1469,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
     }
   };
   int cur = 0;
-  if ((int)blockIdx.x < p.ntiles) stage_halo(blockIdx.x, lds0);
+  const int t_first = (int)xcd_order(blockIdx.x, gridDim.x);      // XCD-aware tile order: vertically adjacent tiles (shared halo rows) in ONE L2
+  if (t_first < p.ntiles) stage_halo(t_first, lds0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+  for (int t = t_first; t < p.ntiles; t += gridDim.x) {
     const int b = t / tpi, tr = t - b * tpi;
     const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
     if (t + (int)gridDim.x < p.ntiles) stage_halo(t + gridDim.x, lds0 + (cur ^ 1) * XB);

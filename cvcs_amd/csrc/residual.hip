@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const char* x, int64_
   const int CC = C / V;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t total = (int64_t)B * Ho * Wo * CC;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+  const unsigned xbid = xcd_order(blockIdx.x, gridDim.x);      // (XCD-aware order: overlapping windows of neighbouring rows in ONE L2)
+  for (int64_t id = (int64_t)xbid * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int cc = (int)(id % CC);
     const int64_t op = id / CC;
     const int ox = (int)(op % Wo);
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const char* g0, int64
   const int CC = C / V;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int64_t total = (int64_t)B * H * W * CC;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+  const unsigned xbid = xcd_order(blockIdx.x, gridDim.x);      // (XCD-aware order: overlapping windows of neighbouring rows in ONE L2)
+  for (int64_t id = (int64_t)xbid * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     const int cc = (int)(id % CC);
     const int64_t pix = id / CC;
     const int x = (int)(pix % W);

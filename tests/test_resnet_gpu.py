@@ -535,9 +535,10 @@ def check_gram_tail(eng, u):
     return e
 
 
-@pytest.mark.parametrize("arch,B,S,NC", [("resnet18", 8, 256, 5), ("resnet50", 2, 256, 16), ("resnet50", 2, 512, 16)])
+@pytest.mark.parametrize("arch,B,S,NC", [("resnet18", 8, 256, 5), ("resnet50", 2, 256, 16), ("resnet50", 2, 512, 16), ("resnet50", 3, 224, 16)])
 def test_bf16_path_layer_by_layer_and_end_to_end(arch, B, S, NC):
-    """The benchmarked precision (cfg 1 shape for ResNet-18; 256 and 512 tiles for ResNet-50).
+    """The benchmarked precision (cfg 1 shape for ResNet-18; 256 and 512 tiles for ResNet-50; 3 x 224 - the reference's default tile size,
+    configs/train/server.yaml:23: maps of 56 / 28 / 14 / 7 pixels, ragged last pixel tiles in every 1x1 launch, odd maps under the stride-2 blocks).
     (1) LAYER BY LAYER, no error amplification: every conv output the bf16 path stored is recomputed in f32 on the CPU from
         the path's own stored bf16 input and bf16-rounded weights - it must agree to bf16 storage rounding (2^-8 of the
         tensor's max; measured ~2^-9), its BatchNorm batch statistics to 1e-3, the activation it feeds forward likewise.
