@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcvcs_hip.so")
 
 F32, BF16 = 0, 1
 E4M3, E5M2 = 0, 1          # fp8 formats (CVCS_E4M3 / CVCS_E5M2)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class CvcsError(RuntimeError):
@@ -80,7 +80,8 @@ class TailBwdDesc(C.Structure):
                 ("dz", C.c_void_p), ("dz_ld", C.c_int64),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("y", C.c_void_p * 2), ("y_ld", C.c_int64 * 2), ("mean", C.c_void_p * 2), ("invstd", C.c_void_p * 2),
-                ("part_dz", C.c_void_p), ("part_dzx", C.c_void_p * 2)]
+                ("part_dz", C.c_void_p), ("part_dzx", C.c_void_p * 2),
+                ("pool_g", C.c_void_p * 2), ("pool_g_ld", C.c_int64 * 2), ("pool_idx", C.c_void_p)]
 
 
 CALL_MAX_INT, CALL_MAX_FLT = 28, 8
@@ -245,6 +246,7 @@ SIGNATURES = {
     "cvcs_bn_gram_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvcs_bn_gram_mmat_workspace_floats": (_i64, [_i, _i]),
     "cvcs_bn_gram_mmat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "cvcs_bn_gram_fold": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "cvcs_head_ce_rows": (_i, [_i64]),
     "cvcs_head_ce": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i64, _vp, _vp, _vp, _i, _vp]),
     "cvcs_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),

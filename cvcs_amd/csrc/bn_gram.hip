@@ -225,6 +225,27 @@ __global__ __launch_bounds__(256) void bn_gram_mmat_reduce_kernel(const float* _
   }
 }
 
+// out[c][0 .. m1) = bf16(scale1[c] * w1[c][:]), out[c][m1 .. m1 + m2) = bf16(scale2[c] * w2[c][:]), bias[c] = shift1[c] + shift2[c]: the operand of
+// ONE two-source GEMM relu([a | h] out^T + bias) = relu(BN3(W3 a) + BNd(Wd h)), the tail of a bottleneck block with a same-resolution projection
+// shortcut whose two BatchNorms both come from Gram matrices (neither conv output is ever stored).  A thread converts 8 consecutive columns.
+__global__ __launch_bounds__(256) void bn_gram_fold_kernel(const bf16_t* __restrict__ w1, const float* __restrict__ scale1, const float* __restrict__ shift1, int m1,
+                                                          const bf16_t* __restrict__ w2, const float* __restrict__ scale2, const float* __restrict__ shift2, int m2,
+                                                          int C, bf16_t* __restrict__ out, float* __restrict__ bias) {
+  const int per = (m1 + m2) / 8;
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id < C) bias[id] = shift1[id] + shift2[id];
+  if (id >= C * per) return;
+  const int c = id / per, k0 = (id - c * per) * 8;
+  const bool first = k0 < m1;
+  const bf16_t* src = first ? w1 + (int64_t)c * m1 + k0 : w2 + (int64_t)c * m2 + (k0 - m1);
+  const float sc = first ? scale1[c] : scale2[c];
+  float f[8];
+  Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(src), f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] *= sc;
+  *reinterpret_cast<uint4*>(out + (int64_t)c * (m1 + m2) + k0) = Elem<bf16_t>::pack(f);
+}
+
 }  // namespace cvcs
 
 using namespace cvcs;
@@ -269,5 +290,17 @@ extern "C" int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, i
   hipLaunchKernelGGL(bn_gram_mmat_reduce_kernel, dim3((unsigned)cdiv((int64_t)m * m + m, 256)), dim3(256), 0, (hipStream_t)stream, workspace, nchunk, C, m,
                      (bf16_t*)wd2_bf16, bias);
   CVCS_CHECK_LAUNCH("cvcs_bn_gram_mmat(reduce)");
+  return CVCS_OK;
+}
+
+extern "C" int cvcs_bn_gram_fold(const void* w1_bf16, const float* scale1, const float* shift1, int m1, const void* w2_bf16, const float* scale2,
+                                 const float* shift2, int m2, int C, void* w_out_bf16, float* bias, void* stream) {
+  CVCS_CHECK_ARG(w1_bf16 && scale1 && shift1 && w2_bf16 && scale2 && shift2 && w_out_bf16 && bias, "cvcs_bn_gram_fold: null argument");
+  CVCS_CHECK_ARG(C > 0 && m1 > 0 && m2 > 0 && m1 % 8 == 0 && m2 % 8 == 0, "cvcs_bn_gram_fold: C=%d m1=%d m2=%d (rows of whole 16-byte chunks)", C, m1, m2);
+  CVCS_CHECK_ARG(((uintptr_t)w1_bf16 % 16) == 0 && ((uintptr_t)w2_bf16 % 16) == 0 && ((uintptr_t)w_out_bf16 % 16) == 0, "cvcs_bn_gram_fold: alignment");
+  const int64_t n = (int64_t)C * ((m1 + m2) / 8);
+  hipLaunchKernelGGL(bn_gram_fold_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w1_bf16, scale1, shift1, m1,
+                     (const bf16_t*)w2_bf16, scale2, shift2, m2, C, (bf16_t*)w_out_bf16, bias);
+  CVCS_CHECK_LAUNCH("cvcs_bn_gram_fold");
   return CVCS_OK;
 }

@@ -90,6 +90,18 @@ __device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Workgroups of `fn` (block size, dynamic LDS) the whole chip holds at once: the grid of a persistent (grid-stride) kernel.  Falls back to
+// `fallback` when there is no device to ask (the launch-plan dry runs of the CPU tests).
+inline int resident_workgroups(const void* fn, int threads, size_t lds, int fallback = 1024) {
+  int dev = 0, cus = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || per <= 0) {
+    (void)hipGetLastError();
+    return fallback;
+  }
+  return per * cus;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1420,10 +1420,15 @@ struct ThinConvArgs {
   int64_t in_ld, out_ld;
   int B, H, W, Cin, Cout, relu;
   int tiles_x, tiles_y, ntiles;
+  // BWD instance (a data-gradient launch): the first pass of the BatchNorm backward that consumes `out` (cvcs_conv_desc.bwd_y, mode 0) - sums of
+  // dz = out * [scale * y + shift > 0] and dz * xhat per channel over this workgroup's tiles, ONE partial row per workgroup
+  const char* bwd_y; int64_t bwd_y_ld;
+  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
+  float* bwd_p0; float* bwd_p1;
 };
 constexpr int kTcTH = 4, kTcTW = 64, kTcHC = kTcTW + 2, kTcHR = kTcTH + 2;
 
-template <int CI, int CO>
+template <int CI, int CO, bool BWD = false>
 __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
   constexpr int XPIX = kTcHR * kTcHC;
   constexpr int XB = (XPIX * CI * 2 + 1023) / 1024 * 1024, NX = XB / 1024;
@@ -1450,11 +1455,26 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
     sh[i] = p.pre_scale ? *reinterpret_cast<const f32x4*>(p.pre_shift + i * 16 + fg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const float lo = p.relu ? 0.f : -INFINITY;
+  f32x4 bsc[MB], bsh[MB], bia[MB], bib[MB], bs0[MB], bs1[MB];      // (BWD) xhat = y * ia + ib
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      bsc[i] = *reinterpret_cast<const f32x4*>(p.bwd_scale + i * 16 + fg * 4);
+      bsh[i] = *reinterpret_cast<const f32x4*>(p.bwd_shift + i * 16 + fg * 4);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bwd_mean + i * 16 + fg * 4);
+      bia[i] = *reinterpret_cast<const f32x4*>(p.bwd_invstd + i * 16 + fg * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { bib[i][r] = -mu[r] * bia[i][r]; bs0[i][r] = 0.f; bs1[i][r] = 0.f; }
+    }
+  }
   const int xpx = lane / XCH, xch = lane % XCH;
   const bool kvalid = fg * 16 < CI * 2;            // this lane's 16 bytes of K exist in the input (a 16-channel input fills k-groups 0, 1)
 
-  // Two halo buffers: the LDS-DMA of tile t + 1 is issued before tile t is computed and lands while its MFMAs, statistics and stores run
-  // (single-buffered, a workgroup alternated between waiting for its halo and computing: 2.2-3.3 TB/s on layers that are pure HBM traffic)
+  // Two halo buffers, two tiles of look-ahead: an iteration computes tile t, THEN waits (vmcnt(0) + barrier: the halo of the next tile, issued
+  // one iteration ago, and the stores of the previous tile), issues the LDS-DMA of the tile after next into the buffer it has just read, and
+  // only then its own stores - so both the DMA and the stores have a whole compute phase to complete.  (Round 4's first double buffer issued
+  // the stores last and waited for them at once: vmcnt counts stores too, a workgroup sat out its own write latency once per tile -
+  // 2.0-2.8 TB/s on layers that are pure HBM traffic; single-buffered before that: 2.2-3.3 TB/s of the smaller total.)
   auto stage_halo = [&](int tt, unsigned base) {
     const int b = tt / tpi, tr = tt - b * tpi;
     const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
@@ -1471,13 +1491,25 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
   int cur = 0;
   const int t_first = (int)xcd_order(blockIdx.x, gridDim.x);      // XCD-aware tile order: vertically adjacent tiles (shared halo rows) in ONE L2
   if (t_first < p.ntiles) stage_halo(t_first, lds0);
+  if (t_first + (int)gridDim.x < p.ntiles) stage_halo(t_first + gridDim.x, lds0 + XB);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   for (int t = t_first; t < p.ntiles; t += gridDim.x) {
     const int b = t / tpi, tr = t - b * tpi;
     const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
-    if (t + (int)gridDim.x < p.ntiles) stage_halo(t + gridDim.x, lds0 + (cur ^ 1) * XB);
     const char* hbuf = smem + cur * XB;
     const int y = ty0 + wave;
+    // (BWD) the saved activation under this lane's output pieces: fetched before the MFMAs, used after them
+    uint2 yraw[4][MB];
+    if constexpr (BWD) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int x = tx0 + g * 16 + fr;
+        const bool ok = y < p.H && x < p.W;
+        const char* ysrc = p.bwd_y + ((((int64_t)b * p.H + (ok ? y : 0)) * p.W + (ok ? x : 0)) * p.bwd_y_ld) * 2;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) yraw[g][i] = *reinterpret_cast<const uint2*>(ysrc + (i * 16 + fg * 4) * 2);
+      }
+    }
     f32x4 acc[4][MB];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -1504,6 +1536,29 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
       for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[g][i][r] = fmaxf(acc[g][i][r] * sc[i][r] + sh[i][r], lo);
+    // every wave is done with this halo buffer, the next tile's halo has landed (and the previous tile's stores are out): refill the buffer
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 2 * (int)gridDim.x < p.ntiles) stage_halo(t + 2 * gridDim.x, lds0 + cur * XB);
+    if constexpr (BWD) {
+      // sums over the gradient AS STORED (bf16) - what the apply pass reads back
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bool ok = y < p.H && tx0 + g * 16 + fr < p.W;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const uint32_t g01 = pack2_bf16(acc[g][i][0], acc[g][i][1]), g23 = pack2_bf16(acc[g][i][2], acc[g][i][3]);
+          const float gs[4] = {__uint_as_float(g01 << 16), __uint_as_float(g01 & 0xffff0000u), __uint_as_float(g23 << 16), __uint_as_float(g23 & 0xffff0000u)};
+          const float yv[4] = {__uint_as_float(yraw[g][i].x << 16), __uint_as_float(yraw[g][i].x & 0xffff0000u),
+                               __uint_as_float(yraw[g][i].y << 16), __uint_as_float(yraw[g][i].y & 0xffff0000u)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = (ok && yv[r] * bsc[i][r] + bsh[i][r] > 0.f) ? gs[r] : 0.f;
+            bs0[i][r] += dz;
+            bs1[i][r] += dz * (yv[r] * bia[i][r] + bib[i][r]);
+          }
+        }
+      }
+    }
     if (p.stat_sum) {
       const int nvalid = y < p.H ? (p.W - tx0 < kTcTW ? p.W - tx0 : kTcTW) : 0;
       const float inv = nvalid > 0 ? 1.f / (float)nvalid : 0.f;
@@ -1547,17 +1602,59 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the next halo has landed, every wave is done with this one
     cur ^= 1;
+  }
+  if constexpr (BWD) {
+    // the 16 pixel lanes of a channel quadruple by xor-shuffles, the four waves through LDS in wave order: one row per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [2][4 waves][CO]
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = bs0[i][r], c = bs1[i][r];
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+        if (fr == 0) { red[wave * CO + i * 16 + fg * 4 + r] = a; red[(4 + wave) * CO + i * 16 + fg * 4 + r] = c; }
+      }
+    __syncthreads();
+    if (tid < CO) {
+      const float a = ((red[tid] + red[CO + tid]) + red[2 * CO + tid]) + red[3 * CO + tid];
+      const float c = ((red[4 * CO + tid] + red[5 * CO + tid]) + red[6 * CO + tid]) + red[7 * CO + tid];
+      p.bwd_p0[(int64_t)blockIdx.x * CO + tid] = a;
+      p.bwd_p1[(int64_t)blockIdx.x * CO + tid] = c;
+    }
   }
 }
 
+// persistent workgroups of the thin kernel: exactly as many as the chip holds at once (LDS: two halo buffers of 12.4 / 24.8 KiB; registers), so
+// that no workgroup starts its share of the tiles only after another has finished (1024 groups of the 32-channel instances were 768 resident + 256)
+template <int CI, int CO, bool BWD>
+static int thin_conv_groups(int ntiles) {
+  static const int thin_wgs = getenv("CVCS_THIN_WGS") ? atoi(getenv("CVCS_THIN_WGS")) : 0;   // tuning knob (0 = from the occupancy query)
+  constexpr size_t lds = 2 * ((kTcHR * kTcHC * CI * 2 + 1023) / 1024 * 1024);
+  static const int cap = resident_workgroups(reinterpret_cast<const void*>(&conv3x3_thin_kernel<CI, CO, BWD>), 256, lds);
+  const int want = thin_wgs > 0 ? thin_wgs : cap;
+  return ntiles < want ? ntiles : want;
+}
+static int thin_conv_groups(int ci, int co, bool bwd, int ntiles) {
+  if (ci == 16 && co == 16) return bwd ? thin_conv_groups<16, 16, true>(ntiles) : thin_conv_groups<16, 16, false>(ntiles);
+  if (ci == 16) return bwd ? thin_conv_groups<16, 32, true>(ntiles) : thin_conv_groups<16, 32, false>(ntiles);
+  if (co == 16) return bwd ? thin_conv_groups<32, 16, true>(ntiles) : thin_conv_groups<32, 16, false>(ntiles);
+  return bwd ? thin_conv_groups<32, 32, true>(ntiles) : thin_conv_groups<32, 32, false>(ntiles);
+}
+
+static bool thin_bwd_on() {
+  static const int on = getenv("CVCS_THIN_BN_BWD") ? atoi(getenv("CVCS_THIN_BN_BWD")) : 1;   // tuning knob
+  return on != 0;
+}
 static bool thin_conv_shape(const cvcs_conv_desc* d) {
   static const int on = getenv("CVCS_CONV_THIN") ? atoi(getenv("CVCS_CONV_THIN")) : 1;   // tuning knob
   const int cin_valid = d->Cin_valid > 0 ? d->Cin_valid : d->Cin;
   return on && d->dtype == CVCS_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle &&
          !d->aniso && !d->in_row_pitch && !d->in_img_pitch && d->Cin == 32 && (cin_valid == 16 || cin_valid == 32) &&
-         (d->Cout == 16 || d->Cout == 32) && d->H >= 4 && d->W >= 16 && !d->post_scale && !d->pool_out && !d->bwd_y;
+         (d->Cout == 16 || d->Cout == 32) && d->H >= 4 && d->W >= 16 && !d->post_scale && !d->pool_out &&
+         (!d->bwd_y || (thin_bwd_on() && d->bwd_mode == 0 && !d->stat_sum && !d->pre_scale && !d->relu));
 }
 
 template <int TAPS, bool EPI = false>
@@ -1645,7 +1742,11 @@ static int halo_wm(const cvcs_conv_desc* d) { return d->dtype == CVCS_BF16 ? 1 :
 
 extern "C" int cvcs_conv_stat_rows(const cvcs_conv_desc* d) {
   if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVCS_EINVAL;
-  if (thin_conv_shape(d)) return d->B * (int)cdiv(d->H, kTcTH) * (int)cdiv(d->W, kTcTW) * kTcTH;      // one row per wave = tile row
+  if (thin_conv_shape(d)) {
+    const int ntiles = d->B * (int)cdiv(d->H, kTcTH) * (int)cdiv(d->W, kTcTW);
+    if (d->bwd_y) return thin_conv_groups(d->Cin_valid > 0 ? d->Cin_valid : d->Cin, d->Cout, true, ntiles);      // (BatchNorm-backward partials: one row per workgroup)
+    return ntiles * kTcTH;      // one row per wave = tile row
+  }
   if (use_halo(d) && !d->aniso && !d->in_row_pitch && !d->in_img_pitch)
     return d->B * (int)cdiv(d->H, 16) * (int)cdiv(d->W, 16) * halo_wm(d);
   // (the statistics pointers of the descriptor are not set by every caller of this query: the row count is that of the
@@ -1719,7 +1820,8 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.bwd_y = (const char*)d->bwd_y; a.bwd_y_ld = d->bwd_y_ld; a.bwd_scale = d->bwd_scale; a.bwd_shift = d->bwd_shift;
   a.bwd_mean = d->bwd_mean; a.bwd_invstd = d->bwd_invstd; a.bwd_p0 = d->bwd_part_dz; a.bwd_p1 = d->bwd_part_dzx; a.bwd_mode = d->bwd_mode;
   if (d->bwd_y) {
-    CVCS_CHECK_ARG(use_halo(d) && d->dtype == CVCS_BF16 && !thin, "cvcs_conv2d: the fused BatchNorm-backward reduce is built for bf16 3x3 / stride 1 / pad 1 launches of at least 64 output channels");
+    CVCS_CHECK_ARG((use_halo(d) && d->dtype == CVCS_BF16 && !thin) || thin_conv_shape(d),
+                   "cvcs_conv2d: the fused BatchNorm-backward reduce is built for bf16 3x3 / stride 1 / pad 1 launches (halo kernel: >= 64 output channels; thin kernel: mode 0)");
     CVCS_CHECK_ARG(d->bwd_scale && d->bwd_shift && d->bwd_mean && d->bwd_invstd && d->bwd_part_dz && d->bwd_part_dzx,
                    "cvcs_conv2d: bwd_y needs its four per-channel vectors and both partial-sum buffers");
     CVCS_CHECK_ARG(d->bwd_mode == 0 || d->bwd_mode == 1, "cvcs_conv2d: bwd_mode");
@@ -1771,9 +1873,21 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     ta.in_ld = d->in_ld; ta.out_ld = d->out_ld;
     ta.B = d->B; ta.H = d->H; ta.W = d->W; ta.Cin = cin_valid; ta.Cout = d->Cout; ta.relu = d->relu;
     ta.tiles_x = (int)cdiv(d->W, kTcTW); ta.tiles_y = (int)cdiv(d->H, kTcTH); ta.ntiles = d->B * ta.tiles_x * ta.tiles_y;
-    const int groups = ta.ntiles < 1024 ? ta.ntiles : 1024;
+    ta.bwd_y = (const char*)d->bwd_y; ta.bwd_y_ld = d->bwd_y_ld; ta.bwd_scale = d->bwd_scale; ta.bwd_shift = d->bwd_shift;
+    ta.bwd_mean = d->bwd_mean; ta.bwd_invstd = d->bwd_invstd; ta.bwd_p0 = d->bwd_part_dz; ta.bwd_p1 = d->bwd_part_dzx;
+    if (d->bwd_y) {
+      CVCS_CHECK_ARG(d->bwd_scale && d->bwd_shift && d->bwd_mean && d->bwd_invstd && d->bwd_part_dz && d->bwd_part_dzx,
+                     "cvcs_conv2d: bwd_y needs its four per-channel vectors and both partial-sum buffers");
+      CVCS_CHECK_ARG(((uintptr_t)d->bwd_y % 16) == 0 && d->bwd_y_ld >= d->Cout && (d->bwd_y_ld * 2) % 16 == 0, "cvcs_conv2d: bwd_y view");
+    }
+    const bool tbwd = d->bwd_y != nullptr;
+    const int groups = thin_conv_groups(cin_valid, d->Cout, tbwd, ta.ntiles);
 #define LAUNCH_TC(CI_, CO_)                                                                                              \
-  hipLaunchKernelGGL((conv3x3_thin_kernel<CI_, CO_>), dim3((unsigned)groups), dim3(256), 2 * ((kTcHR * kTcHC * (CI_) * 2 + 1023) / 1024 * 1024), st, ta)
+  do {                                                                                                                   \
+    constexpr size_t lds_ = 2 * ((kTcHR * kTcHC * (CI_) * 2 + 1023) / 1024 * 1024);                                       \
+    if (tbwd) hipLaunchKernelGGL((conv3x3_thin_kernel<CI_, CO_, true>), dim3((unsigned)groups), dim3(256), lds_, st, ta); \
+    else hipLaunchKernelGGL((conv3x3_thin_kernel<CI_, CO_, false>), dim3((unsigned)groups), dim3(256), lds_, st, ta);     \
+  } while (0)
     if (cin_valid == 16 && d->Cout == 16) LAUNCH_TC(16, 16);
     else if (cin_valid == 16) LAUNCH_TC(16, 32);
     else if (d->Cout == 16) LAUNCH_TC(32, 16);

@@ -218,28 +218,41 @@ struct BnActArgs {
   Q8Out q8;
 };
 
-template <typename T, bool POOL>
+// RELU (0 none, 1 ReLU, 2 hardswish) is a template parameter (as an argument: a scalar branch per element).  Work items are indexed in 32 bits
+// (the host refuses maps of 2^31 chunks); when the grid stride is a multiple of the row's chunk count - every power-of-two width - a thread
+// keeps its channel chunk, and its 2 x V scale / shift values, for the whole loop.
+template <typename T, bool POOL, int RELU>
 __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
   constexpr int ES = sizeof(T), V = 16 / ES;
-  const int CC = p.C / V;
+  const unsigned CC = (unsigned)(p.C / V);
   const int64_t items = POOL ? (int64_t)p.B * (p.H / 2) * (p.W / 2) : (int64_t)p.B * p.H * p.W;
-  const int64_t total = items * CC;
+  const unsigned total = (unsigned)(items * CC);
   float am = 0.f;
   const float q_inv = p.q8.q ? p.q8.slot[2] : 0.f, q_fmax = p.q8.q ? p.q8.slot[3] : 0.f;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(id % CC);
-    const int64_t it = id / CC;
-    float sc[V], sh[V];
+  const unsigned S = gridDim.x * 256u;
+  const bool fixed = S % CC == 0;                 // wave-uniform
+  const unsigned id0 = blockIdx.x * 256u + threadIdx.x;
+  unsigned cc = id0 % CC, it32 = id0 / CC;
+  const unsigned it_step = S / CC;
+  float sc[V], sh[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) { sc[k] = p.scale[cc * V + k]; sh[k] = p.shift[cc * V + k]; }
+  for (int k = 0; k < V; ++k) { sc[k] = p.scale[cc * V + k]; sh[k] = p.shift[cc * V + k]; }
+  for (unsigned id = id0; id < total; id += S) {
+    if (!fixed) {
+      cc = id % CC; it32 = id / CC;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { sc[k] = p.scale[cc * V + k]; sh[k] = p.shift[cc * V + k]; }
+    }
+    const int64_t it = it32;
+    if (fixed) it32 += it_step;
     if constexpr (!POOL) {
       float f[V];
       Elem<T>::unpack(*reinterpret_cast<const uint4*>(p.y + (it * p.y_ld) * ES + cc * 16), f);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         f[k] = f[k] * sc[k] + sh[k];
-        if (p.relu == 1) f[k] = fmaxf(f[k], 0.f);
-        else if (p.relu == 2) f[k] = hardswish(f[k]);
+        if constexpr (RELU == 1) f[k] = fmaxf(f[k], 0.f);
+        else if constexpr (RELU == 2) f[k] = hardswish(f[k]);
       }
       const uint4 pk = Elem<T>::pack(f);
       *reinterpret_cast<uint4*>(p.out + (it * p.out_ld) * ES + cc * 16) = pk;
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs p) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
           f[k] = f[k] * sc[k] + sh[k];
-          if (p.relu) f[k] = fmaxf(f[k], 0.f);
+          if constexpr (RELU != 0) f[k] = fmaxf(f[k], 0.f);
           mx[k] = fmaxf(mx[k], f[k]);
         }
         if (p.out) *reinterpret_cast<uint4*>(p.out + (pix * p.out_ld) * ES + cc * 16) = Elem<T>::pack(f);
@@ -290,7 +303,9 @@ struct BnBwdArgs {
 // One work item = one pixel (POOL=false) or one 2x2 window (POOL=true) x one 16-byte channel chunk.
 // APPLY=false: accumulate sum(dz), sum(dz*xhat).  APPLY=true: write dy, accumulate sum(dy).
 constexpr int kBnBwdChunks = 32;
-template <typename T, bool POOL, bool APPLY>
+// MODE (the activation around the BatchNorm: 0 ReLU after, 1 ReLU before, 2 none, 3 hardswish after) is a template parameter: as a kernel
+// argument it cost two or three scalar branches PER ELEMENT inside the unrolled loop (the passes ran 30-40 % under a plain 2R1W stream)
+template <typename T, bool POOL, bool APPLY, int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   constexpr int ES = sizeof(T), V = 16 / ES;
   constexpr int NPIX = POOL ? 4 : 1;
@@ -317,21 +332,27 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
 
   // U independent work items per trip: all their 16-byte loads are issued before the first use (a single item in flight per
   // thread left the small layers latency-bound: 0.8-3 TB/s)
+  // The U items of a trip are ADJACENT pixel groups (a workgroup streams U * PL consecutive pixels, consecutive workgroups consecutive
+  // blocks): with the items a whole grid stride apart (gridDim.x * PL pixels = a power-of-two number of MiB) a thread's loads in flight all
+  // fell on the same memory channels, and the passes ran at 3.6-4.9 TB/s where a plain two-stream add reaches 6.
   constexpr int U = POOL ? 1 : 4;
-  const int64_t step = (int64_t)gridDim.x * PL;
+  int64_t step = (int64_t)gridDim.x * PL;
   int64_t it = (int64_t)blockIdx.x * PL + pl;
   if constexpr (!POOL) {
-    for (; it + (U - 1) * step < items; it += U * step) {
+    const int64_t grp = (int64_t)U * PL;
+    const int64_t nfull = items / grp;                  // whole groups (0 for the idle threads)
+    for (int64_t gi = blockIdx.x; gi < nfull; gi += gridDim.x) {
+      const int64_t it0 = gi * grp + pl;
       uint4 yr[U], gr[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int64_t px = it + u * step;
+        const int64_t px = it0 + u * PL;
         yr[u] = *reinterpret_cast<const uint4*>(p.y + (px * p.y_ld) * ES + cc * 16);
         gr[u] = *reinterpret_cast<const uint4*>(p.g1 + (px * p.g1_ld) * ES + cc * 16);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int64_t px = it + u * step;
+        const int64_t px = it0 + u * PL;
         float yv[V], gv[V], out[V];
         Elem<T>::unpack(yr[u], yv);
         Elem<T>::unpack(gr[u], gv);
@@ -339,14 +360,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
         for (int k = 0; k < V; ++k) {
           const float xh = (yv[k] - mu[k]) * is[k];
           float dz = gv[k];
-          if (p.mode == 0) dz = (yv[k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;
-          else if (p.mode == 3) dz *= hardswish_grad(yv[k] * sc[k] + sh[k]);
+          if constexpr (MODE == 0) dz = (yv[k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;
+          else if constexpr (MODE == 3) dz *= hardswish_grad(yv[k] * sc[k] + sh[k]);
           if constexpr (!APPLY) {
             s0[k] += dz;
             s1[k] += dz * xh;
           } else {
             float d = sc[k] * (dz - ca[k] - xh * cb[k]);
-            if (p.mode == 1) d = (yv[k] > 0.f) ? d : 0.f;
+            if constexpr (MODE == 1) d = (yv[k] > 0.f) ? d : 0.f;
             out[k] = d;
             s0[k] += d;
           }
@@ -360,6 +381,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
         }
       }
     }
+  }
+  if constexpr (!POOL) {      // the last, partial group: one workgroup, one pixel at a time
+    const int64_t grp = (int64_t)U * PL, nfull = items / grp;
+    it = (int64_t)blockIdx.x == nfull % gridDim.x ? nfull * grp + pl : items;
+    step = PL;
   }
   for (; it < items; it += step) {
     int64_t pix[NPIX];
@@ -405,14 +431,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
       for (int k = 0; k < V; ++k) {
         const float xh = (yv[w][k] - mu[k]) * is[k];
         float dz = gv[w][k];
-        if (p.mode == 0) dz = (yv[w][k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;  // encoder: ReLU after BN
-        else if (p.mode == 3) dz *= hardswish_grad(yv[w][k] * sc[k] + sh[k]);  // hardswish after BN
+        if constexpr (MODE == 0) dz = (yv[w][k] * sc[k] + sh[k] > 0.f) ? dz : 0.f;  // encoder: ReLU after BN
+        else if constexpr (MODE == 3) dz *= hardswish_grad(yv[w][k] * sc[k] + sh[k]);  // hardswish after BN
         if constexpr (!APPLY) {
           s0[k] += dz;
           s1[k] += dz * xh;
         } else {
           float d = sc[k] * (dz - ca[k] - xh * cb[k]);
-          if (p.mode == 1) d = (yv[w][k] > 0.f) ? d : 0.f;                  // decoder: ReLU before BN
+          if constexpr (MODE == 1) d = (yv[w][k] > 0.f) ? d : 0.f;                  // decoder: ReLU before BN
           out[k] = d;
           s0[k] += d;
         }
@@ -429,16 +455,25 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs p) {
   if constexpr (APPLY && ES == 2) {
     if (p.q8.q && p.q8.take_amax) q8_commit_amax(am, p.q8.slot);
   }
-  // ---- combine the PL pixel lanes
+  // ---- combine the PL pixel lanes: red[.][q][e], e = one of the workgroup's n_out = ccw * V channels.  Every thread sums a slice of the
+  // lanes of ONE channel, the slices are merged in order (ccw threads walking all PL lanes of V channels each - 2048 dependent LDS reads
+  // for a 16-channel map - were a serial tail of 10-50 us behind every launch)
 #pragma unroll
   for (int k = 0; k < V; ++k) { red[0][tid * V + k] = s0[k]; red[1][tid * V + k] = s1[k]; }
   __syncthreads();
-  if (pl == 0) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      float a = 0.f, b2 = 0.f;
-      for (int q = 0; q < PL; ++q) { a += red[0][(q * ccw + cl) * V + k]; b2 += red[1][(q * ccw + cl) * V + k]; }
-      const int64_t o = (int64_t)blockIdx.x * p.C + cc * V + k;
+  {
+    const int n_out = ccw * V, P = 256 / n_out > 0 ? 256 / n_out : 1;
+    const int e = tid % n_out, part = tid / n_out;
+    float a = 0.f, b2 = 0.f;
+    if (part < P)
+      for (int q = part; q < PL; q += P) { a += red[0][q * n_out + e]; if constexpr (!APPLY) b2 += red[1][q * n_out + e]; }
+    __syncthreads();
+    if (part < P) { red[0][part * n_out + e] = a; red[1][part * n_out + e] = b2; }
+    __syncthreads();
+    if (tid < n_out) {
+      a = 0.f; b2 = 0.f;
+      for (int j = 0; j < P; ++j) { a += red[0][j * n_out + e]; if constexpr (!APPLY) b2 += red[1][j * n_out + e]; }
+      const int64_t o = (int64_t)blockIdx.x * p.C + (int64_t)blockIdx.y * n_out + e;
       p.part0[o] = a;
       if constexpr (!APPLY) p.part1[o] = b2;
     }
@@ -710,31 +745,35 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_item* __restrict__ items) {
   constexpr int CO = 16, CI = 64, MAXT = 9;
-  __shared__ float sw[CO][CI * MAXT + 1];
+  __shared__ float sw[CO][CI * MAXT + CI * MAXT / 32 + 1];      // element j of a row sits at j + j / 32: the 16-byte gathers below step 8 floats per lane
+  auto at = [](int j) { return j + (j >> 5); };
   const cvcs_pack_item it = items[blockIdx.y];
   const float* __restrict__ w = it.w;
   T* wf = reinterpret_cast<T*>(it.w_fwd);
   T* wd = reinterpret_cast<T*>(it.w_dgrad);
   const int Cout = it.Cout, Cin = it.Cin, Cin_pad = it.Cin_pad, taps = it.KH * it.KW;
   const int Cout_pad = it.Cout_pad > 0 ? it.Cout_pad : Cout;      // row length of the data-gradient image (columns Cout.. stay as allocated: zero)
-  const int nci = (Cin_pad + CI - 1) / CI, nco = Cout / CO;
+  // input channels per block: as many 64-channel groups as the 576-float LDS rows hold (1x1 convs: 576 channels - at 64 a block was 4 KiB
+  // between two barriers, and the 1x1 layers, half of the bytes, ran at a quarter of the 3x3 layers' rate)
+  const int CIb = CI * (MAXT / taps);
+  const int nci = (Cin_pad + CIb - 1) / CIb, nco = Cout / CO;
   for (int blk = blockIdx.x; blk < nco * nci; blk += gridDim.x) {
-    const int co0 = (blk / nci) * CO, ci0 = (blk % nci) * CI;
-    const int cin_here = Cin - ci0 < CI ? (Cin - ci0 < 0 ? 0 : Cin - ci0) : CI;      // real input channels in this block
+    const int co0 = (blk / nci) * CO, ci0 = (blk % nci) * CIb;
+    const int cin_here = Cin - ci0 < CIb ? (Cin - ci0 < 0 ? 0 : Cin - ci0) : CIb;    // real input channels in this block
     const int run = cin_here * taps;                                                   // contiguous floats per output channel
+    const int cpad_here = Cin_pad - ci0 < CIb ? Cin_pad - ci0 : CIb;                   // a multiple of V (Cin_pad is a K-group)
     __syncthreads();
-    for (int id = threadIdx.x; id < CO * CI * taps; id += 256) {
-      const int c = id / (CI * taps), r = id - c * (CI * taps);
-      sw[c][r] = r < run ? w[((int64_t)(co0 + c) * Cin + ci0) * taps + r] : 0.f;       // r = ci_local * taps + t
+    for (int id = threadIdx.x; id < CO * cpad_here * taps; id += 256) {
+      const int c = id / (cpad_here * taps), r = id - c * (cpad_here * taps);
+      sw[c][at(r)] = r < run ? w[((int64_t)(co0 + c) * Cin + ci0) * taps + r] : 0.f;   // r = ci_local * taps + t
     }
     __syncthreads();
     constexpr int V = 16 / sizeof(T);                                                  // elements per 16-byte store
-    const int cpad_here = Cin_pad - ci0 < CI ? Cin_pad - ci0 : CI;                     // a multiple of V (Cin_pad is a K-group)
     for (int id = threadIdx.x; id < taps * CO * (cpad_here / V); id += 256) {          // wf[t][co][ci]: 16 bytes of ci per lane
       const int cv = id % (cpad_here / V), r = id / (cpad_here / V), c = r % CO, t = r / CO;
       float f[V];
 #pragma unroll
-      for (int k = 0; k < V; ++k) f[k] = sw[c][(cv * V + k) * taps + t];
+      for (int k = 0; k < V; ++k) f[k] = sw[c][at((cv * V + k) * taps + t)];
       *reinterpret_cast<uint4*>(wf + ((int64_t)t * Cout + co0 + c) * Cin_pad + ci0 + cv * V) = Elem<T>::pack(f);
     }
     if (wd) {
@@ -742,7 +781,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
         const int cv = id % (CO / V), r = id / (CO / V), ci = r % cin_here, tp = r / cin_here;
         float f[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) f[k] = sw[cv * V + k][ci * taps + (taps - 1 - tp)];
+        for (int k = 0; k < V; ++k) f[k] = sw[cv * V + k][at(ci * taps + (taps - 1 - tp))];
         *reinterpret_cast<uint4*>(wd + ((int64_t)tp * Cin + ci0 + ci) * Cout_pad + co0 + cv * V) = Elem<T>::pack(f);
       }
     }
@@ -913,13 +952,17 @@ static int bn_act_impl(const void* y, int64_t y_ld, int B, int H, int W, int C, 
   const int64_t total = (pool ? (int64_t)B * (H / 2) * (W / 2) : (int64_t)B * H * W) * (C / (16 / es));
   dim3 grid(grid_for(total, 256, 256 * 32));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVCS_F32) {
-    if (pool) hipLaunchKernelGGL((bn_act_kernel<float, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((bn_act_kernel<float, false>), grid, dim3(256), 0, st, a);
-  } else {
-    if (pool) hipLaunchKernelGGL((bn_act_kernel<bf16_t, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((bn_act_kernel<bf16_t, false>), grid, dim3(256), 0, st, a);
-  }
+  CVCS_CHECK_ARG(total < (1ll << 31), "cvcs_bn_act: map too large (2^31 16-byte chunks)");
+  CVCS_CHECK_ARG(relu >= 0 && relu <= 2 && !(pool && relu == 2), "cvcs_bn_act: relu=%d", relu);
+#define LAUNCH_BNA(TT, PP)                                                                                   \
+  do {                                                                                                       \
+    if (relu == 0) hipLaunchKernelGGL((bn_act_kernel<TT, PP, 0>), grid, dim3(256), 0, st, a);                \
+    else if (relu == 1) hipLaunchKernelGGL((bn_act_kernel<TT, PP, 1>), grid, dim3(256), 0, st, a);           \
+    else hipLaunchKernelGGL((bn_act_kernel<TT, PP, 2>), grid, dim3(256), 0, st, a);                          \
+  } while (0)
+  if (dtype == CVCS_F32) { if (pool) LAUNCH_BNA(float, true); else LAUNCH_BNA(float, false); }
+  else { if (pool) LAUNCH_BNA(bf16_t, true); else LAUNCH_BNA(bf16_t, false); }
+#undef LAUNCH_BNA
   CVCS_CHECK_LAUNCH("cvcs_bn_act");
   return CVCS_OK;
 }
@@ -975,14 +1018,22 @@ static int bn_bwd_common(const char* fn, bool apply, const void* y, int64_t y_ld
   a.ccw = ccw;
   dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)B * H * W), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_BNB(TT)                                                                                      \
-  do {                                                                                                      \
-    if (g2) { if (apply) hipLaunchKernelGGL((bn_bwd_kernel<TT, true, true>), grid, dim3(256), 0, st, a);    \
-              else hipLaunchKernelGGL((bn_bwd_kernel<TT, true, false>), grid, dim3(256), 0, st, a); }       \
-    else    { if (apply) hipLaunchKernelGGL((bn_bwd_kernel<TT, false, true>), grid, dim3(256), 0, st, a);   \
-              else hipLaunchKernelGGL((bn_bwd_kernel<TT, false, false>), grid, dim3(256), 0, st, a); }      \
+#define LAUNCH_BNB3(TT, PP, AA)                                                                                       \
+  do {                                                                                                                \
+    switch (mode) {                                                                                                   \
+      case 0: hipLaunchKernelGGL((bn_bwd_kernel<TT, PP, AA, 0>), grid, dim3(256), 0, st, a); break;                   \
+      case 1: hipLaunchKernelGGL((bn_bwd_kernel<TT, PP, AA, 1>), grid, dim3(256), 0, st, a); break;                   \
+      case 2: hipLaunchKernelGGL((bn_bwd_kernel<TT, PP, AA, 2>), grid, dim3(256), 0, st, a); break;                   \
+      default: hipLaunchKernelGGL((bn_bwd_kernel<TT, PP, AA, 3>), grid, dim3(256), 0, st, a); break;                  \
+    }                                                                                                                 \
+  } while (0)
+#define LAUNCH_BNB(TT)                                                                                                \
+  do {                                                                                                                \
+    if (g2) { if (apply) LAUNCH_BNB3(TT, true, true); else LAUNCH_BNB3(TT, true, false); }                            \
+    else    { if (apply) LAUNCH_BNB3(TT, false, true); else LAUNCH_BNB3(TT, false, false); }                          \
   } while (0)
   if (dtype == CVCS_F32) LAUNCH_BNB(float); else LAUNCH_BNB(bf16_t);
+#undef LAUNCH_BNB3
 #undef LAUNCH_BNB
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;

@@ -111,8 +111,11 @@ struct TailBwdArgs {
   const char* y[2]; int64_t y_ld[2];
   const float* mean[2]; const float* invstd[2];
   float* part_dz; float* part_dzx[2];
+  // POOLG: one more gradient term comes through a MaxPool2d(3, 2, 1) of this map (the ResNet stem): pooled gradients pg[0] (+ pg[1]) at
+  // (H + 1) / 2 x (W + 1) / 2 with the arg-max tap index of every pooled element - the max-pool backward without a gradient map of its own
+  const char* pg[2]; int64_t pg_ld[2]; const uint8_t* pidx;
 };
-template <typename T>
+template <typename T, bool POOLG>
 __global__ __launch_bounds__(256) void relu_bwd_sum_bn_kernel(TailBwdArgs q) {
   constexpr int ES = sizeof(T), V = 16 / ES;
   __shared__ float red[3][256 * V];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void relu_bwd_sum_bn_kernel(TailBwdArgs q) {
   for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < M; pix += (int64_t)gridDim.x * PL) {
     int x = 0, y = 0;
     int64_t b = 0;
-    if (any_half) {
+    if (any_half || POOLG) {
       x = (int)(pix % p.W);
       const int64_t t = pix / p.W;
       y = (int)(t % p.H);
@@ -172,6 +175,45 @@ __global__ __launch_bounds__(256) void relu_bwd_sum_bn_kernel(TailBwdArgs q) {
 #pragma unroll
       for (int k = 0; k < V; ++k) s[k] += f[k];
     }
+    if constexpr (POOLG) {
+      // windows (oy, ox) that contain (y, x): 2*oy - 1 <= y <= 2*oy + 1, i.e. oy = y >> 1 and, for odd y, (y + 1) >> 1 as well; the pooled
+      // gradient goes to the element the forward recorded.  All four candidate windows are fetched unconditionally (clamped addresses, a
+      // duplicate or out-of-range window counts for nothing): twelve independent loads in flight instead of a chain of guarded ones.
+      const int Ho = (p.H + 1) >> 1, Wo = (p.W + 1) >> 1;
+      const int oyv[2] = {y >> 1, (y + 1) >> 1}, oxv[2] = {x >> 1, (x + 1) >> 1};
+      const bool oyok[2] = {true, (y & 1) && oyv[1] < Ho}, oxok[2] = {true, (x & 1) && oxv[1] < Wo};
+      uint2 iwr[4];
+      uint4 g0r[4], g1r[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int oy = oyok[w >> 1] ? oyv[w >> 1] : oyv[0], ox = oxok[w & 1] ? oxv[w & 1] : oxv[0];
+        const int64_t op = (b * Ho + oy) * Wo + ox;
+        const uint8_t* ip = q.pidx + op * p.C + cc * V;
+        if constexpr (V == 8) iwr[w] = *reinterpret_cast<const uint2*>(ip);
+        else iwr[w] = make_uint2(*reinterpret_cast<const unsigned*>(ip), 0u);
+        g0r[w] = *reinterpret_cast<const uint4*>(q.pg[0] + op * q.pg_ld[0] * ES + cc * 16);
+        g1r[w] = q.pg[1] ? *reinterpret_cast<const uint4*>(q.pg[1] + op * q.pg_ld[1] * ES + cc * 16) : make_uint4(0u, 0u, 0u, 0u);
+      }
+      float sp[V];       // (summed apart and rounded to the storage type first: the value cvcs_maxpool3x3s2_bwd would have stored)
+#pragma unroll
+      for (int k = 0; k < V; ++k) sp[k] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const bool ok = oyok[w >> 1] && oxok[w & 1];
+        const int want = ok ? (y - (2 * oyv[w >> 1] - 1)) * 3 + (x - (2 * oxv[w & 1] - 1)) : 255;      // (tap indices are 0 .. 8)
+        float f[V], f1[V];
+        Elem<T>::unpack(g0r[w], f);
+        Elem<T>::unpack(g1r[w], f1);
+        const unsigned iw[2] = {iwr[w].x, iwr[w].y};
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          if ((int)((iw[k >> 2] >> ((k & 3) * 8)) & 0xff) == want) sp[k] += f[k] + f1[k];
+      }
+      float spr[V];
+      Elem<T>::unpack(Elem<T>::pack(sp), spr);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] += spr[k];
+    }
     if (p.out) {
       float o[V];
       Elem<T>::unpack(orw, o);
@@ -197,12 +239,20 @@ __global__ __launch_bounds__(256) void relu_bwd_sum_bn_kernel(TailBwdArgs q) {
 #pragma unroll
   for (int k = 0; k < V; ++k) { red[0][tid * V + k] = s0[k]; red[1][tid * V + k] = s1[0][k]; red[2][tid * V + k] = s1[1][k]; }
   __syncthreads();
-  if (pl == 0) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      float a = 0.f, b0 = 0.f, b1 = 0.f;
-      for (int w = 0; w < PL; ++w) { a += red[0][(w * ccw + cl) * V + k]; b0 += red[1][(w * ccw + cl) * V + k]; b1 += red[2][(w * ccw + cl) * V + k]; }
-      const int64_t o = (int64_t)blockIdx.x * p.C + cc * V + k;
+  {
+    // (every thread sums a slice of the pixel lanes of ONE of the workgroup's n_out channels, the slices are merged in order: bn_bwd_kernel)
+    const int n_out = ccw * V, P = 256 / n_out > 0 ? 256 / n_out : 1;
+    const int e = tid % n_out, part = tid / n_out;
+    float a = 0.f, b0 = 0.f, b1 = 0.f;
+    if (part < P)
+      for (int w = part; w < PL; w += P) { a += red[0][w * n_out + e]; b0 += red[1][w * n_out + e]; b1 += red[2][w * n_out + e]; }
+    __syncthreads();
+    if (part < P) { red[0][part * n_out + e] = a; red[1][part * n_out + e] = b0; red[2][part * n_out + e] = b1; }
+    __syncthreads();
+    if (tid < n_out) {
+      a = 0.f; b0 = 0.f; b1 = 0.f;
+      for (int j = 0; j < P; ++j) { a += red[0][j * n_out + e]; b0 += red[1][j * n_out + e]; b1 += red[2][j * n_out + e]; }
+      const int64_t o = (int64_t)blockIdx.x * p.C + (int64_t)blockIdx.y * n_out + e;
       q.part_dz[o] = a;
       if (q.y[0]) q.part_dzx[0][o] = b0;
       if (q.y[1]) q.part_dzx[1][o] = b1;
@@ -596,7 +646,9 @@ extern "C" int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream) {
   CVCS_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % V == 0, "%s: bad shape", fn);
   const int CC = d->C / V;
   CVCS_CHECK_ARG((CC & (CC - 1)) == 0 || CC % 32 == 0, "%s: C/%d must be a power of two or a multiple of 32", fn, V);
-  CVCS_CHECK_ARG(d->g[0] != nullptr && d->dz && d->y[0] && d->part_dz && d->part_dzx[0], "%s: g[0], dz, y[0] and the partial buffers are required", fn);
+  CVCS_CHECK_ARG((d->g[0] != nullptr || d->pool_idx != nullptr) && d->dz && d->y[0] && d->part_dz && d->part_dzx[0],
+                 "%s: a gradient (g[0] or the pooled one), dz, y[0] and the partial buffers are required", fn);
+  CVCS_CHECK_ARG(!d->pool_idx || d->pool_g[0], "%s: pool_idx needs pool_g[0]", fn);
   CVCS_CHECK_ARG(!(d->g_half[0] || (d->g[1] && d->g_half[1]) || (d->g[2] && d->g_half[2])) || (d->H % 2 == 0 && d->W % 2 == 0),
                  "%s: a half-resolution gradient needs even H, W", fn);
   int rc;
@@ -620,8 +672,18 @@ extern "C" int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream) {
   const int ccw = CC < 32 ? CC : 32;
   const dim3 grid((unsigned)cvcs_bn_bwd_rows((int64_t)d->B * d->H * d->W), (unsigned)(CC / ccw));
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == CVCS_F32) hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<float>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+  if (d->pool_idx) {
+    for (int j = 0; j < 2; ++j) {
+      if (d->pool_g[j] && (rc = res_check_view(fn, d->pool_g[j], d->pool_g_ld[j], d->C, es))) return rc;
+      a.pg[j] = (const char*)d->pool_g[j]; a.pg_ld[j] = d->pool_g_ld[j];
+    }
+    a.pidx = d->pool_idx;
+    if (d->dtype == CVCS_F32) hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<float, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<bf16_t, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (d->dtype == CVCS_F32) hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<float, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((relu_bwd_sum_bn_kernel<bf16_t, false>), grid, dim3(256), 0, st, a);
+  }
   CVCS_CHECK_LAUNCH(fn);
   return CVCS_OK;
 }

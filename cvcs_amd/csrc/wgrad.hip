@@ -1028,6 +1028,97 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWgArgs p) {
         for (int r = 0; r < 4; ++r) ws[((int64_t)tap * CO + i * 16 + fg * 4 + r) * CI + j * 16 + fr] = acc[tap][i][j][r];
 }
 
+// The same layer under a WIDE input (Cin a multiple of 128 under Cout = 16 | 32: the 128 -> 32 stage of the light decoder, 256^2 pixels).  As
+// 32-channel groups of the kernel above it took one launch per group - the thin dy re-read every time, and a 64-byte slice of every 256-byte
+// pixel fetched as whole lines: 4 x 0.54 GB for 0.67 GB of operands.  Here the four waves of a workgroup own one 32-channel group EACH and all
+// walk the same 4 x 32-pixel tile (K = one tile row per MFMA): the dy tile and the 6 x 34-pixel halo of all 128 channels are staged once.
+// A halo pixel is 256 bytes = the whole bank period, so its sixteen 16-byte chunks are stored XOR-swizzled by a key of the pixel index
+// (chunk c of halo pixel p sits at chunk c ^ key(p)): the sixteen pixels of a transposed read then spread over all banks (two-way instead of
+// sixteen-way).  Slabs ws[group][workgroup][tap][co][32], summed per group by the reduce kernel below (blockIdx.y = group).
+constexpr int kWideTH = 4, kWideTW = 32, kWideHC = kWideTW + 2, kWideHR = kWideTH + 2;
+__device__ __forceinline__ unsigned wide_key(unsigned p) { return 2u * ((p & 3u) | (((p >> 3) & 1u) << 2)); }
+
+template <int CO>
+__global__ __launch_bounds__(256) void wgrad_thin_wide_kernel(ThinWgArgs p) {
+  constexpr int DYB = kWideTH * kWideTW * CO * 2;                      // 4 | 8 KiB of dy
+  constexpr int XPIX = kWideHR * kWideHC;                              // 204 halo pixels x 256 bytes = 51 pieces of 1 KiB exactly
+  constexpr int NDY = DYB / 1024, NX = XPIX * 256 / 1024;
+  constexpr int MB = CO / 16, NB = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int ci0 = blockIdx.y * 128;                                    // this launch row's 128 input channels
+  f32x4 acc[9][MB][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int DPP = 1024 / (CO * 2), DCH = CO * 2 / 16;             // dy pixels per piece, chunks per pixel
+  const int dpx = lane / DCH, dch = lane % DCH;
+  const int xs = lane >> 4, xc = lane & 15;                            // x: pixel slot of the piece, chunk POSITION in LDS
+  const int q = fr >> 2, pp = fr & 3;
+
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    const int b = t / tpi, tr = t - b * tpi;
+    const int ty0 = (tr / p.tiles_x) * kWideTH, tx0 = (tr % p.tiles_x) * kWideTW;
+    for (int pi = wave; pi < NDY; pi += 4) {
+      const int k = pi * DPP + dpx;                                    // tile pixel: row k / 32, column k % 32
+      const int oy = ty0 + (k >> 5), ox = tx0 + (k & 31);
+      const char* src = (oy < p.H && ox < p.W) ? p.dy + ((((int64_t)b * p.H + oy) * p.W + ox) * p.dy_ld) * 2 + dch * 16
+                                               : reinterpret_cast<const char*>(&g_tzero16);
+      dma16(src, lds0 + pi * 1024);
+    }
+    for (int pi = wave; pi < NX; pi += 4) {
+      const int r = pi * 4 + xs;                                       // halo pixel: row r / 34, column r % 34
+      const int hy = r / kWideHC, hx = r - hy * kWideHC;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      const unsigned c = (unsigned)xc ^ wide_key((unsigned)r);        // the chunk that belongs at this position
+      const char* src = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                            ? p.x + ((((int64_t)b * p.H + iy) * p.W + ix) * p.x_ld + ci0) * 2 + c * 16
+                            : reinterpret_cast<const char*>(&g_tzero16);
+      dma16(src, lds0 + DYB + pi * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < kWideTH; ++r) {
+      const int px0 = r * kWideTW + 8 * fg + q;                        // dy tile pixel of this lane's first transposed read
+      bf16x8 af[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+        af[i] = tr_pair(smem, px0 * (CO * 2) + i * 32 + pp * 8, (px0 + 4) * (CO * 2) + i * 32 + pp * 8);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const unsigned hp = (unsigned)((r + kh) * kWideHC + 8 * fg + q + kw);   // halo pixel under tile pixel px0 for this tap
+        const unsigned k0 = wide_key(hp), k1 = wide_key(hp + 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const unsigned c = (unsigned)(wave * 4 + j * 2 + (pp >> 1));           // 16-byte chunk of this lane's four channels
+          const bf16x8 bf = tr_pair(smem, DYB + hp * 256 + ((c ^ k0) << 4) + (pp & 1) * 8, DYB + (hp + 4) * 256 + ((c ^ k1) << 4) + (pp & 1) * 8);
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[tap][i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();            // every wave is done with the tile before the next one is staged over it
+  }
+  // ---- this wave's partial slab of its channel group: ws[group][workgroup][tap][co][32]
+  float* ws = p.ws + ((int64_t)(blockIdx.y * 4 + wave) * gridDim.x + blockIdx.x) * 9 * CO * 32;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[((int64_t)tap * CO + i * 16 + fg * 4 + r) * 32 + j * 16 + fr] = acc[tap][i][j][r];
+}
+
 // sum of the thin kernel's S partial slabs ws[s][tap][co][ci] -> dw[co][ci][tap] (OIHW), fixed order: 1024 threads = 16 slice lanes x 64
 // consecutive slab elements (a wave reads 256 contiguous bytes of one slab); slice lane l sums slabs l, l + 16, ... eight loads in
 // flight, then the 16 lanes are added in order.  (The generic reduce kernel above walks the slices with 16 lanes per OUTPUT PAIR: with
@@ -1036,6 +1127,8 @@ __global__ __launch_bounds__(1024) void wgrad_thin_reduce_kernel(const float* __
                                                                  int ci0 = 0) {
   __shared__ float sh[16][64];
   const int n = 9 * CO * CI;
+  ws += (int64_t)blockIdx.y * S * n;      // (the wide-input kernel: one launch row per 32-channel group, its S slabs back to back)
+  ci0 += blockIdx.y * CI;
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6;
   float a = 0.f;
   if (e < n) {
@@ -1070,6 +1163,15 @@ static bool thin_wgrad_shape(const cvcs_wgrad_desc* d) {
 static int thin_wgrad_groups(const cvcs_wgrad_desc* d) {
   const int64_t ntiles = (int64_t)d->B * cdiv(d->H, kThinTH) * cdiv(d->W, kThinTW);
   return (int)(ntiles < 768 ? ntiles : 768);       // three workgroups per CU
+}
+
+static bool thin_wide_shape(const cvcs_wgrad_desc* d) {
+  static const int on = getenv("CVCS_WGRAD_THIN_WIDE") ? atoi(getenv("CVCS_WGRAD_THIN_WIDE")) : 1;   // tuning knob
+  return on && thin_wgrad_shape(d) && d->Cin % 128 == 0;
+}
+static int thin_wide_groups(const cvcs_wgrad_desc* d) {
+  const int64_t ntiles = (int64_t)d->B * cdiv(d->H, kWideTH) * cdiv(d->W, kWideTW);
+  return (int)(ntiles < 512 ? ntiles : 512);       // two workgroups per CU (59 KiB of LDS each)
 }
 
 static int fast_path(const cvcs_wgrad_desc* d) {
@@ -1270,7 +1372,10 @@ static int64_t wgrad_slab_floats(const cvcs_wgrad_desc* d) {
     const int64_t o = (int64_t)cvcs_wgrad_slices(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 2) * d->Cout * d->Cin;
     return g > o ? g : o;
   }
-  if (thin_wgrad_shape(d)) return (int64_t)thin_wgrad_groups(d) * 4 * 9 * d->Cout * (d->Cin > 32 ? 32 : d->Cin);     // (one 32-channel group at a time)
+  if (thin_wgrad_shape(d)) {
+    if (thin_wide_shape(d)) return (int64_t)thin_wide_groups(d) * (d->Cin / 32) * 9 * d->Cout * 32;      // every group's slabs at once
+    return (int64_t)thin_wgrad_groups(d) * 4 * 9 * d->Cout * (d->Cin > 32 ? 32 : d->Cin);     // (one 32-channel group at a time)
+  }
   if (d->dil > 1) {   // nine shifted 1x1 problems into one [slice][9][co][ci] slab
     const int a = make_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin, 1, 1, 1, 0).nslice;
     const int g = gemm_shape(1, 1, 1, d->Cout, d->Cin) ? gemm_plan(d->B, d->Ho, d->Wo, d->Cout, d->Cin).nslice : 0;
@@ -1313,8 +1418,21 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     ta.x = (const char*)d->x; ta.dy = (const char*)d->dy; ta.ws = d->workspace; ta.x_ld = d->x_ld; ta.dy_ld = d->dy_ld;
     ta.B = d->B; ta.H = d->H; ta.W = d->W; ta.Cin = d->Cin; ta.Cout = d->Cout;
     ta.tiles_x = (int)cdiv(d->W, kThinTW); ta.tiles_y = (int)cdiv(d->H, kThinTH); ta.ntiles = d->B * ta.tiles_x * ta.tiles_y;
-    const int groups = thin_wgrad_groups(d);
     hipStream_t tst = (hipStream_t)stream;
+    if (thin_wide_shape(d)) {
+      ta.tiles_x = (int)cdiv(d->W, kWideTW); ta.tiles_y = (int)cdiv(d->H, kWideTH); ta.ntiles = d->B * ta.tiles_x * ta.tiles_y;
+      const int wg = thin_wide_groups(d);
+      const size_t lds = (size_t)kWideTH * kWideTW * d->Cout * 2 + (size_t)kWideHR * kWideHC * 256;
+      const dim3 grid((unsigned)wg, (unsigned)(d->Cin / 128));
+      if (d->Cout == 16) hipLaunchKernelGGL((wgrad_thin_wide_kernel<16>), grid, dim3(256), lds, tst, ta);
+      else hipLaunchKernelGGL((wgrad_thin_wide_kernel<32>), grid, dim3(256), lds, tst, ta);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin, wide input)");
+      hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)cdiv(9 * d->Cout * 32, 64), (unsigned)(d->Cin / 32)), dim3(1024), 0, tst, d->workspace, d->dw, wg,
+                         d->Cout, 32, d->Cin, 0);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin reduce)");
+      return CVCS_OK;
+    }
+    const int groups = thin_wgrad_groups(d);
 #define LAUNCH_THIN(CO_, CI_)                                                                                              \
   do {                                                                                                                     \
     const int lds = kThinTH * kThinTW * (CO_) * 2 + (kThinHR * kThinHC * (CI_) * 2 + 1023) / 1024 * 1024;                  \
@@ -1491,9 +1609,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 struct GramPlan { int BM, tiles, ktiles, per_slice, nslice; };
-static GramPlan gram_plan(int64_t M, int C) {
+static GramPlan gram_plan(int64_t M, int C, int bm = 0) {
   GramPlan g;
-  g.BM = C % 128 == 0 ? 128 : 64;
+  g.BM = bm ? bm : (C % 128 == 0 ? 128 : 64);
   g.tiles = (C / g.BM) * (C / g.BM);
   g.ktiles = (int)cdiv(M, 32);
   int want = (int)cdiv(512, g.tiles);
@@ -1504,6 +1622,10 @@ static GramPlan gram_plan(int64_t M, int C) {
   if (want < 1) want = 1;
   g.per_slice = (int)cdiv(g.ktiles, want);
   g.nslice = (int)cdiv(g.ktiles, g.per_slice);
+  // the slab cap leaves 128 .. 512-channel matrices with 128 workgroups of 128 x 128 tiles - half the chip idle, 30-35 us for 4 GFLOP:
+  // 64 x 64 tiles give four times the workgroups under the same cap
+  static const int tile64 = getenv("CVCS_GRAM_TILE64") ? atoi(getenv("CVCS_GRAM_TILE64")) : 1;   // tuning knob
+  if (!bm && tile64 && g.BM == 128 && g.tiles * g.nslice < 256) return gram_plan(M, C, 64);
   return g;
 }
 }  // namespace cvcs

@@ -142,11 +142,14 @@ class _Shape:
         return 0
 
 
-def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None) -> int:
-    """number of partial-statistics rows cvcs_conv2d writes for this geometry"""
+def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None, bwd=False) -> int:
+    """number of partial-statistics rows cvcs_conv2d writes for this geometry (bwd: of partial rows of the fused BatchNorm-backward reduce,
+    cvcs_conv_desc.bwd_y - the thin kernel writes one per workgroup)"""
     # (the weight image's contraction axis is at least one K-group wide: a 16-channel bf16 input runs under a zero-padded 32-channel K-group)
     d, _, _, _ = _conv_desc(x, _Shape(KH * KW, Cout, 32 if virt else max(x.C, KGROUP[x.code])), None, None, KH, KW, stride, pad, dil, False, False, None,
                             virt=virt)
+    if bwd:
+        d.bwd_y, d.bwd_mode = 16, 0      # (a non-null marker: the query reads no tensor)
     n = _lib.lib().cvcs_conv_stat_rows(C.byref(d))
     if n < 0:
         raise _lib.CvcsError("cvcs_conv_stat_rows: bad shape")
@@ -184,7 +187,7 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         d.Cin, d.Cin_valid = x.C, 0          # (_conv_desc read the longer weight rows as a zero-padded K-group)
     if bn_bwd is not None:
         yv, bsc, bsh, bmu, bis, bmode, p0, p1 = bn_bwd
-        rows = conv_stat_rows(x, Cout, KH, KW, stride, pad)
+        rows = conv_stat_rows(x, Cout, KH, KW, stride, pad, bwd=bmode == 0)
         assert (yv.B, yv.H, yv.W, yv.C) == (x.B, Ho, Wo, Cout) and yv.t.dtype == x.t.dtype
         assert p0.numel() >= rows * Cout and p1.numel() >= rows * Cout and p0.dtype == torch.float32
         d.bwd_y, d.bwd_y_ld = yv.ptr, yv.ld
@@ -548,6 +551,16 @@ def bn_gram_mmat(w, coef, wd2, bias, workspace=None):
           "cvcs_bn_gram_mmat")
 
 
+def bn_gram_fold(w1, scale1, shift1, w2, scale2, shift2, w_out, bias):
+    """w_out [C][m1 + m2] = [scale1 * w1 | scale2 * w2] (bf16), bias = shift1 + shift2: the operand of the two-source GEMM that is a bottleneck
+    tail with a same-resolution projection shortcut (both BatchNorms from Gram matrices)"""
+    C_, m1, m2 = w1.shape[-2], w1.shape[-1], w2.shape[-1]
+    assert w2.shape[-2] == C_ and w_out.numel() == C_ * (m1 + m2) and bias.dtype == torch.float32 and bias.numel() == C_
+    assert w1.dtype == w2.dtype == w_out.dtype == torch.bfloat16 and w1.is_contiguous() and w2.is_contiguous() and w_out.is_contiguous()
+    check(_lib.lib().cvcs_bn_gram_fold(w1.data_ptr(), scale1.data_ptr(), shift1.data_ptr(), m1, w2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), m2,
+                                       C_, w_out.data_ptr(), bias.data_ptr(), _stream()), "cvcs_bn_gram_fold")
+
+
 # ------------------------------------------------------------------------------------------------ residual networks
 def bn_add_act(y1: View, s1, b1, y2: View, s2, b2, out: View, q8=None):
     """out = relu(s1*y1 + b1 + (s2*y2 + b2 | y2)): the tail of a residual block in one pass (q8: also its fp8 image, cvcs_bn_add_act_q8)"""
@@ -562,15 +575,24 @@ def bn_add_act(y1: View, s1, b1, y2: View, s2, b2, out: View, q8=None):
                                      out.ptr, out.ld, y1.code, _stream()), "cvcs_bn_add_act")
 
 
-def relu_bwd_sum_bn(out: View | None, grads, dz: View, bns, part_dz, part_dzx):
+def relu_bwd_sum_bn(out: View | None, grads, dz: View, bns, part_dz, part_dzx, pooled=None):
     """relu_bwd_sum + the reduce pass of up to two BatchNorm backwards that consume dz: bns = [(y view, mean, invstd)], part_dzx = one buffer
-    per BatchNorm; partial rows = bn_bwd_rows(B*H*W)"""
-    assert 1 <= len(grads) <= 3 and 1 <= len(bns) <= 2 and len(part_dzx) == len(bns)
+    per BatchNorm; partial rows = bn_bwd_rows(B*H*W).  pooled = ([gradient views of the MaxPool2d(3, 2, 1) of this map], idx): the max-pool
+    backward as one more term of the sum (the ResNet stem)"""
+    assert (1 <= len(grads) <= 3 or (pooled is not None and len(grads) <= 3)) and 1 <= len(bns) <= 2 and len(part_dzx) == len(bns)
     d = _lib.TailBwdDesc()
+    if pooled is not None:
+        pg, idx = pooled
+        assert 1 <= len(pg) <= 2 and idx.dtype == torch.uint8
+        for j, v in enumerate(pg):
+            assert (v.B, v.H, v.W, v.C) == (dz.B, (dz.H + 1) // 2, (dz.W + 1) // 2, dz.C) and v.t.dtype == dz.t.dtype, "pooled gradient view mismatch"
+            d.pool_g[j], d.pool_g_ld[j] = v.ptr, v.ld
+        assert idx.numel() == pg[0].B * pg[0].H * pg[0].W * pg[0].C
+        d.pool_idx = idx.data_ptr()
     if out is not None:
         d.out, d.out_ld = out.ptr, out.ld
     nbytes = dz.B * dz.H * dz.W * dz.C * dz.t.element_size()
-    units = 1.0 + (out is not None) + len(bns)
+    units = 1.0 + (out is not None) + len(bns) + (0.375 * len(pooled[0]) if pooled is not None else 0.0)
     for j, (v, half) in enumerate(grads):
         want = (dz.B, dz.H // 2, dz.W // 2, dz.C) if half else (dz.B, dz.H, dz.W, dz.C)
         assert (v.B, v.H, v.W, v.C) == want and v.t.dtype == dz.t.dtype, "gradient view mismatch"

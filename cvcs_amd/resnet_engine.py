@@ -133,6 +133,9 @@ class ResNetUNetEngine:
         # bottleneck tails without a stored conv3 output: BatchNorm statistics from the Gram matrix of conv3's input, BatchNorm + shortcut +
         # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
         self.gram_bn = os.environ.get("CVCS_GRAM_BN", "1") == "1"
+        self.thin_bn_bwd = os.environ.get("CVCS_THIN_BN_BWD", "1") == "1"     # the thin kernel's data-gradient launches carry the next BatchNorm's reduce (_fusable)
+        self.fuse_stem_bwd = os.environ.get("CVCS_FUSE_STEM_BWD", "1") == "1"   # see _stem
+        self.gram_ds = os.environ.get("CVCS_GRAM_DS", "1") == "1"     # a same-resolution projection shortcut joins its Gram tail as a second GEMM source (_block)
         self.fuse_tail_dz = os.environ.get("CVCS_FUSE_TAIL_DZ", "1") == "1"   # a Gram tail's dz out of the consumer block's first data-gradient launch (_tail_fusable)
         self.gram_512_pixels = int(os.environ.get("CVCS_GRAM_512_PIXELS", "65536"))   # 512-channel conv3 inputs take it from this many pixels on
         self.gram_max_m = int(os.environ.get("CVCS_GRAM_MAX_M", "256"))   # widest conv3 input that takes the path (the finalizes are O(C m^2))
@@ -407,9 +410,22 @@ class ResNetUNetEngine:
             ops.im2col(h.v, hs, 1, 1, 2, 0, 0)
             ud = self._unit(hs, p + ".downsample.0", p + ".downsample.1", 1, 1, 0, train, None)
             ud.half_out = True            # its data gradient lives at half the resolution of h (scattered by the consumer)
+        elif has_ds and stride == 1 and getattr(ut, "gram", False) and self.gram_ds and self._gram_ok(p, h.v, out, bn=".downsample.1"):
+            # same-resolution projection (layer1.0): its input is as narrow as conv3's - statistics from the Gram matrix of h, the conv itself the
+            # second source of the tail's GEMM: no projection output, no pass of its BatchNorm in either direction
+            ud = self._unit_gram(h.v, p + ".downsample.0", p + ".downsample.1")
         else:
             ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
-        if getattr(ut, "gram", False):
+        if getattr(ut, "gram", False) and ud is not None and getattr(ud, "gram", False):
+            s3, sd = self.bn[ut.bn], self.bn[ud.bn]
+            w3, wdn = self.packed[ut.conv]["wf"], self.packed[ud.conv]["wf"]
+            w2s = self._buf(ut.conv + ".w2s", (1, out.C, w3.shape[2] + wdn.shape[2]))
+            b2s = self._buf(ut.conv + ".b2s", (out.C,), torch.float32)
+            ops.bn_gram_fold(w3, s3.scale, s3.shift, wdn, sd.scale, sd.shift, w2s, b2s)
+            ops.SCOPE = "enc"
+            ut.out, ut.res, ut.res_bn, ut.res_gram = out, None, None, ud      # (tests)
+            ops.conv2d(a2.v, w2s, b2s, out, 1, 1, relu=True, x2=h.v)
+        elif getattr(ut, "gram", False):
             # conv3 -> BatchNorm -> + shortcut (its own BatchNorm for a projection) -> ReLU in ONE launch: the conv output is never stored
             s3 = self.bn[ut.bn]
             ops.SCOPE = "enc"
@@ -435,7 +451,7 @@ class ResNetUNetEngine:
                     if o.dz_ready is not None:
                         assert not o.grads
                         dz = o.dz_ready           # written by the consumer block's first data-gradient launch
-                    elif ud is not None and self.fuse_tail_bn:
+                    elif ud is not None and self.fuse_tail_bn and not getattr(ud, "gram", False):
                         n_ = ops.bn_bwd_rows(out.B * out.H * out.W) * out.C
                         pz = [self._scratch(f"tz{i}", n_) for i in range(2)]
                         rows_t = ops.relu_bwd_sum_bn(o.v, o.grads, dz, [(ud.y, self.bn[ud.bn].mean, self.bn[ud.bn].invstd)], pz[0], pz[1:2])
@@ -472,7 +488,7 @@ class ResNetUNetEngine:
         return o
 
     # ------------------------------------------------------------------------------------------------ BatchNorm from the Gram matrix
-    def _gram_ok(self, p, a: View, out: View):
+    def _gram_ok(self, p, a: View, out: View, bn=".bn3"):
         """does the block's conv3 -> bn3 -> (+ shortcut) -> ReLU run without a stored conv3 output?  bf16 bottlenecks whose conv3 input is
         64 ... gram_max_m wide; not in exact data-parallel mode (its exchanges are written against per-layer moments) and not when the block
         output also leaves as an fp8 image (the tail pass writes that image)"""
@@ -480,7 +496,7 @@ class ResNetUNetEngine:
         #  encoders - output stride 8: 64^2 pixels x 32 tiles - and lose on the 16^2 maps of the U-Net encoder)
         m_ok = 64 <= a.C <= self.gram_max_m or (a.C == 512 and self.gram_max_m >= 256 and a.B * a.H * a.W >= self.gram_512_pixels)
         return (self.gram_bn and self.kind == "bottleneck" and self.dtype == torch.bfloat16 and self.sync_bn is None and
-                (p + ".bn3.running_mean") in self.Bf and a.C % 64 == 0 and m_ok and out.C % 128 == 0 and self._q8_of(out) is None)
+                (p + bn + ".running_mean") in self.Bf and a.C % 64 == 0 and m_ok and out.C % 128 == 0 and self._q8_of(out) is None)
 
     def _unit_gram(self, a: View, conv, bn) -> Unit:
         """statistics of bn(conv1x1(a)) from the Gram matrix of a: scale / shift / saved statistics / running statistics, Q = W G kept for
@@ -531,6 +547,11 @@ class ResNetUNetEngine:
         _tail_fusable says so, summed and masked by the first conv's data-gradient launch itself (h.dz_ready)"""
         u1 = chain[0][0]
         gxd = None
+        identity = ud is None      # the shortcut hands dz itself to the block input
+        if ud is not None and getattr(ud, "gram", False):
+            # same-resolution projection from the Gram path: weight gradient + ONE two-source data gradient, no BatchNorm passes
+            h.grads.append((self._gram_bwd(ud, dz, ud.conv + ".gx"), False))
+            ud, identity = None, False
         if ud is not None and self._tail_fusable(h, u1, ds=True):
             # (before the chain: the BatchNorm backward of the chain's units reuses the dy scratch this one writes)
             dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
@@ -543,7 +564,7 @@ class ResNetUNetEngine:
             if n_ > 0 and self._fusable(u, chain[n_ - 1][0]):
                 gx, half, fz = self._dgrad(u, dy, u.conv + ".gx", fuse_into=chain[n_ - 1][0])
                 xin.grads.append((gx, half))
-            elif n_ == 0 and ud is None and self._tail_fusable(h, u):
+            elif n_ == 0 and identity and self._tail_fusable(h, u):
                 self._dgrad_into_tail(u, dy, h, dz)
                 tail_done = True
             elif n_ == 0 and gxd is not None:
@@ -554,7 +575,7 @@ class ResNetUNetEngine:
         if ud is not None and gxd is None:
             dyd = self._unit_bwd(ud, dz, 2, reduced=red_d)
             h.grads.append(self._dgrad(ud, dyd, ud.conv + ".gx"))
-        elif ud is None and not tail_done:
+        elif identity and not tail_done:
             h.grads.append((dz, False))
 
     def _tail_fusable(self, h: Act, u1: Unit, ds: bool = False):
@@ -588,8 +609,12 @@ class ResNetUNetEngine:
         y = consumer.y
         if getattr(producer, "fp8", False):      # the fp8 kernel has no fused reduce epilogue
             return False
-        return (self.fuse_bn_bwd and not getattr(consumer, "gn", False) and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
-                producer.dil == 1 and y.H >= 8 and y.W >= 8 and y.C <= 128 and y.C % 64 == 0)
+        if not (self.fuse_bn_bwd and not getattr(consumer, "gn", False) and self.dtype == torch.bfloat16 and producer.k == 3 and producer.stride == 1 and
+                producer.dil == 1 and y.H >= 8 and y.W >= 8):
+            return False
+        if self.thin_bn_bwd and y.C in (16, 32) and producer.y is not None and producer.y.C in (16, 32) and y.W >= 16:
+            return True       # the thin kernel of the light decoder stages (one partial row per workgroup)
+        return y.C <= 128 and y.C % 64 == 0
 
     def _unit_bwd(self, u: Unit, g: View, mode, fused=None, reduced=None) -> View:
         """BatchNorm (+ReLU, mode 0) backward of a unit, its conv's weight gradient; returns dy (gradient w.r.t. the conv
@@ -618,11 +643,15 @@ class ResNetUNetEngine:
                                 st.ca, st.cb)
         elif fused is not None:
             f0, f1, trows = fused
-            rows1 = ops.bn_bwd_rows(trows)
-            for src, dst in ((f0, p0), (f1, p1)):
-                ops.colsum_partial(View(src[:trows * C_].view(1, trows, 1, C_), 0, C_), dst[:rows1 * C_])
-            ops.bn_bwd_finalize(p0, p1, rows1, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"],
-                                self.G[u.bn + ".bias"], st.ca, st.cb)
+            if trows <= 4096:       # the finalize takes the tile rows as they are (two column-sum launches less per unit)
+                ops.bn_bwd_finalize(f0, f1, trows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"],
+                                    self.G[u.bn + ".bias"], st.ca, st.cb)
+            else:
+                rows1 = ops.bn_bwd_rows(trows)
+                for src, dst in ((f0, p0), (f1, p1)):
+                    ops.colsum_partial(View(src[:trows * C_].view(1, trows, 1, C_), 0, C_), dst[:rows1 * C_])
+                ops.bn_bwd_finalize(p0, p1, rows1, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"],
+                                    self.G[u.bn + ".bias"], st.ca, st.cb)
         else:
             ops.bn_bwd_reduce(y, g, None, st.scale, st.shift, st.mean, st.invstd, mode, p0, p1)
             ops.bn_bwd_finalize(p0, p1, rows, M, C_, self.P[u.bn + ".weight"], st.invstd, self.G[u.bn + ".weight"], self.G[u.bn + ".bias"],
@@ -676,7 +705,7 @@ class ResNetUNetEngine:
         belongs to (mode-0 BatchNorm backward): its reduce pass rides on this launch; returns (view, half, fused partials)"""
         if fuse_into is not None:
             yv, st = fuse_into.y, self.bn[fuse_into.bn]
-            trows = ops.conv_stat_rows(dy, yv.C, 3, 3, 1, 1)
+            trows = ops.conv_stat_rows(dy, yv.C, 3, 3, 1, 1, bwd=True)
             f0, f1 = self._scratch("fz0", trows * yv.C), self._scratch("fz1", trows * yv.C)
             gx = ops.view(self._act(name, yv.B, yv.H, yv.W, yv.C))
             ops.SCOPE = "enc" if u.conv.startswith("encoder.") else "dec"
@@ -844,13 +873,22 @@ class ResNetUNetEngine:
         ops.maxpool3x3s2_fwd(f1.v, p0.v, idx)
         if train:
             def stem_bwd():
-                dx = ops.view(self._act("pool0.dx", B, S // 2, S // 2, 64))
                 g = [v for v, _ in p0.grads]
-                ops.maxpool3x3s2_bwd(g[0], g[1] if len(g) > 1 else None, idx, dx)
-                f1.grads.append((dx, False))
                 dz = ops.view(self._act("stem.dz", B, S // 2, S // 2, 64))
-                ops.relu_bwd_sum(f1.v, f1.grads, dz)
-                self._unit_bwd(u0, dz, 0)
+                if self.fuse_stem_bwd and len(g) <= 2 and len(f1.grads) <= 3 and not any(half for _, half in f1.grads) and self.sync_bn is None:
+                    # max-pool backward + the skip gradients + the ReLU mask + the reduce pass of the stem's BatchNorm in ONE launch (four
+                    # passes over the largest encoder map before: 0.66 ms of the 512^2 x 32 step)
+                    st0 = self.bn[u0.bn]
+                    n_ = ops.bn_bwd_rows(B * (S // 2) * (S // 2)) * 64
+                    pz = [self._scratch(f"tz{i}", n_) for i in range(2)]
+                    rows_t = ops.relu_bwd_sum_bn(f1.v, f1.grads, dz, [(u0.y, st0.mean, st0.invstd)], pz[0], pz[1:2], pooled=(g, idx))
+                    self._unit_bwd(u0, dz, 0, reduced=(pz[0], pz[1], rows_t))
+                else:
+                    dx = ops.view(self._act("pool0.dx", B, S // 2, S // 2, 64))
+                    ops.maxpool3x3s2_bwd(g[0], g[1] if len(g) > 1 else None, idx, dx)
+                    f1.grads.append((dx, False))
+                    ops.relu_bwd_sum(f1.v, f1.grads, dz)
+                    self._unit_bwd(u0, dz, 0)
                 self._ready("encoder.conv1.weight")
             tape.append(stem_bwd)
         return f1, p0

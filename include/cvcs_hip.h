@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVCS_ABI_VERSION 13
+#define CVCS_ABI_VERSION 14
 
 enum { CVCS_F32 = 0, CVCS_BF16 = 1 };
 enum { CVCS_E4M3 = 0, CVCS_E5M2 = 1 };   /* OCP fp8 formats of the fp8 convolution path (gfx950: e4m3fn / e5m2, not the MI300 fnuz forms) */
@@ -633,6 +633,11 @@ typedef struct {
   const void* y[2]; int64_t y_ld[2];
   const float* mean[2]; const float* invstd[2];
   float* part_dz; float* part_dzx[2];
+  /* (ABI 14) one more term of the sum arrives THROUGH a MaxPool2d(3, 2, 1) of this map - the ResNet stem (torchvision resnet.py: conv1 -> bn1 -> relu
+   * -> maxpool, the relu output also being the U-Net's first skip): pool_g[0] (+ pool_g[1]) are gradients of the pooled map [(H+1)/2][(W+1)/2],
+   * pool_idx the arg-max tap of every pooled element as cvcs_maxpool3x3s2_fwd wrote it.  NULL pool_idx: none.  Replaces cvcs_maxpool3x3s2_bwd +
+   * cvcs_relu_bwd_sum + cvcs_bn_bwd_reduce of the stem by one launch (g[0] may then be NULL: no other gradient).                                  */
+  const void* pool_g[2]; int64_t pool_g_ld[2]; const uint8_t* pool_idx;
 } cvcs_tail_bwd_desc;
 int cvcs_relu_bwd_sum_bn(const cvcs_tail_bwd_desc* d, void* stream);
 /* x[0..n) *= *scalar_device unless it is exactly 1 (decided on the device: no host synchronisation).  Used for the incoming gradient of the fused
@@ -666,6 +671,12 @@ int cvcs_bn_gram_bwd(const float* r, const float* sum_dz, const void* w_bf16, co
                      float* dgamma, float* dbeta, float* dw, void* wd2_bf16, float* coef, void* stream);
 int64_t cvcs_bn_gram_mmat_workspace_floats(int C, int m);
 int cvcs_bn_gram_mmat(const void* w_bf16, const float* coef, int C, int m, void* wd2_bf16, float* bias, float* workspace, void* stream);
+/* (ABI 14) a block with a SAME-RESOLUTION projection shortcut (torchvision Bottleneck.downsample at stride 1: layer1.0, the dilated stages of the
+ * DeepLab encoders; torchvision/models/resnet.py as S/nets.py:8 imports it): both 1x1 convs of the tail read narrow inputs (a: m1 channels, the block
+ * input h: m2 channels), both BatchNorms come from Gram matrices, and relu(BN3(W3 a) + BNd(Wd h)) is ONE two-source GEMM (cvcs_conv_desc.in2) whose
+ * operand [C][m1 + m2] = [scale3 * W3 | scaled * Wd] (bf16) and bias = shift3 + shiftd this call writes: the projection's output is never stored.   */
+int cvcs_bn_gram_fold(const void* w1_bf16, const float* scale1, const float* shift1, int m1, const void* w2_bf16, const float* scale2,
+                      const float* shift2, int m2, int C, void* w_out_bf16, float* bias, void* stream);
 /* ---- 1x1 head + cross-entropy + their backward in ONE pass (ABI 13) ----------------------------------------------------------------
  * replaces: `logits = net(x)` (the head nn.Conv2d(C, NC, 1), S/nets.py:172), `criterion(logits, target)` (nn.CrossEntropyLoss, S/utils.py:230,238)
  * and the head's half of `loss.backward()` (S/train.py:121-125) for bf16 activations with C = 16 | 32 | 64 channels and NC <= 32 classes:

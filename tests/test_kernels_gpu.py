@@ -247,17 +247,21 @@ def test_conv_dgrad_through_flipped_weights(dtype):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(2, 32, 48, 64, 64), (1, 24, 40, 128, 128), (2, 20, 36, 128, 64), (1, 16, 16, 64, 256)])
+@pytest.mark.parametrize("shape", [(2, 32, 48, 64, 64), (1, 24, 40, 128, 128), (2, 20, 36, 128, 64), (1, 16, 16, 64, 256),
+                                   (2, 32, 64, 16, 16), (1, 21, 100, 32, 32), (3, 18, 40, 16, 32), (2, 64, 128, 32, 16)])
 def test_conv_launch_takes_the_first_pass_of_the_batchnorm_backward(shape, mode):
     """cvcs_conv_desc.bwd_y: the data-gradient launch above a conv->BN->ReLU (mode 0) / conv->ReLU->BN (mode 1) block
     (S/blocks.py:13-17, :40-45) also sums dz and dz * xhat of that block over the gradient it stores - compared with
     cvcs_bn_bwd_reduce on the stored output, and the output itself with the plain launch (bit for bit)."""
     B, H, W, Cin, Cout = shape
+    thin = Cout <= 32       # the thin kernel of the light decoder stages: mode 0 only, one partial row per workgroup
+    if thin and mode == 1:
+        pytest.skip("the thin kernel carries the reduce of conv -> BN -> ReLU blocks only")
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(31 + mode)
     gy = rq(torch.randn(B, Cin, H, W, generator=g), dtype)
     w = rq(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
-    wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), max(Cin, 32), dtype)      # (a 16-channel input runs under a zero-padded 32-channel K-group)
     xin = ops.view(to_nhwc(gy, dtype))
     y = torch.randn(B, H, W, Cout, generator=g)
     if mode == 1:
@@ -270,8 +274,8 @@ def test_conv_launch_takes_the_first_pass_of_the_batchnorm_backward(shape, mode)
     rows = ops.bn_bwd_rows(B * H * W)
     r0, r1 = torch.zeros(rows * Cout, device=DEV), torch.zeros(rows * Cout, device=DEV)
     ops.bn_bwd_reduce(ops.view(y), ops.view(plain), None, scale, shift, mean, invstd, mode, r0, r1)
-    trows = ops.conv_stat_rows(xin, Cout, 3, 3, 1, 1)
-    assert trows == B * ((H + 15) // 16) * ((W + 15) // 16)
+    trows = ops.conv_stat_rows(xin, Cout, 3, 3, 1, 1, bwd=True)
+    assert (1 <= trows <= B * ((H + 3) // 4) * ((W + 63) // 64)) if thin else trows == B * ((H + 15) // 16) * ((W + 15) // 16)
     p0, p1 = torch.full((trows * Cout,), float("nan"), device=DEV), torch.full((trows * Cout,), float("nan"), device=DEV)
     fused = torch.empty_like(plain)
     ops.conv2d(xin, wf, None, ops.view(fused), 3, 3, 1, 1, bn_bwd=(ops.view(y), scale, shift, mean, invstd, mode, p0, p1))
