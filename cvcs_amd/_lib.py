@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32),
         ("mask", C.c_void_p), ("mask_ld", C.c_int64),
         ("res2", C.c_void_p), ("res2_ld", C.c_int64), ("res2_half", C.c_int32),
+        ("mask_bits_out", C.c_void_p), ("mask_bits", C.c_void_p),
     ]
 
 

@@ -56,6 +56,7 @@ struct ConvArgs {
   const char* res; int64_t res_ld; const float* res_scale; const float* res_shift;
   const char* in2; int64_t in2_ld; int Cin2;
   const char* mask; int64_t mask_ld;   // taps kernel: out = (mask > 0) ? value : 0 (the ReLU backward of the activation the gradient belongs to)
+  unsigned char* mask_bits_out; const unsigned char* mask_bits;   // taps kernel: the same mask as one byte per 16-byte chunk of a pixel row (written / read)
   const char* res2; int64_t res2_ld; int res2_half;   // taps kernel: a second tile added beside res (optionally at half resolution: even pixels only)
 };
 
@@ -1128,6 +1129,17 @@ __global__ __launch_bounds__(WM * WN * 64, (halo_packed<T, BN, WM, WN, TPS>() ? 
 // (packed staging of the whole 256 x 128 tile, LDS reads in flight before the stores).
 // Workgroup: 256 output pixels (linear index) x 128 channels, 8 waves (4 x 2, 64 pixels x 64 channels each), K-slice of
 // 32 channels per step through a 3-stage LDS-DMA ring of 24 KiB (two workgroups per CU).
+// (value > 0) of the eight bf16 of a 16-byte chunk as one byte (bit e = element e); the values come out of a ReLU: > 0 <=> not +-0
+__device__ __forceinline__ unsigned mask8(const u32x4& v) {
+  unsigned m = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    m |= ((v[w] & 0x7fffu) != 0u ? 1u : 0u) << (2 * w);
+    m |= ((v[w] & 0x7fff0000u) != 0u ? 1u : 0u) << (2 * w + 1);
+  }
+  return m;
+}
+
 template <int TAPS, bool EPI = false>      // EPI: the BatchNorm / residual epilogue of cvcs_conv_desc.pre_scale / res (its own instance: +16 registers)
 __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      // (4 waves per SIMD = two workgroups per CU: at most 128 registers)
   using T = bf16_t;
@@ -1309,7 +1321,7 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
         *reinterpret_cast<uint2*>(smem + (wm * 64 + i * 16 + fr) * OROW + (wn * 64 + j * 16 + fg * 4) * ES) = u;
       }
   };
-  const bool walk_epi = EPI && (p.res != nullptr || p.mask != nullptr || p.res2 != nullptr);      // shortcut / mask (and then the ReLU) in the store walk
+  const bool walk_epi = EPI && (p.res != nullptr || p.mask != nullptr || p.mask_bits != nullptr || p.res2 != nullptr);      // shortcut / mask (and then the ReLU) in the store walk
   if (p.relu && !walk_epi) stage(std::true_type{}); else stage(std::false_type{});   // wave-uniform
   __syncthreads();
   {
@@ -1337,13 +1349,14 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
 #pragma unroll
         for (int h = 0; h < 8; h += 4) {
-          u32x4 rr[4], mk[4], r2[4];
+          u32x4 rr[4], mk[4], r2[4];      // (mk[k][0] holds the byte of a bit mask: mask and mask_bits exclude each other)
           bool has2[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             int mr = m0 + lrow0 + (h + k) * RPT; mr = mr < p.M ? mr : p.M - 1;
             if (p.res) rr[k] = *reinterpret_cast<const u32x4*>(p.res + ((int64_t)mr * p.res_ld + n) * ES);
             if (p.mask) mk[k] = *reinterpret_cast<const u32x4*>(p.mask + ((int64_t)mr * p.mask_ld + n) * ES);
+            if (p.mask_bits) mk[k][0] = p.mask_bits[(int64_t)mr * (p.Cout >> 3) + (n >> 3)];
             has2[k] = false;
             if (p.res2) {
               int64_t r2pix = mr;
@@ -1385,6 +1398,10 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
 #pragma unroll
               for (int e = 0; e < 8; ++e) f[e] = g[e] > 0.f ? f[e] : 0.f;
             }
+            if (p.mask_bits) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = ((mk[k][0] >> e) & 1u) ? f[e] : 0.f;
+            }
             v[h + k] = __builtin_bit_cast(u32x4, Elem<bf16_t>::pack(f));
           }
         }
@@ -1396,6 +1413,7 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
       if (m < p.M) {
         const int64_t pix = p.pixel_shuffle ? ((int64_t)b * (2 * p.Ho) + 2 * oy + (q >> 1)) * (2 * p.Wo) + 2 * ox + (q & 1) : (int64_t)m;
         *reinterpret_cast<u32x4*>(p.out + (pix * p.out_ld + co) * ES) = v[k];
+        if (p.mask_bits_out) p.mask_bits_out[(int64_t)m * (p.Cout >> 3) + (n >> 3)] = (unsigned char)mask8(v[k]);
       }
       m += RPT; ox += RPT;
       while (ox >= p.Wo) { ox -= p.Wo; ++oy; }
@@ -1831,6 +1849,11 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.res = (const char*)d->res; a.res_ld = d->res_ld; a.res_scale = d->res_scale; a.res_shift = d->res_shift;
   a.in2 = (const char*)d->in2; a.in2_ld = d->in2_ld; a.Cin2 = d->in2 ? d->Cin2 : 0;
   a.mask = (const char*)d->mask; a.mask_ld = d->mask_ld;
+  a.mask_bits_out = (unsigned char*)d->mask_bits_out; a.mask_bits = (const unsigned char*)d->mask_bits;
+  if (d->mask_bits) CVCS_CHECK_ARG(!d->mask && use_taps(d) && d->KH == 1 && !d->stat_sum && !d->relu && !d->pixel_shuffle,
+                                   "cvcs_conv2d: mask_bits is built for bf16 1x1 launches with Cout %% 128 == 0 (and excludes mask)");
+  if (d->mask_bits_out) CVCS_CHECK_ARG(d->relu && use_taps(d) && d->KH == 1 && !d->stat_sum && !d->pixel_shuffle && !d->mask && !d->mask_bits,
+                                       "cvcs_conv2d: mask_bits_out goes with the ReLU of a bf16 1x1 launch with Cout %% 128 == 0");
   a.res2 = (const char*)d->res2; a.res2_ld = d->res2_ld; a.res2_half = d->res2_half;
   if (d->res2) {
     CVCS_CHECK_ARG(use_taps(d) && d->KH == 1 && !d->stat_sum && !d->pixel_shuffle, "cvcs_conv2d: res2 is built for bf16 1x1 launches with Cout %% 128 == 0");
@@ -1913,7 +1936,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
     return launch_halo<bf16_t, 64, 4, 1, 3>(a, st);
   }
   if (d->dtype == CVCS_F32) return bn == 128 ? launch<float, 128>(a, st) : launch<float, 64>(a, st);
-  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res || d->mask || d->res2) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
+  if (use_taps(d)) return (d->KH == 1) ? ((d->pre_scale || d->res || d->mask || d->mask_bits || d->res2) ? launch_taps<1, true>(a, st) : launch_taps<1>(a, st)) : launch_taps<4>(a, st);
   CVCS_CHECK_ARG(!d->res && !d->mask && !d->res2, "cvcs_conv2d: the residual / mask epilogue runs on the 1x1 taps kernel only");
   return bn == 128 ? launch<bf16_t, 128>(a, st) : launch<bf16_t, 64>(a, st);
 }

@@ -739,12 +739,13 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
 }
 
 // every conv of the network in ONE launch (the per-step re-pack after the optimiser): blockIdx.y = table entry.
-// A workgroup moves a block of 16 output x 64 input channels x all taps through LDS: the OIHW source is read as 16
+// A workgroup moves a block of 32 output x 32 input channels x all taps through LDS: the OIHW source is read as 32
 // contiguous runs (coalesced; a thread-per-output-element gather re-fetched every line ~30x), the forward operand leaves
-// as 128-byte rows wf[t][co][ci0..ci0+63], the flipped data-gradient operand as 32-byte pieces wd[t'][ci][co0..co0+15].
+// as 64-byte rows wf[t][co][ci0..ci0+31], the flipped data-gradient operand as 64-byte pieces wd[t'][ci][co0..co0+31]
+// (16 x 64 blocks left wd as scattered 32-byte pieces - half a memory burst each: the launch wrote at a quarter of the rate it read).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_item* __restrict__ items) {
-  constexpr int CO = 16, CI = 64, MAXT = 9;
+  constexpr int CO = 32, CI = 32, MAXT = 9;
   __shared__ float sw[CO][CI * MAXT + CI * MAXT / 32 + 1];      // element j of a row sits at j + j / 32: the 16-byte gathers below step 8 floats per lane
   auto at = [](int j) { return j + (j >> 5); };
   const cvcs_pack_item it = items[blockIdx.y];
@@ -753,10 +754,9 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
   T* wd = reinterpret_cast<T*>(it.w_dgrad);
   const int Cout = it.Cout, Cin = it.Cin, Cin_pad = it.Cin_pad, taps = it.KH * it.KW;
   const int Cout_pad = it.Cout_pad > 0 ? it.Cout_pad : Cout;      // row length of the data-gradient image (columns Cout.. stay as allocated: zero)
-  // input channels per block: as many 64-channel groups as the 576-float LDS rows hold (1x1 convs: 576 channels - at 64 a block was 4 KiB
-  // between two barriers, and the 1x1 layers, half of the bytes, ran at a quarter of the 3x3 layers' rate)
+  // input channels per block: as many 32-channel groups as the 288-float LDS rows hold (1x1 convs: 288 channels)
   const int CIb = CI * (MAXT / taps);
-  const int nci = (Cin_pad + CIb - 1) / CIb, nco = Cout / CO;
+  const int nci = (Cin_pad + CIb - 1) / CIb, nco = (Cout + CO - 1) / CO;      // (a 16-channel layer: the rows beyond Cout load zeros, store nothing)
   for (int blk = blockIdx.x; blk < nco * nci; blk += gridDim.x) {
     const int co0 = (blk / nci) * CO, ci0 = (blk % nci) * CIb;
     const int cin_here = Cin - ci0 < CIb ? (Cin - ci0 < 0 ? 0 : Cin - ci0) : CIb;    // real input channels in this block
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
     __syncthreads();
     for (int id = threadIdx.x; id < CO * cpad_here * taps; id += 256) {
       const int c = id / (cpad_here * taps), r = id - c * (cpad_here * taps);
-      sw[c][at(r)] = r < run ? w[((int64_t)(co0 + c) * Cin + ci0) * taps + r] : 0.f;   // r = ci_local * taps + t
+      sw[c][at(r)] = (r < run && co0 + c < Cout) ? w[((int64_t)(co0 + c) * Cin + ci0) * taps + r] : 0.f;   // r = ci_local * taps + t
     }
     __syncthreads();
     constexpr int V = 16 / sizeof(T);                                                  // elements per 16-byte store
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
       float f[V];
 #pragma unroll
       for (int k = 0; k < V; ++k) f[k] = sw[c][at((cv * V + k) * taps + t)];
-      *reinterpret_cast<uint4*>(wf + ((int64_t)t * Cout + co0 + c) * Cin_pad + ci0 + cv * V) = Elem<T>::pack(f);
+      if (co0 + c < Cout) *reinterpret_cast<uint4*>(wf + ((int64_t)t * Cout + co0 + c) * Cin_pad + ci0 + cv * V) = Elem<T>::pack(f);
     }
     if (wd) {
       for (int id = threadIdx.x; id < taps * cin_here * (CO / V); id += 256) {         // wd[t'][ci][co]: 16 bytes of co per lane
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const cvcs_pack_
         float f[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) f[k] = sw[cv * V + k][at(ci * taps + (taps - 1 - tp))];
-        *reinterpret_cast<uint4*>(wd + ((int64_t)tp * Cin + ci0 + ci) * Cout_pad + co0 + cv * V) = Elem<T>::pack(f);
+        if (co0 + cv * V < Cout) *reinterpret_cast<uint4*>(wd + ((int64_t)tp * Cin + ci0 + ci) * Cout_pad + co0 + cv * V) = Elem<T>::pack(f);
       }
     }
   }

@@ -269,13 +269,13 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* smem_base, unsigned off0, 
 // WMV waves along the co axis x 2 along ci (4 or 8 waves).  The kernel is bound by the L2 -> LDS path, not by the matrix cores: a BM x BN
 // tile moves (BM + BN) * 64 bytes per 32-pixel K-tile for BM * BN * 64 FLOP, i.e. BM*BN/(BM+BN) FLOP per byte - 64 for 128 x 128, 85 for
 // 256 x 128 (8 waves, still two workgroups per CU), 128 for 256 x 256 (8 waves, 96 KB of LDS, one workgroup per CU).
-template <int BM, int BN, int WMV = 2>
+template <int BM, int BN, int WMV = 2, int NSTAGE = 3>
 __global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgrad_gemm_kernel(WgradArgs p) {
   constexpr int NWV = WMV * 2;                    // waves
   constexpr int MB = BM / 64, NB = BN / 64;       // 64-channel blocks of the dy / x tile
   constexpr int BLK = 32 * 128;                   // bytes of one block: 32 pixels x 64 channels
   constexpr int STAGE = (MB + NB) * BLK;
-  constexpr int NS = 3, D = 2;
+  constexpr int NS = NSTAGE, D = NSTAGE - 1;      // ring stages, K-tiles in flight ahead of the one being multiplied
   constexpr int PIECES = (MB + NB) * 4;           // 1 KiB DMA pieces per K-tile (8 pixel rows of one block each)
   constexpr int PPW = PIECES / NWV;               // per wave
   static_assert(PIECES % NWV == 0 && PPW <= 4, "DMA pieces must divide over the waves");
@@ -363,12 +363,13 @@ __global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgra
   wait_vm_barrier_n(0);
   int st = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    int issued = 0;
     if (kt + D < kt_end) {
       int st2 = st + D; if (st2 >= NS) st2 -= NS;
       issue_tile(kt + D, st2);
-      issued = PPW;
     }
+    // K-tiles that may stay in flight behind the next one (kt + 1 must have landed)
+    int ahead = (kt + D < kt_end ? kt + D : kt_end - 1) - (kt + 1);
+    ahead = ahead < 0 ? 0 : ahead;
     const char* sb = smem + st * STAGE;
     bf16x8 af[MR], bfr[NR];
 #pragma unroll
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(WMV * 128, (BM * BN > 256 * 128 ? 1 : 2)) void wgra
         bsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
       }
     }
-    wait_vm_barrier_n(issued);
+    wait_vm_barrier_n(ahead * PPW);
     if (++st == NS) st = 0;
   }
   // partials ws[slice][co][ci]; D layout: row (co) = fg*4 + r, col (ci) = fr
@@ -1484,23 +1485,35 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
     a.tiles_mn = g.tiles_mn;
     if (d->dbias) a.bias_ws = d->workspace + wgrad_slab_floats(d);
     const dim3 grid((unsigned)(g.tiles_mn * g.nslice));
-#define LAUNCH_GEMM(BM_, BN_, WMV_)                                                                                             \
+    // ring depth of the 4-wave tiles (K-tiles in flight = depth - 1): these launches are bound by the latency of the L2 -> LDS path - two
+    // 16 KiB tiles in flight per workgroup, ~1 us per 32-pixel K-tile - and LDS has room for a deeper ring at two workgroups per CU
+    static const int gemm_ns = getenv("CVCS_WGRAD_GEMM_NS") ? atoi(getenv("CVCS_WGRAD_GEMM_NS")) : 3;   // tuning knob (3 | 4 | 5)
+#define LAUNCH_GEMM_NS(BM_, BN_, WMV_, NS_)                                                                                     \
   do {                                                                                                                          \
-    const int lds = 3 * ((BM_) / 64 + (BN_) / 64) * 4096;                                                                       \
+    const int lds = (NS_) * ((BM_) / 64 + (BN_) / 64) * 4096;                                                                   \
     static bool attr_done = false;                                                                                              \
     if (!attr_done) {                                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_, WMV_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_gemm_kernel<BM_, BN_, WMV_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
       attr_done = true;                                                                                                         \
     }                                                                                                                           \
-    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_, WMV_>), grid, dim3((WMV_) * 128), lds, st, a);                              \
+    hipLaunchKernelGGL((wgrad_gemm_kernel<BM_, BN_, WMV_, NS_>), grid, dim3((WMV_) * 128), lds, st, a);                         \
+  } while (0)
+#define LAUNCH_GEMM(BM_, BN_, WMV_) LAUNCH_GEMM_NS(BM_, BN_, WMV_, 3)
+#define LAUNCH_GEMM4(BM_, BN_)                                                  \
+  do {                                                                          \
+    if (gemm_ns >= 5 && (BM_) + (BN_) <= 192) LAUNCH_GEMM_NS(BM_, BN_, 2, 5);   \
+    else if (gemm_ns >= 4) LAUNCH_GEMM_NS(BM_, BN_, 2, 4);                      \
+    else LAUNCH_GEMM_NS(BM_, BN_, 2, 3);                                        \
   } while (0)
     if (g.BM == 256 && g.BN == 256) LAUNCH_GEMM(256, 256, 4);
     else if (g.BM == 256) LAUNCH_GEMM(256, 128, 4);
-    else if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM(128, 128, 2);
-    else if (g.BM == 128) LAUNCH_GEMM(128, 64, 2);
-    else if (g.BN == 64) LAUNCH_GEMM(64, 64, 2);
-    else LAUNCH_GEMM(64, 128, 2);
+    else if (g.BM == 128 && g.BN == 128) LAUNCH_GEMM4(128, 128);
+    else if (g.BM == 128) LAUNCH_GEMM4(128, 64);
+    else if (g.BN == 64) LAUNCH_GEMM4(64, 64);
+    else LAUNCH_GEMM4(64, 128);
+#undef LAUNCH_GEMM4
 #undef LAUNCH_GEMM
+#undef LAUNCH_GEMM_NS
     if (d->dbias)
       hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)cdiv(d->Cout, 32)), dim3(256), 0, st, a.bias_ws, g.nslice, d->Cout, d->dbias);
     CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(gemm)");

@@ -158,7 +158,8 @@ def conv_stat_rows(x: View, Cout, KH, KW, stride=1, pad=0, dil=1, virt=None, bwd
 
 def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, dil=1, relu=False,
            pixel_shuffle=False, stats=None, cin_real=None, pre_affine=None, post_affine=None, pool: View | None = None,
-           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None, mask: View | None = None, res2=None):
+           bn_bwd=None, virt=None, flops=None, res: View | None = None, res_affine=None, x2: View | None = None, mask: View | None = None, res2=None,
+           mask_bits: torch.Tensor | None = None, mask_bits_out: torch.Tensor | None = None):
     """out = act(conv(x, wt) + bias); wt packed [KH*KW][Cout][Cin]; out.C = Cout (or Cout/4 when pixel_shuffle).
     stats = (sum[rows*Cout], m2[rows*Cout], cnt[rows]) f32 buffers, rows = conv_stat_rows(...).
     bn_bwd = (y view, scale, shift, mean, invstd, mode, part_dz, part_dzx): the launch also takes the first pass of the
@@ -180,6 +181,13 @@ def conv2d(x: View, wt: torch.Tensor, bias, out: View, KH, KW, stride=1, pad=0, 
         # ReLU backward in the epilogue: out = value * (mask > 0)
         assert (mask.B, mask.H, mask.W, mask.C) == (x.B, Ho, Wo, Cout) and mask.t.dtype == x.t.dtype
         d.mask, d.mask_ld = mask.ptr, mask.ld
+    if mask_bits is not None:
+        # the same mask as bits (one byte per 8 channels of a pixel, written by the forward launch: mask_bits_out)
+        assert mask is None and mask_bits.dtype == torch.uint8 and mask_bits.is_contiguous() and mask_bits.numel() == x.B * Ho * Wo * Cout // 8
+        d.mask_bits = mask_bits.data_ptr()
+    if mask_bits_out is not None:
+        assert relu and mask_bits_out.dtype == torch.uint8 and mask_bits_out.is_contiguous() and mask_bits_out.numel() == x.B * Ho * Wo * Cout // 8
+        d.mask_bits_out = mask_bits_out.data_ptr()
     if x2 is not None:
         # second contraction source of the same pixels (bf16 1x1): wt rows are x.C + x2.C long
         assert (x2.B, x2.H, x2.W) == (x.B, x.H, x.W) and x2.t.dtype == x.t.dtype and wt.shape[2] == x.C + x2.C

@@ -133,6 +133,7 @@ class ResNetUNetEngine:
         # bottleneck tails without a stored conv3 output: BatchNorm statistics from the Gram matrix of conv3's input, BatchNorm + shortcut +
         # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
         self.gram_bn = os.environ.get("CVCS_GRAM_BN", "1") == "1"
+        self.mask_bits = os.environ.get("CVCS_MASK_BITS", "1") == "1"       # ReLU masks of the Gram tails as bits (_block, _dgrad_into_tail)
         self.thin_bn_bwd = os.environ.get("CVCS_THIN_BN_BWD", "1") == "1"     # the thin kernel's data-gradient launches carry the next BatchNorm's reduce (_fusable)
         self.fuse_stem_bwd = os.environ.get("CVCS_FUSE_STEM_BWD", "1") == "1"   # see _stem
         self.gram_ds = os.environ.get("CVCS_GRAM_DS", "1") == "1"     # a same-resolution projection shortcut joins its Gram tail as a second GEMM source (_block)
@@ -416,6 +417,11 @@ class ResNetUNetEngine:
             ud = self._unit_gram(h.v, p + ".downsample.0", p + ".downsample.1")
         else:
             ud = self._unit(h.v, p + ".downsample.0", p + ".downsample.1", 1, stride, 0, train, None) if has_ds else None
+        # the ReLU mask of a Gram tail's output as bits (one byte per 8 channels): what the consumer block's tail-fused data gradient reads
+        # instead of the output itself (_dgrad_into_tail)
+        mbits = None
+        if getattr(ut, "gram", False) and self.mask_bits and train and out.C % 128 == 0 and self._grid == 1:
+            mbits = self._buf(p + ".mbits", (out.B * out.H * out.W * out.C // 8,), torch.uint8)
         if getattr(ut, "gram", False) and ud is not None and getattr(ud, "gram", False):
             s3, sd = self.bn[ut.bn], self.bn[ud.bn]
             w3, wdn = self.packed[ut.conv]["wf"], self.packed[ud.conv]["wf"]
@@ -424,7 +430,7 @@ class ResNetUNetEngine:
             ops.bn_gram_fold(w3, s3.scale, s3.shift, wdn, sd.scale, sd.shift, w2s, b2s)
             ops.SCOPE = "enc"
             ut.out, ut.res, ut.res_bn, ut.res_gram = out, None, None, ud      # (tests)
-            ops.conv2d(a2.v, w2s, b2s, out, 1, 1, relu=True, x2=h.v)
+            ops.conv2d(a2.v, w2s, b2s, out, 1, 1, relu=True, x2=h.v, mask_bits_out=mbits)
         elif getattr(ut, "gram", False):
             # conv3 -> BatchNorm -> + shortcut (its own BatchNorm for a projection) -> ReLU in ONE launch: the conv output is never stored
             s3 = self.bn[ut.bn]
@@ -432,15 +438,17 @@ class ResNetUNetEngine:
             ut.out, ut.res, ut.res_bn = out, (ud.y if ud is not None else h.v), (ud.bn if ud is not None else None)   # (tests)
             if ud is not None:
                 sd = self.bn[ud.bn]
-                ops.conv2d(a2.v, self.packed[ut.conv]["wf"], None, out, 1, 1, relu=True, pre_affine=(s3.scale, s3.shift), res=ud.y, res_affine=(sd.scale, sd.shift))
+                ops.conv2d(a2.v, self.packed[ut.conv]["wf"], None, out, 1, 1, relu=True, pre_affine=(s3.scale, s3.shift), res=ud.y, res_affine=(sd.scale, sd.shift),
+                           mask_bits_out=mbits)
             else:
-                ops.conv2d(a2.v, self.packed[ut.conv]["wf"], None, out, 1, 1, relu=True, pre_affine=(s3.scale, s3.shift), res=h.v)
+                ops.conv2d(a2.v, self.packed[ut.conv]["wf"], None, out, 1, 1, relu=True, pre_affine=(s3.scale, s3.shift), res=h.v, mask_bits_out=mbits)
         else:
             self._tail(ut, ud, h, out, train)
         self.relu_order.append(out if self._grid == 1 else GridView(out, self._grid))
         o = Act(out)
         if getattr(ut, "gram", False):
             o.tail_dz, o.dz_ready = p + ".dz", None      # (its tail backward needs no BatchNorm reduce: the consumer's data gradient may write dz, _tail_fusable)
+            o.mask_bits = mbits
         if train:
             def bwd():
                 dz = ops.view(self._act(p + ".dz", out.B, out.H, out.W, out.C))
@@ -595,7 +603,8 @@ class ResNetUNetEngine:
         v = h.v
         dzk = ops.view(self._act(h.tail_dz, v.B, v.H, v.W, v.C))
         ops.SCOPE = "enc"
-        ops.conv2d(dy, self.packed[u1.conv]["wd"], None, dzk, 1, 1, res=res, res2=res2, mask=v)
+        mb = getattr(h, "mask_bits", None)
+        ops.conv2d(dy, self.packed[u1.conv]["wd"], None, dzk, 1, 1, res=res, res2=res2, mask=v if mb is None else None, mask_bits=mb)
         h.dz_ready = dzk
         h.grads = []
         if self.keep_all:

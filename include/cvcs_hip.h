@@ -114,6 +114,10 @@ typedef struct {
   /* res2: a second tile added beside res (no affine); res2_half = 1: it lives at HALF the resolution and contributes at the even pixels only -
    * the data gradient of a 1x1 / stride-2 projection shortcut, so that the block below a down-sampling block gets its dz from ONE launch too */
   const void* res2;  int64_t res2_ld;  int32_t res2_half;
+  /* (ABI 14) the ReLU mask as BITS, one byte per 16-byte chunk of a pixel row ([pixels][Cout / 8], bit e = channel 8 * chunk + e):
+   * mask_bits_out - a forward launch that applies a ReLU also writes (value > 0) of what it stores; mask_bits - a data-gradient launch reads the
+   * mask from there instead of `mask` (the block output itself: 16 x the bytes).  bf16 1x1 launches of the taps kernel (Cout % 128 == 0).   */
+  void* mask_bits_out;  const void* mask_bits;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */

@@ -192,6 +192,44 @@ def test_data_gradient_that_writes_the_previous_blocks_dz(case):
     assert (dz.torch().float().cpu()[out_act == 0] == 0).all()
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (1, 19, 13, 128, 512)])
+def test_relu_mask_as_bits_written_by_the_forward_and_read_by_the_data_gradient(case):
+    """cvcs_conv_desc.mask_bits_out / mask_bits: the forward launch of a block tail writes (out > 0) as one byte per 8 channels of a pixel; the
+    consumer's tail-fused data gradient masked by those bits equals the launch masked by the output tensor itself, bit for bit"""
+    B, H, W, m, C_ = case
+    g = torch.Generator().manual_seed(m + 1)
+    a = _rq(torch.randn(B, H, W, m, generator=g))
+    w3 = _rq(torch.randn(C_, m, generator=g) / m ** 0.5)
+    short = _rq(torch.randn(B, H, W, C_, generator=g))
+    out = ops.view(torch.zeros(B, H, W, C_, dtype=BF, device=DEV))
+    bits = torch.full((B * H * W * C_ // 8,), 0xa5, dtype=torch.uint8, device=DEV)
+    one, zero = torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV)
+    ops.conv2d(_dev_view(a), w3.to(BF).to(DEV).view(1, C_, m), None, out, 1, 1, relu=True, pre_affine=(one, zero), res=_dev_view(short), mask_bits_out=bits)
+    torch.cuda.synchronize()
+    o = out.torch().float().cpu().reshape(-1, C_ // 8, 8)
+    want = ((o > 0).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits.cpu().view(-1, C_ // 8), want)
+    assert 0.2 < (o > 0).float().mean() < 0.8
+    # a plain two-source launch with a ReLU (the tail with a same-resolution projection shortcut) writes them too
+    h = _rq(torch.randn(B, H, W, m, generator=g))
+    w2 = torch.cat([w3, _rq(torch.randn(C_, m, generator=g) / m ** 0.5)], 1).contiguous()
+    out2 = ops.view(torch.zeros(B, H, W, C_, dtype=BF, device=DEV))
+    bits2 = torch.zeros_like(bits)
+    ops.conv2d(_dev_view(a), w2.to(BF).to(DEV).view(1, C_, 2 * m), None, out2, 1, 1, relu=True, x2=_dev_view(h), mask_bits_out=bits2)
+    torch.cuda.synchronize()
+    o2 = out2.torch().float().cpu().reshape(-1, C_ // 8, 8)
+    assert torch.equal(bits2.cpu().view(-1, C_ // 8), ((o2 > 0).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8))
+    # the consumer: dz = (W dy + g_shortcut) * mask, from the tensor and from the bits
+    dy = _rq(torch.randn(B, H, W, m, generator=g))
+    gs = _rq(torch.randn(B, H, W, C_, generator=g))
+    dz_t, dz_b = (ops.view(torch.zeros(B, H, W, C_, dtype=BF, device=DEV)) for _ in range(2))
+    wd = w3.to(BF).to(DEV).view(1, C_, m)
+    ops.conv2d(_dev_view(dy), wd, None, dz_t, 1, 1, res=_dev_view(gs), mask=out)
+    ops.conv2d(_dev_view(dy), wd, None, dz_b, 1, 1, res=_dev_view(gs), mask_bits=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(dz_t.torch(), dz_b.torch())
+
+
 @pytest.mark.parametrize("half", [False, True])
 def test_data_gradient_with_two_more_gradient_sources(half):
     """dz = (W x + g_a + g_b) * (out > 0) where g_b may live at half resolution (the data gradient of a 1x1 / stride-2 projection shortcut
