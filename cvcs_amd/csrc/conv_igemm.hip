@@ -56,6 +56,7 @@ struct ConvArgs {
   const char* res; int64_t res_ld; const float* res_scale; const float* res_shift;
   const char* in2; int64_t in2_ld; int Cin2;
   const char* mask; int64_t mask_ld;   // taps kernel: out = (mask > 0) ? value : 0 (the ReLU backward of the activation the gradient belongs to)
+  int stat_rounded;   // taps kernel: partial statistics of the bf16-rounded values (what is stored) instead of the f32 accumulators
   unsigned char* mask_bits_out; const unsigned char* mask_bits;   // taps kernel: the same mask as one byte per 16-byte chunk of a pixel row (written / read)
   const char* res2; int64_t res2_ld; int res2_half;   // taps kernel: a second tile added beside res (optionally at half resolution: even pixels only)
 };
@@ -1277,6 +1278,19 @@ __global__ __launch_bounds__(512, 4) void conv_taps_kernel(ConvArgs p) {      //
   // M2 centred on the block's own mean) of the f32 accumulators, as the generic kernel emits them; the 16 lanes that share
   // a channel quadruple (fg) are merged with xor-shuffles.
   if (p.stat_sum) {
+    // Statistics of the values AS STORED (bf16), like the halo and thin kernels: the BatchNorm that follows normalises the stored tensor, and
+    // its backward recomputes xhat from it.  Statistics of the unrounded accumulators left that normalisation off by 2^-9 |mean| / sigma per
+    // element - nothing over the 10^5 pixels of an encoder map, a visible inconsistency over the 8 ... 288 pixels of UPerNet's pooled maps.
+    if (p.stat_rounded) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t lo = pack2_bf16(acc[i][j][0], acc[i][j][1]), hi = pack2_bf16(acc[i][j][2], acc[i][j][3]);
+          acc[i][j][0] = __uint_as_float(lo << 16); acc[i][j][1] = __uint_as_float(lo & 0xffff0000u);
+          acc[i][j][2] = __uint_as_float(hi << 16); acc[i][j][3] = __uint_as_float(hi & 0xffff0000u);
+        }
+    }
     const int rbase = m0 + wm * 64;
     int nvalid = p.M - rbase;
     nvalid = nvalid < 0 ? 0 : (nvalid > 64 ? 64 : nvalid);
@@ -1850,6 +1864,10 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
   a.in2 = (const char*)d->in2; a.in2_ld = d->in2_ld; a.Cin2 = d->in2 ? d->Cin2 : 0;
   a.mask = (const char*)d->mask; a.mask_ld = d->mask_ld;
   a.mask_bits_out = (unsigned char*)d->mask_bits_out; a.mask_bits = (const unsigned char*)d->mask_bits;
+  {
+    static const int rounded = getenv("CVCS_TAPS_STATS_ROUNDED") ? atoi(getenv("CVCS_TAPS_STATS_ROUNDED")) : 1;   // tuning / bisection knob
+    a.stat_rounded = rounded;
+  }
   if (d->mask_bits) CVCS_CHECK_ARG(!d->mask && use_taps(d) && d->KH == 1 && !d->stat_sum && !d->relu && !d->pixel_shuffle,
                                    "cvcs_conv2d: mask_bits is built for bf16 1x1 launches with Cout %% 128 == 0 (and excludes mask)");
   if (d->mask_bits_out) CVCS_CHECK_ARG(d->relu && use_taps(d) && d->KH == 1 && !d->stat_sum && !d->pixel_shuffle && !d->mask && !d->mask_bits,

@@ -97,18 +97,37 @@ __device__ __forceinline__ Moments merge_rows(const float* __restrict__ ssum, co
 // over the partial rows: 64 row-lanes cut the loop 4x against 16); lanes are merged in two levels, in a fixed order
 constexpr int kRL = 64;
 __device__ __forceinline__ Moments merge_lanes(Moments a, int rl, int cl) {
+  // The 64 lane results of a channel without a chain of pairwise merges (two f64 divisions each: 16 dependent merges were a third of the
+  // kernel): N = sum n, mean = sum(n mean) / N - ONE division - then M2 = sum(m2 + n (mean_q - mean)^2), the standard parallel form (no
+  // cancellation).  Eight lanes sum eight entries each, in a fixed order.
   __shared__ double sh[3][kRL][17];
+  __shared__ double part[3][8][17];
   sh[0][rl][cl] = a.n; sh[1][rl][cl] = a.mean; sh[2][rl][cl] = a.m2;
   __syncthreads();
-  if (rl < 8) {   // level 1: lane rl merges entries rl, rl+8, ...
-    Moments t{0.0, 0.0, 0.0};
-    for (int q = rl; q < kRL; q += 8) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
-    sh[0][rl][cl] = t.n; sh[1][rl][cl] = t.mean; sh[2][rl][cl] = t.m2;
+  if (rl < 8) {
+    double n = 0.0, s1 = 0.0;
+    for (int q = rl; q < kRL; q += 8) { n += sh[0][q][cl]; s1 += sh[0][q][cl] * sh[1][q][cl]; }
+    part[0][rl][cl] = n; part[1][rl][cl] = s1;
+  }
+  __syncthreads();
+  double N = 0.0, S = 0.0;
+  if (rl < 8) {
+    for (int q = 0; q < 8; ++q) { N += part[0][q][cl]; S += part[1][q][cl]; }
+    const double mean = N > 0.0 ? S / N : 0.0;
+    double m2 = 0.0;
+    for (int q = rl; q < kRL; q += 8) {
+      const double d = sh[1][q][cl] - mean;
+      m2 += sh[2][q][cl] + sh[0][q][cl] * d * d;
+    }
+    part[2][rl][cl] = m2;
   }
   __syncthreads();
   Moments t{0.0, 0.0, 0.0};
-  if (rl == 0)
-    for (int q = 0; q < 8; ++q) merge(t, sh[0][q][cl], sh[1][q][cl], sh[2][q][cl]);
+  if (rl == 0) {
+    double m2 = 0.0;
+    for (int q = 0; q < 8; ++q) m2 += part[2][q][cl];
+    t.n = N; t.mean = N > 0.0 ? S / N : 0.0; t.m2 = m2;
+  }
   return t;
 }
 

@@ -10,5 +10,6 @@ for d in gpurun_out/r04_*/; do
   cp "$d/mfma_util.txt" profiles/r04_${tag}_mfma_util.txt
   cp "$d/pmc_traffic.json" profiles/r04_pmc_traffic_$tag.json
 done
+for d in gpurun_out/disp_*/; do [ -s "$d/table.txt" ] && cp "$d/table.txt" profiles/r04_dispatch_table_$(basename "$d" | sed s/disp_//).txt; done
 for f in gpurun_out/r04_lines/*.json; do [ -s "$f" ] && cp "$f" profiles/r04_bench_$(basename "$f"); done
 ls profiles | grep r04

@@ -44,12 +44,12 @@ def _setup(model, precision, emulate=False, seed=3):
     return tr, fwd, (net.to(DEV) if torch.cuda.is_available() else net)
 
 
-def oracle_only(steps, S, model, emulate):
-    """held-out metrics of the CPU oracle alone (f32, or trained and evaluated in its bf16-emulation mode)"""
+def oracle_only(steps, S, model, emulate, seed=0):
+    """held-out metrics of the CPU oracle alone (f32, or trained and evaluated in its bf16-emulation mode); seed: the ensemble member of run()"""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    train = [O.synthetic_tiles(B, S, NC, seed=100 + i, structured=True) for i in range(8)]
+    train = [O.synthetic_tiles(B, S, NC, seed=100 + i + 1000 * seed, structured=True) for i in range(8)]
     held = [O.synthetic_tiles(B, S, NC, seed=900 + i, structured=True) for i in range(4)]
-    tr, fwd, _ = _setup(model, "bf16", emulate)
+    tr, fwd, _ = _setup(model, "bf16", emulate, seed=3 + seed)
     for s in range(steps):
         tr.step(*train[s % len(train)])
     p = {k: v.detach() for k, v in tr.p.items()}
@@ -58,31 +58,48 @@ def oracle_only(steps, S, model, emulate):
     return O.metrics(conf)
 
 
-def run(precision="bf16", steps=40, S=64, verbose=True, model="Unetv2", seed=0):
-    """seed: another member of the ensemble - other initial parameters and other training tiles (the held-out set stays the same)"""
+def run(precision="bf16", steps=40, S=64, verbose=True, model="Unetv2", seed=0, epoch_steps=None, cross=False):
+    """seed: another member of the ensemble - other initial parameters and other training tiles (the held-out set stays the same).
+    epoch_steps: every so many steps count as one epoch of the reference's schedule (S/utils.py:213-221: SGD2 = PolynomialLR over 20 epochs,
+    stepped once per epoch, S/train.py): with steps = 20 * epoch_steps the learning rate decays linearly to ~0 by the end of the run, as it
+    does at the end of the reference's training; None: no scheduler step, constant learning rate"""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     train = [O.synthetic_tiles(B, S, NC, seed=100 + i + 1000 * seed, structured=True) for i in range(8)]
     held = [O.synthetic_tiles(B, S, NC, seed=900 + i, structured=True) for i in range(4)]
     tr, fwd, net = _setup(model, precision, seed=3 + seed)
     crit = utils.CrossEntropyLoss(ignore_index=0)
-    opt, _ = utils.load_optimizer({"opt": "SGD2", "epochs": 1}, net)
+    epochs = 1 if epoch_steps is None else -(-steps // epoch_steps)
+    opt, sched = utils.load_optimizer({"opt": "SGD2", "epochs": epochs}, net)
     net.train()
     for s in range(steps):
         img, lab = train[s % len(train)]
         lo = tr.step(img, lab)[0]
         loss = crit(net(img.to(DEV), None), lab.to(DEV))
         opt.zero_grad(); loss.backward(); opt.step()
+        if epoch_steps is not None and (s + 1) % epoch_steps == 0:
+            tr.epoch += 1
+            sched.step()
         if verbose and (s % 10 == 0 or s == steps - 1):
             print(f"step {s:3d}  oracle loss {lo:.4f}  hip loss {loss.item():.4f}", flush=True)
     p = {k: v.detach() for k, v in tr.p.items()}
     with torch.no_grad():
         conf_o = sum(O.confusion_matrix(O.predict_labels(fwd(p, img.float())).numpy(), lab.numpy(), 16, ignore_index=0) for img, lab in held)
-    net.eval()
-    cm = utils.ConfusionMatrix(16, ignore_index=0, device=DEV)
-    with torch.no_grad():
-        for img, lab in held:
-            cm.update_from_logits(net(img.to(DEV), None), lab.to(DEV))
-    return O.metrics(conf_o), utils.print_metrics(cm.compute(), silent=True)
+
+    def hip_eval(n):
+        n.eval()
+        cm = utils.ConfusionMatrix(16, ignore_index=0, device=DEV)
+        with torch.no_grad():
+            for img, lab in held:
+                cm.update_from_logits(n(img.to(DEV), None), lab.to(DEV))
+        return utils.print_metrics(cm.compute(), silent=True)
+    m_h = hip_eval(net)
+    if not cross:
+        return O.metrics(conf_o), m_h
+    # the ORACLE'S trained model on the HIP evaluation path: no trajectory in between - the held-out mIoU of the same weights and running
+    # statistics through the reference's model.eval() + metric code (S/utils.py:311-364) must agree
+    _, _, net2 = _setup(model, precision, seed=3 + seed)
+    net2.load_state_dict({k: v.clone() for k, v in p.items()}, strict=False)
+    return O.metrics(conf_o), m_h, hip_eval(net2)
 
 
 if __name__ == "__main__":

@@ -308,6 +308,44 @@ def test_stem_backward_in_one_launch(dtype, B, H, W, nskip, npool):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("B,H,W,C_", [(8, 1, 1, 512), (8, 2, 2, 512), (8, 3, 3, 512), (8, 6, 6, 512), (8, 4, 4, 512), (3, 5, 7, 96), (2, 9, 9, 160), (8, 32, 32, 512)])
+def test_batchnorm_backward_on_tiny_and_odd_maps(dtype, mode, B, H, W, C_):
+    """the BatchNorm backward passes on the pooled maps of UPerNet's pyramid (1x1 ... 6x6 pixels x 8 tiles x 512 channels: fewer pixels than one
+    workgroup's group of four items), on channel counts whose chunks do not fill a workgroup (96, 160) and on a map of whole groups: dgamma,
+    dbeta, dy against float64 autograd of F.batch_norm (+ ReLU for mode 0)"""
+    g = torch.Generator().manual_seed(B * H * W + C_ + mode)
+    y = rq(torch.randn(B, C_, H, W, generator=g) * 2 + 1, dtype)
+    gz = rq(torch.randn(B, C_, H, W, generator=g), dtype)
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.5
+    yr, gr, br = y.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    out = F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)
+    (F.relu(out) if mode == 0 else out).backward(gz.double())
+    mean = y.double().mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.double().var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    scale, shift = gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd
+    M = B * H * W
+    rows = ops.bn_bwd_rows(M)
+    p0, p1, p2 = (torch.full((rows * C_,), float("nan"), device=DEV) for _ in range(3))
+    dgamma, dbeta, ca, cb = (torch.empty(C_, device=DEV) for _ in range(4))
+    yd, gd = to_nhwc(y, dtype), to_nhwc(gz, dtype)
+    dv = [t.float().to(DEV) for t in (scale, shift, mean, invstd)]
+    ops.bn_bwd_reduce(ops.view(yd), ops.view(gd), None, *dv, mode, p0, p1)
+    ops.bn_bwd_finalize(p0, p1, rows, M, C_, gamma.to(DEV), dv[3], dgamma, dbeta, ca, cb)
+    dy = torch.full_like(yd, float("nan"))
+    ops.bn_bwd_apply(ops.view(yd), ops.view(gd), None, *dv, ca, cb, mode, ops.view(dy), p2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(p0).all() and torch.isfinite(p1).all() and torch.isfinite(p2).all() and torch.isfinite(dy.float()).all()
+    close(dgamma.cpu().double(), gr.grad, 2e-4, "dgamma")
+    close(dbeta.cpu().double(), br.grad, 2e-4, "dbeta")
+    close(from_nhwc(dy).double(), yr.grad, 2e-4 if dtype == torch.float32 else 1e-2, "dy")
+    stored = from_nhwc(dy).double()      # the apply pass also returns the column sums of the dy it stored (bias gradients of the conv below)
+    err = (p2.view(rows, C_).double().sum(0).cpu() - stored.sum(dim=(0, 2, 3))).abs().max().item()
+    # (summed in f32 before the rounding to the storage type: up to 2^-9 of sum |dy| in bf16)
+    assert err <= (1e-4 if dtype == torch.float32 else 4e-3) * stored.abs().sum(dim=(0, 2, 3)).max().item() + 1e-6, f"column sums of dy off by {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm_backward_without_relu(dtype):
     """mode 2 of cvcs_bn_bwd_*: the last BatchNorm of a residual block (its ReLU comes after the add)"""
     g = torch.Generator().manual_seed(11)
