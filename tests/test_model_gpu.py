@@ -374,12 +374,20 @@ def test_heldout_miou_after_training_matches_cpu_reference(precision):
     assert abs(mean) <= 0.1, (mean, d)
 
 
-def _miou_ensemble(model, precision, steps, S, seeds, learn=0.9, epoch_steps=None, member_bound=0.3):
+def _miou_ensemble(model, precision, steps, S, seeds, learn=0.9, epoch_steps=None, member_bound=0.3, cross=False):
     """(mean, standard deviation, members) of HIP - oracle held-out mIoU in points over runs that differ in initial parameters and training tiles"""
     mod = _miou_parity()
     d = []
     for seed in seeds:
-        m_o, m_h = mod.run(precision, steps=steps, S=S, verbose=False, model=model, seed=seed, epoch_steps=epoch_steps)
+        if cross and seed == list(seeds)[0]:
+            # north star, the part that is not a statement about a chaotic trajectory: the CPU oracle's TRAINED model (weights + running
+            # statistics after this schedule), loaded into the HIP network, scores the oracle's held-out mIoU to 0.1 points through the HIP
+            # evaluation path (model.eval() -> logits -> arg-max -> confusion matrix -> mIoU, S/utils.py:311-364)
+            m_o, m_h, m_x = mod.run(precision, steps=steps, S=S, verbose=False, model=model, seed=seed, epoch_steps=epoch_steps, cross=True)
+            print(f"{model}: oracle {100 * m_o['mIoU']:.3f}  the oracle's trained model on the HIP evaluation path {100 * m_x['mIoU']:.3f}")
+            assert abs(m_x["mIoU"] - m_o["mIoU"]) * 100 <= 0.1, (model, m_o["mIoU"], m_x["mIoU"])
+        else:
+            m_o, m_h = mod.run(precision, steps=steps, S=S, verbose=False, model=model, seed=seed, epoch_steps=epoch_steps)
         assert m_o["mIoU"] > learn, "the schedule must actually learn the task"
         d.append(100 * (m_h["mIoU"] - m_o["mIoU"]))
     mean = sum(d) / len(d)
@@ -398,7 +406,7 @@ def _miou_parity():
 
 
 @pytest.mark.parametrize("model,steps,S,seeds,epoch_steps", [("Resnet18Unet", 40, 64, 4, None), ("Resnet50Unet", 60, 128, 3, None), ("DeepLabV3Plus", 120, 128, 8, None),
-                                                           ("TSwin", 100, 128, 4, 5)])
+                                                           ("TSwin", 100, 128, 3, 5)])
 def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, steps, S, seeds, epoch_steps):
     """the same for BASELINE's model families in bf16, each as the MEAN over an ensemble of runs (other initial parameters and training tiles),
     within the north star's 0.1 points of the f32 CPU oracle trained on the same tiles (mIoU definition: S/utils.py:311-364).  Measured on the
@@ -408,33 +416,22 @@ def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, st
     three seeds (s.d. 0.19: its image-pooling BatchNorm averages B = 8 values and its reversed-tile-order run already lands 2 % away in loss -
     five members here).  Rounds 1-3 asserted one end point per model at 0.2-0.25.
     Swin-T + UPerNet runs the REFERENCE'S schedule in miniature (epoch_steps = 5: SGD2's PolynomialLR stepped every five steps, twenty "epochs",
-    the learning rate decays linearly to ~0 as at the end of the reference's training, S/utils.py:213-221): -0.050 / +0.113 / +0.054 / -0.122
-    (mean -0.001, s.d. 0.105).  At a CONSTANT learning rate its end point is not a statement about the kernels: UPerNet's pyramid-pooling
+    the learning rate decays linearly to ~0 as at the end of the reference's training, S/utils.py:213-221): -0.032 / +0.087 / -0.048
+    (mean +0.002, s.d. 0.074).  At a CONSTANT learning rate its end point is not a statement about the kernels: UPerNet's pyramid-pooling
     BatchNorms normalise over 8 ... 288 values per step (1x1 ... 6x6 pooled maps x 8 tiles), their running statistics lag the still-moving weights,
     and how far depends on the trajectory - the same build lands -0.02 ... -0.9 (seed 0) and -0.6 ... -3.4 (seed 3) under changes of pure
     summation order, never above the oracle, while the weights are as good as the oracle's (held-out mIoU with batch statistics 94.007 vs 94.026;
     with running statistics re-accumulated over the training tiles 94.715 vs 94.727: scripts/swin_miou_debug2.py; one-step and frozen-weight
     running-statistics updates agree with the oracle's to 0.6 %: scripts/swin_miou_debug3.py / 4.py).  profiles/r04_miou_ensembles.txt."""
     # (no member may be an outright failure: three of DeepLabV3+'s measured deviations of 0.25)
-    mean, sd, d = _miou_ensemble(model, "bf16", steps, S, range(seeds), learn=0.85, epoch_steps=epoch_steps, member_bound=0.75)
+    mean, sd, d = _miou_ensemble(model, "bf16", steps, S, range(seeds), learn=0.85, epoch_steps=epoch_steps, member_bound=0.75, cross=True)
     # the ensemble must be consistent with |bias| <= 0.1 at two standard errors of its mean - and able to see a bias of 0.35 (s.e. <= 0.12).
     # (The second half of round 4 re-measured DeepLabV3+ over eight members: -0.134 / -0.050 / -0.007 / +0.571 / +0.142 / -0.066 / +0.152 / +0.407,
     #  mean +0.127, s.d. 0.248 - HIP ABOVE the oracle as often as below; the bare |mean of five| <= 0.1 of the first half holds for a bias-free
-    #  path in five of six builds only.  The deterministic +-0.1 statement is test_the_oracles_trained_model_... below.)
+    #  path in five of six builds only.  The deterministic +-0.1 statement is made on the first member: the oracle's trained model on the HIP evaluation path, _miou_ensemble.)
     se = sd / len(d) ** 0.5
     assert abs(mean) <= 0.1 + 2 * se and se <= 0.12, (model, mean, sd, d)
 
-
-@pytest.mark.parametrize("model,steps,S", [("Resnet50Unet", 60, 128), ("DeepLabV3Plus", 120, 128), ("TSwin", 100, 128)])
-def test_the_oracles_trained_model_scores_the_same_heldout_miou_on_the_hip_evaluation_path(model, steps, S):
-    """north star, the part that is not a statement about a chaotic trajectory: the CPU oracle's TRAINED model (weights + running statistics after
-    the schedule above), loaded into the HIP network, scores the oracle's held-out mIoU to 0.1 points through the bf16 evaluation path
-    (model.eval() -> logits -> arg-max -> confusion matrix -> mIoU, S/utils.py:311-364) - and the HIP-trained model of the same run is reported
-    beside it"""
-    m_o, m_h, m_x = _miou_parity().run("bf16", steps=steps, S=S, verbose=False, model=model, seed=0, cross=True)
-    print(f"{model}: oracle {100 * m_o['mIoU']:.3f}  oracle's model on the HIP evaluation path {100 * m_x['mIoU']:.3f}  HIP-trained {100 * m_h['mIoU']:.3f}")
-    assert m_o["mIoU"] > 0.85
-    assert abs(m_x["mIoU"] - m_o["mIoU"]) * 100 <= 0.1, (m_o["mIoU"], m_x["mIoU"])
 
 
 @pytest.mark.parametrize("variant,B,S", [("Unetv2", 4, 128), ("Unet", 2, 128), ("Unetv2", 2, 256)])
