@@ -202,3 +202,36 @@ def test_round4_entry_points_reject_bad_arguments(lib):
     assert lib.cvcs_head_ce(*args(C_=48)) == -1 and b"C=48" in lib.cvcs_last_error()
     assert lib.cvcs_head_ce(*args(NC=40)) == -1 and b"NC=40" in lib.cvcs_last_error()
     assert lib.cvcs_head_ce_rows(1 << 20) == 1024
+
+
+def test_abi14_entry_points_reject_bad_arguments(lib):
+    """second half of round 4: ReLU bit masks, the folded two-source tail operand, the pooled gradient source of the tail backward, the row query of the
+    thin kernel's fused BatchNorm-backward reduce"""
+    keep, a = _buf(1 << 16)
+    # bit masks belong to bf16 1x1 launches of the taps kernel; the writer goes with a ReLU, the reader excludes the tensor mask
+    d = _desc(a, mask_bits=a)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"mask_bits" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, Cout=128, out_ld=128, mask_bits=a, mask=a, mask_ld=128)
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"mask" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, Cout=128, out_ld=128, mask_bits_out=a)          # no ReLU
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"mask_bits_out goes with the ReLU" in lib.cvcs_last_error()
+    d = _desc(a, KH=1, KW=1, pad=0, Cout=64, relu=1, mask_bits_out=a)               # not a taps shape
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"mask_bits_out" in lib.cvcs_last_error()
+    # [scale3 W3 | scaled Wd]: whole 16-byte chunks per row, aligned operands
+    assert lib.cvcs_bn_gram_fold(a, a, a, 60, a, a, a, 64, 256, a, a, None) == -1 and b"m1=60" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_gram_fold(a, a, a, 64, None, a, a, 64, 256, a, a, None) == -1 and b"null" in lib.cvcs_last_error()
+    assert lib.cvcs_bn_gram_fold(a + 8, a, a, 64, a, a, a, 64, 256, a, a, None) == -1 and b"alignment" in lib.cvcs_last_error()
+    # the tail backward with a pooled gradient source: the arg-max indices need the pooled gradient
+    t = _lib.TailBwdDesc()
+    t.dz, t.dz_ld, t.B, t.H, t.W, t.C, t.dtype = a, 64, 1, 8, 8, 64, 1
+    t.y[0], t.y_ld[0], t.mean[0], t.invstd[0], t.part_dz, t.part_dzx[0] = a, 64, a, a, a, a
+    assert lib.cvcs_relu_bwd_sum_bn(C.byref(t), None) == -1 and b"a gradient" in lib.cvcs_last_error()       # neither g[0] nor a pooled source
+    t.pool_idx = a
+    assert lib.cvcs_relu_bwd_sum_bn(C.byref(t), None) == -1 and b"pool_idx needs pool_g" in lib.cvcs_last_error()
+    # row query of a thin data-gradient launch that carries the BatchNorm-backward reduce: one row per resident workgroup, never more than the tiles
+    d = _desc(a, Cin=32, in_ld=32, Cout=16, out_ld=16, H=16, W=64, Ho=16, Wo=64, bwd_y=16, bwd_mode=0)
+    rows = lib.cvcs_conv_stat_rows(C.byref(d))
+    assert 1 <= rows <= 4              # (4 tiles of 4 x 64 pixels; without a device the resident-workgroup query falls back to 1024)
+    d.bwd_y = None
+    assert lib.cvcs_conv_stat_rows(C.byref(d)) == 16      # forward statistics: one row per tile row
+
