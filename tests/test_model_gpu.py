@@ -423,9 +423,12 @@ def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, st
     summation order, never above the oracle, while the weights are as good as the oracle's (held-out mIoU with batch statistics 94.007 vs 94.026;
     with running statistics re-accumulated over the training tiles 94.715 vs 94.727: scripts/swin_miou_debug2.py; one-step and frozen-weight
     running-statistics updates agree with the oracle's to 0.6 %: scripts/swin_miou_debug3.py / 4.py).  profiles/r04_miou_ensembles.txt."""
-    # (no member may be an outright failure: three of DeepLabV3+'s measured deviations of 0.25)
-    mean, sd, d = _miou_ensemble(model, "bf16", steps, S, range(seeds), learn=0.85, epoch_steps=epoch_steps, member_bound=0.75, cross=True)
-    # the ensemble must be consistent with |bias| <= 0.1 at two standard errors of its mean - and able to see a bias of 0.35 (s.e. <= 0.12).
+    wide = model == "DeepLabV3Plus"      # (its members: three of the measured deviations of 0.25; everyone else 0.3 as before)
+    mean, sd, d = _miou_ensemble(model, "bf16", steps, S, range(seeds), learn=0.85, epoch_steps=epoch_steps, member_bound=0.75 if wide else 0.3, cross=True)
+    if not wide:
+        assert abs(mean) <= 0.1, (model, mean, d)      # ResNet18 / 50-UNet, Swin-T + UPerNet: the north star's bound on the ensemble mean, as measured
+        return
+    # DeepLabV3+: the ensemble must be consistent with |bias| <= 0.1 at two standard errors of its mean - and able to see a bias of 0.35 (s.e. <= 0.12).
     # (The second half of round 4 re-measured DeepLabV3+ over eight members: -0.134 / -0.050 / -0.007 / +0.571 / +0.142 / -0.066 / +0.152 / +0.407,
     #  mean +0.127, s.d. 0.248 - HIP ABOVE the oracle as often as below; the bare |mean of five| <= 0.1 of the first half holds for a bias-free
     #  path in five of six builds only.  The deterministic +-0.1 statement is made on the first member: the oracle's trained model on the HIP evaluation path, _miou_ensemble.)
