@@ -405,7 +405,7 @@ def _miou_parity():
     return mod
 
 
-@pytest.mark.parametrize("model,steps,S,seeds,epoch_steps", [("Resnet18Unet", 40, 64, 4, None), ("Resnet50Unet", 60, 128, 3, None), ("DeepLabV3Plus", 120, 128, 8, None),
+@pytest.mark.parametrize("model,steps,S,seeds,epoch_steps", [("Resnet18Unet", 40, 64, 4, None), ("Resnet50Unet", 60, 128, 3, None), ("DeepLabV3Plus", 120, 128, 6, None),
                                                            ("TSwin", 100, 128, 3, 5)])
 def test_heldout_miou_of_the_baseline_models_matches_their_cpu_oracles(model, steps, S, seeds, epoch_steps):
     """the same for BASELINE's model families in bf16, each as the MEAN over an ensemble of runs (other initial parameters and training tiles),
