@@ -204,3 +204,39 @@ def test_c_replay_trampoline_passes_register_stack_and_float_arguments_in_place(
     arr = (_lib.Call * 1)()
     assert h.cvcs_replay(arr, 1, None, None) == -1 and "bad record" in h.cvcs_last_error().decode()
 
+
+def test_dispatch_table_joins_trace_and_counter_passes_of_the_last_step(tmp_path):
+    """scripts/dispatch_table.py: the launches of the LAST training step (between the last two sgd_kernel dispatches) of a kernel trace, joined by
+    dispatch order with separate FETCH_SIZE / WRITE_SIZE passes of the same command (gfx950 correction: FETCH_SIZE doubled, both in KiB)"""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["pack_k", "conv_k<unsigned short, 64>", "sgd_kernel"]
+    trace = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp",'
+             '"LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"']
+    did = 0
+    for step in range(3):
+        for j, n in enumerate(names):
+            did += 1
+            t0 = did * 100000
+            trace.append(f'"KERNEL_DISPATCH","Agent 2",1,0,1,{did},{j},"{n}",{did},{t0},{t0 + 1000 * (j + 1) * (step + 1)},0,0,8,0,32,256,1,1,{256 * 4},2,1')
+
+    def counters(name, base):
+        rows = ['"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size",'
+                '"Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"']
+        d = 0
+        for step in range(2):
+            for j, n in enumerate(names):
+                d += 1
+                rows.append(f'{d},{d},"Agent 2",1,1,1,1024,{j},"{n}",256,0,0,8,0,32,"{name}",{base * (j + 1)},0,1')
+        return rows
+    (tmp_path / "t.csv").write_text("\n".join(trace) + "\n")
+    (tmp_path / "f.csv").write_text("\n".join(counters("FETCH_SIZE", 1000.0)) + "\n")
+    (tmp_path / "w.csv").write_text("\n".join(counters("WRITE_SIZE", 500.0)) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dispatch_table.py"), str(tmp_path / "t.csv"), str(tmp_path / "f.csv"), str(tmp_path / "w.csv")],
+                         capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0].startswith("# 3 dispatches in the last step; pmc passes aligned: True")
+    assert "pack_k" in out[1] and "4x2x1" in out[1] and "3.0 us" in out[1]                 # step 2 (the last): 1000 * 1 * 3 ns
+    assert "conv_k<bf16, 64>" in out[2] and f"rd {2 * 2000 * 1024 / 1e6:8.1f} MB" in out[2] and f"wr {1000 * 1024 / 1e6:8.1f} MB" in out[2]
+    assert out[-1].startswith("# total 0.02 ms")
+
