@@ -240,3 +240,27 @@ def test_dispatch_table_joins_trace_and_counter_passes_of_the_last_step(tmp_path
     assert "conv_k<bf16, 64>" in out[2] and f"rd {2 * 2000 * 1024 / 1e6:8.1f} MB" in out[2] and f"wr {1000 * 1024 / 1e6:8.1f} MB" in out[2]
     assert out[-1].startswith("# total 0.02 ms")
 
+
+def test_wide_input_weight_gradient_swizzle_spreads_a_transposed_read_over_all_banks():
+    """wgrad_thin_wide_kernel (csrc/wgrad.hip): a halo pixel is 256 bytes = the LDS bank period, so chunk c of halo pixel p is stored at chunk
+    c ^ key(p), key(p) = 2 * ((p & 3) | (((p >> 3) & 1) << 2)).  Restated here: (a) the map is a bijection of a pixel's sixteen 16-byte chunks
+    (the DMA source permutation and the read address are inverse to each other); (b) for every tap offset and wave, the 64 lanes of one
+    ds_read_b64_tr_b16 (pixels base + 8 fg + q, q = 0..3, fg = 0..3; two adjacent chunks per pixel, 8 bytes each) land on each of the sixteen
+    16-byte bank groups exactly four times (512 bytes over 256 bytes of banks: two-way, the minimum) - un-swizzled they all fall on two groups"""
+    key = lambda p: 2 * ((p & 3) | (((p >> 3) & 1) << 2))   # noqa: E731
+    for p in range(64):
+        assert sorted(c ^ key(p) for c in range(16)) == list(range(16))
+    for base in range(0, 6 * 34):                  # any halo pixel a tap / tile row can start from
+        for c0 in range(0, 16, 2):                 # (wave, j): the even chunk of a 16-channel block
+            for second in (0, 4):                  # the two transposed reads of a fragment
+                hits, plain = [0] * 16, [0] * 16
+                for fg in range(4):
+                    for q in range(4):
+                        px = base + 8 * fg + q + second
+                        for half in (0, 1):        # lanes pp = 0..3: chunks c0, c0 + 1, two 8-byte halves each
+                            for _ in (0, 1):
+                                hits[(c0 + half) ^ key(px)] += 1
+                                plain[c0 + half] += 1
+                assert max(hits) == 4 and min(hits) == 4, (base, c0, hits)
+                assert max(plain) == 32
+
