@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ("mask", C.c_void_p), ("mask_ld", C.c_int64),
         ("res2", C.c_void_p), ("res2_ld", C.c_int64), ("res2_half", C.c_int32),
         ("mask_bits_out", C.c_void_p), ("mask_bits", C.c_void_p),
+        ("in_up2", C.c_int32),
     ]
 
 
@@ -105,6 +106,7 @@ class WgradDesc(C.Structure):
         ("x_row_pitch", C.c_int64), ("x_img_pitch", C.c_int64),
         ("dil", C.c_int32),
         ("dbias", C.c_void_p),
+        ("x_up2", C.c_int32),
     ]
 
 

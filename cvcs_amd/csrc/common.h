@@ -90,6 +90,37 @@ __device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// ---- nn.Upsample(x2, bilinear) computed on the fly while a thin 3x3 kernel stages its input (conv3x3_thin_kernel<.., UP>, wgrad_thin_kernel<.., UP>):
+// the 6 x 66-pixel halo of a 4 x 64 tile of the UP-SAMPLED map is interpolated LDS -> LDS from the 4 x 34-pixel patch of the low-resolution map
+// under it (staged by LDS-DMA with clamped coordinates), with cvcs_upsample2x_fwd's own taps and expression and the same bf16 rounding - the
+// matrix cores see the operand the stored up-sampled tensor would have given them.
+__device__ __forceinline__ void up2_taps(int o, int n, int& i0, int& i1, float& w0, float& w1) {      // = up_taps of elementwise.hip
+  const int k = o >> 1;
+  if (o & 1) { i0 = k; i1 = k + 1 < n ? k + 1 : k; w0 = 0.75f; w1 = 0.25f; }
+  else       { i0 = k > 0 ? k - 1 : 0; i1 = k; w0 = k > 0 ? 0.25f : 0.f; w1 = k > 0 ? 0.75f : 1.f; }
+}
+constexpr int kUpPatchRows = 4, kUpPatchCols = 34;      // low-resolution pixels under a 6 x 66 halo (tile origin a multiple of 4 x 64)
+// halo pixel hp = hy * 66 + hx of the tile at (ty0, tx0), 16-byte chunk ch: interpolated from the patch in LDS (pixel-major rows of CI * 2 bytes)
+template <int CI>
+__device__ __forceinline__ uint4 up2_halo_chunk(const char* patch, int hp, int ch, int ty0, int tx0, int H, int W) {
+  const int hy = hp / 66, hx = hp - hy * 66;
+  const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+  if ((unsigned)gy >= (unsigned)H || (unsigned)gx >= (unsigned)W) return make_uint4(0u, 0u, 0u, 0u);      // the conv's zero padding
+  int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+  up2_taps(gy, H >> 1, y0, y1, wy0, wy1);
+  up2_taps(gx, W >> 1, x0, x1, wx0, wx1);
+  const int ly0 = (ty0 >> 1) - 1, lx0 = (tx0 >> 1) - 1;        // patch origin (patch pixel (pr, pc) holds the low-resolution pixel clamped from (ly0 + pr, lx0 + pc))
+  const int r0 = (y0 - ly0) * kUpPatchCols, r1 = (y1 - ly0) * kUpPatchCols, c0 = x0 - lx0, c1 = x1 - lx0;
+  float a[8], bb[8], c[8], d[8], o[8];
+  Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(patch + (r0 + c0) * (CI * 2) + ch * 16), a);
+  Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(patch + (r0 + c1) * (CI * 2) + ch * 16), bb);
+  Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(patch + (r1 + c0) * (CI * 2) + ch * 16), c);
+  Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(patch + (r1 + c1) * (CI * 2) + ch * 16), d);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = wy0 * (wx0 * a[k] + wx1 * bb[k]) + wy1 * (wx0 * c[k] + wx1 * d[k]);
+  return Elem<bf16_t>::pack(o);
+}
+
 // Workgroups of `fn` (block size, dynamic LDS) the whole chip holds at once: the grid of a persistent (grid-stride) kernel.  Falls back to
 // `fallback` when there is no device to ask (the launch-plan dry runs of the CPU tests).
 inline int resident_workgroups(const void* fn, int threads, size_t lds, int fallback = 1024) {

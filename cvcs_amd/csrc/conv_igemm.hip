@@ -1460,7 +1460,10 @@ struct ThinConvArgs {
 };
 constexpr int kTcTH = 4, kTcTW = 64, kTcHC = kTcTW + 2, kTcHR = kTcTH + 2;
 
-template <int CI, int CO, bool BWD = false>
+// UP instance (cvcs_conv_desc.in_up2): `in` is the map at HALF the resolution and the conv runs on its bilinear x2 up-sampling, interpolated
+// while the halo is staged (common.h: up2_halo_chunk) - nn.Upsample(2, 'bilinear') -> Conv2d of the light decoder stage (S/blocks.py:29 in
+// front of the reference's conv units) without the up-sampled tensor: two low-resolution patches in flight by LDS-DMA, one halo buffer.
+template <int CI, int CO, bool BWD = false, bool UP = false>
 __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
   constexpr int XPIX = kTcHR * kTcHC;
   constexpr int XB = (XPIX * CI * 2 + 1023) / 1024 * 1024, NX = XB / 1024;
@@ -1520,15 +1523,45 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
       dma16(src, base + pi * 1024);
     }
   };
+  // UP: the low-resolution patch under a tile's halo (4 x 34 pixels, coordinates clamped: the replicate border of the bilinear kernel)
+  constexpr int PPIX = kUpPatchRows * kUpPatchCols;
+  constexpr int PB = (PPIX * CI * 2 + 1023) / 1024 * 1024, NP = PB / 1024;
+  auto stage_patch = [&](int tt, unsigned base) {
+    const int b = tt / tpi, tr = tt - b * tpi;
+    const int ly0 = (((tr / p.tiles_x) * kTcTH) >> 1) - 1, lx0 = (((tr % p.tiles_x) * kTcTW) >> 1) - 1;
+    const int Hl = p.H >> 1, Wl = p.W >> 1;
+    for (int pi = wave; pi < NP; pi += 4) {
+      const int r = pi * XPP + xpx;
+      const int pr = r / kUpPatchCols, pc = r - pr * kUpPatchCols;
+      int ly = ly0 + pr, lx = lx0 + pc;
+      ly = ly < 0 ? 0 : (ly >= Hl ? Hl - 1 : ly);
+      lx = lx < 0 ? 0 : (lx >= Wl ? Wl - 1 : lx);
+      const char* src = r < PPIX ? p.in + ((((int64_t)b * Hl + ly) * Wl + lx) * p.in_ld) * 2 + xch * 16 : reinterpret_cast<const char*>(&g_zero16);
+      dma16(src, base + pi * 1024);
+    }
+  };
   int cur = 0;
   const int t_first = (int)xcd_order(blockIdx.x, gridDim.x);      // XCD-aware tile order: vertically adjacent tiles (shared halo rows) in ONE L2
-  if (t_first < p.ntiles) stage_halo(t_first, lds0);
-  if (t_first + (int)gridDim.x < p.ntiles) stage_halo(t_first + gridDim.x, lds0 + XB);
+  if constexpr (UP) {      // LDS: [halo XB][patch 0][patch 1]
+    if (t_first < p.ntiles) stage_patch(t_first, lds0 + XB);
+    if (t_first + (int)gridDim.x < p.ntiles) stage_patch(t_first + gridDim.x, lds0 + XB + PB);
+  } else {
+    if (t_first < p.ntiles) stage_halo(t_first, lds0);
+    if (t_first + (int)gridDim.x < p.ntiles) stage_halo(t_first + gridDim.x, lds0 + XB);
+  }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   for (int t = t_first; t < p.ntiles; t += gridDim.x) {
     const int b = t / tpi, tr = t - b * tpi;
     const int ty0 = (tr / p.tiles_x) * kTcTH, tx0 = (tr % p.tiles_x) * kTcTW;
-    const char* hbuf = smem + cur * XB;
+    if constexpr (UP) {
+      const char* patch = smem + XB + cur * PB;
+      for (int id = tid; id < XPIX * XCH; id += 256) {
+        const int hp = id / XCH, ch = id - hp * XCH;
+        *reinterpret_cast<uint4*>(smem + hp * (CI * 2) + ch * 16) = up2_halo_chunk<CI>(patch, hp, ch, ty0, tx0, p.H, p.W);
+      }
+      __syncthreads();      // the halo is complete, every wave is done with this patch buffer
+    }
+    const char* hbuf = UP ? smem : smem + cur * XB;
     const int y = ty0 + wave;
     // (BWD) the saved activation under this lane's output pieces: fetched before the MFMAs, used after them
     uint2 yraw[4][MB];
@@ -1570,7 +1603,10 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(ThinConvArgs p) {
         for (int r = 0; r < 4; ++r) acc[g][i][r] = fmaxf(acc[g][i][r] * sc[i][r] + sh[i][r], lo);
     // every wave is done with this halo buffer, the next tile's halo has landed (and the previous tile's stores are out): refill the buffer
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + 2 * (int)gridDim.x < p.ntiles) stage_halo(t + 2 * gridDim.x, lds0 + cur * XB);
+    if (t + 2 * (int)gridDim.x < p.ntiles) {
+      if constexpr (UP) stage_patch(t + 2 * gridDim.x, lds0 + XB + cur * PB);
+      else stage_halo(t + 2 * gridDim.x, lds0 + cur * XB);
+    }
     if constexpr (BWD) {
       // sums over the gradient AS STORED (bf16) - what the apply pass reads back
 #pragma unroll
@@ -1686,7 +1722,8 @@ static bool thin_conv_shape(const cvcs_conv_desc* d) {
   return on && d->dtype == CVCS_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->pixel_shuffle &&
          !d->aniso && !d->in_row_pitch && !d->in_img_pitch && d->Cin == 32 && (cin_valid == 16 || cin_valid == 32) &&
          (d->Cout == 16 || d->Cout == 32) && d->H >= 4 && d->W >= 16 && !d->post_scale && !d->pool_out &&
-         (!d->bwd_y || (thin_bwd_on() && d->bwd_mode == 0 && !d->stat_sum && !d->pre_scale && !d->relu));
+         (!d->bwd_y || (thin_bwd_on() && d->bwd_mode == 0 && !d->stat_sum && !d->pre_scale && !d->relu)) &&
+         (!d->in_up2 || (cin_valid == 32 && d->Cout == 16 && !d->bwd_y && d->H % 2 == 0 && d->W % 2 == 0));
 }
 
 template <int TAPS, bool EPI = false>
@@ -1874,6 +1911,7 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
                                    "cvcs_conv2d: mask_bits is built for bf16 1x1 launches with Cout %% 128 == 0 (and excludes mask)");
   if (d->mask_bits_out) CVCS_CHECK_ARG(d->relu && use_taps(d) && d->KH == 1 && !d->stat_sum && !d->pixel_shuffle && !d->mask && !d->mask_bits,
                                        "cvcs_conv2d: mask_bits_out goes with the ReLU of a bf16 1x1 launch with Cout %% 128 == 0");
+  if (d->in_up2) CVCS_CHECK_ARG(thin_conv_shape(d), "cvcs_conv2d: in_up2 (a conv over the bilinear x2 up-sampling of `in`) is built for the thin bf16 3x3 32 -> 16 instance, even H, W");
   a.res2 = (const char*)d->res2; a.res2_ld = d->res2_ld; a.res2_half = d->res2_half;
   if (d->res2) {
     CVCS_CHECK_ARG(use_taps(d) && d->KH == 1 && !d->stat_sum && !d->pixel_shuffle, "cvcs_conv2d: res2 is built for bf16 1x1 launches with Cout %% 128 == 0");
@@ -1924,6 +1962,14 @@ extern "C" int cvcs_conv2d(const cvcs_conv_desc* d, void* stream) {
       CVCS_CHECK_ARG(((uintptr_t)d->bwd_y % 16) == 0 && d->bwd_y_ld >= d->Cout && (d->bwd_y_ld * 2) % 16 == 0, "cvcs_conv2d: bwd_y view");
     }
     const bool tbwd = d->bwd_y != nullptr;
+    if (d->in_up2) {
+      constexpr size_t lds_up = ((kTcHR * kTcHC * 32 * 2 + 1023) / 1024 * 1024) + 2 * ((kUpPatchRows * kUpPatchCols * 32 * 2 + 1023) / 1024 * 1024);
+      static const int cap_up = resident_workgroups(reinterpret_cast<const void*>(&conv3x3_thin_kernel<32, 16, false, true>), 256, lds_up);
+      const int gup = ta.ntiles < cap_up ? ta.ntiles : cap_up;
+      hipLaunchKernelGGL((conv3x3_thin_kernel<32, 16, false, true>), dim3((unsigned)gup), dim3(256), lds_up, st, ta);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d(thin, up-sampled input)");
+      return CVCS_OK;
+    }
     const int groups = thin_conv_groups(cin_valid, d->Cout, tbwd, ta.ntiles);
 #define LAUNCH_TC(CI_, CO_)                                                                                              \
   do {                                                                                                                   \

@@ -945,7 +945,9 @@ constexpr int kThinTH = 4, kThinTW = 64, kThinHC = kThinTW + 2, kThinHR = kThinT
 
 __device__ uint4 g_tzero16;
 
-template <int CO, int CI>
+// UP instance (cvcs_wgrad_desc.x_up2): x is the map at HALF the resolution and the layer's input its bilinear x2 up-sampling, interpolated LDS -> LDS
+// from the 4 x 34-pixel patch under the tile's halo (common.h: up2_halo_chunk; the forward's conv3x3_thin_kernel<.., UP> stages the same way)
+template <int CO, int CI, bool UP = false>
 __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWgArgs p) {
   constexpr int DYB = kThinTH * kThinTW * CO * 2;                      // bytes of the dy tile
   constexpr int XPIX = kThinHR * kThinHC;                              // 396 halo pixels
@@ -985,6 +987,25 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWgArgs p) {
                                                : reinterpret_cast<const char*>(&g_tzero16);
       dma16(src, lds0 + pi * 1024);
     }
+    if constexpr (UP) {
+      constexpr int PPIX = kUpPatchRows * kUpPatchCols, NP = (PPIX * CI * 2 + 1023) / 1024;
+      const int ly0 = (ty0 >> 1) - 1, lx0 = (tx0 >> 1) - 1, Hl = p.H >> 1, Wl = p.W >> 1;
+      for (int pi = wave; pi < NP; pi += 4) {                          // the low-resolution patch behind the halo region (clamped coordinates)
+        const int r = pi * XPP + xpx;
+        const int pr = r / kUpPatchCols, pc = r - pr * kUpPatchCols;
+        int ly = ly0 + pr, lx = lx0 + pc;
+        ly = ly < 0 ? 0 : (ly >= Hl ? Hl - 1 : ly);
+        lx = lx < 0 ? 0 : (lx >= Wl ? Wl - 1 : lx);
+        const char* src = r < PPIX ? p.x + ((((int64_t)b * Hl + ly) * Wl + lx) * p.x_ld) * 2 + xch * 16 : reinterpret_cast<const char*>(&g_tzero16);
+        dma16(src, lds0 + DYB + XB + pi * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      for (int id = tid; id < XPIX * XCH; id += 256) {
+        const int hp = id / XCH, ch = id - hp * XCH;
+        *reinterpret_cast<uint4*>(smem + DYB + hp * (CI * 2) + ch * 16) = up2_halo_chunk<CI>(smem + DYB + XB, hp, ch, ty0, tx0, p.H, p.W);
+      }
+      __syncthreads();
+    } else {
     for (int pi = wave; pi < NX; pi += 4) {
       const int r = pi * XPP + xpx;                                    // halo pixel: row r / 66, column r % 66
       const int hy = r / kThinHC, hx = r - hy * kThinHC;
@@ -995,6 +1016,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinWgArgs p) {
       dma16(src, lds0 + DYB + pi * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     // ---- wave `wave` = tile row `wave`: two K-steps of 32 pixels
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1159,7 +1181,8 @@ static bool thin_wgrad_shape(const cvcs_wgrad_desc* d) {
   const bool special = d->aniso != 0 || d->x_row_pitch != 0 || d->x_img_pitch != 0;
   return on && d->dtype == CVCS_BF16 && !special && d->dil <= 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
          (d->Cout == 16 || d->Cout == 32) && (d->Cin == 16 || d->Cin == 32 || (d->Cin % 32 == 0 && d->Cin <= 256)) && d->Cin_real == d->Cin &&
-         d->H == d->Ho && d->W == d->Wo && d->H >= 4 && d->W >= 32;
+         d->H == d->Ho && d->W == d->Wo && d->H >= 4 && d->W >= 32 &&
+         (!d->x_up2 || (d->Cout == 16 && d->Cin == 32 && d->H % 2 == 0 && d->W % 2 == 0));
 }
 static int thin_wgrad_groups(const cvcs_wgrad_desc* d) {
   const int64_t ntiles = (int64_t)d->B * cdiv(d->H, kThinTH) * cdiv(d->W, kThinTW);
@@ -1414,6 +1437,7 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
   const int64_t row_pitch = d->x_row_pitch ? d->x_row_pitch : (int64_t)d->W * d->x_ld;
   const int64_t img_pitch = d->x_img_pitch ? d->x_img_pitch : (int64_t)d->H * row_pitch;
   CVCS_CHECK_ARG(row_pitch * es % 16 == 0 && img_pitch * es % 16 == 0 && row_pitch > 0 && img_pitch >= row_pitch, "cvcs_conv2d_wgrad: pitches of x");
+  if (d->x_up2) CVCS_CHECK_ARG(thin_wgrad_shape(d), "cvcs_conv2d_wgrad: x_up2 (the weight gradient over the bilinear x2 up-sampling of `x`) is built for the thin bf16 3x3 32 -> 16 instance, even H, W");
   if (thin_wgrad_shape(d)) {
     ThinWgArgs ta;
     ta.x = (const char*)d->x; ta.dy = (const char*)d->dy; ta.ws = d->workspace; ta.x_ld = d->x_ld; ta.dy_ld = d->dy_ld;
@@ -1434,6 +1458,14 @@ extern "C" int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream) {
       return CVCS_OK;
     }
     const int groups = thin_wgrad_groups(d);
+    if (d->x_up2) {
+      const int lds = kThinTH * kThinTW * 16 * 2 + (kThinHR * kThinHC * 32 * 2 + 1023) / 1024 * 1024 + (kUpPatchRows * kUpPatchCols * 32 * 2 + 1023) / 1024 * 1024;
+      hipLaunchKernelGGL((wgrad_thin_kernel<16, 32, true>), dim3((unsigned)groups), dim3(256), lds, tst, ta);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin, up-sampled input)");
+      hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)cdiv(9 * 16 * 32, 64)), dim3(1024), 0, tst, d->workspace, d->dw, groups * 4, 16, 32, 32, 0);
+      CVCS_CHECK_LAUNCH("cvcs_conv2d_wgrad(thin reduce)");
+      return CVCS_OK;
+    }
 #define LAUNCH_THIN(CO_, CI_)                                                                                              \
   do {                                                                                                                     \
     const int lds = kThinTH * kThinTW * (CO_) * 2 + (kThinHR * kThinHC * (CI_) * 2 + 1023) / 1024 * 1024;                  \

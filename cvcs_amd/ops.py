@@ -92,6 +92,19 @@ class View:
         return self.t[..., self.off:self.off + self.C]
 
 
+class UpView(View):
+    """the bilinear x2 up-sampling of a view that is never stored: H and W are those of the up-sampled map, ptr / ld those of the map at half the
+    resolution (cvcs_conv_desc.in_up2, cvcs_wgrad_desc.x_up2: the thin 3x3 kernels interpolate while they stage their input)"""
+    @property
+    def H(self): return 2 * self.t.shape[1]
+    @property
+    def W(self): return 2 * self.t.shape[2]
+
+
+def up_view(v: View) -> UpView:
+    return UpView(v.t, v.off, v.C)
+
+
 def view(t: torch.Tensor, off: int = 0, C_: int | None = None) -> View:
     assert t.dim() == 4 and t.is_contiguous()
     return View(t, off, t.shape[3] - off if C_ is None else C_)
@@ -121,6 +134,8 @@ def _conv_desc(x: View, wt, bias, out: View, KH, KW, stride, pad, dil, relu, pix
     else:
         Ho, Wo = conv_out_hw(x.H, x.W, KH, KW, stride, pad, dil)
         d.in_, d.in_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    if isinstance(x, UpView):
+        d.in_up2 = 1
     if virt is None and wt.shape[2] > x.C:     # narrow input (the 3-channel tile stored 16 bytes per pixel) under a zero-padded K-group
         d.Cin, d.Cin_valid = wt.shape[2], x.C
     d.wt, d.bias = _ptr(wt), _ptr(bias)
@@ -261,6 +276,8 @@ def _wgrad_desc(x: View, dy: View, KH, KW, stride, pad, virt=None, dil=1):
         d.x_row_pitch, d.x_img_pitch = x.W * 4, x.H * x.W * 4
     else:
         d.x, d.x_ld, d.B, d.H, d.W, d.Cin = x.ptr, x.ld, x.B, x.H, x.W, x.C
+    if isinstance(x, UpView):
+        d.x_up2 = 1
     d.dy, d.dy_ld, d.Ho, d.Wo, d.Cout = dy.ptr, dy.ld, dy.H, dy.W, dy.C
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.Cin_real = d.Cin         # (conv2d_wgrad overrides it for the zero-padded first layer; the workspace query sees the same value)

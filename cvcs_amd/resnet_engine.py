@@ -134,6 +134,7 @@ class ResNetUNetEngine:
         # ReLU in conv3's epilogue, the BatchNorm backward folded into the weight- / data-gradient GEMMs (_block, csrc/bn_gram.hip)
         self.gram_bn = os.environ.get("CVCS_GRAM_BN", "1") == "1"
         self.mask_bits = os.environ.get("CVCS_MASK_BITS", "1") == "1"       # ReLU masks of the Gram tails as bits (_block, _dgrad_into_tail)
+        self.fuse_upsample = os.environ.get("CVCS_FUSE_UPSAMPLE", "0") == "1"   # opt-in (validated at kernel level only): see the decoder loop of _plan
         self.thin_bn_bwd = os.environ.get("CVCS_THIN_BN_BWD", "1") == "1"     # the thin kernel's data-gradient launches carry the next BatchNorm's reduce (_fusable)
         self.fuse_stem_bwd = os.environ.get("CVCS_FUSE_STEM_BWD", "1") == "1"   # see _stem
         self.gram_ds = os.environ.get("CVCS_GRAM_DS", "1") == "1"     # a same-resolution projection shortcut joins its Gram tail as a second GEMM source (_block)
@@ -787,13 +788,18 @@ class ResNetUNetEngine:
         for i in range(5):
             s = S >> (4 - i)
             up = View(cat[i], 0, upc[i])
-            ops.upsample2x_fwd(h.v, up, q8=self._q8_of(up))
+            # (opt-in, CVCS_FUSE_UPSAMPLE=1) a stage without a skip feature whose first conv is the thin 32 -> 16 instance - the full-resolution stage
+            # of the default decoder - never stores its up-sampled input: forward and weight gradient interpolate while they stage (ops.UpView)
+            fuse_up = (self.fuse_upsample and train and skipc[i] == 0 and self.dtype == torch.bfloat16 and upc[i] == 32 and dec[i] == 16 and
+                       not self.keep_all and self._q8_of(up) is None)
+            if not fuse_up:
+                ops.upsample2x_fwd(h.v, up, q8=self._q8_of(up))
             pre = f"decoder.blocks.{i}"
             a1 = Act(ops.view(self._act(pre + ".a1", B, s, s, dec[i])))
             a2 = Act(ops.view(self._act(pre + ".a2", B, s, s, dec[i])))
             if train and self._fp8_ok(pre + ".conv2.0", a1.v, 3, 1, 1):
                 self._register_q8(a1.v.t, "a:" + pre + ".conv2.0")
-            xin = ops.view(cat[i])
+            xin = ops.up_view(h.v) if fuse_up else ops.view(cat[i])
             u1 = self._unit(xin, pre + ".conv1.0", pre + ".conv1.1", 3, 1, 1, train, a1.v)
             u2 = self._unit(a1.v, pre + ".conv2.0", pre + ".conv2.1", 3, 1, 1, train, a2.v)
             if train:

@@ -118,6 +118,10 @@ typedef struct {
    * mask_bits_out - a forward launch that applies a ReLU also writes (value > 0) of what it stores; mask_bits - a data-gradient launch reads the
    * mask from there instead of `mask` (the block output itself: 16 x the bytes).  bf16 1x1 launches of the taps kernel (Cout % 128 == 0).   */
   void* mask_bits_out;  const void* mask_bits;
+  /* (ABI 14, opt-in) in_up2 = 1: `in` is the map at HALF the resolution ([B][H/2][W/2], H and W of this descriptor being those of the conv's input)
+   * and the convolution runs on its bilinear x2 up-sampling (nn.Upsample(2, 'bilinear'), S/blocks.py:29), interpolated while the input tile is
+   * staged - bit-identical to cvcs_upsample2x_fwd followed by this conv, without the up-sampled tensor.  Thin bf16 3x3 32 -> 16 instance.      */
+  int32_t in_up2;
 } cvcs_conv_desc;
 int cvcs_conv2d(const cvcs_conv_desc* d, void* stream);
 /* number of partial-statistics rows cvcs_conv2d writes for this descriptor */
@@ -149,6 +153,9 @@ typedef struct {
    * cvcs_wgrad_takes_bias() accepts (bf16, 1x1 / stride 1 on the GEMM kernel); NULL = none.  The workspace grows by slices * Cout floats
    * (cvcs_wgrad_workspace_floats accounts for it when dbias is set).                                                                       */
   float* dbias;
+  /* (ABI 14, opt-in) x_up2 = 1: `x` is the map at HALF the resolution and the layer's input its bilinear x2 up-sampling (H, W of this descriptor),
+   * interpolated while the tile is staged - the weight half of cvcs_conv_desc.in_up2.  Thin bf16 3x3 instance Cin = 32, Cout = 16.                */
+  int32_t x_up2;
 } cvcs_wgrad_desc;
 int cvcs_conv2d_wgrad(const cvcs_wgrad_desc* d, void* stream);
 /* 1 if cvcs_conv2d_wgrad can also produce `dbias` for this descriptor, else 0 */

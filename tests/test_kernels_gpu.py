@@ -288,6 +288,44 @@ def test_conv_launch_takes_the_first_pass_of_the_batchnorm_backward(shape, mode)
         close(a, b, 1e-4, what)
 
 
+@pytest.mark.parametrize("B,Hl,Wl", [(2, 8, 32), (1, 10, 24), (2, 6, 40), (1, 64, 64)])
+def test_thin_conv_and_weight_gradient_over_an_upsampled_input_equal_the_stored_route(B, Hl, Wl):
+    """cvcs_conv_desc.in_up2 / cvcs_wgrad_desc.x_up2 (opt-in in the engine: CVCS_FUSE_UPSAMPLE): nn.Upsample(2, 'bilinear') -> Conv2d(32, 16, 3, padding=1)
+    of the light decoder's full-resolution stage with the up-sampling interpolated while the thin kernels stage their input - conv output,
+    BatchNorm partial statistics and weight gradient BIT-IDENTICAL to cvcs_upsample2x_fwd followed by the same launches on the stored tensor
+    (whole and ragged 4 x 64 tiles, borders of the replicate-clamped bilinear kernel and of the conv's zero padding)"""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(B * Hl + Wl)
+    Cin, Cout, H, W = 32, 16, 2 * Hl, 2 * Wl
+    xl = torch.randn(B, Hl, Wl, Cin, generator=g).to(dtype).to(DEV)
+    up = torch.empty(B, H, W, Cin, dtype=dtype, device=DEV)
+    ops.upsample2x_fwd(ops.view(xl), ops.view(up))
+    w = rq(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5, dtype)
+    wf, _ = ops.pack_conv_weight(w.to(DEV), Cin, dtype)
+    outs, stats = [], []
+    for xin in (ops.view(up), ops.up_view(ops.view(xl))):
+        assert (xin.H, xin.W) == (H, W)
+        rows = ops.conv_stat_rows(xin, Cout, 3, 3, 1, 1)
+        st = (torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, Cout, device=DEV), torch.zeros(rows, device=DEV))
+        out = torch.full((B, H, W, Cout), 7.0, dtype=dtype, device=DEV)
+        ops.conv2d(xin, wf, None, ops.view(out), 3, 3, 1, 1, stats=st)
+        outs.append(out); stats.append(st)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(a, b) for a, b in zip(stats[0], stats[1]))
+    ref = F.conv2d(F.interpolate(from_nhwc(xl), scale_factor=2, mode="bilinear", align_corners=False).to(dtype).float(), w, None, padding=1)
+    close(from_nhwc(outs[1]), ref, 2.0 ** -7, "conv over the up-sampled input")
+    dy = torch.randn(B, H, W, Cout, generator=g).to(dtype).to(DEV)
+    dws = []
+    for xin in (ops.view(up), ops.up_view(ops.view(xl))):
+        dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
+        ws = torch.empty(ops.wgrad_workspace_floats_for(xin, ops.view(dy), 3, 3, 1, 1), device=DEV)
+        ops.conv2d_wgrad(xin, ops.view(dy), dw, 3, 3, 1, 1, ws)
+        dws.append(dw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dws[1]).all() and torch.equal(dws[0], dws[1])
+
+
 WGRAD_CASES = [
     # B, H, W, Cin(stored), Cin_real, Cout, K, stride, pad
     (2, 8, 40, 64, 64, 64, 3, 1, 1),     # TW=32 strips, ragged width
