@@ -234,4 +234,13 @@ def test_abi14_entry_points_reject_bad_arguments(lib):
     assert 1 <= rows <= 4              # (4 tiles of 4 x 64 pixels; without a device the resident-workgroup query falls back to 1024)
     d.bwd_y = None
     assert lib.cvcs_conv_stat_rows(C.byref(d)) == 16      # forward statistics: one row per tile row
+    # a conv / weight gradient over the bilinear x2 up-sampling of its stored input: the thin 32 -> 16 instance only
+    d = _desc(a, in_up2=1)                                              # 32 -> 64: not a thin shape
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"in_up2" in lib.cvcs_last_error()
+    d = _desc(a, Cout=16, out_ld=16, H=15, W=64, Ho=15, Wo=64, in_up2=1)   # odd height
+    assert lib.cvcs_conv2d(C.byref(d), None) == -1 and b"in_up2" in lib.cvcs_last_error()
+    w = _lib.WgradDesc()
+    w.x, w.x_ld, w.B, w.H, w.W, w.Cin, w.dy, w.dy_ld, w.Ho, w.Wo, w.Cout = a, 64, 1, 16, 64, 64, a, 64, 16, 64, 64
+    w.KH, w.KW, w.stride, w.pad, w.dw, w.Cin_real, w.workspace, w.dtype, w.x_up2 = 3, 3, 1, 1, a, 64, a, 1, 1
+    assert lib.cvcs_conv2d_wgrad(C.byref(w), None) == -1 and b"x_up2" in lib.cvcs_last_error()
 
